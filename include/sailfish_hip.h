@@ -1,0 +1,169 @@
+/* sailfish_hip.h -- C ABI of libsailfish_hip.so, the MI355X (gfx950) backend
+ * for the Sailfish Lattice-Boltzmann hot path.
+ *
+ * This is the drop-in boundary: the reference's plugin seam is the *backend
+ * module* (sailfish/util.py:52-59 get_backends; instantiated per subdomain
+ * process at sailfish/master.py:46-49).  Each entry point below states which
+ * method of the reference's backend interface (sailfish/backend_cuda.py,
+ * identical in backend_opencl.py) it replaces.  sailfish_amd/backend_hip.py
+ * binds these with ctypes and exposes exactly the reference's Python-side
+ * contract; INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a
+ * non-zero status otherwise (the message is available from slf_last_error());
+ * device pointers are passed as void* (64-bit device addresses); all launches
+ * and *_async copies are asynchronous on the given stream (NULL = the
+ * context's default stream); no callbacks; no global mutable state other than
+ * the per-thread last-error string.
+ */
+#ifndef SAILFISH_HIP_H
+#define SAILFISH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLF_ABI_VERSION 1
+
+typedef struct slf_ctx slf_ctx;
+typedef struct slf_stream slf_stream;
+typedef struct slf_event slf_event;
+typedef struct slf_module slf_module;
+typedef struct slf_kernel slf_kernel;
+
+enum { SLF_OK = 0, SLF_ERR_INVALID = 1, SLF_ERR_HIP = 2, SLF_ERR_UNSUPPORTED = 3, SLF_ERR_NOT_FOUND = 4 };
+
+enum { SLF_D2Q9 = 0, SLF_D3Q19 = 1 };
+enum { SLF_BGK = 0, SLF_MRT = 1 };
+enum { SLF_AB = 0, SLF_AA = 1 };
+
+/* Canonical node kinds understood by the kernels (reference node_type.py:86-109,
+ * 115-168, 198-, 269-; wet/excluded semantics from templates/geo_helpers.mako:42-84). */
+enum {
+  SLF_NK_FLUID = 0,
+  SLF_NK_GHOST = 1,
+  SLF_NK_UNUSED = 2,
+  SLF_NK_PROPAGATION_ONLY = 3,
+  SLF_NK_FULL_BB = 4,
+  SLF_NK_HALF_BB = 5,
+  SLF_NK_REGULARIZED_VELOCITY = 6,
+  SLF_NK_EQUILIBRIUM_DENSITY = 7,
+  SLF_NK_EQUILIBRIUM_VELOCITY = 8
+};
+
+#define SLF_MAX_NODE_TYPES 16
+#define SLF_MAX_Q 27
+
+/* Replaces the *source text* handed to backend.build() (reference
+ * sailfish/codegen.py:104-180 renders Mako -> CUDA C; backend_cuda.py:193-218
+ * compiles it).  Kernels here are pre-built for gfx950, so build() receives
+ * this descriptor: the same information the reference puts in its template
+ * context (subdomain_runner.py:181-247 update_context, lb_base.py:120-137,
+ * geo_encoder.py:341-363). */
+typedef struct slf_module_desc {
+  uint32_t struct_size;        /* sizeof(slf_module_desc), ABI check */
+  int32_t lattice;             /* SLF_D2Q9 | SLF_D3Q19            (--grid) */
+  int32_t model;               /* SLF_BGK | SLF_MRT               (--model) */
+  int32_t precision;           /* 4 (single) | 8 (double)          (--precision) */
+  int32_t access_pattern;      /* SLF_AB | SLF_AA                  (--access_pattern) */
+  int32_t lat_nx, lat_ny, lat_nz; /* logical size incl. the ghost envelope; lat_nz = 1 in 2-D */
+  int32_t arr_nx, arr_ny, arr_nz; /* padded in-memory size (subdomain_runner.py:359-373) */
+  int32_t envelope;            /* ghost layer width, always 1 (controller.py:482-494) */
+  int32_t periodic_fused[3];   /* 1: the sweep wraps this axis itself (no ghost traffic, no PBC kernel) */
+  int32_t incompressible;      /* --incompressible */
+  int32_t relaxation_enabled;  /* 0 = streaming only (regtest propagation KATs) */
+  int32_t has_force;           /* body force present (lb_base.py:331-359) */
+  int32_t fluid_only;          /* 1: no node map is read; every real node is a fluid node */
+  double tau;                  /* (6 visc + 1)/2, sym.py:847-848 */
+  double visc;
+  double accel[3];             /* body-force acceleration */
+  double mrt_rates[SLF_MAX_Q]; /* per-moment relaxation rates (sym.py:78-149, 331-406) */
+  /* node-code bit fields, geo_encoder.py:365-382: orientation | scratch | param | type */
+  uint32_t nt_type_mask;
+  uint32_t nt_misc_shift;      /* bits of the type field */
+  uint32_t nt_param_shift;     /* bits of the param-index field */
+  uint32_t nt_scratch_shift;   /* bits of the scratch-id field */
+  int32_t n_types;
+  int32_t type_kind[SLF_MAX_NODE_TYPES]; /* dense type id -> SLF_NK_* */
+  int32_t use_link_tags;       /* orientation field of half-BB nodes holds link tags (subdomain.py:593-642) */
+  int32_t n_node_params;
+  const double* node_params;   /* kernel_common.mako:523-536; copied at module creation */
+} slf_module_desc;
+
+/* Region of the lattice a sweep launch covers (replaces the reference's
+ * bulk/boundary grid arithmetic, subdomain_runner.py:396-475 +
+ * kernel_common.mako:242-457).  Rows y in [y0, y1), planes z in [z0, z1);
+ * x always spans the whole row.  NULL region = every real node. */
+typedef struct slf_region {
+  int32_t y0, y1, z0, z1;
+} slf_region;
+
+/* ---- context / memory: backend.__init__, alloc_buf, alloc_async_host_buf,
+ *      to_buf/from_buf(_async)  (backend_cuda.py:67-191) ---- */
+int slf_abi_version(void);
+int slf_device_count(int* count);
+int slf_ctx_create(int device, slf_ctx** out);
+int slf_ctx_destroy(slf_ctx* ctx);
+int slf_ctx_sync(slf_ctx* ctx);                                  /* backend.sync() */
+int slf_ctx_info(slf_ctx* ctx, char* name, size_t name_len, size_t* total_mem, int* cu_count,
+                 int* wavefront);                                /* backend.info / total_memory / get_defines */
+int slf_malloc(slf_ctx* ctx, size_t bytes, void** dptr);         /* alloc_buf */
+int slf_free(slf_ctx* ctx, void* dptr);
+int slf_memset(slf_ctx* ctx, void* dptr, int value, size_t bytes, slf_stream* stream);
+int slf_host_alloc_pinned(size_t bytes, void** hptr);            /* alloc_async_host_buf */
+int slf_host_free(void* hptr);
+int slf_memcpy_h2d(slf_ctx* ctx, void* dptr, const void* hptr, size_t bytes);        /* to_buf */
+int slf_memcpy_d2h(slf_ctx* ctx, void* hptr, const void* dptr, size_t bytes);        /* from_buf */
+int slf_memcpy_h2d_async(slf_ctx* ctx, void* dptr, const void* hptr, size_t bytes, slf_stream* s); /* to_buf_async */
+int slf_memcpy_d2h_async(slf_ctx* ctx, void* hptr, const void* dptr, size_t bytes, slf_stream* s); /* from_buf_async */
+int slf_memcpy_d2d_async(slf_ctx* ctx, void* dst, const void* src, size_t bytes, slf_stream* s);
+int slf_memcpy_peer_async(slf_ctx* ctx, void* dst, int dst_device, const void* src, int src_device,
+                          size_t bytes, slf_stream* s);          /* same-process multi-GPU halo */
+
+/* ---- streams / events: make_stream, make_event, sync_stream
+ *      (backend_cuda.py:291-308, 24-52) ---- */
+int slf_stream_create(slf_ctx* ctx, slf_stream** out);
+int slf_stream_destroy(slf_stream* s);
+int slf_stream_sync(slf_stream* s);
+int slf_stream_native(slf_stream* s, void** hip_stream);         /* raw hipStream_t, for torch.cuda.ExternalStream */
+int slf_stream_wait_event(slf_stream* s, slf_event* ev);         /* stream.wait_for_event */
+int slf_event_create(slf_ctx* ctx, int timing, slf_event** out);
+int slf_event_destroy(slf_event* ev);
+int slf_event_record(slf_event* ev, slf_stream* s);
+int slf_event_sync(slf_event* ev);
+int slf_event_elapsed_ms(slf_event* start, slf_event* end, float* ms); /* ev.time_since */
+
+/* ---- modules / kernels: build, get_kernel, set_iteration, run_kernel
+ *      (backend_cuda.py:193-251, 128-130) ---- */
+int slf_module_create(slf_ctx* ctx, const slf_module_desc* desc, slf_module** out); /* build() */
+int slf_module_destroy(slf_module* m);
+/* Kernel names are the reference's: "CollideAndPropagate",
+ * "SetInitialConditions", "ApplyPeriodicBoundaryConditions",
+ * "ApplyPeriodicBoundaryConditionsWithSwap", "ApplyMacroPeriodicBoundaryConditions",
+ * "CollectContinuousData[WithSwap]", "DistributeContinuousData[WithSwap]",
+ * "CollectSparseData", "DistributeSparseData",
+ * "CollectContinuousMacroData", "DistributeContinuousMacroData". */
+int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out);
+int slf_kernel_destroy(slf_kernel* k);
+/* fmt: one char per argument, 'P' = device pointer (8 bytes), 'i' = int32,
+ * 'f' = float, 'd' = double (reference lb_single.py:122 struct-style formats).
+ * argv[i] points at the value.  Argument order = the reference kernel's.
+ * needs_iteration: a trailing uint32 iteration counter is appended and
+ * rewritten by slf_kernel_set_iteration (backend_cuda.py:241-245). */
+int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv, int argc,
+                        int needs_iteration);
+int slf_kernel_set_iteration(slf_kernel* k, uint32_t iteration);
+int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* stream); /* run_kernel */
+
+/* number of x-threads per workgroup the sweep uses for this module (diagnostics) */
+int slf_module_block_size(slf_module* m, int* threads);
+
+const char* slf_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAILFISH_HIP_H */

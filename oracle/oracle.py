@@ -1,0 +1,129 @@
+"""ctypes front-end of the CPU oracle (oracle/lbm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by sailfish_amd/.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from sailfish_amd.hipabi import SlfModuleDesc  # the problem-description struct (interface only)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_libs = {}
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', HERE])
+
+
+def lib(precision=4):
+    """precision: 4 -> liboracle_f32.so, 8 -> liboracle_f64.so"""
+    if precision in _libs:
+        return _libs[precision]
+    name = os.path.join(HERE, 'liboracle_f32.so' if precision == 4 else 'liboracle_f64.so')
+    src = os.path.join(HERE, 'lbm_oracle.c')
+    if not os.path.exists(name) or os.path.getmtime(name) < os.path.getmtime(src):
+        build()
+    L = ctypes.CDLL(name)
+    assert L.orc_real_size() == precision
+    P = ctypes.POINTER
+    dp = P(ctypes.c_double)
+    L.orc_node_feq.argtypes = [ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp]
+    L.orc_node_macro.argtypes = [ctypes.c_int, dp, ctypes.c_int, dp, dp]
+    L.orc_node_update.argtypes = [P(SlfModuleDesc), ctypes.c_int, ctypes.c_int, dp, dp, dp, dp]
+    vp = ctypes.c_void_p
+    L.orc_init.argtypes = [P(SlfModuleDesc), vp, vp, vp, vp, vp]
+    L.orc_step.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32,
+                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.orc_pbc.argtypes = [P(SlfModuleDesc), vp, ctypes.c_int, ctypes.c_int]
+    L.orc_macro_pbc.argtypes = [P(SlfModuleDesc), vp, ctypes.c_int]
+    L.orc_sparse.argtypes = [ctypes.c_int, vp, vp, vp, ctypes.c_int]
+    L.orc_compute_macro.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp, vp, vp, vp]
+    for fn in (L.orc_node_feq, L.orc_node_macro, L.orc_node_update, L.orc_init, L.orc_step, L.orc_pbc,
+               L.orc_macro_pbc, L.orc_sparse, L.orc_compute_macro):
+        fn.restype = None
+    _libs[precision] = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def node_feq(lattice, rho, v, incompressible=False, precision=8):
+    Q = 9 if lattice == 0 else 19
+    out = np.zeros(Q)
+    vv = np.zeros(3)
+    vv[:len(v)] = v
+    lib(precision).orc_node_feq(lattice, float(rho), _dp(vv), int(incompressible), _dp(out))
+    return out
+
+
+def node_macro(lattice, f, incompressible=False, precision=8):
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    rho = np.zeros(1)
+    v = np.zeros(3)
+    lib(precision).orc_node_macro(lattice, _dp(f), int(incompressible), _dp(rho), _dp(v))
+    return rho[0], v
+
+
+def node_update(desc, kind, orientation, par, f, precision=8):
+    f = np.array(f, dtype=np.float64)
+    rho = np.zeros(1)
+    v = np.zeros(3)
+    pp = np.zeros(3)
+    if par is not None:
+        pp[:len(par)] = par
+    lib(precision).orc_node_update(ctypes.byref(desc), kind, orientation, _dp(pp), _dp(f), _dp(rho), _dp(v))
+    return f, rho[0], v
+
+
+class OracleSim(object):
+    """Whole-subdomain oracle operating on numpy arrays in the reference's memory layout."""
+
+    def __init__(self, desc):
+        self.desc = desc
+        self.precision = desc.precision
+        self.dtype = np.float32 if desc.precision == 4 else np.float64
+        self.L = lib(desc.precision)
+        self.Q = 9 if desc.lattice == 0 else 19
+        self.dim = 2 if desc.lattice == 0 else 3
+        self.shape = (desc.arr_nz, desc.arr_ny, desc.arr_nx)
+        self.n = desc.arr_nz * desc.arr_ny * desc.arr_nx
+
+    def new_dist(self):
+        return np.full((self.Q,) + self.shape, np.nan, dtype=self.dtype)
+
+    def new_field(self, fill=0.0):
+        return np.full(self.shape, fill, dtype=self.dtype)
+
+    def init(self, dist, rho, vx, vy, vz=None):
+        self.L.orc_init(ctypes.byref(self.desc), _vp(dist), _vp(rho), _vp(vx), _vp(vy), _vp(vz))
+
+    def step(self, prop, nmap, din, dout, rho, vx, vy, vz, options=0, region=None):
+        d = self.desc
+        y0, y1, z0, z1 = 1, d.lat_ny - 1, 1, d.lat_nz - 1
+        if region is not None:
+            y0, y1, z0, z1 = region
+        self.L.orc_step(ctypes.byref(d), prop, _vp(nmap), _vp(din), _vp(dout), _vp(rho), _vp(vx), _vp(vy),
+                        _vp(vz), options, y0, y1, z0, z1)
+
+    def pbc(self, dist, axis, with_swap=False):
+        self.L.orc_pbc(ctypes.byref(self.desc), _vp(dist), axis, int(with_swap))
+
+    def macro_pbc(self, field, axis):
+        self.L.orc_macro_pbc(ctypes.byref(self.desc), _vp(field), axis)
+
+    def sparse(self, collect, idx, dist, buf):
+        self.L.orc_sparse(int(collect), _vp(idx), _vp(dist), _vp(buf), len(idx))
+
+    def compute_macro(self, prop, nmap, din, rho, vx, vy, vz):
+        self.L.orc_compute_macro(ctypes.byref(self.desc), prop, _vp(nmap), _vp(din), _vp(rho), _vp(vx), _vp(vy),
+                                 _vp(vz))

@@ -1,0 +1,510 @@
+// C ABI of libsailfish_hip.so (see include/sailfish_hip.h for the contract and
+// the reference interfaces each entry point replaces).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sailfish_hip.h"
+#include "slf_kernels.h"
+#include "slf_node.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(SLF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SLF_HIP(call)                            \
+  do {                                           \
+    hipError_t _e = (call);                      \
+    if (_e != hipSuccess) return hip_fail(_e, #call); \
+  } while (0)
+
+enum KernelKind {
+  KK_COLLIDE_AND_PROPAGATE,
+  KK_SET_INITIAL_CONDITIONS,
+  KK_PBC,
+  KK_PBC_SWAP,
+  KK_MACRO_PBC,
+  KK_COLLECT_SPARSE,
+  KK_DISTRIBUTE_SPARSE,
+  KK_COMPUTE_MACRO,
+};
+
+}  // namespace
+
+struct slf_ctx {
+  int device;
+};
+struct slf_stream {
+  slf_ctx* ctx;
+  hipStream_t s;
+};
+struct slf_event {
+  slf_ctx* ctx;
+  hipEvent_t e;
+};
+struct slf_module {
+  slf_ctx* ctx;
+  slf::KernelSelector sel;
+  slf::Geometry geo;
+  slf::Physics phys;
+  int access_pattern;
+  int block_x;
+  void* node_params;  // device copy, in the module's precision
+};
+struct slf_kernel {
+  slf_module* mod;
+  KernelKind kind;
+  std::vector<unsigned long long> ptrs;  // 'P' args in order
+  std::vector<long long> ints;           // 'i' args in order
+  int needs_iteration;
+  uint32_t iteration;
+  bool bound;
+};
+
+static hipStream_t native(slf_stream* s) { return s ? s->s : (hipStream_t)0; }
+
+extern "C" {
+
+int slf_abi_version(void) { return SLF_ABI_VERSION; }
+
+const char* slf_last_error(void) { return g_last_error.c_str(); }
+
+int slf_device_count(int* count) {
+  if (!count) return fail(SLF_ERR_INVALID, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return hip_fail(e, "hipGetDeviceCount");
+  }
+  return SLF_OK;
+}
+
+int slf_ctx_create(int device, slf_ctx** out) {
+  if (!out) return fail(SLF_ERR_INVALID, "out is NULL");
+  int n = 0;
+  SLF_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(SLF_ERR_INVALID, "no such HIP device");
+  SLF_HIP(hipSetDevice(device));
+  slf_ctx* c = new slf_ctx;
+  c->device = device;
+  *out = c;
+  return SLF_OK;
+}
+
+int slf_ctx_destroy(slf_ctx* ctx) {
+  delete ctx;
+  return SLF_OK;
+}
+
+int slf_ctx_sync(slf_ctx* ctx) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipSetDevice(ctx->device));
+  SLF_HIP(hipDeviceSynchronize());
+  return SLF_OK;
+}
+
+int slf_ctx_info(slf_ctx* ctx, char* name, size_t name_len, size_t* total_mem, int* cu_count, int* wavefront) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  hipDeviceProp_t prop;
+  SLF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_len) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (total_mem) *total_mem = prop.totalGlobalMem;
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (wavefront) *wavefront = prop.warpSize;
+  return SLF_OK;
+}
+
+int slf_malloc(slf_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(ctx->device));
+  SLF_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+  return SLF_OK;
+}
+
+int slf_free(slf_ctx* ctx, void* dptr) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  if (dptr) SLF_HIP(hipFree(dptr));
+  return SLF_OK;
+}
+
+int slf_memset(slf_ctx* ctx, void* dptr, int value, size_t bytes, slf_stream* stream) {
+  if (!ctx || !dptr) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipMemsetAsync(dptr, value, bytes, native(stream)));
+  return SLF_OK;
+}
+
+int slf_host_alloc_pinned(size_t bytes, void** hptr) {
+  if (!hptr) return fail(SLF_ERR_INVALID, "hptr is NULL");
+  SLF_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return SLF_OK;
+}
+
+int slf_host_free(void* hptr) {
+  if (hptr) SLF_HIP(hipHostFree(hptr));
+  return SLF_OK;
+}
+
+int slf_memcpy_h2d(slf_ctx* ctx, void* dptr, const void* hptr, size_t bytes) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipMemcpy(dptr, hptr, bytes, hipMemcpyHostToDevice));
+  return SLF_OK;
+}
+
+int slf_memcpy_d2h(slf_ctx* ctx, void* hptr, const void* dptr, size_t bytes) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipMemcpy(hptr, dptr, bytes, hipMemcpyDeviceToHost));
+  return SLF_OK;
+}
+
+int slf_memcpy_h2d_async(slf_ctx* ctx, void* dptr, const void* hptr, size_t bytes, slf_stream* s) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, native(s)));
+  return SLF_OK;
+}
+
+int slf_memcpy_d2h_async(slf_ctx* ctx, void* hptr, const void* dptr, size_t bytes, slf_stream* s) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, native(s)));
+  return SLF_OK;
+}
+
+int slf_memcpy_d2d_async(slf_ctx* ctx, void* dst, const void* src, size_t bytes, slf_stream* s) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, native(s)));
+  return SLF_OK;
+}
+
+int slf_memcpy_peer_async(slf_ctx* ctx, void* dst, int dst_device, const void* src, int src_device, size_t bytes,
+                          slf_stream* s) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, native(s)));
+  return SLF_OK;
+}
+
+int slf_stream_create(slf_ctx* ctx, slf_stream** out) {
+  if (!ctx || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(ctx->device));
+  slf_stream* s = new slf_stream;
+  s->ctx = ctx;
+  hipError_t e = hipStreamCreateWithFlags(&s->s, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete s;
+    return hip_fail(e, "hipStreamCreateWithFlags");
+  }
+  *out = s;
+  return SLF_OK;
+}
+
+int slf_stream_destroy(slf_stream* s) {
+  if (s) {
+    hipStreamDestroy(s->s);
+    delete s;
+  }
+  return SLF_OK;
+}
+
+int slf_stream_sync(slf_stream* s) {
+  SLF_HIP(hipStreamSynchronize(native(s)));
+  return SLF_OK;
+}
+
+int slf_stream_native(slf_stream* s, void** hip_stream) {
+  if (!hip_stream) return fail(SLF_ERR_INVALID, "hip_stream is NULL");
+  *hip_stream = (void*)native(s);
+  return SLF_OK;
+}
+
+int slf_stream_wait_event(slf_stream* s, slf_event* ev) {
+  if (!ev) return fail(SLF_ERR_INVALID, "event is NULL");
+  SLF_HIP(hipStreamWaitEvent(native(s), ev->e, 0));
+  return SLF_OK;
+}
+
+int slf_event_create(slf_ctx* ctx, int timing, slf_event** out) {
+  if (!ctx || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(ctx->device));
+  slf_event* ev = new slf_event;
+  ev->ctx = ctx;
+  hipError_t e = hipEventCreateWithFlags(&ev->e, timing ? hipEventDefault : hipEventDisableTiming);
+  if (e != hipSuccess) {
+    delete ev;
+    return hip_fail(e, "hipEventCreateWithFlags");
+  }
+  *out = ev;
+  return SLF_OK;
+}
+
+int slf_event_destroy(slf_event* ev) {
+  if (ev) {
+    hipEventDestroy(ev->e);
+    delete ev;
+  }
+  return SLF_OK;
+}
+
+int slf_event_record(slf_event* ev, slf_stream* s) {
+  if (!ev) return fail(SLF_ERR_INVALID, "event is NULL");
+  SLF_HIP(hipEventRecord(ev->e, native(s)));
+  return SLF_OK;
+}
+
+int slf_event_sync(slf_event* ev) {
+  if (!ev) return fail(SLF_ERR_INVALID, "event is NULL");
+  SLF_HIP(hipEventSynchronize(ev->e));
+  return SLF_OK;
+}
+
+int slf_event_elapsed_ms(slf_event* start, slf_event* end, float* ms) {
+  if (!start || !end || !ms) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipEventElapsedTime(ms, start->e, end->e));
+  return SLF_OK;
+}
+
+int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) {
+  if (!ctx || !d || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (d->struct_size != sizeof(slf_module_desc)) return fail(SLF_ERR_INVALID, "slf_module_desc size mismatch (ABI)");
+  if (d->lattice != SLF_D2Q9 && d->lattice != SLF_D3Q19) return fail(SLF_ERR_UNSUPPORTED, "unsupported lattice");
+  if (d->model != SLF_BGK && d->model != SLF_MRT) return fail(SLF_ERR_UNSUPPORTED, "unsupported collision model");
+  if (d->precision != 4 && d->precision != 8) return fail(SLF_ERR_UNSUPPORTED, "precision must be 4 or 8");
+  if (d->access_pattern != SLF_AB && d->access_pattern != SLF_AA)
+    return fail(SLF_ERR_UNSUPPORTED, "unsupported access pattern");
+  const int dim = d->lattice == SLF_D2Q9 ? 2 : 3;
+  if (d->envelope != 1) return fail(SLF_ERR_UNSUPPORTED, "envelope size must be 1");
+  if (d->lat_nx < 3 || d->lat_ny < 3 || (dim == 3 && d->lat_nz < 3) || (dim == 2 && d->lat_nz != 1))
+    return fail(SLF_ERR_INVALID, "bad lattice size");
+  if (d->arr_nx < d->lat_nx || d->arr_ny < d->lat_ny || d->arr_nz < d->lat_nz)
+    return fail(SLF_ERR_INVALID, "padded size smaller than lattice size");
+  if (d->tau <= 0.5 && d->relaxation_enabled) return fail(SLF_ERR_INVALID, "tau must be > 0.5");
+  if (d->n_types < 0 || d->n_types > SLF_MAX_NODE_TYPES) return fail(SLF_ERR_INVALID, "too many node types");
+  const unsigned long long total = (unsigned long long)d->arr_nx * d->arr_ny * d->arr_nz;
+  if (total >= 0xFFFFFFFFull) return fail(SLF_ERR_UNSUPPORTED, "subdomain too large for 32-bit node indices");
+
+  slf_module* m = new slf_module;
+  m->ctx = ctx;
+  m->sel.lattice = d->lattice;
+  m->sel.model = d->model;
+  m->sel.precision = d->precision;
+  m->sel.general = !d->fluid_only;
+  m->access_pattern = d->access_pattern;
+  slf::Geometry& g = m->geo;
+  g.dim = dim;
+  g.lat_nx = d->lat_nx; g.lat_ny = d->lat_ny; g.lat_nz = d->lat_nz;
+  g.arr_nx = d->arr_nx; g.arr_ny = d->arr_ny; g.arr_nz = d->arr_nz;
+  g.arr_nxy = d->arr_nx * d->arr_ny;
+  g.dist_size = (uint32_t)total;
+  for (int i = 0; i < 3; i++) g.wrap[i] = (i < dim) ? (d->periodic_fused[i] != 0) : 0;
+  g.type_mask = d->nt_type_mask;
+  g.param_shift = d->nt_misc_shift;
+  g.param_mask = (1u << d->nt_param_shift) - 1u;
+  g.orient_shift = d->nt_misc_shift + d->nt_param_shift + d->nt_scratch_shift;
+  g.type_lut = 0;
+  for (int i = 0; i < d->n_types; i++) {
+    const int k = d->type_kind[i];
+    if (k < 0 || k >= slf::NK_COUNT) {
+      delete m;
+      return fail(SLF_ERR_UNSUPPORTED, "node type kind not supported by the HIP backend");
+    }
+    g.type_lut |= (unsigned long long)k << (4 * i);
+  }
+  g.use_link_tags = d->use_link_tags;
+  slf::Physics& ph = m->phys;
+  ph.tau = d->tau;
+  ph.visc = d->visc;
+  for (int i = 0; i < 3; i++) ph.accel[i] = d->accel[i];
+  for (int i = 0; i < 27; i++) ph.mrt_rates[i] = d->mrt_rates[i];
+  ph.incompressible = d->incompressible;
+  ph.has_force = d->has_force;
+  ph.relaxation_enabled = d->relaxation_enabled;
+  // Workgroup = an x-chunk of one row.  Whole rows up to 1024 nodes are one
+  // workgroup; longer rows are cut into 256-thread chunks.
+  int bx = ((d->lat_nx + 63) / 64) * 64;
+  if (bx > 1024) bx = 256;
+  const char* env = getenv("SLF_BLOCK_X");
+  if (env && atoi(env) >= 64 && atoi(env) <= 1024 && atoi(env) % 64 == 0) bx = atoi(env);
+  m->block_x = bx;
+  m->node_params = nullptr;
+  const int np = d->n_node_params > 0 ? d->n_node_params : 1;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc(&m->node_params, (size_t)np * d->precision);
+  if (e != hipSuccess) {
+    delete m;
+    return hip_fail(e, "hipMalloc(node_params)");
+  }
+  if (d->precision == 4) {
+    std::vector<float> tmp(np, 0.0f);
+    for (int i = 0; i < d->n_node_params; i++) tmp[i] = (float)d->node_params[i];
+    e = hipMemcpy(m->node_params, tmp.data(), np * sizeof(float), hipMemcpyHostToDevice);
+  } else {
+    std::vector<double> tmp(np, 0.0);
+    for (int i = 0; i < d->n_node_params; i++) tmp[i] = d->node_params[i];
+    e = hipMemcpy(m->node_params, tmp.data(), np * sizeof(double), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    hipFree(m->node_params);
+    delete m;
+    return hip_fail(e, "hipMemcpy(node_params)");
+  }
+  *out = m;
+  return SLF_OK;
+}
+
+int slf_module_destroy(slf_module* m) {
+  if (m) {
+    if (m->node_params) hipFree(m->node_params);
+    delete m;
+  }
+  return SLF_OK;
+}
+
+int slf_module_block_size(slf_module* m, int* threads) {
+  if (!m || !threads) return fail(SLF_ERR_INVALID, "NULL argument");
+  *threads = m->block_x;
+  return SLF_OK;
+}
+
+int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
+  if (!m || !name || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  KernelKind kk;
+  if (!strcmp(name, "CollideAndPropagate")) kk = KK_COLLIDE_AND_PROPAGATE;
+  else if (!strcmp(name, "SetInitialConditions")) kk = KK_SET_INITIAL_CONDITIONS;
+  else if (!strcmp(name, "ApplyPeriodicBoundaryConditions")) kk = KK_PBC;
+  else if (!strcmp(name, "ApplyPeriodicBoundaryConditionsWithSwap")) kk = KK_PBC_SWAP;
+  else if (!strcmp(name, "ApplyMacroPeriodicBoundaryConditions")) kk = KK_MACRO_PBC;
+  else if (!strcmp(name, "CollectSparseData")) kk = KK_COLLECT_SPARSE;
+  else if (!strcmp(name, "DistributeSparseData")) kk = KK_DISTRIBUTE_SPARSE;
+  else if (!strcmp(name, "ComputeMacroFields")) kk = KK_COMPUTE_MACRO;
+  else return fail(SLF_ERR_NOT_FOUND, std::string("unknown kernel: ") + name);
+  if (kk == KK_PBC_SWAP && m->access_pattern != SLF_AA)
+    return fail(SLF_ERR_NOT_FOUND, "ApplyPeriodicBoundaryConditionsWithSwap only exists for the AA access pattern");
+  slf_kernel* k = new slf_kernel;
+  k->mod = m;
+  k->kind = kk;
+  k->needs_iteration = 0;
+  k->iteration = 0;
+  k->bound = false;
+  *out = k;
+  return SLF_OK;
+}
+
+int slf_kernel_destroy(slf_kernel* k) {
+  delete k;
+  return SLF_OK;
+}
+
+int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv, int argc, int needs_iteration) {
+  if (!k || !fmt || (!argv && argc > 0)) return fail(SLF_ERR_INVALID, "NULL argument");
+  if ((int)strlen(fmt) != argc) return fail(SLF_ERR_INVALID, "format / argc mismatch");
+  k->ptrs.clear();
+  k->ints.clear();
+  for (int i = 0; i < argc; i++) {
+    switch (fmt[i]) {
+      case 'P': k->ptrs.push_back(*(const unsigned long long*)argv[i]); break;
+      case 'i': k->ints.push_back(*(const int32_t*)argv[i]); break;
+      default: return fail(SLF_ERR_INVALID, std::string("unsupported format char: ") + fmt[i]);
+    }
+  }
+  const int dim = k->mod->geo.dim;
+  size_t want_p = 0, want_i = 0;
+  switch (k->kind) {
+    case KK_COLLIDE_AND_PROPAGATE:
+    case KK_COMPUTE_MACRO: want_p = 4 + dim; want_i = 1; break;   // map, dist_in, dist_out, rho, v.., options
+    case KK_SET_INITIAL_CONDITIONS: want_p = 3 + dim; want_i = 0; break;  // dist, v.., rho, map
+    case KK_PBC:
+    case KK_PBC_SWAP:
+    case KK_MACRO_PBC: want_p = 1; want_i = 1; break;             // dist|field, axis
+    case KK_COLLECT_SPARSE:
+    case KK_DISTRIBUTE_SPARSE: want_p = 3; want_i = 1; break;     // idx_array, dist, buffer, n
+  }
+  if (k->ptrs.size() != want_p || k->ints.size() != want_i)
+    return fail(SLF_ERR_INVALID, "argument list does not match the kernel's signature");
+  k->needs_iteration = needs_iteration;
+  k->bound = true;
+  return SLF_OK;
+}
+
+int slf_kernel_set_iteration(slf_kernel* k, uint32_t iteration) {
+  if (!k) return fail(SLF_ERR_INVALID, "kernel is NULL");
+  k->iteration = iteration;
+  return SLF_OK;
+}
+
+int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* stream) {
+  if (!k) return fail(SLF_ERR_INVALID, "kernel is NULL");
+  if (!k->bound) return fail(SLF_ERR_INVALID, "kernel arguments not set");
+  slf_module* m = k->mod;
+  const slf::Geometry& g = m->geo;
+  hipStream_t s = native(stream);
+  hipError_t e = hipSuccess;
+  switch (k->kind) {
+    case KK_COLLIDE_AND_PROPAGATE:
+    case KK_COMPUTE_MACRO: {
+      slf::SweepArgs a;
+      a.map = (const void*)k->ptrs[0];
+      a.dist_in = (void*)k->ptrs[1];
+      a.dist_out = (void*)k->ptrs[2];
+      a.rho = (void*)k->ptrs[3];
+      a.v[0] = (void*)k->ptrs[4];
+      a.v[1] = (void*)k->ptrs[5];
+      a.v[2] = g.dim == 3 ? (void*)k->ptrs[6] : nullptr;
+      a.node_params = m->node_params;
+      a.options = (uint32_t)k->ints[0];
+      if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
+      slf::Prop prop = slf::PROP_AB;
+      if (m->access_pattern == SLF_AA) {
+        if (!k->needs_iteration) return fail(SLF_ERR_INVALID, "AA kernels need the iteration argument");
+        prop = (k->iteration & 1u) ? slf::PROP_AA_ODD : slf::PROP_AA_EVEN;
+      }
+      if (k->kind == KK_COMPUTE_MACRO) {
+        e = slf::launch_macro(m->sel, prop, g, m->phys, a, s);
+        break;
+      }
+      int y0 = 1, y1 = g.lat_ny - 1, z0 = 1, z1 = g.lat_nz - 1;
+      if (g.dim == 2) { z0 = 0; z1 = 1; }
+      if (region) {
+        y0 = region->y0; y1 = region->y1;
+        if (g.dim == 3) { z0 = region->z0; z1 = region->z1; }
+        if (y0 < 1 || y1 > g.lat_ny - 1 || y0 > y1 || (g.dim == 3 && (z0 < 1 || z1 > g.lat_nz - 1 || z0 > z1)))
+          return fail(SLF_ERR_INVALID, "region outside the real nodes of the subdomain");
+      }
+      e = slf::launch_sweep(m->sel, prop, g, m->phys, a, y0, y1, z0, z1, m->block_x, s);
+      break;
+    }
+    case KK_SET_INITIAL_CONDITIONS: {
+      // (dist, vx, vy[, vz], rho, map)  -- reference lb_single.py:72-94
+      const void* v[3] = {(const void*)k->ptrs[1], (const void*)k->ptrs[2],
+                          g.dim == 3 ? (const void*)k->ptrs[3] : nullptr};
+      e = slf::launch_init(m->sel, g, m->phys, (void*)k->ptrs[0], (const void*)k->ptrs[1 + g.dim], v, s);
+      break;
+    }
+    case KK_PBC:
+    case KK_PBC_SWAP:
+      e = slf::launch_pbc(m->sel, g, (void*)k->ptrs[0], (int)k->ints[0], k->kind == KK_PBC_SWAP, s);
+      break;
+    case KK_MACRO_PBC:
+      e = slf::launch_macro_pbc(m->sel, g, (void*)k->ptrs[0], (int)k->ints[0], s);
+      break;
+    case KK_COLLECT_SPARSE:
+    case KK_DISTRIBUTE_SPARSE:
+      e = slf::launch_sparse(m->sel, k->kind == KK_COLLECT_SPARSE, (const unsigned long long*)k->ptrs[0],
+                             (void*)k->ptrs[1], (void*)k->ptrs[2], (int)k->ints[0], s);
+      break;
+  }
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  return SLF_OK;
+}
+
+}  // extern "C"

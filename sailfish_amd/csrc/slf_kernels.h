@@ -1,0 +1,70 @@
+// Host-visible launch interface of the gfx950 kernels (C++ linkage, used only by
+// slf_api.hip).  See slf_kernels.hip for the kernels themselves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slf {
+
+enum Prop : int { PROP_AB = 0, PROP_AA_EVEN = 1, PROP_AA_ODD = 2 };
+
+// Geometry + decode information shared by all kernels of a module.
+struct Geometry {
+  int dim;
+  int lat_nx, lat_ny, lat_nz;  // incl. ghosts (lat_nz == 1 in 2-D)
+  int arr_nx, arr_ny, arr_nz;
+  int arr_nxy;                 // arr_nx * arr_ny
+  uint32_t dist_size;          // arr_nx * arr_ny * arr_nz
+  int wrap[3];                 // in-kernel periodic wrap per axis
+  // node code decoding
+  uint32_t type_mask;
+  uint32_t param_shift;        // = bits of the type field
+  uint32_t param_mask;
+  uint32_t orient_shift;
+  unsigned long long type_lut; // 4 bits per dense type id -> NodeKind
+  int use_link_tags;
+};
+
+struct Physics {
+  double tau, visc;
+  double accel[3];
+  double mrt_rates[27];
+  int incompressible;
+  int has_force;
+  int relaxation_enabled;
+};
+
+struct SweepArgs {
+  const void* map;
+  void* dist_in;
+  void* dist_out;
+  void* rho;
+  void* v[3];
+  const void* node_params;
+  uint32_t options;
+};
+
+// One module = one (lattice, model, precision, access pattern) specialisation.
+struct KernelSelector {
+  int lattice, model, precision;
+  bool general;  // reads the node map / handles BC nodes
+};
+
+hipError_t launch_sweep(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                        const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s);
+
+hipError_t launch_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist,
+                       const void* rho, const void* const v[3], hipStream_t s);
+
+hipError_t launch_pbc(const KernelSelector& sel, const Geometry& g, void* dist, int axis, bool with_swap,
+                      hipStream_t s);
+
+hipError_t launch_macro_pbc(const KernelSelector& sel, const Geometry& g, void* field, int axis, hipStream_t s);
+
+hipError_t launch_sparse(const KernelSelector& sel, bool collect, const unsigned long long* idx, void* dist, void* buffer,
+                         int n, hipStream_t s);
+
+hipError_t launch_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                        const SweepArgs& a, hipStream_t s);
+
+}  // namespace slf

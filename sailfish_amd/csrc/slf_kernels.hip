@@ -1,0 +1,516 @@
+// gfx950 (MI355X, CDNA4) kernels of the Sailfish hot path.
+//
+//   sweep_kernel      fused collide-and-stream  = reference CollideAndPropagate
+//                     (sailfish/templates/models/lb_single_fluid.mako:161-229)
+//   init_kernel       SetInitialConditions      (lb_single_fluid.mako:101-127)
+//   pbc_kernel        ApplyPeriodicBoundaryConditions[WithSwap] (kernel_utils.mako:19-384)
+//   macro_pbc_kernel  ApplyMacroPeriodicBoundaryConditions      (kernel_utils.mako:410-474)
+//   sparse_kernel     Collect/DistributeSparseData              (kernel_utils.mako:796-836)
+//
+// Design: bandwidth-bound stencil, no MFMA.  SoA layout
+// dist[q][z][y][x] with x padded (reference subdomain_runner.py:367-373), one
+// thread per node along x so that every population access of a wave is one
+// contiguous 256-byte row segment; a workgroup owns a contiguous x-chunk of one
+// (y, z) row, so y/z neighbour offsets (and the periodic wrap of those axes) are
+// wave-uniform scalars and only the +-1 x shift is per lane.  Streaming is
+// "push" for AB and the odd AA step, in-place opposite-slot for the even AA step
+// (reference propagation.mako:170-174, 384-421; geo_helpers.mako:248-276).
+#include "slf_kernels.h"
+#include "slf_node.h"
+
+namespace slf {
+
+template <class L, class R>
+struct SweepParams {
+  const uint32_t* __restrict__ map;
+  const R* din;
+  R* dout;
+  R* rho;
+  R* vx;
+  R* vy;
+  R* vz;
+  const R* __restrict__ node_params;
+  uint32_t options;
+  int y0, z0;
+  int relaxation_enabled;
+  Geometry g;
+  CollideParams<L, R> cp;
+};
+
+// Offsets (in elements) to the +-1 neighbours along each axis, with the
+// optional in-kernel periodic wrap.  Real nodes are 1 .. lat-2.
+struct AxisOff {
+  int p, m;
+};
+__device__ __forceinline__ AxisOff axis_off(int c, int lat, int stride, int wrap) {
+  AxisOff o;
+  o.p = stride;
+  o.m = -stride;
+  if (wrap) {
+    if (c == lat - 2) o.p = -(lat - 3) * stride;
+    if (c == 1) o.m = (lat - 3) * stride;
+  }
+  return o;
+}
+
+template <class L, int I>
+__device__ __forceinline__ int dir_offset(const AxisOff& ox, const AxisOff& oy, const AxisOff& oz, bool forward) {
+  // forward: offset of x + e_i ; !forward: offset of x - e_i
+  int off = 0;
+  constexpr int ex = L::ex(I), ey = L::ey(I), ez = L::ez(I);
+  if constexpr (ex != 0) off += ((ex > 0) == forward) ? ox.p : ox.m;
+  if constexpr (ey != 0) off += ((ey > 0) == forward) ? oy.p : oy.m;
+  if constexpr (ez != 0) off += ((ez > 0) == forward) ? oz.p : oz.m;
+  return off;
+}
+
+template <class L, class R, int MODEL, int PROP, bool GENERAL>
+__global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx < 1 || gx > g.lat_nx - 2) return;
+
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+
+  int kind = NK_FLUID;
+  uint32_t code = 0;
+  if constexpr (GENERAL) {
+    code = p.map[gi];
+    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if (kind_is_excluded(kind)) return;
+  }
+
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  const size_t ds = g.dist_size;
+
+  // ---- load (reference getDist, geo_helpers.mako:258-276)
+  R f[L::Q];
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_ODD) {
+      const int off = dir_offset<L, I>(ox, oy, oz, false);
+      f[I] = (p.din + ds * (size_t)L::opp(I))[(uint32_t)((int)gi + off)];
+    } else {
+      f[I] = (p.din + ds * (size_t)I)[gi];
+    }
+  });
+
+  R rho, v[3];
+  bool wet = true;
+  if constexpr (GENERAL) {
+    wet = kind_is_wet(kind);
+    const int orientation = (int)(code >> g.orient_shift);
+    const int pidx = (int)((code >> g.param_shift) & g.param_mask);
+    const bool inc = p.cp.incompressible != 0;
+    // ---- macroscopic quantities (getMacro, boundary.mako:465-507)
+    const bool bc_macro = (kind == NK_REGULARIZED_VELOCITY || kind == NK_EQUILIBRIUM_VELOCITY ||
+                           kind == NK_EQUILIBRIUM_DENSITY) && orientation != 0;
+    if (!bc_macro) {
+      macro_standard<L, R>(f, inc, rho, v);
+    } else if (kind == NK_EQUILIBRIUM_DENSITY) {
+      with_orientation<L>(orientation, [&](auto O) { macro_density_bc<L, R, O>(f, p.node_params[pidx], rho, v); });
+    } else {
+      with_orientation<L>(orientation,
+                          [&](auto O) { macro_velocity_bc<L, R, O>(f, p.node_params + pidx, inc, rho, v); });
+    }
+    // ---- pre-collision boundary conditions (boundary.mako:784-878)
+    const R rho0 = inc ? (R)1 : rho;
+    if (kind == NK_FULL_BB) {
+      bounce_back<L, R>(f);
+    } else if (kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY) {
+      set_equilibrium<L, R>(f, rho, rho0, v);
+    } else if (kind == NK_REGULARIZED_VELOCITY) {
+      if (orientation == 0) {
+        bounce_back<L, R>(f);  // nt_dir_other fallback, boundary.mako:336-338
+      } else {
+        with_orientation<L>(orientation, [&](auto O) { regularized_bc<L, R, O>(f, rho, rho0, v); });
+      }
+    }
+    // ---- collision (relaxate, relaxation.mako:196-202: wet nodes only)
+    if (wet && p.relaxation_enabled) {
+      if constexpr (MODEL == 0) {
+        bgk_relax<L, R>(f, rho, v, p.cp);
+      } else {
+        mrt_relax<L, R>(f, v, p.cp, kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY);
+      }
+    }
+    // ---- post-collision: half-way bounce-back (boundary.mako:653-683)
+    if (kind == NK_HALF_BB) {
+      static_for<1, L::Q>([&](auto I) {
+        bool missing;
+        if (g.use_link_tags) {
+          missing = ((orientation >> (I - 1)) & 1) == 0;  // direction I points to a non-fluid node
+        } else {
+          missing = false;
+          with_orientation<L>(orientation, [&](auto O) {
+            if constexpr (is_missing<L, L::opp(I), O>()) missing = true;
+          });
+        }
+        if (missing) {
+          // population opp(I) is undefined here: feed it with the reflected f_I.
+          if constexpr (PROP == PROP_AA_EVEN) {
+            const int off = dir_offset<L, I>(ox, oy, oz, true);
+            (p.dout + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+          } else {
+            (p.dout + ds * (size_t)L::opp(I))[gi] = f[I];
+          }
+        }
+      });
+    }
+  } else {
+    macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
+    if (p.relaxation_enabled) {
+      if constexpr (MODEL == 0) bgk_relax<L, R>(f, rho, v, p.cp);
+      else mrt_relax<L, R>(f, v, p.cp, false);
+    }
+  }
+
+  // ---- macroscopic output (save_macro_fields, kernel_common.mako:213-240)
+  if ((p.options & 1u) && wet) {
+    p.rho[gi] = rho;
+    p.vx[gi] = v[0];
+    p.vy[gi] = v[1];
+    if constexpr (L::dim == 3) p.vz[gi] = v[2];
+  }
+
+  // ---- streaming (propagate, propagation.mako:384-421)
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_EVEN) {
+      (p.dout + ds * (size_t)L::opp(I))[gi] = f[I];
+    } else {
+      const int off = dir_offset<L, I>(ox, oy, oz, true);
+      (p.dout + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+    }
+  });
+}
+
+// SetInitialConditions: f_i = feq_i(rho, v) on *every* node of the lattice box,
+// no type test (ghost nodes carry the non-finite sentinels of the host fields).
+template <class L, class R>
+__global__ void __launch_bounds__(256) init_kernel(R* dist, const R* __restrict__ irho, const R* __restrict__ ivx,
+                                                   const R* __restrict__ ivy, const R* __restrict__ ivz, Geometry g,
+                                                   int incompressible) {
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int gy = (int)blockIdx.y;
+  const int gz = (int)blockIdx.z;
+  if (gx > g.lat_nx - 1) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const R rho = irho[gi];
+  R v[3];
+  v[0] = ivx[gi];
+  v[1] = ivy[gi];
+  v[2] = (R)0;
+  if constexpr (L::dim == 3) v[2] = ivz[gi];
+  const R rho0 = incompressible ? (R)1 : rho;
+  const R u15 = usq15<L, R>(v);
+  static_for<0, L::Q>([&](auto I) { (dist + (size_t)g.dist_size * (size_t)I)[gi] = feq<L, R, I>(rho, rho0, v, u15); });
+}
+
+__device__ __forceinline__ bool slf_isfinite(float x) { return __builtin_isfinite(x); }
+__device__ __forceinline__ bool slf_isfinite(double x) { return __builtin_isfinite(x); }
+
+// Periodic boundary conditions inside one subdomain for one axis.
+//
+// !SWAP (after a push step; effect of kernel_utils.mako:295-336): populations
+// that were pushed into the ghost layer of `axis` are moved to the real layer on
+// the opposite side.  The face spans the *full* extent (ghosts included) of the
+// other axes; applied in x, y, z order this moves edge/corner populations one
+// axis at a time.  A population with e_b = +1 (-1) can only have been pushed to
+// coordinate b >= 2 (<= lat_b - 3) along another axis b, everything else is
+// skipped, as are non-finite values (never-written ghost slots).
+//
+// SWAP (after the in-place even AA step; effect of kernel_utils.mako:343-384):
+// real layer -> opposite ghost layer, opposite slots, so that the next (odd)
+// step can pull through the periodic face.  Axes already processed (lower
+// index) contribute their ghost columns, later axes only their real range.
+template <class L, class R, bool SWAP>
+__global__ void __launch_bounds__(256) pbc_kernel(R* dist, Geometry g, int axis) {
+  const int lat[3] = {g.lat_nx, g.lat_ny, g.lat_nz};
+  const int stride[3] = {1, g.arr_nx, g.arr_nxy};
+  int b_ax, c_ax;  // the two other axes, b fastest
+  if (axis == 0) { b_ax = 1; c_ax = 2; }
+  else if (axis == 1) { b_ax = 0; c_ax = 2; }
+  else { b_ax = 0; c_ax = 1; }
+  const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int c = (L::dim == 3) ? (int)blockIdx.y : 0;
+  if (b > lat[b_ax] - 1) return;
+  if (L::dim == 2) c_ax = 2;  // lat_nz == 1, c == 0
+
+  const int n = lat[axis];
+  const size_t ds = g.dist_size;
+  const uint32_t base = (uint32_t)b * (uint32_t)stride[b_ax] + (uint32_t)c * (uint32_t)stride[c_ax];
+
+  static_for<1, L::Q>([&](auto I) {
+    const int e[3] = {L::ex(I), L::ey(I), L::ez(I)};
+    const int ea = e[axis];
+    if (ea == 0) return;
+    const int eb = e[b_ax];
+    const int ec = (L::dim == 3) ? e[c_ax] : 0;
+    if constexpr (!SWAP) {
+      if (eb > 0 && b < 2) return;
+      if (eb < 0 && b > lat[b_ax] - 3) return;
+      if (L::dim == 3) {
+        if (ec > 0 && c < 2) return;
+        if (ec < 0 && c > lat[c_ax] - 3) return;
+      }
+      // ea = -1: landed in the low ghost (0) -> high real (n-2); ea = +1: high ghost (n-1) -> low real (1)
+      const uint32_t src = base + (uint32_t)((ea < 0 ? 0 : n - 1) * stride[axis]);
+      const uint32_t dst = base + (uint32_t)((ea < 0 ? n - 2 : 1) * stride[axis]);
+      R* d = dist + ds * (size_t)I;
+      const R val = d[src];
+      if (slf_isfinite(val)) d[dst] = val;
+    } else {
+      // The puller sits at g + e_i and must be a real node along the other axes;
+      // ghost columns are only meaningful for axes that were processed before.
+      const int blo = (b_ax < axis) ? 0 : 1, bhi = (b_ax < axis) ? lat[b_ax] - 1 : lat[b_ax] - 2;
+      if (b < blo || b > bhi) return;
+      if (b + eb < 1 || b + eb > lat[b_ax] - 2) return;
+      if (L::dim == 3) {
+        const int clo = (c_ax < axis) ? 0 : 1, chi = (c_ax < axis) ? lat[c_ax] - 1 : lat[c_ax] - 2;
+        if (c < clo || c > chi) return;
+        if (c + ec < 1 || c + ec > lat[c_ax] - 2) return;
+      }
+      // ea = +1: puller at 1 reads ghost 0 <- real n-2 ; ea = -1: puller at n-2 reads ghost n-1 <- real 1
+      const uint32_t src = base + (uint32_t)((ea > 0 ? n - 2 : 1) * stride[axis]);
+      const uint32_t dst = base + (uint32_t)((ea > 0 ? 0 : n - 1) * stride[axis]);
+      R* d = dist + ds * (size_t)L::opp(I);
+      const R val = d[src];
+      if (slf_isfinite(val)) d[dst] = val;
+    }
+  });
+}
+
+// Ghost fill of a scalar field for one periodic axis (kernel_utils.mako:410-474).
+template <class R>
+__global__ void __launch_bounds__(256) macro_pbc_kernel(R* field, Geometry g, int axis) {
+  const int lat[3] = {g.lat_nx, g.lat_ny, g.lat_nz};
+  const int stride[3] = {1, g.arr_nx, g.arr_nxy};
+  int b_ax, c_ax;
+  if (axis == 0) { b_ax = 1; c_ax = 2; }
+  else if (axis == 1) { b_ax = 0; c_ax = 2; }
+  else { b_ax = 0; c_ax = 1; }
+  const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int c = (int)blockIdx.y;
+  if (b > lat[b_ax] - 1 || c > lat[c_ax] - 1) return;
+  const int n = lat[axis];
+  const uint32_t base = (uint32_t)b * (uint32_t)stride[b_ax] + (uint32_t)c * (uint32_t)stride[c_ax];
+  const R hi = field[base + (uint32_t)((n - 2) * stride[axis])];
+  if (slf_isfinite(hi)) field[base] = hi;
+  const R lo = field[base + (uint32_t)stride[axis]];
+  if (slf_isfinite(lo)) field[base + (uint32_t)((n - 1) * stride[axis])] = lo;
+}
+
+// Index-list gather / scatter of populations (halo pack / unpack).
+template <class R, bool COLLECT>
+__global__ void __launch_bounds__(256) sparse_kernel(const unsigned long long* __restrict__ idx, R* dist, R* buffer,
+                                                     int n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const unsigned long long gi = idx[i];
+  if (gi == ~0ull) return;
+  if constexpr (COLLECT) buffer[i] = dist[gi];
+  else dist[gi] = buffer[i];
+}
+
+// PrepareMacroFields-style pass: density/velocity of every wet node without
+// collision or streaming (lb_single_fluid.mako:129-159, used for output of
+// the current state, e.g. right after initialisation or a restore).
+template <class L, class R, int PROP, bool GENERAL>
+__global__ void __launch_bounds__(1024) macro_kernel(const SweepParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx < 1 || gx > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  int kind = NK_FLUID;
+  if constexpr (GENERAL) {
+    const uint32_t code = p.map[gi];
+    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if (!kind_is_wet(kind)) return;
+  }
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  const size_t ds = g.dist_size;
+  R f[L::Q];
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_ODD) {
+      const int off = dir_offset<L, I>(ox, oy, oz, false);
+      f[I] = (p.din + ds * (size_t)L::opp(I))[(uint32_t)((int)gi + off)];
+    } else {
+      f[I] = (p.din + ds * (size_t)I)[gi];
+    }
+  });
+  R rho, v[3];
+  macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
+  p.rho[gi] = rho;
+  p.vx[gi] = v[0];
+  p.vy[gi] = v[1];
+  if constexpr (L::dim == 3) p.vz[gi] = v[2];
+}
+
+// ---------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------
+
+template <class L, class R>
+static SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const SweepArgs& a, int y0, int z0) {
+  SweepParams<L, R> p;
+  p.map = (const uint32_t*)a.map;
+  p.din = (const R*)a.dist_in;
+  p.dout = (R*)a.dist_out;
+  p.rho = (R*)a.rho;
+  p.vx = (R*)a.v[0];
+  p.vy = (R*)a.v[1];
+  p.vz = (R*)a.v[2];
+  p.node_params = (const R*)a.node_params;
+  p.options = a.options;
+  p.y0 = y0;
+  p.z0 = z0;
+  p.relaxation_enabled = ph.relaxation_enabled;
+  p.g = g;
+  p.cp.omega = (R)(1.0 / ph.tau);
+  for (int k = 0; k < L::Q; k++) p.cp.mrt_s[k] = (R)ph.mrt_rates[k];
+  for (int d = 0; d < 3; d++) p.cp.accel[d] = (R)ph.accel[d];
+  p.cp.guo_pref = (R)(3.0 * (1.0 - 0.5 / ph.tau));
+  p.cp.incompressible = ph.incompressible;
+  p.cp.has_force = ph.has_force;
+  return p;
+}
+
+template <class L, class R, int MODEL, int PROP>
+static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& ph, const SweepArgs& a, int y0, int y1,
+                                int z0, int z1, int block_x, hipStream_t s) {
+  const SweepParams<L, R> p = make_params<L, R>(g, ph, a, y0, z0);
+  dim3 block(block_x, 1, 1);
+  dim3 grid((g.lat_nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
+  if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false>), grid, block, 0, s, p);
+  return hipGetLastError();
+}
+
+template <class L, class R, int MODEL>
+static hipError_t launch_sweep3(Prop prop, bool general, const Geometry& g, const Physics& ph, const SweepArgs& a,
+                                int y0, int y1, int z0, int z1, int bx, hipStream_t s) {
+  switch (prop) {
+    case PROP_AB: return launch_sweep4<L, R, MODEL, PROP_AB>(general, g, ph, a, y0, y1, z0, z1, bx, s);
+    case PROP_AA_EVEN: return launch_sweep4<L, R, MODEL, PROP_AA_EVEN>(general, g, ph, a, y0, y1, z0, z1, bx, s);
+    default: return launch_sweep4<L, R, MODEL, PROP_AA_ODD>(general, g, ph, a, y0, y1, z0, z1, bx, s);
+  }
+}
+
+template <class L, class R>
+static hipError_t launch_sweep2(int model, Prop prop, bool general, const Geometry& g, const Physics& ph,
+                                const SweepArgs& a, int y0, int y1, int z0, int z1, int bx, hipStream_t s) {
+  if (model == 0) return launch_sweep3<L, R, 0>(prop, general, g, ph, a, y0, y1, z0, z1, bx, s);
+  return launch_sweep3<L, R, 1>(prop, general, g, ph, a, y0, y1, z0, z1, bx, s);
+}
+
+#define SLF_DISPATCH_LR(sel, CALL)                                   \
+  do {                                                               \
+    if ((sel).lattice == 0) {                                        \
+      if ((sel).precision == 4) { using L = D2Q9; using R = float; CALL; }  \
+      else { using L = D2Q9; using R = double; CALL; }               \
+    } else {                                                         \
+      if ((sel).precision == 4) { using L = D3Q19; using R = float; CALL; } \
+      else { using L = D3Q19; using R = double; CALL; }              \
+    }                                                                \
+  } while (0)
+
+hipError_t launch_sweep(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                        const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (launch_sweep2<L, R>(sel.model, prop, sel.general, g, ph, a, y0, y1, z0, z1, block_x, s)));
+  return hipErrorInvalidValue;
+}
+
+template <class L, class R>
+static hipError_t launch_init2(const Geometry& g, const Physics& ph, void* dist, const void* rho, const void* const v[3],
+                               hipStream_t s) {
+  dim3 block(256, 1, 1);
+  dim3 grid((g.lat_nx + 255) / 256, g.lat_ny, g.lat_nz);
+  hipLaunchKernelGGL((init_kernel<L, R>), grid, block, 0, s, (R*)dist, (const R*)rho, (const R*)v[0], (const R*)v[1],
+                     (const R*)v[2], g, ph.incompressible);
+  return hipGetLastError();
+}
+
+hipError_t launch_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist, const void* rho,
+                       const void* const v[3], hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (launch_init2<L, R>(g, ph, dist, rho, v, s)));
+  return hipErrorInvalidValue;
+}
+
+template <class L, class R>
+static hipError_t launch_pbc2(const Geometry& g, void* dist, int axis, bool with_swap, hipStream_t s) {
+  const int lat[3] = {g.lat_nx, g.lat_ny, g.lat_nz};
+  int b_ax = (axis == 0) ? 1 : 0;
+  int c_ax = (axis == 2) ? 1 : 2;
+  dim3 block(256, 1, 1);
+  dim3 grid((lat[b_ax] + 255) / 256, L::dim == 3 ? lat[c_ax] : 1, 1);
+  if (with_swap) hipLaunchKernelGGL((pbc_kernel<L, R, true>), grid, block, 0, s, (R*)dist, g, axis);
+  else hipLaunchKernelGGL((pbc_kernel<L, R, false>), grid, block, 0, s, (R*)dist, g, axis);
+  return hipGetLastError();
+}
+
+hipError_t launch_pbc(const KernelSelector& sel, const Geometry& g, void* dist, int axis, bool with_swap,
+                      hipStream_t s) {
+  if (axis < 0 || axis >= g.dim) return hipErrorInvalidValue;
+  SLF_DISPATCH_LR(sel, return (launch_pbc2<L, R>(g, dist, axis, with_swap, s)));
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_macro_pbc(const KernelSelector& sel, const Geometry& g, void* field, int axis, hipStream_t s) {
+  if (axis < 0 || axis >= g.dim) return hipErrorInvalidValue;
+  const int lat[3] = {g.lat_nx, g.lat_ny, g.lat_nz};
+  int b_ax = (axis == 0) ? 1 : 0;
+  int c_ax = (axis == 2) ? 1 : 2;
+  dim3 block(256, 1, 1);
+  dim3 grid((lat[b_ax] + 255) / 256, lat[c_ax], 1);
+  if (sel.precision == 4) hipLaunchKernelGGL((macro_pbc_kernel<float>), grid, block, 0, s, (float*)field, g, axis);
+  else hipLaunchKernelGGL((macro_pbc_kernel<double>), grid, block, 0, s, (double*)field, g, axis);
+  return hipGetLastError();
+}
+
+hipError_t launch_sparse(const KernelSelector& sel, bool collect, const unsigned long long* idx, void* dist,
+                         void* buffer, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  dim3 block(256, 1, 1);
+  dim3 grid((n + 255) / 256, 1, 1);
+  if (sel.precision == 4) {
+    if (collect) hipLaunchKernelGGL((sparse_kernel<float, true>), grid, block, 0, s, idx, (float*)dist, (float*)buffer, n);
+    else hipLaunchKernelGGL((sparse_kernel<float, false>), grid, block, 0, s, idx, (float*)dist, (float*)buffer, n);
+  } else {
+    if (collect) hipLaunchKernelGGL((sparse_kernel<double, true>), grid, block, 0, s, idx, (double*)dist, (double*)buffer, n);
+    else hipLaunchKernelGGL((sparse_kernel<double, false>), grid, block, 0, s, idx, (double*)dist, (double*)buffer, n);
+  }
+  return hipGetLastError();
+}
+
+template <class L, class R>
+static hipError_t launch_macro2(Prop prop, bool general, const Geometry& g, const Physics& ph, const SweepArgs& a,
+                                hipStream_t s) {
+  const SweepParams<L, R> p = make_params<L, R>(g, ph, a, 1, L::dim == 3 ? 1 : 0);
+  const int bx = 256;
+  dim3 block(bx, 1, 1);
+  dim3 grid((g.lat_nx + bx - 1) / bx, g.lat_ny - 2, L::dim == 3 ? g.lat_nz - 2 : 1);
+  if (prop == PROP_AA_ODD) {
+    if (general) hipLaunchKernelGGL((macro_kernel<L, R, PROP_AA_ODD, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((macro_kernel<L, R, PROP_AA_ODD, false>), grid, block, 0, s, p);
+  } else {
+    if (general) hipLaunchKernelGGL((macro_kernel<L, R, PROP_AB, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((macro_kernel<L, R, PROP_AB, false>), grid, block, 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                        const SweepArgs& a, hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (launch_macro2<L, R>(prop, sel.general, g, ph, a, s)));
+  return hipErrorInvalidValue;
+}
+
+}  // namespace slf

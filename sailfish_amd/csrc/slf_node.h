@@ -1,0 +1,373 @@
+// Per-node arithmetic of the collide-and-stream sweep (registers only).
+//
+// This is the "arithmetic contract" of DESIGN.md §4: every function below has a
+// fixed floating-point operation order, compiled with -ffp-contract=off, which
+// the CPU oracle (oracle/lbm_oracle.c) restates independently with table-driven
+// loops.  What is computed follows the reference:
+//   moments        sailfish/templates/boundary.mako:267-319, sym.py:573-682
+//   equilibrium    sailfish/sym_equilibrium.py:90-120
+//   BGK            sailfish/templates/relaxation.mako:99-181
+//   Guo forcing    sailfish/templates/relaxation_common.mako:56-64,110-149, sym_force.py:121-160
+//   MRT            sailfish/templates/relaxation_mrt.mako:31-97, sym.py:78-149,331-406,716-735
+//   BCs            sailfish/templates/boundary.mako:255-264,330-340,425-459,784-835
+#pragma once
+#include "slf_lattice.h"
+
+namespace slf {
+
+// Canonical node kinds the kernels understand.  The per-subdomain dense type
+// ids produced by the geometry encoder (reference geo_encoder.py:83-91) are
+// mapped to these through a 4-bit LUT passed with the kernel parameters.
+enum NodeKind : int {
+  NK_FLUID = 0,
+  NK_GHOST = 1,             // excluded
+  NK_UNUSED = 2,            // excluded
+  NK_PROPAGATION_ONLY = 3,  // no work in this design (no LDS hand-shake needed)
+  NK_FULL_BB = 4,
+  NK_HALF_BB = 5,
+  NK_REGULARIZED_VELOCITY = 6,
+  NK_EQUILIBRIUM_DENSITY = 7,
+  NK_EQUILIBRIUM_VELOCITY = 8,
+  NK_COUNT = 9
+};
+
+SLF_HD bool kind_is_wet(int k) {
+  return k == NK_FLUID || k == NK_HALF_BB || k == NK_REGULARIZED_VELOCITY || k == NK_EQUILIBRIUM_DENSITY ||
+         k == NK_EQUILIBRIUM_VELOCITY;
+}
+SLF_HD bool kind_is_excluded(int k) { return k == NK_GHOST || k == NK_UNUSED || k == NK_PROPAGATION_ONLY; }
+
+template <class L, class R>
+struct Weights {
+  static constexpr R w(int i) { return (R)((double)L::wnum(i) / (double)L::wden(i)); }
+  static constexpr R w6(int i) { return (R)(6.0 * (double)L::wnum(i) / (double)L::wden(i)); }
+  static constexpr R w45(int i) { return (R)(4.5 * (double)L::wnum(i) / (double)L::wden(i)); }
+};
+
+// C1: rho = ((f0 + f1) + f2) + ...
+template <class L, class R>
+SLF_D R density(const R (&f)[L::Q]) {
+  R rho = f[0];
+  static_for<1, L::Q>([&](auto I) { rho = rho + f[I]; });
+  return rho;
+}
+
+// C2: j_d = sum_i e_id f_i, index order, +-1 as add/sub.
+template <class L, class R, int D>
+SLF_D R momentum(const R (&f)[L::Q]) {
+  R acc = (R)0;
+  static_for<1, L::Q>([&](auto I) {
+    constexpr int e = e_comp<L>(I, D);
+    if constexpr (e > 0) acc = acc + f[I];
+    if constexpr (e < 0) acc = acc - f[I];
+  });
+  return acc;
+}
+
+// C1-C3: standard macroscopic quantities.
+template <class L, class R>
+SLF_D void macro_standard(const R (&f)[L::Q], bool incompressible, R& rho, R (&v)[3]) {
+  rho = density<L, R>(f);
+  v[0] = momentum<L, R, 0>(f);
+  v[1] = momentum<L, R, 1>(f);
+  v[2] = (R)0;
+  if constexpr (L::dim == 3) v[2] = momentum<L, R, 2>(f);
+  if (!incompressible) {
+    v[0] = v[0] / rho;
+    v[1] = v[1] / rho;
+    if constexpr (L::dim == 3) v[2] = v[2] / rho;
+  }
+}
+
+template <class L, class R>
+SLF_D R usq15(const R (&v)[3]) {
+  R s = v[0] * v[0] + v[1] * v[1];
+  if constexpr (L::dim == 3) s = s + v[2] * v[2];
+  return (R)1.5 * s;
+}
+
+// e_i . v with the components taken in x,y,z order.
+template <class L, class R, int I>
+SLF_D R edotv(const R (&v)[3]) {
+  R acc = (R)0;
+  static_for<0, L::dim>([&](auto D) {
+    constexpr int e = e_comp<L>(I, D);
+    if constexpr (e > 0) acc = acc + v[D];
+    if constexpr (e < 0) acc = acc - v[D];
+  });
+  return acc;
+}
+
+// C4: feq_i = w_i (rho + rho0 (eu (3 + 4.5 eu) - 1.5 u^2))
+template <class L, class R, int I>
+SLF_D R feq(R rho, R rho0, const R (&v)[3], R u15) {
+  constexpr bool rest = (L::ex(I) == 0 && L::ey(I) == 0 && L::ez(I) == 0);
+  if constexpr (rest) {
+    return Weights<L, R>::w(I) * (rho + rho0 * ((R)0 - u15));
+  } else {
+    const R eu = edotv<L, R, I>(v);
+    return Weights<L, R>::w(I) * (rho + rho0 * (eu * ((R)3 + (R)4.5 * eu) - u15));
+  }
+}
+
+template <class L, class R>
+struct CollideParams {
+  R omega;        // 1/tau
+  R mrt_s[L::Q];  // MRT relaxation rates (0 for conserved moments)
+  R accel[3];     // body-force acceleration
+  R guo_pref;     // 3 (1 - 1/(2 tau))
+  int incompressible;
+  int has_force;
+};
+
+// C5 + C6: BGK relaxation with optional Guo forcing.  v is updated to the
+// output velocity (u + a/2) when a force is present.
+template <class L, class R>
+SLF_D void bgk_relax(R (&f)[L::Q], R rho, R (&v)[3], const CollideParams<L, R>& cp) {
+  const R rho0 = cp.incompressible ? (R)1 : rho;
+  if (cp.has_force) {
+    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * cp.accel[D]; });
+  }
+  const R u15 = usq15<L, R>(v);
+  static_for<0, L::Q>([&](auto I) {
+    const R fe = feq<L, R, I>(rho, rho0, v, u15);
+    f[I] = f[I] + cp.omega * (fe - f[I]);
+  });
+  if (cp.has_force) {
+    const R pref = rho * cp.guo_pref;
+    R va = v[0] * cp.accel[0] + v[1] * cp.accel[1];
+    if constexpr (L::dim == 3) va = va + v[2] * cp.accel[2];
+    static_for<0, L::Q>([&](auto I) {
+      const R eu = edotv<L, R, I>(v);
+      const R ea = edotv<L, R, I>(cp.accel);
+      const R t = (ea - va) + (R)3 * eu * ea;
+      f[I] = f[I] + pref * Weights<L, R>::w(I) * t;
+    });
+  }
+}
+
+// C7 helpers: one row of the integer moment matrix applied to a vector.
+template <class L, class R, int K>
+SLF_D R mrt_row(const R (&f)[L::Q]) {
+  R acc = (R)0;
+  static_for<0, L::Q>([&](auto I) {
+    constexpr int c = L::mrt(K, I);
+    if constexpr (c == 1) acc = acc + f[I];
+    else if constexpr (c == -1) acc = acc - f[I];
+    else if constexpr (c != 0) acc = acc + (R)c * f[I];
+  });
+  return acc;
+}
+template <class L, class R, int I>
+SLF_D R mrt_col(const R (&m)[L::Q]) {
+  R acc = (R)0;
+  static_for<0, L::Q>([&](auto K) {
+    constexpr int c = L::mrt(K, I);
+    if constexpr (c == 1) acc = acc + m[K];
+    else if constexpr (c == -1) acc = acc - m[K];
+    else if constexpr (c != 0) acc = acc + (R)c * m[K];
+  });
+  return acc;
+}
+
+template <class L, class R>
+SLF_D void mrt_equilibrium(const R (&m)[L::Q], R inv_rho, R (&meq)[L::Q]) {
+  static_for<0, L::Q>([&](auto K) { meq[K] = (R)0; });
+  const R rho = m[L::M_RHO];
+  const R mx = m[L::M_MX], my = m[L::M_MY];
+  if constexpr (L::id == D2Q9::id) {
+    // sym.py:101-149: en = -2 rho + 3 j^2, ens = rho - 3 j^2, ex = -mx, ey = -my,
+    // pxx = mx^2 - my^2, pxy = mx my  (no 1/rho in the reference's D2Q9 basis).
+    const R jsq = mx * mx + my * my;
+    meq[1] = (R)3 * jsq - (R)2 * rho;
+    meq[2] = rho - (R)3 * jsq;
+    meq[4] = (R)0 - mx;
+    meq[6] = (R)0 - my;
+    meq[7] = mx * mx - my * my;
+    meq[8] = mx * my;
+  } else {
+    // sym.py:380-406 (d'Humieres 2002).
+    const R mz = m[L::M_MZ];
+    const R jsq = (mx * mx + my * my) + mz * mz;
+    const R irj = inv_rho * jsq;
+    meq[1] = (R)19 * irj - (R)11 * rho;
+    meq[2] = (R)(-475.0 / 63.0) * irj;
+    meq[4] = (R)(-2.0 / 3.0) * mx;
+    meq[6] = (R)(-2.0 / 3.0) * my;
+    meq[8] = (R)(-2.0 / 3.0) * mz;
+    meq[9] = inv_rho * ((R)2 * (mx * mx) - ((my * my) + (mz * mz)));
+    meq[11] = inv_rho * ((my * my) - (mz * mz));
+    meq[13] = inv_rho * (mx * my);
+    meq[14] = inv_rho * (my * mz);
+    meq[15] = inv_rho * (mx * mz);
+  }
+}
+
+// C7: relaxation in moment space.  force_eq: equilibrium-type node (moments
+// forced to equilibrium, relaxation_mrt.mako:58-77).
+template <class L, class R>
+SLF_D void mrt_relax(R (&f)[L::Q], R (&v)[3], const CollideParams<L, R>& cp, bool force_eq) {
+  R m[L::Q];
+  static_for<0, L::Q>([&](auto K) { m[K] = mrt_row<L, R, K>(f); });
+  if (cp.has_force) {
+    m[L::M_MX] = m[L::M_MX] + (R)0.5 * cp.accel[0];
+    m[L::M_MY] = m[L::M_MY] + (R)0.5 * cp.accel[1];
+    if constexpr (L::dim == 3) m[L::M_MZ] = m[L::M_MZ] + (R)0.5 * cp.accel[2];
+  }
+  const R inv_rho = cp.incompressible ? (R)1 : (R)1 / m[L::M_RHO];
+  R meq[L::Q];
+  mrt_equilibrium<L, R>(m, inv_rho, meq);
+  static_for<0, L::Q>([&](auto K) {
+    constexpr bool conserved =
+        (K == L::M_RHO || K == L::M_MX || K == L::M_MY || (L::dim == 3 && K == L::M_MZ));
+    if constexpr (!conserved) {
+      if (force_eq) m[K] = meq[K];
+      m[K] = m[K] - cp.mrt_s[K] * (m[K] - meq[K]);
+    }
+  });
+  if (cp.has_force) {
+    m[L::M_MX] = m[L::M_MX] + (R)0.5 * cp.accel[0];
+    m[L::M_MY] = m[L::M_MY] + (R)0.5 * cp.accel[1];
+    if constexpr (L::dim == 3) m[L::M_MZ] = m[L::M_MZ] + (R)0.5 * cp.accel[2];
+  }
+  static_for<0, L::Q>([&](auto K) { m[K] = m[K] * (R)(1.0 / (double)L::mrt_norm(K)); });
+  static_for<0, L::Q>([&](auto I) { f[I] = mrt_col<L, R, I>(m); });
+  if (cp.has_force) {
+    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * cp.accel[D]; });
+  }
+}
+
+// C8: full-way bounce-back (boundary.mako:255-264).
+template <class L, class R>
+SLF_D void bounce_back(R (&f)[L::Q]) {
+  static_for<1, L::Q>([&](auto I) {
+    constexpr int o = L::opp(I);
+    if constexpr (I < o) {
+      const R t = f[I];
+      f[I] = f[o];
+      f[o] = t;
+    }
+  });
+}
+
+// Is population I unknown at a node whose inward normal is orientation O (1..2 dim)?
+template <class L, int I, int O>
+constexpr bool is_missing() {
+  constexpr int n = L::dir2vecidx(O);
+  return (L::ex(I) * L::ex(n) + L::ey(I) * L::ey(n) + L::ez(I) * L::ez(n)) > 0;
+}
+
+// boundary.mako:418-422: replace unknown populations by their opposites.
+template <class L, class R, int O>
+SLF_D void fill_missing_with_opposite(R (&f)[L::Q]) {
+  static_for<1, L::Q>([&](auto I) {
+    if constexpr (is_missing<L, I, O>()) f[I] = f[L::opp(I)];
+  });
+}
+
+// Signed normal component n.v for orientation O.
+template <class L, class R, int O>
+SLF_D R ndotv(const R (&v)[3]) {
+  return edotv<L, R, L::dir2vecidx(O)>(v);
+}
+
+// C9a: macroscopic quantities on a velocity-BC node (boundary.mako:443-459).
+template <class L, class R, int O>
+SLF_D void macro_velocity_bc(R (&f)[L::Q], const R* par, bool incompressible, R& rho, R (&v)[3]) {
+  fill_missing_with_opposite<L, R, O>(f);
+  const R rs = density<L, R>(f);
+  v[0] = par[0];
+  v[1] = par[1];
+  v[2] = (R)0;
+  if constexpr (L::dim == 3) v[2] = par[2];
+  const R nv = ndotv<L, R, O>(v);
+  rho = incompressible ? (rs + nv) : (rs / ((R)1 - nv));
+}
+
+// C10a: macroscopic quantities on a density-BC node (boundary.mako:425-441).
+template <class L, class R, int O>
+SLF_D void macro_density_bc(R (&f)[L::Q], R par_rho, R& rho, R (&v)[3]) {
+  fill_missing_with_opposite<L, R, O>(f);
+  const R rs = density<L, R>(f);
+  const R t = (rs - par_rho) / par_rho;
+  constexpr int n = L::dir2vecidx(O);
+  v[0] = v[1] = v[2] = (R)0;
+  static_for<0, L::dim>([&](auto D) {
+    constexpr int e = e_comp<L>(n, D);
+    if constexpr (e > 0) v[D] = (R)0 - t;
+    if constexpr (e < 0) v[D] = t;
+  });
+  rho = par_rho;
+}
+
+template <class L, class R>
+SLF_D void set_equilibrium(R (&f)[L::Q], R rho, R rho0, const R (&v)[3]) {
+  const R u15 = usq15<L, R>(v);
+  static_for<0, L::Q>([&](auto I) { f[I] = feq<L, R, I>(rho, rho0, v, u15); });
+}
+
+// Index of the (a, b), a <= b, component in the order xx xy [xz] yy [yz zz].
+template <class L>
+constexpr int flux_index(int a, int b) {
+  return a * L::dim - a * (a - 1) / 2 + (b - a);
+}
+
+// C9b: regularized velocity/density node, pre-collision (boundary.mako:817-835,
+// sym.py:750-766 non-equilibrium bounce-back, sym.py:882-891 regularisation).
+template <class L, class R, int O>
+SLF_D void regularized_bc(R (&f)[L::Q], R rho, R rho0, const R (&v)[3]) {
+  // f_i = f_opp(i) + 6 w_i rho0 (e_i . v) for the unknown populations.
+  static_for<1, L::Q>([&](auto I) {
+    if constexpr (is_missing<L, I, O>()) {
+      f[I] = f[L::opp(I)] + Weights<L, R>::w6(I) * (rho0 * edotv<L, R, I>(v));
+    }
+  });
+  // Non-equilibrium momentum flux, components xx xy [xz] yy [yz zz].
+  constexpr int NP = L::dim * (L::dim + 1) / 2;
+  R P[NP];
+  {
+    static_for<0, L::dim>([&](auto A) {
+      static_for<A, L::dim>([&](auto B) {
+        constexpr int idx = flux_index<L>(A, B);
+        R acc = (R)0;
+        static_for<1, L::Q>([&](auto I) {
+          constexpr int c = e_comp<L>(I, A) * e_comp<L>(I, B);
+          if constexpr (c > 0) acc = acc + f[I];
+          if constexpr (c < 0) acc = acc - f[I];
+        });
+        if constexpr (A == B) acc = acc - rho * (v[A] * v[A] + (R)(1.0 / 3.0));
+        else acc = acc - rho * (v[A] * v[B]);
+        P[idx] = acc;
+      });
+    });
+  }
+  const R u15 = usq15<L, R>(v);
+  static_for<0, L::Q>([&](auto I) {
+    R acc = (R)0;
+    static_for<0, L::dim>([&](auto A) {
+      static_for<A, L::dim>([&](auto B) {
+        constexpr int idx = flux_index<L>(A, B);
+        constexpr int ea = e_comp<L>(I, A), eb = e_comp<L>(I, B);
+        if constexpr (A == B) {
+          if constexpr (ea != 0) acc = acc + (R)(2.0 / 3.0) * P[idx];
+          else acc = acc + (R)(-1.0 / 3.0) * P[idx];
+        } else {
+          if constexpr (ea * eb > 0) acc = acc + (R)2 * P[idx];
+          if constexpr (ea * eb < 0) acc = acc - (R)2 * P[idx];
+        }
+      });
+    });
+    const R val = feq<L, R, I>(rho, rho0, v, u15) + Weights<L, R>::w45(I) * acc;
+    f[I] = val > (R)1e-7 ? val : (R)1e-7;
+  });
+}
+
+// Dispatch a functor templated on the orientation constant (1..2 dim).
+template <class L, class F>
+SLF_D void with_orientation(int o, F&& fn) {
+  static_for<1, 2 * L::dim + 1>([&](auto O) {
+    if (o == O) fn(O);
+  });
+}
+
+}  // namespace slf

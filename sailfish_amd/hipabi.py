@@ -1,0 +1,147 @@
+"""ctypes binding of include/sailfish_hip.h (the C ABI of libsailfish_hip.so).
+
+There is no CPU fallback: if the library is missing or a call fails, an
+exception is raised.
+"""
+import ctypes
+import os
+
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint32,
+                    c_void_p)
+
+SLF_MAX_NODE_TYPES = 16
+SLF_MAX_Q = 27
+SLF_D2Q9, SLF_D3Q19 = 0, 1
+SLF_BGK, SLF_MRT = 0, 1
+SLF_AB, SLF_AA = 0, 1
+(SLF_NK_FLUID, SLF_NK_GHOST, SLF_NK_UNUSED, SLF_NK_PROPAGATION_ONLY, SLF_NK_FULL_BB, SLF_NK_HALF_BB,
+ SLF_NK_REGULARIZED_VELOCITY, SLF_NK_EQUILIBRIUM_DENSITY, SLF_NK_EQUILIBRIUM_VELOCITY) = range(9)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsailfish_hip.so')
+
+
+class SlfModuleDesc(Structure):
+    """Mirror of slf_module_desc."""
+    _fields_ = [
+        ('struct_size', c_uint32),
+        ('lattice', c_int32), ('model', c_int32), ('precision', c_int32), ('access_pattern', c_int32),
+        ('lat_nx', c_int32), ('lat_ny', c_int32), ('lat_nz', c_int32),
+        ('arr_nx', c_int32), ('arr_ny', c_int32), ('arr_nz', c_int32),
+        ('envelope', c_int32),
+        ('periodic_fused', c_int32 * 3),
+        ('incompressible', c_int32), ('relaxation_enabled', c_int32), ('has_force', c_int32),
+        ('fluid_only', c_int32),
+        ('tau', c_double), ('visc', c_double),
+        ('accel', c_double * 3),
+        ('mrt_rates', c_double * SLF_MAX_Q),
+        ('nt_type_mask', c_uint32), ('nt_misc_shift', c_uint32), ('nt_param_shift', c_uint32),
+        ('nt_scratch_shift', c_uint32),
+        ('n_types', c_int32),
+        ('type_kind', c_int32 * SLF_MAX_NODE_TYPES),
+        ('use_link_tags', c_int32),
+        ('n_node_params', c_int32),
+        ('node_params', POINTER(c_double)),
+    ]
+
+
+class SlfRegion(Structure):
+    _fields_ = [('y0', c_int32), ('y1', c_int32), ('z0', c_int32), ('z1', c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/sailfish_hip.h declares.
+SIGNATURES = {
+    'slf_abi_version': (c_int, []),
+    'slf_device_count': (c_int, [POINTER(c_int)]),
+    'slf_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
+    'slf_ctx_destroy': (c_int, [c_void_p]),
+    'slf_ctx_sync': (c_int, [c_void_p]),
+    'slf_ctx_info': (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_size_t), POINTER(c_int), POINTER(c_int)]),
+    'slf_malloc': (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    'slf_free': (c_int, [c_void_p, c_void_p]),
+    'slf_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'slf_host_alloc_pinned': (c_int, [c_size_t, POINTER(c_void_p)]),
+    'slf_host_free': (c_int, [c_void_p]),
+    'slf_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'slf_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'slf_memcpy_h2d_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'slf_memcpy_d2h_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'slf_memcpy_d2d_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'slf_memcpy_peer_async': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_size_t, c_void_p]),
+    'slf_stream_create': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'slf_stream_destroy': (c_int, [c_void_p]),
+    'slf_stream_sync': (c_int, [c_void_p]),
+    'slf_stream_native': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'slf_stream_wait_event': (c_int, [c_void_p, c_void_p]),
+    'slf_event_create': (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    'slf_event_destroy': (c_int, [c_void_p]),
+    'slf_event_record': (c_int, [c_void_p, c_void_p]),
+    'slf_event_sync': (c_int, [c_void_p]),
+    'slf_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    'slf_module_create': (c_int, [c_void_p, POINTER(SlfModuleDesc), POINTER(c_void_p)]),
+    'slf_module_destroy': (c_int, [c_void_p]),
+    'slf_module_block_size': (c_int, [c_void_p, POINTER(c_int)]),
+    'slf_kernel_get': (c_int, [c_void_p, c_char_p, POINTER(c_void_p)]),
+    'slf_kernel_destroy': (c_int, [c_void_p]),
+    'slf_kernel_set_args': (c_int, [c_void_p, c_char_p, POINTER(c_void_p), c_int, c_int]),
+    'slf_kernel_set_iteration': (c_int, [c_void_p, c_uint32]),
+    'slf_kernel_launch': (c_int, [c_void_p, POINTER(SlfRegion), c_void_p]),
+    'slf_last_error': (c_char_p, []),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load libsailfish_hip.so and attach the signatures.  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipLibraryMissing(
+            'libsailfish_hip.so not found at %s -- run `python -m sailfish_amd.build` '
+            '(there is no CPU fallback for the HIP backend)' % p)
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.slf_abi_version() != 1:
+        raise RuntimeError('libsailfish_hip.so ABI version mismatch')
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def make_desc(**kw):
+    d = SlfModuleDesc()
+    d.struct_size = ctypes.sizeof(SlfModuleDesc)
+    d.envelope = 1
+    d.relaxation_enabled = 1
+    d.lat_nz = 1
+    d.arr_nz = 1
+    keep = []
+    for k, v in kw.items():
+        if k in ('periodic_fused', 'accel'):
+            for i, x in enumerate(v):
+                getattr(d, k)[i] = x
+        elif k == 'mrt_rates':
+            for i, x in enumerate(v):
+                d.mrt_rates[i] = float(x)
+        elif k == 'type_kind':
+            d.n_types = len(v)
+            for i, x in enumerate(v):
+                d.type_kind[i] = int(x)
+        elif k == 'node_params':
+            arr = (c_double * max(1, len(v)))(*[float(x) for x in v])
+            keep.append(arr)
+            d.node_params = ctypes.cast(arr, POINTER(c_double))
+            d.n_node_params = len(v)
+        else:
+            setattr(d, k, v)
+    d._keepalive = keep
+    return d

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json from the reference's importable symbolic /
+host layer (sympy expressions, node-map encoder, connection tables).
+
+Runs ONLY in the authoring container (needs /root/reference); the produced
+fixtures are data (inputs + expected outputs) and are committed.  Nothing in
+tests/ or the product reads /root/reference at run time.
+
+Every expected value is produced by *evaluating the reference's own sympy
+expression objects* (sailfish/sym.py, sym_equilibrium.py, sym_force.py) in
+float64; the composition order follows the reference's templates (cited inline).
+
+    PYTHONPATH=tools python tools/capture_goldens.py
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_shim  # noqa: F401  (installs import stubs, puts /root/reference on sys.path)
+
+import numpy as np
+import sympy
+from sympy import Symbol
+
+from sailfish import sym, sym_equilibrium, sym_force  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+S = sym.S
+
+
+class _Cfg(object):
+    def __init__(self, incompressible=False, minimize_roundoff=False):
+        self.incompressible = incompressible
+        self.minimize_roundoff = minimize_roundoff
+
+
+def _evalf(expr, subs):
+    """Evaluate a sympy expression in float64 after substituting symbols by name."""
+    if isinstance(expr, (int, float)):
+        return float(expr)
+    e = expr
+    m = {}
+    for s in e.free_symbols:
+        if s.name not in subs:
+            raise KeyError('unbound symbol %s in %s' % (s.name, expr))
+        m[s] = sympy.Float(subs[s.name], 30)
+    return float(e.subs(m).evalf(30))
+
+
+def _fi_subs(grid, f, ptr='fi'):
+    return {'%s->%s' % (ptr, n): float(v) for n, v in zip(grid.idx_name, f)}
+
+
+def _macro_subs(grid, rho, v, rho0=None):
+    d = {'g0m0': float(rho), 'rho': float(rho)}
+    for c, val in zip('xyz', v):
+        d['g0m1' + c] = float(val)
+    d['rho0'] = float(rho if rho0 is None else rho0)
+    return d
+
+
+def lattice_tables(grid):
+    """Lattice algebra pinned by reference tests/sym.py:6-67."""
+    dim = grid.dim
+    t = {
+        'name': grid.__name__, 'dim': dim, 'Q': grid.Q,
+        'basis': [[int(c) for c in e] for e in grid.basis],
+        'weights_num': [int(w.p) for w in grid.weights],
+        'weights_den': [int(w.q) for w in grid.weights],
+        'idx_name': list(grid.idx_name),
+        'idx_opposite': [int(i) for i in grid.idx_opposite],
+        'dir2vecidx': {str(k): int(v) for k, v in grid.dir2vecidx.items()},
+        'dir_to_vec': {str(o): [int(c) for c in grid.dir_to_vec(o)] for o in range(1, 2 * dim + 1)},
+        'bb_swap_pairs': sorted(int(i) for i in sym.bb_swap_pairs(grid)),
+        'prop_dists': {('%d_%d' % (axis, d)): [int(i) for i in sym.get_prop_dists(grid, d, axis)]
+                       for axis in range(dim) for d in (-1, 0, 1)},
+        'missing_dists': {str(o): [int(i) for i in sym.get_missing_dists(grid, o)]
+                          for o in range(1, 2 * dim + 1)},
+    }
+    import itertools
+    ib = {}
+    for d in itertools.product((-1, 0, 1), repeat=dim):
+        if not any(d):
+            continue
+        key = ','.join(str(c) for c in d)
+        ib[key] = {'normal': [int(i) for i in sym.get_interblock_dists(grid, d)],
+                   'opposite': [int(i) for i in sym.get_interblock_dists(grid, d, opposite=True)]}
+    t['interblock_dists'] = ib
+    if hasattr(grid, 'mrt_matrix'):
+        t['mrt_names'] = list(grid.mrt_names)
+        t['mrt_matrix'] = [[int(x) for x in grid.mrt_matrix.row(i)] for i in range(grid.Q)]
+        coll = []
+        for c in grid.mrt_collision:
+            coll.append('inv_tau' if isinstance(c, sympy.Basic) and c.free_symbols else float(c))
+        t['mrt_collision'] = coll
+    return t
+
+
+def arithmetic_goldens(grid, rng, n=48):
+    dim, Q = grid.dim, grid.Q
+    out = {}
+    rho = rng.uniform(0.9, 1.1, n)
+    v = rng.uniform(-0.1, 0.1, (n, dim))
+    f = np.array([[float(w) for w in grid.weights]] * n) * rho[:, None]
+    f = f * (1.0 + rng.uniform(-0.05, 0.05, (n, Q)))
+    out['rho'], out['v'], out['f'] = rho, v, f
+
+    # --- equilibrium: sym_equilibrium.py:90-120, compressible and incompressible
+    for inc in (False, True):
+        cfg = _Cfg(incompressible=inc)
+        eq = sym_equilibrium.bgk_equilibrium(grid, cfg)
+        res = np.zeros((n, Q))
+        for k in range(n):
+            subs = _macro_subs(grid, rho[k], v[k], rho0=(1.0 if inc else rho[k]))
+            for i, e in enumerate(eq.expression):
+                res[k, i] = _evalf(e, subs)
+        out['feq_inc%d' % int(inc)] = res
+
+    cfg = _Cfg()
+    # --- moments: sym.py:573-682
+    ex_rho = sym.ex_rho(grid, 'fi', False)
+    ex_v = [sym.ex_velocity(grid, 'fi', d, cfg) for d in range(dim)]
+    ex_mom = [sym.ex_velocity(grid, 'fi', d, cfg, momentum=True) for d in range(dim)]
+    m_rho = np.zeros(n)
+    m_v = np.zeros((n, dim))
+    m_mom = np.zeros((n, dim))
+    for k in range(n):
+        subs = _fi_subs(grid, f[k])
+        m_rho[k] = _evalf(ex_rho, subs)
+        subs2 = dict(subs)
+        subs2.update({'g0m0': m_rho[k], 'rho': m_rho[k]})
+        for d in range(dim):
+            m_v[k, d] = _evalf(ex_v[d], subs2)
+            m_mom[k, d] = _evalf(ex_mom[d], subs2)
+    out['mom_rho'], out['mom_v'], out['mom_momentum'] = m_rho, m_v, m_mom
+
+    # --- 2nd moments: sym.py:684-704
+    npairs = dim * (dim + 1) // 2
+    flux = np.zeros((n, npairs))
+    eqflux = np.zeros((n, npairs))
+    for k in range(n):
+        subs = _fi_subs(grid, f[k])
+        ms = _macro_subs(grid, rho[k], v[k])
+        j = 0
+        for a in range(dim):
+            for b in range(a, dim):
+                flux[k, j] = _evalf(sym.ex_flux(grid, 'fi', a, b, cfg), subs)
+                eqflux[k, j] = _evalf(sym.ex_eq_flux(grid, a, b), ms)
+                j += 1
+    out['flux'], out['eq_flux'] = flux, eqflux
+
+    # --- BGK collision: relaxation.mako:127-132, tau = (6 visc + 1)/2 (sym.py:847-848)
+    visc = np.array([1.0 / 6.0, 0.01, 0.0254, 0.1])
+    out['bgk_visc'] = visc
+    post = np.zeros((len(visc), n, Q))
+    eq = sym_equilibrium.bgk_equilibrium(grid, cfg)
+    for a, nu in enumerate(visc):
+        tau = sym.relaxation_time(nu)
+        omega = 1.0 / tau
+        for k in range(n):
+            subs = _macro_subs(grid, m_rho[k], m_v[k])
+            for i, e in enumerate(eq.expression):
+                feq = _evalf(e, subs)
+                post[a, k, i] = f[k, i] + omega * (feq - f[k, i])
+    out['bgk_post'] = post
+
+    # --- BGK + Guo body force: relaxation_common.mako:56-64,110-149, sym_force.py:121-160
+    accel = rng.uniform(-1e-4, 1e-4, (n, dim))
+    out['accel'] = accel
+    postf = np.zeros((n, Q))
+    outv = np.zeros((n, dim))
+    nu = 0.02
+    tau = sym.relaxation_time(nu)
+    out['guo_visc'] = np.array([nu])
+    guo = sym_force.guo_external_force(grid, grid_num=0)
+    pref_e = sym_force.guo_external_force_pref(grid, cfg, grid_num=0)
+    for k in range(n):
+        v0 = m_v[k] + 0.5 * accel[k]
+        subs = _macro_subs(grid, m_rho[k], v0)
+        subs.update({'g0ea' + c: accel[k, j] for j, c in enumerate('xyz'[:dim])})
+        subs['tau0'] = tau
+        pref = _evalf(pref_e, subs)
+        subs['pref'] = pref
+        for i, e in enumerate(eq.expression):
+            feq = _evalf(e, subs)
+            postf[k, i] = f[k, i] + (1.0 / tau) * (feq - f[k, i]) + _evalf(guo[i], subs)
+        outv[k] = m_v[k] + 0.5 * accel[k]
+    out['guo_post'], out['guo_out_v'] = postf, outv
+
+    # --- MRT: relaxation_mrt.mako:31-97, sym.py:716-735 + grid.mrt_*
+    if hasattr(grid, 'mrt_matrix'):
+        M = np.array(grid.mrt_matrix.tolist(), dtype=np.float64)
+        Minv = np.array(grid.mrt_matrix.inv().tolist(), dtype=np.float64)
+        out['mrt_matrix'] = M
+        out['mrt_matrix_inv'] = Minv
+        postm = np.zeros((len(visc), n, Q))
+        for a, nu in enumerate(visc):
+            for k in range(n):
+                m = M.dot(f[k])
+                subs = {'mx': m[grid.mrt_names.index('mx')], 'my': m[grid.mrt_names.index('my')],
+                        'rho': m[0], 'g0m0': m[0], 'rho0': m[0], 'visc': nu}
+                if dim == 3:
+                    subs['mz'] = m[grid.mrt_names.index('mz')]
+                for lv in grid.mrt_eq_symbols:
+                    subs[lv.lhs.name] = _evalf(lv.rhs, subs)
+                for i in range(Q):
+                    c = grid.mrt_collision[i]
+                    cval = _evalf(c, subs) if isinstance(c, sympy.Basic) else float(c)
+                    if cval != 0:
+                        meq = _evalf(grid.mrt_equilibrium[i], subs)
+                        m[i] -= cval * (m[i] - meq)
+                postm[a, k] = Minv.dot(m)
+        out['mrt_post'] = postm
+
+    # --- velocity-BC density: boundary.mako:443-459, sym.py:621-627
+    # --- non-equilibrium bounce-back: sym.py:750-766; regularisation: sym.py:882-891,
+    #     boundary.mako:817-835  (NTRegularizedVelocity full node update, pre-collision)
+    # --- density BC: boundary.mako:425-441, 495-500, 797-809 (NTEquilibriumDensity)
+    eqx = eq.expression
+    reg = sym.reglb_flux_tensor(grid)
+    regv = np.zeros((2 * dim, n, Q))
+    regv_rho = np.zeros((2 * dim, n))
+    eqd = np.zeros((2 * dim, n, Q))
+    eqd_v = np.zeros((2 * dim, n, dim))
+    bc_v = rng.uniform(-0.08, 0.08, (n, dim))
+    bc_rho = rng.uniform(0.95, 1.05, n)
+    out['bc_v'], out['bc_rho'] = bc_v, bc_rho
+    for o in range(1, 2 * dim + 1):
+        missing = sym.get_missing_dists(grid, o)
+        nvec = [int(c) for c in grid.dir_to_vec(o)]
+        for k in range(n):
+            fi = f[k].copy()
+            for i in missing:
+                fi[i] = fi[grid.idx_opposite[i]]
+            rs = _evalf(ex_rho, _fi_subs(grid, fi))
+            # velocity BC
+            subs = _macro_subs(grid, rs, bc_v[k])
+            r = _evalf(sym.ex_rho(grid, 'fi', False, missing_dir=o), subs)
+            regv_rho[o - 1, k] = r
+            subs = _macro_subs(grid, r, bc_v[k])
+            subs.update(_fi_subs(grid, fi))
+            g = fi.copy()
+            for lhs, rhs in sym.noneq_bb(grid, o, eqx):
+                i = grid.idx_name.index(lhs.name.split('->')[1])
+                g[i] = _evalf(rhs, subs)
+            subs.update(_fi_subs(grid, g))
+            fl = []
+            for a in range(dim):
+                for b in range(a, dim):
+                    fl.append(_evalf(sym.ex_flux(grid, 'fi', a, b, cfg), subs)
+                              - _evalf(sym.ex_eq_flux(grid, a, b), subs))
+            subs.update({'flux[%d]' % j: x for j, x in enumerate(fl)})
+            for i in range(Q):
+                regv[o - 1, k, i] = max(1e-7, _evalf(eqx[i], subs) + _evalf(reg[i], subs))
+            # density BC
+            subs = {'g0m0': rs, 'rho': rs, 'par_rho': bc_rho[k]}
+            vv = [_evalf(sym.ex_velocity(grid, 'fi', d, cfg, missing_dir=o, par_rho='par_rho'), subs)
+                  for d in range(dim)]
+            eqd_v[o - 1, k] = vv
+            subs = _macro_subs(grid, bc_rho[k], vv)
+            for i in range(Q):
+                eqd[o - 1, k, i] = _evalf(eqx[i], subs)
+            del nvec[:]
+    out['regvel_rho'], out['regvel_post'] = regv_rho, regv
+    out['eqdens_v'], out['eqdens_post'] = eqd_v, eqd
+    return out
+
+
+def main():
+    rng = np.random.RandomState(20260926)
+    tables = {}
+    for grid in (sym.D2Q9, sym.D3Q19):
+        tables[grid.__name__] = lattice_tables(grid)
+        ar = arithmetic_goldens(grid, rng)
+        np.savez_compressed(os.path.join(OUT, 'arith_%s.npz' % grid.__name__), **ar)
+        print('wrote arithmetic goldens for', grid.__name__)
+    with open(os.path.join(OUT, 'lattices.json'), 'w') as fh:
+        json.dump(tables, fh, indent=1, sort_keys=True)
+    print('wrote lattices.json')
+
+
+if __name__ == '__main__':
+    main()
