@@ -1,0 +1,350 @@
+"""Sailfish HIP backend for MI355X (gfx950).
+
+Drop-in for the reference's backend modules (sailfish/backend_cuda.py,
+backend_opencl.py): same class-level contract -- ``name``, ``FatalError``,
+``add_options``, ``alloc_buf``, ``alloc_async_host_buf``, ``to_buf``,
+``from_buf``, ``to_buf_async``, ``from_buf_async``, ``build``, ``get_kernel``,
+``run_kernel``, ``set_iteration``, ``make_stream``, ``make_event``,
+``sync_stream``, ``sync``, ``get_defines``, ``info``, ``total_memory`` -- and a
+module-level ``backend`` symbol, which is what ``util.get_backends`` looks up
+(reference sailfish/util.py:52-59).  Instantiated as ``backend(config, gpu_id)``
+inside each subdomain process (reference sailfish/master.py:46-49).
+
+Differences forced by the design (pre-built gfx950 kernels instead of run-time
+generated CUDA/OpenCL text):
+  * ``build(source)`` takes a *module descriptor* (hipabi.SlfModuleDesc) instead
+    of C source and returns a module handle;
+  * ``run_kernel(kernel, grid_size, stream)``: ``grid_size`` is either ``None``
+    (whole subdomain) or a region ``(y0, y1, z0, z1)`` for the bulk/boundary
+    split -- launch geometry is chosen inside the library for 64-wide wavefronts.
+
+Everything calls libsailfish_hip.so through ctypes; there is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+
+from sailfish_amd import hipabi
+
+
+class HIPFatalError(RuntimeError):
+    """Raised on any failed HIP call / kernel launch (reference: pycuda.driver.LaunchError)."""
+
+
+def _check(lib, status, what=''):
+    if status != 0:
+        msg = lib.slf_last_error()
+        raise HIPFatalError('%s failed (status %d): %s' % (what, status, msg.decode() if msg else '?'))
+
+
+class HIPStream(object):
+    def __init__(self, backend):
+        self._backend = backend
+        self._lib = backend._lib
+        h = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_stream_create(backend._ctx, ctypes.byref(h)), 'slf_stream_create')
+        self.handle = h
+
+    def synchronize(self):
+        _check(self._lib, self._lib.slf_stream_sync(self.handle), 'slf_stream_sync')
+
+    def wait_for_event(self, event):
+        _check(self._lib, self._lib.slf_stream_wait_event(self.handle, event.handle), 'slf_stream_wait_event')
+
+    @property
+    def native(self):
+        """Raw hipStream_t (for torch.cuda.ExternalStream)."""
+        p = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_stream_native(self.handle, ctypes.byref(p)), 'slf_stream_native')
+        return p.value or 0
+
+    def __del__(self):
+        try:
+            self._lib.slf_stream_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class HIPEvent(object):
+    def __init__(self, backend, timing=False):
+        self._lib = backend._lib
+        h = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_event_create(backend._ctx, int(bool(timing)), ctypes.byref(h)),
+               'slf_event_create')
+        self.handle = h
+
+    def record(self, stream=None):
+        _check(self._lib, self._lib.slf_event_record(self.handle, stream.handle if stream else None),
+               'slf_event_record')
+
+    def synchronize(self):
+        _check(self._lib, self._lib.slf_event_sync(self.handle), 'slf_event_sync')
+
+    def time_since(self, other):
+        """Milliseconds elapsed since `other` (pycuda Event.time_since semantics)."""
+        ms = ctypes.c_float()
+        _check(self._lib, self._lib.slf_event_elapsed_ms(other.handle, self.handle, ctypes.byref(ms)),
+               'slf_event_elapsed_ms')
+        return ms.value
+
+    def __del__(self):
+        try:
+            self._lib.slf_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class HIPModule(object):
+    def __init__(self, backend, desc):
+        self._lib = backend._lib
+        self.desc = desc
+        h = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_module_create(backend._ctx, ctypes.byref(desc), ctypes.byref(h)),
+               'slf_module_create')
+        self.handle = h
+
+    @property
+    def block_size(self):
+        n = ctypes.c_int()
+        _check(self._lib, self._lib.slf_module_block_size(self.handle, ctypes.byref(n)), 'slf_module_block_size')
+        return n.value
+
+    def __del__(self):
+        try:
+            self._lib.slf_module_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class HIPKernel(object):
+    def __init__(self, lib, module, name):
+        self._lib = lib
+        self.module = module
+        self.name = name
+        h = ctypes.c_void_p()
+        _check(lib, lib.slf_kernel_get(module.handle, name.encode(), ctypes.byref(h)), 'slf_kernel_get(%s)' % name)
+        self.handle = h
+        self.args = None
+        self.needs_iteration = False
+
+    def set_args(self, args, args_format, needs_iteration):
+        n = len(args)
+        if n != len(args_format):
+            raise ValueError('args / args_format length mismatch for kernel %s' % self.name)
+        vals = []
+        ptrs = (ctypes.c_void_p * max(1, n))()
+        for i, (a, f) in enumerate(zip(args, args_format)):
+            if f == 'P':
+                v = ctypes.c_uint64(int(a) if a is not None else 0)
+            elif f == 'i':
+                v = ctypes.c_int32(int(a))
+            else:
+                raise ValueError('unsupported argument format %r' % f)
+            vals.append(v)
+            ptrs[i] = ctypes.cast(ctypes.pointer(v), ctypes.c_void_p)
+        _check(self._lib, self._lib.slf_kernel_set_args(self.handle, args_format.encode(), ptrs, n,
+                                                       int(bool(needs_iteration))),
+               'slf_kernel_set_args(%s)' % self.name)
+        self.args = list(args)
+        self.needs_iteration = bool(needs_iteration)
+
+    def __del__(self):
+        try:
+            self._lib.slf_kernel_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class HIPBackend(object):
+    name = 'hip'
+    FatalError = HIPFatalError
+
+    @classmethod
+    def devices_count(cls):
+        lib = hipabi.load()
+        n = ctypes.c_int()
+        lib.slf_device_count(ctypes.byref(n))
+        return n.value
+
+    @classmethod
+    def add_options(cls, group):
+        group.add_argument('--hip-kernel-stats', dest='hip_kernel_stats', action='store_true', default=False,
+                           help='print the workgroup shape chosen for the sweep kernels')
+        group.add_argument('--nohip_fused_periodic', dest='hip_fused_periodic', action='store_false',
+                           default=True,
+                           help='apply periodic boundary conditions with separate ghost-layer kernels '
+                                '(the reference\'s scheme) instead of wrapping inside the sweep')
+        return 1
+
+    def __init__(self, options, gpu_id):
+        """:param options: LBConfig-like object; :param gpu_id: HIP device ordinal"""
+        self._lib = hipabi.load()
+        self.options = options
+        self.gpu_id = gpu_id
+        self.buffers = {}   # device address -> host mirror
+        self._sizes = {}
+        self._iteration_kernels = []
+        self._total_memory_bytes = 0
+        ctx = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_ctx_create(int(gpu_id), ctypes.byref(ctx)), 'slf_ctx_create')
+        self._ctx = ctx
+        name = ctypes.create_string_buffer(256)
+        mem = ctypes.c_size_t()
+        cus = ctypes.c_int()
+        wave = ctypes.c_int()
+        _check(self._lib, self._lib.slf_ctx_info(ctx, name, 256, ctypes.byref(mem), ctypes.byref(cus),
+                                                 ctypes.byref(wave)), 'slf_ctx_info')
+        self._dev_name = name.value.decode()
+        self._total_memory = mem.value
+        self._cu_count = cus.value
+        self._wavefront = wave.value
+
+    def __del__(self):
+        try:
+            self._lib.slf_ctx_destroy(self._ctx)
+        except Exception:
+            pass
+
+    # -- diagnostics ------------------------------------------------------
+    @property
+    def supports_printf(self):
+        return True
+
+    @property
+    def info(self):
+        return '{0} / {1} CUs / MEM {2}'.format(self._dev_name, self._cu_count, self.total_memory)
+
+    @property
+    def total_memory(self):
+        return self._total_memory
+
+    def get_defines(self):
+        return {'warp_size': self._wavefront, 'supports_shuffle': True, 'supports_printf': True,
+                'backend': 'hip'}
+
+    # -- memory -----------------------------------------------------------
+    @staticmethod
+    def _host_base(arr):
+        return arr.base if (arr.base is not None and isinstance(arr.base, np.ndarray)) else arr
+
+    def alloc_buf(self, size=None, like=None, wrap_in_array=False):
+        """Allocates a device buffer; with ``like`` the host array (or its base)
+        becomes the buffer's mirror and is copied to the device immediately
+        (reference backend_cuda.py:132-154)."""
+        if like is not None:
+            host = self._host_base(like)
+            if not host.flags['C_CONTIGUOUS']:
+                raise ValueError('host mirror must be C-contiguous')
+            size = host.nbytes
+        ptr = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_malloc(self._ctx, int(size), ctypes.byref(ptr)), 'slf_malloc')
+        addr = ptr.value
+        self._total_memory_bytes += int(size)
+        self._sizes[addr] = int(size)
+        if like is not None:
+            self.buffers[addr] = self._host_base(like)
+            self.to_buf(addr)
+        return addr
+
+    def free_buf(self, addr):
+        _check(self._lib, self._lib.slf_free(self._ctx, ctypes.c_void_p(addr)), 'slf_free')
+        self.buffers.pop(addr, None)
+        self._total_memory_bytes -= self._sizes.pop(addr, 0)
+
+    def alloc_async_host_buf(self, shape, dtype):
+        """Page-locked host array (reference backend_cuda.py:156-159)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_host_alloc_pinned(max(1, n), ctypes.byref(ptr)), 'slf_host_alloc_pinned')
+        buf = (ctypes.c_char * max(1, n)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        arr[...] = 0
+        return arr
+
+    def _resolve(self, buf, other):
+        if other is None:
+            if buf not in self.buffers:
+                raise ValueError('Unknown compute buffer and source/target not specified.')
+            return self.buffers[buf]
+        return self._host_base(other)
+
+    def to_buf(self, buf, source=None):
+        host = self._resolve(buf, source)
+        _check(self._lib, self._lib.slf_memcpy_h2d(self._ctx, ctypes.c_void_p(buf), host.ctypes.data, host.nbytes),
+               'slf_memcpy_h2d')
+
+    def from_buf(self, buf, target=None):
+        host = self._resolve(buf, target)
+        _check(self._lib, self._lib.slf_memcpy_d2h(self._ctx, host.ctypes.data, ctypes.c_void_p(buf), host.nbytes),
+               'slf_memcpy_d2h')
+
+    def to_buf_async(self, buf, stream=None):
+        host = self.buffers[buf]
+        _check(self._lib, self._lib.slf_memcpy_h2d_async(self._ctx, ctypes.c_void_p(buf), host.ctypes.data,
+                                                        host.nbytes, stream.handle if stream else None),
+               'slf_memcpy_h2d_async')
+
+    def from_buf_async(self, buf, stream=None):
+        host = self.buffers[buf]
+        _check(self._lib, self._lib.slf_memcpy_d2h_async(self._ctx, host.ctypes.data, ctypes.c_void_p(buf),
+                                                        host.nbytes, stream.handle if stream else None),
+               'slf_memcpy_d2h_async')
+
+    def copy_buf_async(self, dst, src, nbytes, stream=None):
+        _check(self._lib, self._lib.slf_memcpy_d2d_async(self._ctx, ctypes.c_void_p(dst), ctypes.c_void_p(src),
+                                                        int(nbytes), stream.handle if stream else None),
+               'slf_memcpy_d2d_async')
+
+    def memset_buf(self, buf, value, nbytes, stream=None):
+        _check(self._lib, self._lib.slf_memset(self._ctx, ctypes.c_void_p(buf), int(value), int(nbytes),
+                                              stream.handle if stream else None), 'slf_memset')
+
+    # -- modules / kernels --------------------------------------------------
+    def build(self, source):
+        """``source`` is a hipabi.SlfModuleDesc (see module docstring)."""
+        if not isinstance(source, hipabi.SlfModuleDesc):
+            raise TypeError('the HIP backend builds from a module descriptor, not from source text')
+        return HIPModule(self, source)
+
+    def get_kernel(self, prog, name, block, args, args_format, shared=0, needs_iteration=False,
+                   more_shared=False):
+        """Same arguments as the reference (backend_cuda.py:220-251); ``block`` and
+        ``shared`` are accepted for compatibility and ignored."""
+        kern = HIPKernel(self._lib, prog, name)
+        kern.set_args(args, args_format, needs_iteration)
+        if needs_iteration:
+            self._iteration_kernels.append(kern)
+        return kern
+
+    def set_iteration(self, it):
+        for kern in self._iteration_kernels:
+            _check(self._lib, self._lib.slf_kernel_set_iteration(kern.handle, int(it) & 0xFFFFFFFF),
+                   'slf_kernel_set_iteration')
+
+    def run_kernel(self, kernel, grid_size=None, stream=None):
+        region = None
+        if grid_size is not None:
+            y0, y1, z0, z1 = grid_size
+            region = ctypes.byref(hipabi.SlfRegion(int(y0), int(y1), int(z0), int(z1)))
+        _check(self._lib, self._lib.slf_kernel_launch(kernel.handle, region, stream.handle if stream else None),
+               'slf_kernel_launch(%s)' % kernel.name)
+
+    # -- streams / events -----------------------------------------------------
+    def make_stream(self):
+        return HIPStream(self)
+
+    def make_event(self, stream, timing=False):
+        """Creates an event *and records it* on `stream` (reference backend_cuda.py:298-305)."""
+        ev = HIPEvent(self, timing)
+        ev.record(stream)
+        return ev
+
+    def sync(self):
+        _check(self._lib, self._lib.slf_ctx_sync(self._ctx), 'slf_ctx_sync')
+
+    def sync_stream(self, *streams):
+        for s in streams:
+            s.synchronize()
+
+
+backend = HIPBackend

@@ -212,15 +212,31 @@ __global__ void __launch_bounds__(256) init_kernel(R* dist, const R* __restrict_
 __device__ __forceinline__ bool slf_isfinite(float x) { return __builtin_isfinite(x); }
 __device__ __forceinline__ bool slf_isfinite(double x) { return __builtin_isfinite(x); }
 
+// Can a pushed population with component e along another axis sit at coordinate
+// c of that axis?  Axes handled earlier (x before y before z) already hold their
+// wrapped copies on real nodes; later axes are still "as pushed from a real node".
+__device__ __forceinline__ bool pbc_push_ok(int c, int e, int lat, bool processed) {
+  if (processed) return c >= 1 && c <= lat - 2;
+  if (e > 0) return c >= 2;
+  if (e < 0) return c <= lat - 3;
+  return c >= 1 && c <= lat - 2;
+}
+
+// Swap variant: axes handled earlier take part with their (already filled) ghost
+// columns as long as the node that will pull the value (at c + e) is real; later
+// axes contribute their real range only.
+__device__ __forceinline__ bool pbc_pull_ok(int c, int e, int lat, bool processed) {
+  if (processed) return c + e >= 1 && c + e <= lat - 2;
+  return c >= 1 && c <= lat - 2;
+}
+
 // Periodic boundary conditions inside one subdomain for one axis.
 //
 // !SWAP (after a push step; effect of kernel_utils.mako:295-336): populations
 // that were pushed into the ghost layer of `axis` are moved to the real layer on
-// the opposite side.  The face spans the *full* extent (ghosts included) of the
-// other axes; applied in x, y, z order this moves edge/corner populations one
-// axis at a time.  A population with e_b = +1 (-1) can only have been pushed to
-// coordinate b >= 2 (<= lat_b - 3) along another axis b, everything else is
-// skipped, as are non-finite values (never-written ghost slots).
+// the opposite side.  Applied in x, y, z order this moves edge/corner populations
+// one axis at a time (see pbc_push_ok for which face nodes take part);
+// non-finite values (never-written ghost slots) are skipped.
 //
 // SWAP (after the in-place even AA step; effect of kernel_utils.mako:343-384):
 // real layer -> opposite ghost layer, opposite slots, so that the next (odd)
@@ -250,11 +266,9 @@ __global__ void __launch_bounds__(256) pbc_kernel(R* dist, Geometry g, int axis)
     const int eb = e[b_ax];
     const int ec = (L::dim == 3) ? e[c_ax] : 0;
     if constexpr (!SWAP) {
-      if (eb > 0 && b < 2) return;
-      if (eb < 0 && b > lat[b_ax] - 3) return;
+      if (!pbc_push_ok(b, eb, lat[b_ax], b_ax < axis)) return;
       if (L::dim == 3) {
-        if (ec > 0 && c < 2) return;
-        if (ec < 0 && c > lat[c_ax] - 3) return;
+        if (!pbc_push_ok(c, ec, lat[c_ax], c_ax < axis)) return;
       }
       // ea = -1: landed in the low ghost (0) -> high real (n-2); ea = +1: high ghost (n-1) -> low real (1)
       const uint32_t src = base + (uint32_t)((ea < 0 ? 0 : n - 1) * stride[axis]);
@@ -263,15 +277,9 @@ __global__ void __launch_bounds__(256) pbc_kernel(R* dist, Geometry g, int axis)
       const R val = d[src];
       if (slf_isfinite(val)) d[dst] = val;
     } else {
-      // The puller sits at g + e_i and must be a real node along the other axes;
-      // ghost columns are only meaningful for axes that were processed before.
-      const int blo = (b_ax < axis) ? 0 : 1, bhi = (b_ax < axis) ? lat[b_ax] - 1 : lat[b_ax] - 2;
-      if (b < blo || b > bhi) return;
-      if (b + eb < 1 || b + eb > lat[b_ax] - 2) return;
+      if (!pbc_pull_ok(b, eb, lat[b_ax], b_ax < axis)) return;
       if (L::dim == 3) {
-        const int clo = (c_ax < axis) ? 0 : 1, chi = (c_ax < axis) ? lat[c_ax] - 1 : lat[c_ax] - 2;
-        if (c < clo || c > chi) return;
-        if (c + ec < 1 || c + ec > lat[c_ax] - 2) return;
+        if (!pbc_pull_ok(c, ec, lat[c_ax], c_ax < axis)) return;
       }
       // ea = +1: puller at 1 reads ghost 0 <- real n-2 ; ea = -1: puller at n-2 reads ghost n-1 <- real 1
       const uint32_t src = base + (uint32_t)((ea > 0 ? n - 2 : 1) * stride[axis]);

@@ -1,0 +1,109 @@
+"""Hand-encoded node maps for parity tests (test-only helper).
+
+Encoding = the reference's bit layout orientation | scratch | param | type
+(sailfish/geo_encoder.py:365-382) with a fixed dense type-id table."""
+import numpy as np
+
+from sailfish_amd import hipabi as h
+
+TYPE_KIND = [h.SLF_NK_FLUID, h.SLF_NK_GHOST, h.SLF_NK_FULL_BB, h.SLF_NK_REGULARIZED_VELOCITY, h.SLF_NK_HALF_BB,
+             h.SLF_NK_EQUILIBRIUM_DENSITY, h.SLF_NK_UNUSED]
+T_FLUID, T_GHOST, T_FULLBB, T_REGVEL, T_HALFBB, T_EQDENS, T_UNUSED = range(7)
+NT_BITS = (3, 3, 0)          # type bits, param bits, scratch bits
+ORIENT_SHIFT = 6
+
+
+def encode(type_id, orientation=0, param=0):
+    return (orientation << ORIENT_SHIFT) | (param << NT_BITS[0]) | type_id
+
+
+def empty_map(desc):
+    m = np.full((desc.arr_nz, desc.arr_ny, desc.arr_nx), encode(T_GHOST), dtype=np.uint32)
+    if desc.lat_nz > 1:
+        m[1:desc.lat_nz - 1, 1:desc.lat_ny - 1, 1:desc.lat_nx - 1] = encode(T_FLUID)
+    else:
+        m[0, 1:desc.lat_ny - 1, 1:desc.lat_nx - 1] = encode(T_FLUID)
+    return m
+
+
+def link_tags(grid, m, z, y, x, wet_types=(T_FLUID, T_HALFBB, T_REGVEL, T_EQDENS)):
+    """bit (i-1) set <=> direction i points to a wet node (reference subdomain.py:593-642)."""
+    tag = 0
+    for i in range(1, grid.Q):
+        e = grid.basis[i]
+        zz = z + (e[2] if grid.dim == 3 else 0)
+        t = m[zz, y + e[1], x + e[0]] & ((1 << NT_BITS[0]) - 1)
+        if t in wet_types:
+            tag |= 1 << (i - 1)
+    return tag
+
+
+def cavity_3d(desc, lid_param=0):
+    """Closed box of full-way bounce-back walls with a moving lid (regularized velocity) on y = max,
+    like the reference's examples/ldc_3d.py."""
+    m = empty_map(desc)
+    nz, ny, nx = desc.lat_nz - 2, desc.lat_ny - 2, desc.lat_nx - 2
+    w = encode(T_FULLBB)
+    m[1, 1:ny + 1, 1:nx + 1] = w
+    m[nz, 1:ny + 1, 1:nx + 1] = w
+    m[1:nz + 1, 1, 1:nx + 1] = w
+    m[1:nz + 1, 1:ny + 1, 1] = w
+    m[1:nz + 1, 1:ny + 1, nx] = w
+    # lid: inward normal = -y = D3Q19 orientation 4
+    m[2:nz, ny, 2:nx] = encode(T_REGVEL, orientation=4, param=lid_param)
+    m[1:nz + 1, ny, 1] = w
+    m[1:nz + 1, ny, nx] = w
+    m[1, ny, 1:nx + 1] = w
+    m[nz, ny, 1:nx + 1] = w
+    return m
+
+
+def cavity_2d(desc, lid_param=0):
+    """examples/ldc_2d.py-like: full-BB walls, regularized-velocity lid on y = max (D2Q9 orientation 4 = -y)."""
+    m = empty_map(desc)
+    ny, nx = desc.lat_ny - 2, desc.lat_nx - 2
+    w = encode(T_FULLBB)
+    m[0, 1, 1:nx + 1] = w
+    m[0, 1:ny + 1, 1] = w
+    m[0, 1:ny + 1, nx] = w
+    m[0, ny, 2:nx] = encode(T_REGVEL, orientation=4, param=lid_param)
+    m[0, ny, 1] = w
+    m[0, ny, nx] = w
+    return m
+
+
+def channel_2d_halfbb(grid, desc):
+    """x-periodic channel with half-way bounce-back walls (link tags) on y = 1 and y = max."""
+    m = empty_map(desc)
+    ny, nx = desc.lat_ny - 2, desc.lat_nx - 2
+    m[0, 1, 1:nx + 1] = encode(T_HALFBB)
+    m[0, ny, 1:nx + 1] = encode(T_HALFBB)
+    # periodic in x: link tags must see the wrapped neighbours -> temporarily fill the x ghosts
+    mm = m.copy()
+    mm[0, :, 0] = mm[0, :, nx]
+    mm[0, :, nx + 1] = mm[0, :, 1]
+    for y in (1, ny):
+        for x in range(1, nx + 1):
+            m[0, y, x] = encode(T_HALFBB, orientation=link_tags(grid, mm, 0, y, x))
+    return m
+
+
+def channel_2d_pressure(desc, p_in=0, p_out=1):
+    """Pressure-driven channel: NTEquilibriumDensity on x = 1 (normal +x: D2Q9 orientation 1) and
+    x = max (normal -x: orientation 3); full-BB walls on y (like examples/poiseuille.py --drive=pressure)."""
+    m = empty_map(desc)
+    ny, nx = desc.lat_ny - 2, desc.lat_nx - 2
+    m[0, 2:ny, 1] = encode(T_EQDENS, orientation=1, param=p_in)
+    m[0, 2:ny, nx] = encode(T_EQDENS, orientation=3, param=p_out)
+    m[0, 1, 1:nx + 1] = encode(T_FULLBB)
+    m[0, ny, 1:nx + 1] = encode(T_FULLBB)
+    return m
+
+
+def channel_3d_fullbb(desc):
+    """x,z-periodic duct with full-BB walls on y (force-driven Poiseuille, examples/poiseuille_3d.py-like)."""
+    m = empty_map(desc)
+    ny = desc.lat_ny - 2
+    m[1:desc.lat_nz - 1, 1, 1:desc.lat_nx - 1] = encode(T_FULLBB)
+    m[1:desc.lat_nz - 1, ny, 1:desc.lat_nx - 1] = encode(T_FULLBB)
+    return m

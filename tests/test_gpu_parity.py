@@ -1,0 +1,195 @@
+"""GPU parity: the hand-written gfx950 kernels (through the C ABI, via
+backend_hip) against the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): 1e-6 relative on the macroscopic rho / u
+fields (u relative to the velocity scale 0.05-0.1 of the cases).  Because the
+kernels and the oracle follow the same IEEE operation order with FMA
+contraction off, the populations are in practice bit-identical; that stronger
+property is asserted for f32 fluid-only runs and reported otherwise.
+"""
+import numpy as np
+import pytest
+
+from sailfish_amd import sym
+from sailfish_amd.box import BoxSim, make_box_desc
+from tests import _geometry as geo
+from tests._oracle_box import OracleBox, synthetic_fields
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+@pytest.fixture(scope='module')
+def backend():
+    from sailfish_amd.backend_hip import HIPBackend
+
+    class Opt(object):
+        pass
+    return HIPBackend(Opt(), 0)
+
+
+def _run_pair(backend, grid, size, steps, periodic, node_map_fn=None, u_scale=0.05, init='synthetic', **kw):
+    desc = make_box_desc(grid, size, **kw)
+    nmap = node_map_fn(desc) if node_map_fn else None
+    rho, v = synthetic_fields(size, grid.dim)
+    if init == 'rest':
+        rho = np.ones_like(rho)
+        v = [np.zeros_like(c) for c in v]
+    sims = []
+    for cls, args in ((BoxSim, (backend, desc)), (OracleBox, (desc,))):
+        s = cls(*args, periodic=periodic, node_map=nmap)
+        s.set_fields(rho, v)
+        s.initial_conditions()
+        s.run(steps, save_last=True)
+        sims.append(s)
+    g, o = sims
+    g_rho, g_v = g.fetch_fields()
+    f_g = g.real_view(g.get_dist())
+    f_o = o.real_view(o.current_dist())
+    wet = np.isfinite(o.real_view(o.rho)) if nmap is None else None
+    res = {'dist_exact': np.array_equal(f_g, f_o, equal_nan=True)}
+    r_g, r_o = g.real_view(g_rho), o.real_view(o.rho)
+    mask = np.isfinite(r_o)
+    assert np.array_equal(mask, np.isfinite(r_g))
+    res['rho_err'] = float(np.max(np.abs(r_g[mask] - r_o[mask]) / np.abs(r_o[mask])))
+    verr = 0.0
+    for d in range(grid.dim):
+        a, b = g.real_view(g_v[d])[mask], o.real_view(o.v[d])[mask]
+        verr = max(verr, float(np.max(np.abs(a - b))) / u_scale)
+    res['v_err'] = verr
+    fm = np.isfinite(f_o)
+    res['dist_err'] = float(np.max(np.abs(f_g[fm] - f_o[fm])))
+    return res
+
+
+BOX = [(sym.D2Q9, (70, 11)), (sym.D3Q19, (70, 6, 5))]
+
+
+@pytest.mark.parametrize('grid,size', BOX)
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('fused', [0, 1])
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+def test_periodic_box_f32(backend, grid, size, pattern, fused, model):
+    r = _run_pair(backend, grid, size, 21, (True, True, True), model=model, precision='single',
+                  access_pattern=pattern, visc=0.01, periodic_fused=[fused] * 3)
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    assert r['dist_exact'], r     # same IEEE operation order -> bit-identical populations
+
+
+@pytest.mark.parametrize('grid,size', BOX)
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_periodic_box_f64(backend, grid, size, pattern):
+    r = _run_pair(backend, grid, size, 12, (True, True, True), model='bgk', precision='double',
+                  access_pattern=pattern, visc=1.0 / 6.0, periodic_fused=[0] * 3)
+    assert r['rho_err'] < 1e-12 and r['v_err'] < 1e-12, r
+
+
+@pytest.mark.parametrize('grid,size', BOX)
+def test_body_force_and_incompressible(backend, grid, size):
+    r = _run_pair(backend, grid, size, 10, (True, True, True), model='bgk', precision='single',
+                  access_pattern='AA', visc=0.02, periodic_fused=[1] * 3, accel=[1e-5, -2e-5, 3e-5][:grid.dim],
+                  incompressible=True)
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    r = _run_pair(backend, grid, size, 10, (True, True, True), model='mrt', precision='single',
+                  access_pattern='AB', visc=0.02, periodic_fused=[0] * 3, accel=[1e-5, -2e-5, 3e-5][:grid.dim])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+def test_cavity_3d(backend, pattern, model):
+    """regtest/ldc_3d-style cavity: full-BB walls + regularized-velocity lid."""
+    r = _run_pair(backend, sym.D3Q19, (20, 14, 12), 40, (False, False, False), node_map_fn=geo.cavity_3d,
+                  u_scale=0.05, init='rest', model=model, precision='single', access_pattern=pattern,
+                  visc=0.03, fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS,
+                  node_params=[0.05, 0.0, 0.0])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_cavity_2d(backend, pattern):
+    r = _run_pair(backend, sym.D2Q9, (66, 40), 60, (False, False, False), node_map_fn=geo.cavity_2d,
+                  u_scale=0.1, init='rest', model='bgk', precision='single', access_pattern=pattern,
+                  visc=0.0254, fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS,
+                  node_params=[0.1, 0.0])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('fused', [0, 1])
+def test_channel_2d_halfbb_force(backend, pattern, fused):
+    grid = sym.D2Q9
+    r = _run_pair(backend, grid, (40, 18), 50, (True, False, False),
+                  node_map_fn=lambda d: geo.channel_2d_halfbb(grid, d), u_scale=0.01, init='rest',
+                  model='bgk', precision='single', access_pattern=pattern, visc=0.05, fluid_only=False,
+                  type_kind=geo.TYPE_KIND, nt_bits=(3, 3, 0), periodic_fused=[fused, 0, 0], accel=[1e-5, 0.0],
+                  use_link_tags=True)
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+
+
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+def test_channel_2d_pressure(backend, model):
+    r = _run_pair(backend, sym.D2Q9, (40, 18), 50, (False, False, False), node_map_fn=geo.channel_2d_pressure,
+                  u_scale=0.01, init='rest', model=model, precision='single', access_pattern='AB', visc=0.05,
+                  fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS, node_params=[1.01, 0.99])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+
+
+def test_channel_3d_fullbb_force(backend):
+    r = _run_pair(backend, sym.D3Q19, (24, 16, 10), 40, (True, False, True), node_map_fn=geo.channel_3d_fullbb,
+                  u_scale=0.01, init='rest', model='bgk', precision='single', access_pattern='AA', visc=0.05,
+                  fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS, periodic_fused=[1, 0, 1],
+                  accel=[1e-5, 0.0, 0.0])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+
+
+def test_region_launches_cover_domain(backend):
+    """bulk/boundary split: sweeping z-planes in three launches == one launch."""
+    grid, size = sym.D3Q19, (33, 9, 8)
+    desc = make_box_desc(grid, size, precision='single', access_pattern='AB', visc=0.02, periodic_fused=[1, 1, 1])
+    rho, v = synthetic_fields(size, 3)
+    out = []
+    for split in (False, True):
+        s = BoxSim(backend, desc, periodic=(True, True, True))
+        s.set_fields(rho, v)
+        s.initial_conditions()
+        for _ in range(4):
+            if split:
+                it = s.iteration
+                s.iteration = it
+                for reg in ((1, 10, 1, 2), (1, 10, 8, 9), (1, 10, 2, 8)):
+                    s.backend.run_kernel(s.k_sweep[0][it & 1], reg, s.stream)
+                s.iteration += 1
+            else:
+                s.step()
+        out.append(s.get_dist())
+    assert np.array_equal(out[0], out[1], equal_nan=True)
+
+
+def test_large_box_invariants(backend):
+    """Size-independent properties at a bench-like size (256^3 would also do; kept at 128^3 for
+    speed): mass and momentum conservation over 20 AA steps, AA == AB bitwise."""
+    grid, n = sym.D3Q19, 128
+    size = (n, n, n)
+    rho, v = synthetic_fields(size, 3, dtype=np.float32)
+    res = {}
+    for pattern in ('AA', 'AB'):
+        desc = make_box_desc(grid, size, precision='single', access_pattern=pattern, visc=0.01,
+                             periodic_fused=[1, 1, 1])
+        s = BoxSim(backend, desc, periodic=(True, True, True))
+        s.set_fields(rho, v)
+        s.initial_conditions()
+        f0 = s.real_view(s.get_dist()).astype(np.float64)
+        s.run(20, save_last=True)
+        f1 = s.real_view(s.get_dist())
+        res[pattern] = f1.copy()
+        m0, m1 = f0.sum(), f1.astype(np.float64).sum()
+        assert abs(m1 - m0) / m0 < 1e-6
+        e = grid.basis_array
+        for d in range(3):
+            p0 = sum(e[i][d] * f0[i].sum() for i in range(grid.Q))
+            p1 = sum(e[i][d] * f1[i].astype(np.float64).sum() for i in range(grid.Q))
+            assert abs(p1 - p0) / m0 < 1e-6
+        del s
+    assert np.array_equal(res['AA'], res['AB'])
