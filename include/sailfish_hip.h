@@ -91,6 +91,9 @@ typedef struct slf_module_desc {
   int32_t use_link_tags;       /* orientation field of half-BB nodes holds link tags (subdomain.py:593-642) */
   int32_t n_node_params;
   const double* node_params;   /* kernel_common.mako:523-536; copied at module creation */
+  uint64_t dist_stride;        /* elements between consecutive direction arrays; 0 = arr_nx*arr_ny*arr_nz (the
+                                  reference's DIST_SIZE, kernel_common.mako:506).  A larger stride only inserts
+                                  unused padding between the Q arrays (HBM channel de-aliasing). */
 } slf_module_desc;
 
 /* Region of the lattice a sweep launch covers (replaces the reference's

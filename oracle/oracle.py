@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from sailfish_amd.hipabi import SlfModuleDesc  # the problem-description struct (interface only)
+from sailfish_amd.hipabi import SlfModuleDesc, dist_stride  # the problem-description struct (interface only)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _libs = {}
@@ -97,9 +97,14 @@ class OracleSim(object):
         self.dim = 2 if desc.lattice == 0 else 3
         self.shape = (desc.arr_nz, desc.arr_ny, desc.arr_nx)
         self.n = desc.arr_nz * desc.arr_ny * desc.arr_nx
+        self.stride = dist_stride(desc)
 
     def new_dist(self):
-        return np.full((self.Q,) + self.shape, np.nan, dtype=self.dtype)
+        """Returns a [Q, nz, ny, nx] view into a buffer with the descriptor's direction stride."""
+        raw = np.full((self.Q, self.stride), np.nan, dtype=self.dtype)
+        view = raw[:, :self.n].reshape((self.Q,) + self.shape)
+        assert view.base is not None
+        return view
 
     def new_field(self, fill=0.0):
         return np.full(self.shape, fill, dtype=self.dtype)

@@ -7,6 +7,8 @@ subdomain runner's step() performs for one subdomain without neighbours
 ApplyPeriodicBoundaryConditions per periodic axis, A/B swap or AA parity), but
 takes plain numpy inputs instead of the LBSim/Subdomain classes.
 """
+import os
+
 import numpy as np
 
 from sailfish_amd import hipabi, sym
@@ -20,7 +22,7 @@ def padded_nx(lat_nx, alignment=32):
 def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='AA', visc=1.0 / 6.0,
                   periodic_fused=(0, 0, 0), fluid_only=True, accel=None, incompressible=False,
                   relaxation_enabled=True, type_kind=None, node_params=None, nt_bits=None, use_link_tags=True,
-                  alignment=32):
+                  alignment=32, dist_pad=None):
     """size = (nx, ny[, nz]) real nodes; a ghost envelope of 1 is added."""
     dim = grid.dim
     assert len(size) == dim
@@ -45,6 +47,10 @@ def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='A
     if nt_bits is not None:
         misc, param, scratch = nt_bits
         kw.update(nt_type_mask=(1 << misc) - 1, nt_misc_shift=misc, nt_param_shift=param, nt_scratch_shift=scratch)
+    if dist_pad is None:
+        dist_pad = int(os.environ.get('SLF_DIST_PAD', '0'))
+    if dist_pad:
+        kw['dist_stride'] = kw['arr_nx'] * kw['arr_ny'] * kw['arr_nz'] + int(dist_pad)
     return hipabi.make_desc(**kw)
 
 
@@ -64,7 +70,8 @@ class BoxSim(object):
         self.pbc_axes = [a for a in range(self.dim) if periodic[a] and not desc.periodic_fused[a]]
         self.iteration = 0
         b = backend
-        fbytes = self.nodes * self.dtype().itemsize
+        self.stride = hipabi.dist_stride(desc)
+        fbytes = self.stride * self.dtype().itemsize
         self.module = b.build(desc)
         self.gpu_dist = [b.alloc_buf(size=self.Q * fbytes)]
         if not self.aa:
@@ -166,11 +173,12 @@ class BoxSim(object):
         """Raw distributions [Q, (nz,) ny, arr_nx] (reference _debug_get_dist, subdomain_runner.py:1363-1381)."""
         self.sync()
         idx = self.current_dist_index() if which is None else which
-        host = np.zeros((self.Q,) + self.shape, dtype=self.dtype)
-        self.backend.from_buf(self.gpu_dist[idx], host)
-        return host
+        raw = np.zeros((self.Q, self.stride), dtype=self.dtype)
+        self.backend.from_buf(self.gpu_dist[idx], raw)
+        return np.ascontiguousarray(raw[:, :self.nodes]).reshape((self.Q,) + self.shape)
 
     def set_dist(self, host, which=None):
         idx = self.current_dist_index() if which is None else which
-        host = np.ascontiguousarray(host, dtype=self.dtype)
-        self.backend.to_buf(self.gpu_dist[idx], host)
+        raw = np.zeros((self.Q, self.stride), dtype=self.dtype)
+        raw[:, :self.nodes] = np.asarray(host, dtype=self.dtype).reshape(self.Q, self.nodes)
+        self.backend.to_buf(self.gpu_dist[idx], raw)

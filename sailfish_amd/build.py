@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libsailfish_hip.so')
-SOURCES = ['slf_kernels.hip', 'slf_api.hip']
-HEADERS = ['slf_kernels.h', 'slf_lattice.h', 'slf_node.h', os.path.join('..', '..', 'include', 'sailfish_hip.h')]
+SOURCES = ['slf_kernels.hip', 'slf_fast.hip', 'slf_api.hip']
+HEADERS = ['slf_kernels.h', 'slf_lattice.h', 'slf_node.h', 'slf_sweep.h', os.path.join('..', '..', 'include', 'sailfish_hip.h')]
 
 # -ffp-contract=off: fixed IEEE operation order (DESIGN.md "arithmetic contract");
 # the sweep is HBM-bound, the extra VALU issue slots are hidden.
@@ -39,11 +39,30 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
-    """Compile every HIP source into sailfish_amd/lib/libsailfish_hip.so."""
+    """Compile every HIP source into sailfish_amd/lib/libsailfish_hip.so (objects in parallel)."""
     if not force and not needs_build():
         return LIBPATH
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ['-o', LIBPATH] + SOURCES
+    objdir = os.path.join(LIBDIR, 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    procs = []
+    objs = []
+    cflags = [f for f in HIPCC_FLAGS if f != '-shared']
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace('.hip', '.o'))
+        objs.append(obj)
+        st = os.path.getmtime(os.path.join(CSRC, src))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(st, hdr_t):
+            continue
+        cmd = [_hipcc()] + cflags + ['-c', '-o', obj, src]
+        if verbose:
+            print('[sailfish_amd.build]', ' '.join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs
     if verbose:
         print('[sailfish_amd.build]', ' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=CSRC)

@@ -11,6 +11,10 @@
 #include "slf_kernels.h"
 #include "slf_node.h"
 
+#ifndef SLF_DEFAULT_VARIANT
+#define SLF_DEFAULT_VARIANT 9
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -291,7 +295,8 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   if (d->tau <= 0.5 && d->relaxation_enabled) return fail(SLF_ERR_INVALID, "tau must be > 0.5");
   if (d->n_types < 0 || d->n_types > SLF_MAX_NODE_TYPES) return fail(SLF_ERR_INVALID, "too many node types");
   const unsigned long long total = (unsigned long long)d->arr_nx * d->arr_ny * d->arr_nz;
-  if (total >= 0xFFFFFFFFull) return fail(SLF_ERR_UNSUPPORTED, "subdomain too large for 32-bit node indices");
+  if (total >= 0xFFFFFFFFull || d->dist_stride >= 0xFFFFFFFFull)
+    return fail(SLF_ERR_UNSUPPORTED, "subdomain too large for 32-bit node indices");
 
   slf_module* m = new slf_module;
   m->ctx = ctx;
@@ -305,7 +310,8 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   g.lat_nx = d->lat_nx; g.lat_ny = d->lat_ny; g.lat_nz = d->lat_nz;
   g.arr_nx = d->arr_nx; g.arr_ny = d->arr_ny; g.arr_nz = d->arr_nz;
   g.arr_nxy = d->arr_nx * d->arr_ny;
-  g.dist_size = (uint32_t)total;
+  g.dist_size = (uint32_t)(d->dist_stride ? d->dist_stride : total);
+  if (g.dist_size < total) { delete m; return fail(SLF_ERR_INVALID, "dist_stride smaller than the subdomain"); }
   for (int i = 0; i < 3; i++) g.wrap[i] = (i < dim) ? (d->periodic_fused[i] != 0) : 0;
   g.type_mask = d->nt_type_mask;
   g.param_shift = d->nt_misc_shift;
@@ -321,6 +327,8 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
     g.type_lut |= (unsigned long long)k << (4 * i);
   }
   g.use_link_tags = d->use_link_tags;
+  g.variant = SLF_DEFAULT_VARIANT;
+  if (const char* ev = getenv("SLF_VARIANT")) g.variant = atoi(ev);
   slf::Physics& ph = m->phys;
   ph.tau = d->tau;
   ph.visc = d->visc;

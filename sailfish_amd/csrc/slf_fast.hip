@@ -1,0 +1,318 @@
+// Tuned sweep kernels for the north-star configuration: D3Q19, single
+// precision, fluid-only subdomain (no node map), x wrapped inside the sweep.
+// Same arithmetic (slf_node.h) and same memory layout as the general kernels in
+// slf_kernels.hip -- results are bit-identical; only the access shape differs.
+//
+// Geometry.variant bits (SLF_VARIANT):
+//   1   non-temporal loads / stores for the populations (streamed once per step)
+//   2,4 even AA step processes 2 / 4 consecutive x nodes per thread with 8 / 16-byte accesses
+//       (the even step touches only the node's own slots -> every access is aligned)
+//   8   x-streaming steps (odd AA, AB) use the whole-row kernel with aligned accesses
+#include "slf_sweep.h"
+
+namespace slf {
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef float2v type; };
+template <> struct VecT<4> { typedef float4v type; };
+
+// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores
+template <int NT, class T>
+__device__ __forceinline__ T ld(const T* p) {
+  if constexpr (NT & 1) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int NT, class T>
+__device__ __forceinline__ void st(T* p, T v) {
+  if constexpr (NT & 2) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <int VEC>
+__device__ __forceinline__ float vget(const typename VecT<VEC>::type& v, int k) {
+  if constexpr (VEC == 1) return v;
+  else return v[k];
+}
+template <int VEC>
+__device__ __forceinline__ void vset(typename VecT<VEC>::type& v, int k, float x) {
+  if constexpr (VEC == 1) v = x;
+  else v[k] = x;
+}
+
+// Even AA step (own node, opposite slot), VEC nodes per thread.
+template <int MODEL, int VEC, int NT>
+__global__ void __launch_bounds__(1024) fast_even_kernel(const SweepParams<D3Q19, float> p) {
+  using L = D3Q19;
+  typedef typename VecT<VEC>::type V;
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = p.z0 + (int)blockIdx.z;
+  const int gx0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (gx0 > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx0 + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const size_t ds = g.dist_size;
+  V fv[L::Q];
+  static_for<0, L::Q>([&](auto I) { fv[I] = ld<NT>((const V*)(p.din + ds * (size_t)I + gi)); });
+  V orho, ovx, ovy, ovz;
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    float f[L::Q];
+    static_for<0, L::Q>([&](auto I) { f[I] = vget<VEC>(fv[I], k); });
+    float rho, v[3];
+    macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
+    if (p.relaxation_enabled) {
+      if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
+      else mrt_relax<L, float>(f, v, p.cp, false);
+    }
+    static_for<0, L::Q>([&](auto I) { vset<VEC>(fv[I], k, f[I]); });
+    vset<VEC>(orho, k, rho);
+    vset<VEC>(ovx, k, v[0]);
+    vset<VEC>(ovy, k, v[1]);
+    vset<VEC>(ovz, k, v[2]);
+  }
+  if (p.options & 1u) {
+    // ghost / padding nodes of the group receive garbage in fields nobody reads (x is wrapped in-sweep)
+    *(V*)(p.rho + gi) = orho;
+    *(V*)(p.vx + gi) = ovx;
+    *(V*)(p.vy + gi) = ovy;
+    *(V*)(p.vz + gi) = ovz;
+  }
+  static_for<0, L::Q>([&](auto I) { st<NT>((V*)(p.dout + ds * (size_t)L::opp(I) + gi), fv[I]); });
+}
+
+// One node per thread, any propagation mode (scalar accesses), optional non-temporal hint.
+template <int MODEL, int PROP, int NT>
+__global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q19, float> p) {
+  using L = D3Q19;
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = p.z0 + (int)blockIdx.z;
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx < 1 || gx > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]);
+  const size_t ds = g.dist_size;
+  float f[L::Q];
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_ODD) {
+      const int off = dir_offset<L, I>(ox, oy, oz, false);
+      f[I] = ld<NT>(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gi + off));
+    } else {
+      f[I] = ld<NT>(p.din + ds * (size_t)I + gi);
+    }
+  });
+  float rho, v[3];
+  macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
+  if (p.relaxation_enabled) {
+    if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
+    else mrt_relax<L, float>(f, v, p.cp, false);
+  }
+  if (p.options & 1u) {
+    p.rho[gi] = rho;
+    p.vx[gi] = v[0];
+    p.vy[gi] = v[1];
+    p.vz[gi] = v[2];
+  }
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_EVEN) {
+      st<NT>(p.dout + ds * (size_t)L::opp(I) + gi, f[I]);
+    } else {
+      const int off = dir_offset<L, I>(ox, oy, oz, true);
+      st<NT>(p.dout + ds * (size_t)I + (uint32_t)((int)gi + off), f[I]);
+    }
+  });
+}
+
+
+// Whole-row workgroup, aligned global accesses for the steps that stream along x
+// (odd AA step: pull + push; AB: push).  Every population row segment is loaded
+// and stored at the thread's own x (one aligned 256-byte request per wave and
+// direction); the +-1 x shift happens in registers (cross-lane shuffle inside a
+// wave, a few LDS words between the waves of the row, the periodic wrap through
+// the two mirror lanes x = 0 and x = nx + 1).  This is the MI355X counterpart of
+// the reference's shuffle / shared-memory propagation (propagation.mako:180-382).
+// Requires blockDim.x >= lat_nx (the row fits one workgroup) and x wrapped in-sweep.
+template <int MODEL, int PROP, int NT>
+__global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19, float> p) {
+  using L = D3Q19;
+  constexpr int NW = 16;
+  __shared__ float s_in_p[NW][5], s_in_m[NW][5], s_out_p[NW][5], s_out_m[NW][5], s_wrap_p[5], s_wrap_m[5];
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = p.z0 + (int)blockIdx.z;
+  const int x = (int)threadIdx.x;
+  const int nx = g.lat_nx - 2;
+  const int lane = x & 63, w = x >> 6;
+  const bool live = (x >= 1 && x <= nx);
+  int xs = x;
+  if (x == 0) xs = nx;
+  else if (x == nx + 1) xs = 1;
+  else if (x > nx + 1) xs = nx + 1;  // idle lanes: any in-row address
+  const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const uint32_t gi = row + (uint32_t)(x <= nx + 1 ? x : nx + 1);
+  const uint32_t gis = row + (uint32_t)xs;
+  const AxisOff ox0 = {0, 0};
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]);
+  const size_t ds = g.dist_size;
+
+  float f[L::Q];
+  if constexpr (PROP == PROP_AA_ODD) {
+    // raw_i(x) = slot opp(i) at (x, y - e_y, z - e_z): the value node x + e_x will use as f_i
+    static_for<0, L::Q>([&](auto I) {
+      const int off = dir_offset<L, I>(ox0, oy, oz, false);
+      f[I] = ld<NT>(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gis + off));
+    });
+    {
+      int kp = 0, km = 0;
+      static_for<1, L::Q>([&](auto I) {
+        if constexpr (L::ex(I) > 0) { if (lane == 63) s_in_p[w][kp] = f[I]; kp++; }
+        if constexpr (L::ex(I) < 0) { if (lane == 0) s_in_m[w][km] = f[I]; km++; }
+      });
+    }
+    __syncthreads();
+    {
+      int kp = 0, km = 0;
+      static_for<1, L::Q>([&](auto I) {
+        if constexpr (L::ex(I) > 0) {
+          float t = __shfl_up(f[I], 1);
+          if (lane == 0 && w > 0) t = s_in_p[w - 1][kp];
+          f[I] = t;
+          kp++;
+        }
+        if constexpr (L::ex(I) < 0) {
+          float t = __shfl_down(f[I], 1);
+          if (lane == 63) t = s_in_m[(w + 1) & (NW - 1)][km];
+          f[I] = t;
+          km++;
+        }
+      });
+    }
+  } else {
+    static_for<0, L::Q>([&](auto I) { f[I] = ld<NT>(p.din + ds * (size_t)I + gi); });
+  }
+
+  float rho, v[3];
+  macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
+  if (p.relaxation_enabled) {
+    if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
+    else mrt_relax<L, float>(f, v, p.cp, false);
+  }
+  if ((p.options & 1u) && live) {
+    p.rho[gi] = rho;
+    p.vx[gi] = v[0];
+    p.vy[gi] = v[1];
+    p.vz[gi] = v[2];
+  }
+
+  // push: the value of node x travels to x + e_x; it is stored by the thread that owns the target x
+  {
+    int kp = 0, km = 0;
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) > 0) {
+        if (lane == 63) s_out_p[w][kp] = f[I];
+        if (x == nx) s_wrap_p[kp] = f[I];
+        kp++;
+      }
+      if constexpr (L::ex(I) < 0) {
+        if (lane == 0) s_out_m[w][km] = f[I];
+        if (x == 1) s_wrap_m[km] = f[I];
+        km++;
+      }
+    });
+  }
+  __syncthreads();
+  {
+    int kp = 0, km = 0;
+    static_for<0, L::Q>([&](auto I) {
+      float t = f[I];
+      if constexpr (L::ex(I) > 0) {
+        t = __shfl_up(f[I], 1);
+        if (lane == 0 && w > 0) t = s_out_p[w - 1][kp];
+        if (x == 1) t = s_wrap_p[kp];
+        kp++;
+      }
+      if constexpr (L::ex(I) < 0) {
+        t = __shfl_down(f[I], 1);
+        if (lane == 63) t = s_out_m[(w + 1) & (NW - 1)][km];
+        if (x == nx) t = s_wrap_m[km];
+        km++;
+      }
+      if (live) {
+        const int off = dir_offset<L, I>(ox0, oy, oz, true);
+        st<NT>(p.dout + ds * (size_t)I + (uint32_t)((int)gi + off), t);
+      }
+    });
+  }
+}
+
+template <int MODEL, int NT>
+static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19, float>& p, int ny, int nz,
+                           int block_x, hipStream_t s) {
+  const int variant = g.variant;
+  const int vec = (variant & 4) ? 4 : ((variant & 2) ? 2 : 1);
+  if (prop == PROP_AA_EVEN && vec > 1) {
+    const int threads_needed = (g.lat_nx + vec - 1) / vec;
+    int bx = ((threads_needed + 63) / 64) * 64;
+    if (bx > block_x) bx = block_x;
+    dim3 block(bx, 1, 1);
+    dim3 grid((threads_needed + bx - 1) / bx, ny, nz);
+    if (vec == 4) hipLaunchKernelGGL((fast_even_kernel<MODEL, 4, NT>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, NT>), grid, block, 0, s, p);
+    return true;
+  }
+  if ((variant & 8) && prop != PROP_AA_EVEN) {
+    const int bx = ((g.lat_nx + 63) / 64) * 64;
+    if (bx <= 1024) {
+      dim3 block(bx, 1, 1);
+      dim3 grid(1, ny, nz);
+      if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT>), grid, block, 0, s, p);
+      return true;
+    }
+  }
+  if (NT == 0) return false;  // plain scalar: the general kernel already does that
+  dim3 block(block_x, 1, 1);
+  dim3 grid((g.lat_nx + block_x - 1) / block_x, ny, nz);
+  switch (prop) {
+    case PROP_AB: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AB, NT>), grid, block, 0, s, p); break;
+    case PROP_AA_EVEN: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_EVEN, NT>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_ODD, NT>), grid, block, 0, s, p); break;
+  }
+  return true;
+}
+
+template <int MODEL>
+static bool launch_fast_model(Prop prop, const Geometry& g, const SweepParams<D3Q19, float>& p, int ny, int nz,
+                              int block_x, hipStream_t s) {
+  // bit 1: NT loads + stores; bit 16: NT loads only; bit 32: NT stores only
+  int nt = 0;
+  if (g.variant & 1) nt = 3;
+  if (g.variant & 16) nt |= 1;
+  if (g.variant & 32) nt |= 2;
+  switch (nt) {
+    case 0: return launch_fast_nt<MODEL, 0>(prop, g, p, ny, nz, block_x, s);
+    case 1: return launch_fast_nt<MODEL, 1>(prop, g, p, ny, nz, block_x, s);
+    case 2: return launch_fast_nt<MODEL, 2>(prop, g, p, ny, nz, block_x, s);
+    default: return launch_fast_nt<MODEL, 3>(prop, g, p, ny, nz, block_x, s);
+  }
+}
+
+bool launch_sweep_fast(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const SweepArgs& a,
+                       int y0, int y1, int z0, int z1, int block_x, hipStream_t s, hipError_t* err) {
+  if (sel.general || sel.lattice != 1 || sel.precision != 4 || !g.wrap[0] || g.variant == 0) return false;
+  if (y1 <= y0 || z1 <= z0) return false;
+  const SweepParams<D3Q19, float> p = make_params<D3Q19, float>(g, ph, a, y0, z0);
+  bool done = sel.model == 0 ? launch_fast_model<0>(prop, g, p, y1 - y0, z1 - z0, block_x, s)
+                             : launch_fast_model<1>(prop, g, p, y1 - y0, z1 - z0, block_x, s);
+  if (done) *err = hipGetLastError();
+  return done;
+}
+
+}  // namespace slf

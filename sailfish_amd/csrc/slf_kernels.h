@@ -14,7 +14,7 @@ struct Geometry {
   int lat_nx, lat_ny, lat_nz;  // incl. ghosts (lat_nz == 1 in 2-D)
   int arr_nx, arr_ny, arr_nz;
   int arr_nxy;                 // arr_nx * arr_ny
-  uint32_t dist_size;          // arr_nx * arr_ny * arr_nz
+  uint32_t dist_size;          // stride between direction arrays (>= arr_nx * arr_ny * arr_nz)
   int wrap[3];                 // in-kernel periodic wrap per axis
   // node code decoding
   uint32_t type_mask;
@@ -23,6 +23,7 @@ struct Geometry {
   uint32_t orient_shift;
   unsigned long long type_lut; // 4 bits per dense type id -> NodeKind
   int use_link_tags;
+  int variant;                 // tuned-kernel selection bits (SLF_VARIANT), see slf_fast.hip
 };
 
 struct Physics {

@@ -17,52 +17,9 @@
 // (reference propagation.mako:170-174, 384-421; geo_helpers.mako:248-276).
 #include "slf_kernels.h"
 #include "slf_node.h"
+#include "slf_sweep.h"
 
 namespace slf {
-
-template <class L, class R>
-struct SweepParams {
-  const uint32_t* __restrict__ map;
-  const R* din;
-  R* dout;
-  R* rho;
-  R* vx;
-  R* vy;
-  R* vz;
-  const R* __restrict__ node_params;
-  uint32_t options;
-  int y0, z0;
-  int relaxation_enabled;
-  Geometry g;
-  CollideParams<L, R> cp;
-};
-
-// Offsets (in elements) to the +-1 neighbours along each axis, with the
-// optional in-kernel periodic wrap.  Real nodes are 1 .. lat-2.
-struct AxisOff {
-  int p, m;
-};
-__device__ __forceinline__ AxisOff axis_off(int c, int lat, int stride, int wrap) {
-  AxisOff o;
-  o.p = stride;
-  o.m = -stride;
-  if (wrap) {
-    if (c == lat - 2) o.p = -(lat - 3) * stride;
-    if (c == 1) o.m = (lat - 3) * stride;
-  }
-  return o;
-}
-
-template <class L, int I>
-__device__ __forceinline__ int dir_offset(const AxisOff& ox, const AxisOff& oy, const AxisOff& oz, bool forward) {
-  // forward: offset of x + e_i ; !forward: offset of x - e_i
-  int off = 0;
-  constexpr int ex = L::ex(I), ey = L::ey(I), ez = L::ez(I);
-  if constexpr (ex != 0) off += ((ex > 0) == forward) ? ox.p : ox.m;
-  if constexpr (ey != 0) off += ((ey > 0) == forward) ? oy.p : oy.m;
-  if constexpr (ez != 0) off += ((ez > 0) == forward) ? oz.p : oz.m;
-  return off;
-}
 
 template <class L, class R, int MODEL, int PROP, bool GENERAL>
 __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) {
@@ -365,31 +322,6 @@ __global__ void __launch_bounds__(1024) macro_kernel(const SweepParams<L, R> p) 
 // host-side dispatch
 // ---------------------------------------------------------------------------
 
-template <class L, class R>
-static SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const SweepArgs& a, int y0, int z0) {
-  SweepParams<L, R> p;
-  p.map = (const uint32_t*)a.map;
-  p.din = (const R*)a.dist_in;
-  p.dout = (R*)a.dist_out;
-  p.rho = (R*)a.rho;
-  p.vx = (R*)a.v[0];
-  p.vy = (R*)a.v[1];
-  p.vz = (R*)a.v[2];
-  p.node_params = (const R*)a.node_params;
-  p.options = a.options;
-  p.y0 = y0;
-  p.z0 = z0;
-  p.relaxation_enabled = ph.relaxation_enabled;
-  p.g = g;
-  p.cp.omega = (R)(1.0 / ph.tau);
-  for (int k = 0; k < L::Q; k++) p.cp.mrt_s[k] = (R)ph.mrt_rates[k];
-  for (int d = 0; d < 3; d++) p.cp.accel[d] = (R)ph.accel[d];
-  p.cp.guo_pref = (R)(3.0 * (1.0 - 0.5 / ph.tau));
-  p.cp.incompressible = ph.incompressible;
-  p.cp.has_force = ph.has_force;
-  return p;
-}
-
 template <class L, class R, int MODEL, int PROP>
 static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& ph, const SweepArgs& a, int y0, int y1,
                                 int z0, int z1, int block_x, hipStream_t s) {
@@ -432,6 +364,10 @@ static hipError_t launch_sweep2(int model, Prop prop, bool general, const Geomet
 
 hipError_t launch_sweep(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
                         const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s) {
+  {
+    hipError_t fe = hipSuccess;
+    if (launch_sweep_fast(sel, prop, g, ph, a, y0, y1, z0, z1, block_x, s, &fe)) return fe;
+  }
   SLF_DISPATCH_LR(sel, return (launch_sweep2<L, R>(sel.model, prop, sel.general, g, ph, a, y0, y1, z0, z1, block_x, s)));
   return hipErrorInvalidValue;
 }

@@ -41,7 +41,13 @@ class SlfModuleDesc(Structure):
         ('use_link_tags', c_int32),
         ('n_node_params', c_int32),
         ('node_params', POINTER(c_double)),
+        ('dist_stride', ctypes.c_uint64),
     ]
+
+
+def dist_stride(desc):
+    """Elements between consecutive direction arrays of a distribution buffer."""
+    return int(desc.dist_stride) or desc.arr_nx * desc.arr_ny * desc.arr_nz
 
 
 class SlfRegion(Structure):

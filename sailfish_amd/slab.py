@@ -19,7 +19,7 @@ SURVEY.md):
 """
 import numpy as np
 
-from sailfish_amd import sym
+from sailfish_amd import hipabi, sym
 from sailfish_amd.box import BoxSim, make_box_desc
 
 
@@ -29,7 +29,7 @@ class SlabPlan(object):
     def __init__(self, grid, desc):
         self.grid, self.desc = grid, desc
         self.nx, self.ny, self.nz = desc.lat_nx - 2, desc.lat_ny - 2, desc.lat_nz - 2
-        self.dist_size = desc.arr_nx * desc.arr_ny * desc.arr_nz
+        self.dist_size = hipabi.dist_stride(desc)
         self.up_dists = sym.get_prop_dists(grid, 1, 2)      # e_z = +1
         self.down_dists = sym.get_prop_dists(grid, -1, 2)   # e_z = -1
         self.count = len(self.up_dists) * self.nx * self.ny
