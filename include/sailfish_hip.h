@@ -94,6 +94,10 @@ typedef struct slf_module_desc {
   uint64_t dist_stride;        /* elements between consecutive direction arrays; 0 = arr_nx*arr_ny*arr_nz (the
                                   reference's DIST_SIZE, kernel_common.mako:506).  A larger stride only inserts
                                   unused padding between the Q arrays (HBM channel de-aliasing). */
+  int32_t periodic_local[3];   /* 1: the subdomain spans this (globally periodic) axis, i.e. it is its own periodic
+                                  neighbour there (SubdomainSpec.enable_local_periodicity, subdomain.py:122-127);
+                                  0: the faces of this axis are walls / open / connected to other subdomains */
+  int32_t reserved0;
 } slf_module_desc;
 
 /* Region of the lattice a sweep launch covers (replaces the reference's

@@ -295,6 +295,12 @@ class HIPBackend(object):
                                                         int(nbytes), stream.handle if stream else None),
                'slf_memcpy_d2d_async')
 
+    def copy_peer_async(self, dst, dst_device, src, src_device, nbytes, stream=None):
+        _check(self._lib, self._lib.slf_memcpy_peer_async(self._ctx, ctypes.c_void_p(dst), int(dst_device),
+                                                         ctypes.c_void_p(src), int(src_device), int(nbytes),
+                                                         stream.handle if stream else None),
+               'slf_memcpy_peer_async')
+
     def memset_buf(self, buf, value, nbytes, stream=None):
         _check(self._lib, self._lib.slf_memset(self._ctx, ctypes.c_void_p(buf), int(value), int(nbytes),
                                               stream.handle if stream else None), 'slf_memset')

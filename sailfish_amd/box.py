@@ -69,6 +69,8 @@ class BoxSim(object):
         # axes that need ghost-layer PBC kernels = periodic and not wrapped by the sweep
         self.pbc_axes = [a for a in range(self.dim) if periodic[a] and not desc.periodic_fused[a]]
         self.iteration = 0
+        for a in range(self.dim):
+            desc.periodic_local[a] = int(bool(periodic[a]))
         b = backend
         self.stride = hipabi.dist_stride(desc)
         fbytes = self.stride * self.dtype().itemsize

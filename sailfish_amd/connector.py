@@ -61,3 +61,60 @@ class RingExchanger(object):
         for r in reqs:
             r.wait()
         return reqs
+
+
+class LocalConnector(object):
+    """All subdomains live in this process (one or several GPUs): halos move with device-to-device
+    copies driven by the group driver (controller.LocalGroup); the reference's counterpart is
+    MPSubdomainConnector (connector.py:120-174), which stages through shared host memory."""
+
+    def alloc_buffer(self, runner, nelems, dtype):
+        import numpy as np
+        return runner.backend.alloc_buf(size=max(1, nelems) * np.dtype(dtype).itemsize)
+
+    def exchange(self, runner):
+        raise RuntimeError('LocalConnector exchanges are driven by controller.LocalGroup')
+
+
+class TorchDistConnector(object):
+    """Neighbours live in other processes (one process per GPU): point-to-point send / receive of the
+    packed halo buffers with torch.distributed (RCCL over xGMI for CUDA tensors, gloo for CPU tensors in
+    the tests).  Replaces ZMQSubdomainConnector (reference connector.py:73-117)."""
+
+    def __init__(self, id_to_rank, device=None):
+        self.id_to_rank = dict(id_to_rank)
+        self.device = device
+        self._tensors = {}
+        self._stream = None
+
+    def alloc_buffer(self, runner, nelems, dtype):
+        import numpy as np
+        import torch
+        tdtype = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        dev = self.device if self.device is not None else torch.device('cuda', runner.backend.gpu_id)
+        t = torch.empty(max(1, nelems), dtype=tdtype, device=dev)
+        self._tensors[t.data_ptr()] = t
+        return t.data_ptr()
+
+    def tensor(self, ptr):
+        return self._tensors[ptr]
+
+    def exchange(self, runner):
+        import torch
+        import torch.distributed as dist
+        ops = []
+        for nid in sorted(runner._links):
+            link = runner._links[nid]
+            n_send, n_recv = runner.halo_counts(nid)
+            peer = self.id_to_rank[nid]
+            if n_send:
+                ops.append(dist.P2POp(dist.isend, self.tensor(link.send_buf)[:n_send], peer))
+            if n_recv:
+                ops.append(dist.P2POp(dist.irecv, self.tensor(link.recv_buf)[:n_recv], peer))
+        if not ops:
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.ExternalStream(runner._data_stream.native)
+        with torch.cuda.stream(self._stream):
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()

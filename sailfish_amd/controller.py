@@ -1,0 +1,296 @@
+"""Simulation controller (reference sailfish/controller.py): option surface,
+domain decomposition, process / GPU mapping and the run loop.
+
+Process model (MI355X-first, one node):
+  * default: this process drives every subdomain; subdomain i runs on GPU
+    gpus[i % len(gpus)] (reference master.py:106-117 round-robin) and the group is
+    stepped in lock-step with device-to-device halo copies (LocalGroup).  With a
+    single subdomain this is the reference's --debug_single_process path.
+  * under ``python -m torch.distributed.run`` (WORLD_SIZE > 1): one process per
+    GPU, subdomain i is owned by rank i, halos travel over RCCL/xGMI
+    (connector.TorchDistConnector).  This replaces the reference's machine master
+    + zmq connectors (master.py, connector.py); cluster launch (PBS/LSF/execnet)
+    is out of scope.
+"""
+import logging
+import os
+import pickle
+import sys
+import time
+
+from sailfish_amd import config, io, subdomain_connection, util
+from sailfish_amd.connector import LocalConnector, TorchDistConnector, init_distributed
+from sailfish_amd.geo import LBGeometry2D, LBGeometry3D
+
+
+class GeometryError(Exception):
+    pass
+
+
+class LBGeometryProcessor(object):
+    """Assigns ids, finds face neighbours (incl. periodic images) and local periodicity
+    (reference controller.py:130-269)."""
+
+    def __init__(self, subdomains, dim, gsize):
+        self.subdomains = subdomains
+        self.dim = dim
+        self.gsize = gsize
+
+    def transform(self, config):
+        for i, s in enumerate(self.subdomains):
+            s.id = i
+        periodic = [config.periodic_x, config.periodic_y]
+        if self.dim == 3:
+            periodic.append(config.periodic_z)
+        subdomain_connection.connect_subdomains(self.subdomains, self.gsize, periodic)
+        if len(self.subdomains) > 1:
+            for s in self.subdomains:
+                if not s.neighbour_ids():
+                    raise GeometryError('Not all subdomains are connected.')
+        return self.subdomains
+
+
+class LocalGroup(object):
+    """Lock-step driver for runners that live in this process."""
+
+    def __init__(self, runners):
+        self.runners = runners
+        self.by_id = dict((r._spec.id, r) for r in runners)
+
+    def exchange(self):
+        """Copies every packed send buffer into the matching receive buffer of the neighbour."""
+        events = {}
+        for r in self.runners:
+            if r._links:
+                events[r._spec.id] = r.backend.make_event(r._data_stream)
+        for r in self.runners:
+            for nid, link in r._links.items():
+                src = self.by_id[nid]
+                src_link = src._links[r._spec.id]
+                n_send, _ = src.halo_counts(r._spec.id)
+                _, n_recv = r.halo_counts(nid)
+                assert n_send == n_recv, 'halo size mismatch between subdomains %d and %d' % (nid, r._spec.id)
+                if n_recv == 0:
+                    continue
+                r._data_stream.wait_for_event(events[nid])
+                nbytes = n_recv * r.float().itemsize
+                if src.backend.gpu_id == r.backend.gpu_id:
+                    r.backend.copy_buf_async(link.recv_buf, src_link.send_buf, nbytes, r._data_stream)
+                else:
+                    r.backend.copy_peer_async(link.recv_buf, r.backend.gpu_id, src_link.send_buf,
+                                              src.backend.gpu_id, nbytes, r._data_stream)
+
+    def run(self):
+        runners = self.runners
+        for r in runners:
+            r.prepare()
+        cfg = runners[0].config
+        t_prev, it_prev = time.time(), runners[0]._sim.iteration
+        t0, it0 = t_prev, it_prev
+        while not any(r.need_quit() for r in runners):
+            reqs = [r.pre_step() for r in runners]
+            for r, (sync_req, fields_req, output_req) in zip(runners, reqs):
+                r.step_compute(fields_req)
+            if len(runners) > 1:
+                self.exchange()
+            for r in runners:
+                r.step_finish()
+            for r, (sync_req, fields_req, output_req) in zip(runners, reqs):
+                r.post_step(sync_req, output_req)
+            it = runners[0]._sim.iteration
+            if cfg.perf_stats_every > 0 and it % cfg.perf_stats_every == 0:
+                for r in runners:
+                    r.backend.sync_stream(r._calc_stream, r._data_stream)
+                now = time.time()
+                nodes = sum(r.num_fluid_nodes for r in runners)
+                cfg.logger.info('iteration:{0}  speed:{1:.2f} MLUPS'.format(
+                    it, nodes * (it - it_prev) / (now - t_prev) * 1e-6))
+                t_prev, it_prev = now, it
+        for r in runners:
+            r.finish()
+        wall = time.time() - t0
+        for r in runners:
+            r.timing = {'steps': r._sim.iteration - it0, 'wall': wall}
+
+
+class LBSimulationController(object):
+    """Controls the execution of a LB simulation (reference controller.py:272-830)."""
+
+    def __init__(self, lb_class, lb_geo=None, default_config=None):
+        self._config_parser = config.LBConfigParser()
+        self._lb_class = lb_class
+        if lb_geo is None:
+            lb_geo = LBGeometry2D if self.dim == 2 else LBGeometry3D
+        self._lb_geo = lb_geo
+
+        group = self._config_parser.add_group('Runtime mode settings')
+        group.add_argument('--mode', help='runtime mode', type=str, choices=['batch', 'benchmark'],
+                           default='batch')
+        group.add_argument('--every', help='save simulation results every N iterations', metavar='N', type=int,
+                           default=100)
+        group.add_argument('--from', dest='from_', help='save simulation results from N iterations', metavar='N',
+                           type=int, default=0)
+        group.add_argument('--perf_stats_every', help='how often to display performance stats', metavar='N',
+                           type=int, default=1000)
+        group.add_argument('--max_iters', help='number of iterations to run; use 0 to run indefinitely',
+                           type=int, default=0)
+        group.add_argument('--output', help='save simulation results to FILE', metavar='FILE', type=str,
+                           default='')
+        group.add_argument('--output_format', help='output format', type=str,
+                           choices=list(io.format_name_to_cls.keys()), default='npy')
+        group.add_argument('--nooutput_compress', dest='output_compress', action='store_false', default=True,
+                           help='store uncompressed .npz files')
+        group.add_argument('--backends', type=str, default='hip',
+                           help='computational backends to use (only "hip" exists)')
+        group.add_argument('--gpus', nargs='+', default=0, type=int, help='which GPUs to use')
+        group.add_argument('--debug_dump_dists', action='store_true', default=False,
+                           help='dump the contents of the distribution arrays to files')
+        group.add_argument('--debug_single_process', action='store_true', default=False,
+                           help='(accepted for compatibility: a single process is the default here)')
+        group.add_argument('--debug_dump_node_type_map', action='store_true', default=False,
+                           help='dump the node type map into a file')
+        group.add_argument('--base_name', type=str, default='',
+                           help='base file name for logging, checkpoint and data output')
+        group.add_argument('--log', type=str, default='', help='name of the file to which data is to be logged')
+        group.add_argument('--loglevel', type=int, default=logging.INFO, help='minimum log level for the file logger')
+        group.add_argument('--nobulk_boundary_split', dest='bulk_boundary_split', action='store_false',
+                           default=True, help='Disable separate handling of bulk and boundary nodes')
+        group.add_argument('--nocheck_invalid_results_host', action='store_false',
+                           dest='check_invalid_results_host', default=True,
+                           help='do not terminate when the host-side results contain inf / nan')
+        group.add_argument('--nocheck_invalid_results_gpu', action='store_false',
+                           dest='check_invalid_results_gpu', default=True, help='(accepted for compatibility)')
+        group.add_argument('--seed', type=int, default=int(time.time()), help='PRNG seed value')
+
+        group = self._config_parser.add_group('Checkpointing')
+        group.add_argument('--checkpoint_file', type=str, help='Location of the checkpoint file.', metavar='PATH',
+                           default='')
+        group.add_argument('--single_checkpoint', action='store_true', default=False)
+        group.add_argument('--restore_from', type=str, metavar='PATH', default='',
+                           help='Location of a checkpoint file from which to start the simulation.')
+        group.add_argument('--norestore_time', action='store_false', dest='restore_time', default=True)
+        group.add_argument('--final_checkpoint', action='store_true', default=False,
+                           help='Generates a checkpoint after the simulation is completed.')
+        group.add_argument('--checkpoint_every', type=int, default=0, metavar='N',
+                           help='Generates a checkpoint every N steps.')
+        group.add_argument('--checkpoint_from', type=int, default=0, metavar='N')
+
+        group = self._config_parser.add_group('Benchmarking')
+        group.add_argument('--benchmark_sample_from', type=int, default=1000, metavar='N')
+        group.add_argument('--benchmark_minibatch', type=int, default=50)
+
+        group = self._config_parser.add_group('Simulation-specific settings')
+        for base in lb_class.mro():
+            if 'add_options' in base.__dict__:
+                base.add_options(group, self.dim)
+
+        group = self._config_parser.add_group('Geometry settings')
+        lb_geo.add_options(group)
+
+        group = self._config_parser.add_group('Code generator options')
+        group.add_argument('--precision', type=str, choices=['single', 'double'], default='single',
+                           help='precision (single, double)')
+        group.add_argument('--block_size', type=int, default=64,
+                           help='(accepted for compatibility; the HIP kernels choose the workgroup shape)')
+        group.add_argument('--mem_alignment', type=int, default=32,
+                           help='number of nodes to which the X dimension of the lattice is padded in memory')
+        group.add_argument('--save_src', type=str, default='', help='(unused: kernels are pre-built)')
+        group.add_argument('--use_src', type=str, default='', help='(unused: kernels are pre-built)')
+
+        for backend in util.get_backends():
+            group = self._config_parser.add_group("'{0}' backend options".format(backend.name))
+            backend.add_options(group)
+
+        defaults = {}
+        lb_class.update_defaults(defaults)
+        self._config_parser.set_defaults(defaults)
+        if default_config is not None:
+            self._config_parser.set_defaults(default_config)
+        self.runners = []
+
+    @property
+    def dim(self):
+        return self._lb_class.subdomain.dim
+
+    def _init_subdomain_envelope(self, sim, subdomains):
+        """Ghost envelope of 1 node (reference controller.py:482-494; nonlocality 0 models)."""
+        envelope_size = max(1, getattr(sim, 'nonlocality', 0))
+        for s in subdomains:
+            s.set_actual_size(envelope_size)
+
+    def save_subdomain_config(self, subdomains):
+        if self.config.output:
+            with open(io.subdomains_filename(self.config.output), 'wb') as f:
+                pickle.dump([(s.location, s.size, s.id) for s in subdomains], f)
+
+    def run(self, ignore_cmdline=False):
+        """Parses options, builds the subdomains and runs the simulation.  Returns self (the runners are
+        available as .runners, the parsed options as .config)."""
+        args = sys.argv[1:] if not ignore_cmdline else []
+        self.config = self._config_parser.parse(args)
+        cfg = self.config
+        self._lb_class.modify_config(cfg)
+        if cfg.base_name:
+            cfg.output = cfg.output or cfg.base_name
+            cfg.checkpoint_file = cfg.checkpoint_file or cfg.base_name
+            cfg.log = cfg.log or (cfg.base_name + '.log')
+        cfg.logger = util.setup_logger(cfg)
+        if cfg.mode == 'benchmark':
+            cfg.output = ''
+
+        geo = self._lb_geo(cfg)
+        subdomains = geo.subdomains()
+        assert subdomains is not None, 'Make sure the subdomain list is returned in geo_class.subdomains()'
+        assert len(subdomains) > 0
+        sim0 = self._lb_class(cfg)
+        self._init_subdomain_envelope(sim0, subdomains)
+        proc = LBGeometryProcessor(subdomains, self.dim, geo.gsize)
+        subdomains = proc.transform(cfg)
+        periodic = [cfg.periodic_x, cfg.periodic_y] + ([cfg.periodic_z] if self.dim == 3 else [])
+        self.save_subdomain_config(subdomains)
+
+        backend_cls = None
+        for b in util.get_backends(cfg.backends.split(',')):
+            backend_cls = b
+            break
+        if backend_cls is None:
+            raise RuntimeError('no usable backend among: %s' % cfg.backends)
+
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        gpus = cfg.gpus if isinstance(cfg.gpus, (list, tuple)) else [cfg.gpus]
+        output_cls = io.format_name_to_cls[cfg.output_format]
+
+        def make_runner(spec, gpu, connector):
+            sim = self._lb_class(cfg)
+            backend = backend_cls(cfg, gpu)
+            output = output_cls(cfg, spec.id)
+            runner_cls = sim.subdomain_runner
+            runner = runner_cls(sim, spec, output, backend, None)
+            runner.set_topology(subdomains, geo.gsize, periodic)
+            runner._connector = connector
+            return runner
+
+        t0 = time.time()
+        if world > 1:
+            rank, world = init_distributed()
+            if len(subdomains) != world:
+                raise GeometryError('torch.distributed run: need exactly one subdomain per rank '
+                                    '(%d subdomains, %d ranks)' % (len(subdomains), world))
+            local_rank = int(os.environ.get('LOCAL_RANK', rank))
+            connector = TorchDistConnector(dict((s.id, s.id) for s in subdomains))
+            runner = make_runner(subdomains[rank], local_rank, connector)
+            self.runners = [runner]
+            runner.run()
+        else:
+            connector = LocalConnector()
+            self.runners = [make_runner(s, gpus[i % len(gpus)], connector) for i, s in enumerate(subdomains)]
+            LocalGroup(self.runners).run()
+        wall = time.time() - t0
+        if cfg.mode == 'benchmark':
+            steps = self.runners[0].timing['steps']
+            nodes = sum(r.num_fluid_nodes for r in self.runners)
+            run_wall = self.runners[0].timing['wall']
+            if steps and run_wall > 0:
+                cfg.logger.info('Total MLUPS: eff:{0:.2f}  (wall incl. setup {1:.2f} s)'.format(
+                    nodes * steps / run_wall * 1e-6, wall))
+        return self

@@ -312,7 +312,10 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   g.arr_nxy = d->arr_nx * d->arr_ny;
   g.dist_size = (uint32_t)(d->dist_stride ? d->dist_stride : total);
   if (g.dist_size < total) { delete m; return fail(SLF_ERR_INVALID, "dist_stride smaller than the subdomain"); }
-  for (int i = 0; i < 3; i++) g.wrap[i] = (i < dim) ? (d->periodic_fused[i] != 0) : 0;
+  for (int i = 0; i < 3; i++) {
+    g.wrap[i] = (i < dim) ? (d->periodic_fused[i] != 0) : 0;
+    g.axis_mode[i] = g.wrap[i] ? 2 : ((i < dim && d->periodic_local[i]) ? 1 : 0);
+  }
   g.type_mask = d->nt_type_mask;
   g.param_shift = d->nt_misc_shift;
   g.param_mask = (1u << d->nt_param_shift) - 1u;

@@ -16,6 +16,7 @@ struct Geometry {
   int arr_nxy;                 // arr_nx * arr_ny
   uint32_t dist_size;          // stride between direction arrays (>= arr_nx * arr_ny * arr_nz)
   int wrap[3];                 // in-kernel periodic wrap per axis
+  int axis_mode[3];            // 0: not locally periodic, 1: ghost-layer PBC kernels, 2: wrapped in-sweep
   // node code decoding
   uint32_t type_mask;
   uint32_t param_shift;        // = bits of the type field

@@ -169,21 +169,30 @@ __global__ void __launch_bounds__(256) init_kernel(R* dist, const R* __restrict_
 __device__ __forceinline__ bool slf_isfinite(float x) { return __builtin_isfinite(x); }
 __device__ __forceinline__ bool slf_isfinite(double x) { return __builtin_isfinite(x); }
 
-// Can a pushed population with component e along another axis sit at coordinate
-// c of that axis?  Axes handled earlier (x before y before z) already hold their
-// wrapped copies on real nodes; later axes are still "as pushed from a real node".
-__device__ __forceinline__ bool pbc_push_ok(int c, int e, int lat, bool processed) {
-  if (processed) return c >= 1 && c <= lat - 2;
-  if (e > 0) return c >= 2;
-  if (e < 0) return c <= lat - 3;
-  return c >= 1 && c <= lat - 2;
+// Which face nodes take part in the PBC copy of `axis`, judged along another axis b
+// (coordinate c, population component e, mode of b: 0 not locally periodic, 1 ghost-layer
+// PBC, 2 wrapped in-sweep; `earlier` = b is handled before `axis` in the x, y, z order).
+//
+// After a push step a ghost slot holds data only if it was pushed from a real node:
+// e = +1 -> c >= 2, e = -1 -> c <= lat-3.  Along a PBC axis handled earlier the wrapped
+// copies already sit on real nodes; along a later PBC axis the ghost rows still hold the
+// edge populations (they are moved on by that axis' kernel).  Ghost rows of axes that are
+// not locally periodic belong to walls or to other subdomains (halo exchange) and never
+// take part; along an in-sweep wrapped axis there are no ghost rows at all.
+__device__ __forceinline__ bool pbc_push_ok(int c, int e, int lat, int mode, bool earlier) {
+  const bool real = c >= 1 && c <= lat - 2;
+  if (mode == 2) return real;
+  if (mode == 1 && earlier) return real;
+  const bool pushed = (e > 0) ? c >= 2 : ((e < 0) ? c <= lat - 3 : real);
+  if (mode == 1) return pushed;
+  return real && pushed;
 }
 
-// Swap variant: axes handled earlier take part with their (already filled) ghost
-// columns as long as the node that will pull the value (at c + e) is real; later
-// axes contribute their real range only.
-__device__ __forceinline__ bool pbc_pull_ok(int c, int e, int lat, bool processed) {
-  if (processed) return c + e >= 1 && c + e <= lat - 2;
+// Swap variant (ghost <- opposite real layer, for the pull of the next step): along a PBC
+// axis handled earlier the already filled ghost columns take part when the pulling node
+// (at c + e) is real; everything else contributes its real range only.
+__device__ __forceinline__ bool pbc_pull_ok(int c, int e, int lat, int mode, bool earlier) {
+  if (mode == 1 && earlier) return c + e >= 1 && c + e <= lat - 2;
   return c >= 1 && c <= lat - 2;
 }
 
@@ -223,9 +232,9 @@ __global__ void __launch_bounds__(256) pbc_kernel(R* dist, Geometry g, int axis)
     const int eb = e[b_ax];
     const int ec = (L::dim == 3) ? e[c_ax] : 0;
     if constexpr (!SWAP) {
-      if (!pbc_push_ok(b, eb, lat[b_ax], b_ax < axis)) return;
+      if (!pbc_push_ok(b, eb, lat[b_ax], g.axis_mode[b_ax], b_ax < axis)) return;
       if (L::dim == 3) {
-        if (!pbc_push_ok(c, ec, lat[c_ax], c_ax < axis)) return;
+        if (!pbc_push_ok(c, ec, lat[c_ax], g.axis_mode[c_ax], c_ax < axis)) return;
       }
       // ea = -1: landed in the low ghost (0) -> high real (n-2); ea = +1: high ghost (n-1) -> low real (1)
       const uint32_t src = base + (uint32_t)((ea < 0 ? 0 : n - 1) * stride[axis]);
@@ -234,9 +243,9 @@ __global__ void __launch_bounds__(256) pbc_kernel(R* dist, Geometry g, int axis)
       const R val = d[src];
       if (slf_isfinite(val)) d[dst] = val;
     } else {
-      if (!pbc_pull_ok(b, eb, lat[b_ax], b_ax < axis)) return;
+      if (!pbc_pull_ok(b, eb, lat[b_ax], g.axis_mode[b_ax], b_ax < axis)) return;
       if (L::dim == 3) {
-        if (!pbc_pull_ok(c, ec, lat[c_ax], c_ax < axis)) return;
+        if (!pbc_pull_ok(c, ec, lat[c_ax], g.axis_mode[c_ax], c_ax < axis)) return;
       }
       // ea = +1: puller at 1 reads ghost 0 <- real n-2 ; ea = -1: puller at n-2 reads ghost n-1 <- real 1
       const uint32_t src = base + (uint32_t)((ea > 0 ? n - 2 : 1) * stride[axis]);

@@ -1,0 +1,81 @@
+"""Global geometry and its partition into subdomains (reference sailfish/geo.py)."""
+from sailfish_amd.subdomain import SubdomainSpec2D, SubdomainSpec3D
+
+
+class LBGeometry(object):
+    def __init__(self, config):
+        self.config = config
+        self.gx = config.lat_nx
+        self.gy = config.lat_ny
+        self.gsize = [self.gx, self.gy]
+
+
+class LBGeometry2D(LBGeometry):
+    @classmethod
+    def add_options(cls, group):
+        group.add_argument('--lat_nx', help='lattice width', type=int, default=0)
+        group.add_argument('--lat_ny', help='lattice height', type=int, default=0)
+        group.add_argument('--periodic_x', dest='periodic_x', action='store_true', default=False,
+                           help='make the lattice periodic in the X direction')
+        group.add_argument('--periodic_y', dest='periodic_y', action='store_true', default=False,
+                           help='make the lattice periodic in the Y direction')
+
+    def subdomains(self):
+        return [SubdomainSpec2D((0, 0), (self.config.lat_nx, self.config.lat_ny))]
+
+
+class LBGeometry3D(LBGeometry):
+    @classmethod
+    def add_options(cls, group):
+        LBGeometry2D.add_options(group)
+        group.add_argument('--lat_nz', help='lattice depth', type=int, default=0)
+        group.add_argument('--periodic_z', dest='periodic_z', action='store_true', default=False,
+                           help='make the lattice periodic in the Z direction')
+
+    def __init__(self, config):
+        LBGeometry.__init__(self, config)
+        self.gz = config.lat_nz
+        self.gsize = [self.gx, self.gy, self.gz]
+
+    def subdomains(self):
+        return [SubdomainSpec3D((0, 0, 0), (self.config.lat_nx, self.config.lat_ny, self.config.lat_nz))]
+
+
+def _split(total, parts):
+    """Equal pieces, remainder to the last one (reference geo.py:113-135)."""
+    base, rest = total // parts, total % parts
+    return [(i * base, base if i < parts - 1 else base + rest) for i in range(parts)]
+
+
+class EqualSubdomainsGeometry2D(LBGeometry2D):
+    """--subdomains equal pieces along --conn_axis."""
+
+    @classmethod
+    def add_options(cls, group):
+        LBGeometry2D.add_options(group)
+        group.add_argument('--subdomains', help='number of subdomains', type=int, default=1)
+        group.add_argument('--conn_axis', type=str, default='x', choices=['x', 'y'],
+                           help='axis along which the subdomains will be connected')
+
+    def subdomains(self):
+        s = self.config.subdomains
+        if self.config.conn_axis == 'x':
+            return [SubdomainSpec2D((o, 0), (n, self.gy)) for o, n in _split(self.gx, s)]
+        return [SubdomainSpec2D((0, o), (self.gx, n)) for o, n in _split(self.gy, s)]
+
+
+class EqualSubdomainsGeometry3D(LBGeometry3D):
+    @classmethod
+    def add_options(cls, group):
+        LBGeometry3D.add_options(group)
+        group.add_argument('--subdomains', help='number of subdomains', type=int, default=1)
+        group.add_argument('--conn_axis', type=str, default='x', choices=['x', 'y', 'z'],
+                           help='axis along which the subdomains will be connected')
+
+    def subdomains(self):
+        s = self.config.subdomains
+        if self.config.conn_axis == 'x':
+            return [SubdomainSpec3D((o, 0, 0), (n, self.gy, self.gz)) for o, n in _split(self.gx, s)]
+        elif self.config.conn_axis == 'y':
+            return [SubdomainSpec3D((0, o, 0), (self.gx, n, self.gz)) for o, n in _split(self.gy, s)]
+        return [SubdomainSpec3D((0, 0, o), (self.gx, self.gy, n)) for o, n in _split(self.gz, s)]

@@ -42,6 +42,8 @@ class SlfModuleDesc(Structure):
         ('n_node_params', c_int32),
         ('node_params', POINTER(c_double)),
         ('dist_stride', ctypes.c_uint64),
+        ('periodic_local', c_int32 * 3),
+        ('reserved0', c_int32),
     ]
 
 
@@ -132,7 +134,7 @@ def make_desc(**kw):
     d.arr_nz = 1
     keep = []
     for k, v in kw.items():
-        if k in ('periodic_fused', 'accel'):
+        if k in ('periodic_fused', 'accel', 'periodic_local'):
             for i, x in enumerate(v):
                 getattr(d, k)[i] = x
         elif k == 'mrt_rates':

@@ -1,0 +1,209 @@
+"""Base classes of LB simulations (reference sailfish/lb_base.py): option surface,
+field declarations, output / checkpoint scheduling hooks, body forces."""
+from collections import namedtuple
+
+import numpy as np
+
+from sailfish_amd import node_type as nt
+from sailfish_amd import sym, util
+
+FieldPair = namedtuple('FieldPair', 'abstract buffer')
+KernelPair = namedtuple('KernelPair', 'primary secondary')
+
+
+class LBMixIn(object):
+    pass
+
+
+class Field(object):
+    def __init__(self, name, expr=None, need_nn=False, init=0.0, gpu_array=False):
+        self.name = name
+        self.expr = expr
+        self.init = init
+        self.need_nn = need_nn
+        self.gpu_array = gpu_array
+
+
+class ScalarField(Field):
+    pass
+
+
+class VectorField(Field):
+    pass
+
+
+class LBSim(object):
+    """Describes a type of LB simulation (reference lb_base.py:30-320)."""
+    subdomain_runner = None
+    nonlocality = 0
+
+    @classmethod
+    def add_options(cls, group, dim):
+        group.add_argument('--dt_per_lattice_time_unit', type=float, default=1.0,
+                           help='physical time delta corresponding to one iteration of the simulation')
+        grids = [x.__name__ for x in sym.KNOWN_GRIDS if x.dim == dim]
+        group.add_argument('--grid', help='LB grid', type=str, choices=grids, default=grids[0])
+        group.add_argument('--access_pattern', type=str, default='AB', choices=('AB', 'AA'),
+                           help='Lattice access pattern: AB (two copies of the whole domain in memory), '
+                                'AA (single domain copy in memory).')
+        group.add_argument('--node_addressing', type=str, default='direct', choices=('direct', 'indirect'),
+                           help='Node addressing mode (only direct is implemented by the HIP backend).')
+        group.add_argument('--minimize_roundoff', action='store_true', default=False,
+                           help='(not implemented by the HIP backend)')
+        group.add_argument('--propagate_on_read', action='store_true', default=False,
+                           help='(accepted for compatibility; the HIP kernels choose the streaming scheme)')
+        group.add_argument('--propagate_with_shuffle', action='store_true', dest='propagate_with_shuffle',
+                           default=False,
+                           help='(accepted for compatibility; the tuned HIP kernels always shift in registers)')
+        group.add_argument('--nouse_link_tags', action='store_false', dest='use_link_tags', default=True,
+                           help='Disables link tagging for node types that support it (orientation only).')
+
+    @classmethod
+    def modify_config(cls, config):
+        pass
+
+    @classmethod
+    def update_defaults(cls, defaults):
+        pass
+
+    @classmethod
+    def fields(cls):
+        return []
+
+    def constants(self):
+        return {}
+
+    @property
+    def grid(self):
+        return max(self.grids, key=lambda grid: grid.Q)
+
+    @property
+    def dim(self):
+        return self.grid.dim
+
+    def init_fields(self, runner):
+        """Creates the host mirrors of the macroscopic fields and exposes them as attributes
+        (sim.rho, sim.v, sim.vx, ... -- reference lb_base.py:139-170)."""
+        suffixes = ['x', 'y', 'z']
+        self._scalar_fields = []
+        self._vector_fields = []
+        self._fields = {}
+        sources = [self]
+        for c in self.__class__.mro()[1:]:
+            if issubclass(c, LBMixIn) and hasattr(c, 'fields') and not issubclass(c, LBSim):
+                sources.append(c)
+        for src in sources:
+            for field in src.fields():
+                if type(field) is ScalarField:
+                    f, _ = runner.make_scalar_field(name=field.name, async_=True)
+                    f[:] = field.init
+                    self._scalar_fields.append(FieldPair(field, f))
+                elif type(field) is VectorField:
+                    f = runner.make_vector_field(name=field.name, async_=True)
+                    self._vector_fields.append(FieldPair(field, f))
+                    for i in range(0, self.grid.dim):
+                        setattr(self, field.name + suffixes[i], f[i])
+                else:
+                    assert False, 'Invalid field type %s' % type(field)
+                setattr(self, field.name, f)
+                assert field.name not in self._fields, 'Field %s defined more than once.' % field.name
+                self._fields[field.name] = FieldPair(field, f)
+
+    def verify_fields(self):
+        for name, field_pair in self._fields.items():
+            assert getattr(self, name) is field_pair.buffer, \
+                'Field {0} redefined (probably in initial_conditions())'.format(name)
+
+    def __init__(self, config):
+        self.config = config
+        self.iteration = 0
+        self.need_sync_flag = False
+        self.need_fields_flag = False
+        self.force_objects = []
+        if config is not None:
+            grid = util.get_grid_from_config(config)
+            if grid is None:
+                raise util.GridError('Invalid grid selected: {0}'.format(config.grid))
+            self.grids = [grid]
+
+    def get_state(self):
+        return {'iteration': self.iteration}
+
+    def set_state(self, state):
+        self.iteration = state['iteration']
+
+    def need_output(self):
+        if self.config.output_required:
+            return ((self.iteration + 1) % self.config.every) == 0 and self.config.from_ <= self.iteration
+        return False
+
+    def need_sync_fields(self):
+        """(sync to host requested, macroscopic fields requested) -- reference lb_base.py:233-252."""
+        need_sync = self.need_sync_flag or self.need_output()
+        need_fields = self.need_fields_flag or need_sync
+        self.need_fields_flag = False
+        self.need_sync_flag = False
+        return need_sync, need_fields
+
+    def need_checkpoint(self):
+        return (self.config.checkpoint_every > 0 and (self.iteration % self.config.checkpoint_every) == 0 and
+                self.iteration >= self.config.checkpoint_from)
+
+    def before_main_loop(self, runner):
+        pass
+
+    def after_step(self, runner):
+        pass
+
+    def after_main_loop(self, runner):
+        pass
+
+    def get_compute_kernels(self, runner, full_output, bulk):
+        return KernelPair(None, None)
+
+    def get_pbc_kernels(self, runner):
+        return []
+
+    def get_aux_kernels(self, runner):
+        return KernelPair([], [])
+
+    def initial_conditions(self, runner):
+        pass
+
+    def fill_module_desc(self, kw):
+        """Contributes to the kernel-module descriptor (the counterpart of the reference's
+        update_context(), lb_base.py:120-137)."""
+        kw['relaxation_enabled'] = int(bool(getattr(self.config, 'relaxation_enabled', True)))
+
+
+class LBForcedSim(LBSim):
+    """Body forces (reference lb_base.py:300-395).  Mix-in: inherit from another LBSim first."""
+
+    def __init__(self, config):
+        super(LBForcedSim, self).__init__(config)
+        self._forces = {}
+
+    @classmethod
+    def add_options(cls, group, dim):
+        group.add_argument('--force_implementation', type=str, choices=['guo'], default='guo',
+                           help='How body forces enter the collision (the HIP kernels implement Guo forcing).')
+
+    def add_body_force(self, force, grid=0, accel=True):
+        """Adds a constant global acceleration (accel=True) acting on the fluid."""
+        dim = self.grids[0].dim
+        assert len(force) == dim
+        if isinstance(force, nt.DynamicValue):
+            raise NotImplementedError('time / space dependent forces are not supported by the HIP backend')
+        if not accel:
+            raise NotImplementedError('force (rather than acceleration) fields are not supported by the HIP backend')
+        if grid != 0:
+            raise NotImplementedError('multi-grid forces are not supported by the HIP backend')
+        self._forces.setdefault(grid, {}).setdefault(accel, np.zeros(dim, np.float64))
+        self._forces[grid][accel] = self._forces[grid][accel] + np.float64(force)
+
+    def fill_module_desc(self, kw):
+        super(LBForcedSim, self).fill_module_desc(kw)
+        f = self._forces.get(0, {}).get(True)
+        if f is not None and np.any(f != 0.0):
+            kw['has_force'] = 1
+            kw['accel'] = list(f) + [0.0] * (3 - len(f))

@@ -1,0 +1,91 @@
+"""Single-fluid LB simulation (reference sailfish/lb_single.py:14-240)."""
+from collections import defaultdict
+
+import numpy as np
+
+from sailfish_amd import hipabi, subdomain_runner, sym
+from sailfish_amd.lb_base import KernelPair, LBSim, ScalarField, VectorField
+
+
+class LBFluidSim(LBSim):
+    """Simulates a single fluid."""
+    subdomain_runner = subdomain_runner.SubdomainRunner
+
+    @classmethod
+    def add_options(cls, group, dim):
+        group.add_argument('--visc', type=float, default=1.0, help='numerical viscosity')
+        group.add_argument('--incompressible', action='store_true', default=False,
+                           help='use the incompressible model of Luo and He')
+        group.add_argument('--model', help='LB collision model to use', type=str, choices=['bgk', 'mrt'],
+                           default='bgk')
+
+    @classmethod
+    def fields(cls):
+        return [ScalarField('rho'), VectorField('v')]
+
+    def fill_module_desc(self, kw):
+        super(LBFluidSim, self).fill_module_desc(kw)
+        cfg = self.config
+        if not self.grid.model_supported(cfg.model):
+            raise ValueError('model %s not supported on grid %s' % (cfg.model, self.grid.__name__))
+        kw.update(lattice=self.grid.slf_id,
+                  model=hipabi.SLF_MRT if cfg.model == 'mrt' else hipabi.SLF_BGK,
+                  tau=sym.relaxation_time(cfg.visc), visc=cfg.visc,
+                  mrt_rates=sym.mrt_rates(self.grid, cfg.visc),
+                  incompressible=int(bool(cfg.incompressible)))
+
+    def initial_conditions(self, runner):
+        """f = feq(rho, v) on every copy of the distributions (reference lb_single.py:72-94)."""
+        gpu_rho = runner.gpu_field(self.rho)
+        gpu_v = runner.gpu_field(self.v)
+        gpu_map = runner.gpu_geo_map()
+        args1 = [runner.gpu_dist(0, 0)] + gpu_v + [gpu_rho, gpu_map]
+        runner.exec_kernel('SetInitialConditions', args1, 'P' * len(args1))
+        if self.config.access_pattern == 'AB':
+            args2 = [runner.gpu_dist(0, 1)] + gpu_v + [gpu_rho, gpu_map]
+            runner.exec_kernel('SetInitialConditions', args2, 'P' * len(args2))
+
+    def _compute_kernels_arguments(self, runner, full_output, bulk):
+        gpu_rho = runner.gpu_field(self.rho)
+        gpu_v = runner.gpu_field(self.v)
+        gpu_dist1a = runner.gpu_dist(0, 0)
+        gpu_dist1b = runner.gpu_dist(0, 1)
+        gpu_map = runner.gpu_geo_map()
+        assert len(gpu_v) == self.dim
+        args1 = [gpu_map, gpu_dist1a, gpu_dist1b, gpu_rho] + gpu_v
+        args2 = [gpu_map, gpu_dist1b, gpu_dist1a, gpu_rho] + gpu_v
+        options = 0
+        if full_output:
+            options |= 1
+        if bulk:
+            options |= 2
+        args1.append(np.uint32(options))
+        args2.append(np.uint32(options))
+        signature = 'P' * (len(args1) - 1) + 'i'
+        return signature, args1, args2
+
+    def get_compute_kernels(self, runner, full_output, bulk):
+        signature, args1, args2 = self._compute_kernels_arguments(runner, full_output, bulk)
+        cnp_primary = runner.get_kernel('CollideAndPropagate', args1, signature,
+                                        needs_iteration=self.config.needs_iteration_num)
+        if self.config.access_pattern == 'AB':
+            cnp_secondary = runner.get_kernel('CollideAndPropagate', args2, signature,
+                                              needs_iteration=self.config.needs_iteration_num)
+            return KernelPair([cnp_primary], [cnp_secondary])
+        return KernelPair([cnp_primary], [cnp_primary])
+
+    def get_pbc_kernels(self, runner):
+        """grid copy (0 primary, 1 secondary) -> axis -> kernels (reference lb_single.py:153-185)."""
+        gpu_dist1a = runner.gpu_dist(0, 0)
+        gpu_dist1b = runner.gpu_dist(0, 1)
+        kernels = defaultdict(lambda: defaultdict(list))
+        for i in range(0, self.dim):
+            kernels[0][i] = [runner.get_kernel('ApplyPeriodicBoundaryConditions',
+                                               [gpu_dist1a, np.uint32(i)], 'Pi')]
+        if self.config.access_pattern == 'AB':
+            gpu_dist, kernel = gpu_dist1b, 'ApplyPeriodicBoundaryConditions'
+        else:
+            gpu_dist, kernel = gpu_dist1a, 'ApplyPeriodicBoundaryConditionsWithSwap'
+        for i in range(0, self.dim):
+            kernels[1][i] = [runner.get_kernel(kernel, [gpu_dist, np.uint32(i)], 'Pi')]
+        return kernels

@@ -1,0 +1,281 @@
+"""Node (boundary condition) types.
+
+Same public names, class attributes and id-assignment rule as the reference's
+sailfish/node_type.py (ids are handed out in the alphabetical order of the class
+names, `_NTFluid` is 0: node_type.py:406-421), so that user geometry code
+(`self.set_node(where, NTFullBBWall)`, `NTRegularizedVelocity((0.1, 0.0))`, ...)
+runs unchanged and un-encoded type maps agree with the reference's.
+
+The gfx950 kernels implement the types the north-star configurations use
+(`HIP_KIND`); any other type raises when a subdomain using it is built for the
+HIP backend.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from sailfish_amd import hipabi
+
+ScratchSize = namedtuple('ScratchSize', ('dim2', 'dim3'))
+
+
+class LBNodeType(object):
+    """Base class for node types (reference node_type.py:18-80)."""
+    id = None
+    wet_node = False            # undergoes the normal relaxation
+    excluded = False            # does not take part in the simulation
+    propagation_only = False
+    standard_macro = False      # macroscopic fields computed the standard way
+    needs_orientation = False
+    link_tags = False           # orientation field holds per-direction link tags
+    scratch_space = 0
+    location = 0.0              # wall position offset along the normal
+    allow_unused = False
+
+    def __init__(self, **params):
+        if 'orientation' in params:
+            self.orientation = params['orientation']
+            del params['orientation']
+        self.params = params
+
+    @classmethod
+    def scratch_space_size(cls, dim):
+        if type(cls.scratch_space) is int:
+            return cls.scratch_space
+        return cls.scratch_space.dim2 if dim == 2 else cls.scratch_space.dim3
+
+
+# -- special types ---------------------------------------------------------------
+class _NTFluid(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    id = 0
+
+
+class _NTGhost(LBNodeType):
+    excluded = True
+
+
+class _NTUnused(LBNodeType):
+    excluded = True
+
+
+class _NTPropagationOnly(LBNodeType):
+    propagation_only = True
+
+
+# -- walls -----------------------------------------------------------------------
+class NTHalfBBWall(LBNodeType):
+    """Half-way bounce-back: f_i(x, t+1) = f_opp(i)^post(x, t) (reference node_type.py:115-141)."""
+    wet_node = True
+    standard_macro = True
+    needs_orientation = True
+    link_tags = True
+    location = -0.5
+    allow_unused = True
+
+
+class NTFullBBWall(LBNodeType):
+    """Full-way bounce-back (reference node_type.py:144-168)."""
+    standard_macro = True
+    location = 0.5
+    needs_orientation = True
+
+
+class NTWallTMS(LBNodeType):
+    wet_node = True
+    needs_orientation = True
+    link_tags = True
+    location = 0.5
+    allow_unused = True
+    standard_macro = True
+
+
+# -- density (pressure) nodes ------------------------------------------------------
+class NTEquilibriumDensity(LBNodeType):
+    """Density BC using the equilibrium distribution (reference node_type.py:198-205)."""
+    needs_orientation = True
+    wet_node = True
+
+    def __init__(self, density, orientation=None):
+        self.params = {'density': density}
+        self.orientation = orientation
+
+
+class NTRegularizedDensity(LBNodeType):
+    needs_orientation = True
+    wet_node = True
+
+    def __init__(self, density, orientation=None):
+        self.params = {'density': density}
+        self.orientation = orientation
+
+
+class NTGuoDensity(LBNodeType):
+    def __init__(self, density):
+        self.params = {'density': density}
+
+
+class NTZouHeDensity(LBNodeType):
+    needs_orientation = True
+    wet_node = True
+
+    def __init__(self, density, orientation=None):
+        self.params = {'density': density}
+        self.orientation = orientation
+
+
+# -- velocity nodes ------------------------------------------------------------------
+class NTEquilibriumVelocity(LBNodeType):
+    needs_orientation = True
+    wet_node = True
+
+    def __init__(self, velocity, orientation=None):
+        self.params = {'velocity': velocity}
+        self.orientation = orientation
+
+
+class NTZouHeVelocity(LBNodeType):
+    needs_orientation = True
+    wet_node = True
+
+    def __init__(self, velocity, orientation=None):
+        self.params = {'velocity': velocity}
+        self.orientation = orientation
+
+
+class NTRegularizedVelocity(LBNodeType):
+    """Regularized velocity BC, Latt et al. PRE 77 056703 (reference node_type.py:269-283)."""
+    needs_orientation = True
+    wet_node = True
+
+    def __init__(self, velocity, orientation=None):
+        self.params = {'velocity': velocity}
+        self.orientation = orientation
+
+
+# -- outflow / misc (declared for API compatibility; not implemented by the HIP kernels) ---
+class NTGradFreeflow(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    scratch_space = ScratchSize(dim2=3, dim3=6)
+
+
+class NTDoNothing(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    needs_orientation = True
+
+
+class NTCopy(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    needs_orientation = True
+
+
+class NTExtendedCopy(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    needs_orientation = True
+
+
+class NTYuOutflow(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    needs_orientation = True
+
+
+class NTNeumann(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    needs_orientation = True
+
+
+class NTLaminarize(LBNodeType):
+    wet_node = True
+    standard_macro = True
+    needs_orientation = True
+
+
+class NTSlip(LBNodeType):
+    standard_macro = True
+
+
+def __init_node_type_list():
+    """Assigns ids in alphabetical (dir()) order, reference node_type.py:406-421."""
+    import sys
+    mod = sys.modules[__name__]
+    ret = []
+    for symbol in dir(mod):
+        obj = getattr(mod, symbol)
+        try:
+            if obj != LBNodeType and issubclass(obj, LBNodeType):
+                ret.append(obj)
+                if obj.id is None:
+                    obj.id = len(ret)
+        except TypeError:
+            pass
+    return dict((t.id, t) for t in ret)
+
+
+_NODE_TYPES = __init_node_type_list()
+
+
+def get_wet_node_type_ids(allow_unused=None):
+    return [i for i, t in _NODE_TYPES.items() if t.wet_node and
+            (allow_unused is None or t.allow_unused == allow_unused)]
+
+
+def get_dry_node_type_ids():
+    return [i for i, t in _NODE_TYPES.items() if not t.wet_node]
+
+
+def get_orientation_node_type_ids():
+    return [i for i, t in _NODE_TYPES.items() if t.needs_orientation]
+
+
+def get_link_tag_node_type_ids():
+    return [i for i, t in _NODE_TYPES.items() if t.link_tags]
+
+
+def multifield(values, where=None):
+    """Collapses arrays / scalars into one structured array usable as a per-node BC
+    parameter (reference node_type.py:436-468)."""
+    shape = None
+    new_values = []
+    for val in values:
+        if isinstance(val, np.ndarray):
+            assert shape is None or shape == val.shape
+            new_values.append(val.astype(np.float64))
+            shape = val.shape
+        else:
+            new_values.append(None)
+    assert shape is not None
+    for i, (old, new) in enumerate(zip(values, new_values)):
+        if new is None:
+            new_values[i] = np.zeros(shape, dtype=np.float64)
+            new_values[i][:] = old
+    rec = np.rec.fromarrays(new_values)
+    return rec[where] if where is not None else rec.flatten()
+
+
+class DynamicValue(object):
+    """Time / space dependent BC values are generated as device code by the reference
+    (node_type.py:471-570); the pre-built gfx950 kernels take constant parameters only."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError('DynamicValue boundary parameters are not supported by the HIP backend')
+
+
+# node type -> canonical kernel kind
+HIP_KIND = {
+    _NTFluid: hipabi.SLF_NK_FLUID,
+    _NTGhost: hipabi.SLF_NK_GHOST,
+    _NTUnused: hipabi.SLF_NK_UNUSED,
+    _NTPropagationOnly: hipabi.SLF_NK_PROPAGATION_ONLY,
+    NTFullBBWall: hipabi.SLF_NK_FULL_BB,
+    NTHalfBBWall: hipabi.SLF_NK_HALF_BB,
+    NTRegularizedVelocity: hipabi.SLF_NK_REGULARIZED_VELOCITY,
+    NTEquilibriumDensity: hipabi.SLF_NK_EQUILIBRIUM_DENSITY,
+    NTEquilibriumVelocity: hipabi.SLF_NK_EQUILIBRIUM_VELOCITY,
+}

@@ -13,6 +13,8 @@ class OracleBox(object):
         self.dim, self.Q, self.dtype, self.shape = self.o.dim, self.o.Q, self.o.dtype, self.o.shape
         self.aa = desc.access_pattern == hipabi.SLF_AA
         self.pbc_axes = [a for a in range(self.dim) if periodic[a] and not desc.periodic_fused[a]]
+        for a in range(self.dim):
+            desc.periodic_local[a] = int(bool(periodic[a]))
         self.dist = [self.o.new_dist()]
         if not self.aa:
             self.dist.append(self.o.new_dist())

@@ -1,0 +1,87 @@
+"""Host geometry layer vs fixtures produced by the reference's own host code
+(tests/golden/geometry_*.npz, tools/capture_geometry.py): node-type ids, subdomain
+connectivity, padded sizes (reference tests/subdomain_runner.py:54-77), unused /
+propagation-only detection and orientation / link tags (tests/subdomain.py:98-576),
+the GeoEncoderConst bit packing, and the initial host fields -- all bit-exact.
+
+Each case is built twice: from this repo's examples/ (written against the same API), and --
+where /root/reference is available -- from the reference's *unchanged* example file imported
+against the `sailfish` alias package.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from sailfish_amd import node_type as nt
+from tests import _host
+
+with open(os.path.join(os.path.dirname(__file__), 'golden', 'geometry_cases.json')) as fh:
+    CASES = json.load(fh)
+NAMES = sorted(k for k in CASES if not k.startswith('_'))
+HAVE_REF = os.path.isdir('/root/reference/examples')
+
+
+def test_node_type_ids_match_reference():
+    ref = CASES['_node_type_ids']
+    mine = dict((t.__name__, i) for i, t in nt._NODE_TYPES.items())
+    assert mine == ref
+
+
+@pytest.mark.parametrize('source', ['repo_examples', 'reference_files'])
+@pytest.mark.parametrize('name', NAMES)
+def test_geometry_matches_reference(name, source, golden_dir):
+    if source == 'reference_files' and not HAVE_REF:
+        pytest.skip('/root/reference not available on this machine')
+    case = CASES[name]
+    G = np.load(os.path.join(golden_dir, 'geometry_%s.npz' % name))
+    sim_cls = _host.load_sim_class(case['module'], case['sim'], use_reference_file=(source == 'reference_files'))
+    cfg, specs, runners = _host.build_runners(sim_cls, case['dim'], case['geo'], case['cfg'])
+    assert len(specs) == case['n_subdomains']
+    for spec, runner in zip(specs, runners):
+        i = spec.id
+        assert list(spec.location) == case['locations'][i] and list(spec.size) == case['sizes'][i]
+        assert [bool(x) for x in spec._periodicity] == case['local_periodicity'][i]
+        assert sorted([int(f), int(n)] for f, n in spec.connecting_subdomains()) == case['face_conns'][i]
+        runner._init_geometry()
+        runner._sim.init_fields(runner)
+        runner._subdomain.init_fields(runner._sim)
+        k = 's%d_' % i
+        assert runner._physical_size == list(G[k + 'physical_size'])
+        assert runner._lat_size == list(G[k + 'lat_size'])
+        sub = runner._subdomain
+        assert np.array_equal(sub._type_vis_map, G[k + 'vis_map'])
+        ctx = {}
+        sub.update_context(ctx)
+        assert [ctx['nt_misc_shift'], ctx['nt_param_shift'], ctx['nt_scratch_shift']] == list(G[k + 'bits'])
+        remap = ctx['type_id_remap']
+        assert sorted(remap.keys()) == list(G[k + 'remap_keys'])
+        assert [remap[x] for x in sorted(remap.keys())] == list(G[k + 'remap_vals'])
+        assert np.allclose(np.array(ctx['node_params'], dtype=np.float64), G[k + 'node_params'], rtol=0, atol=0)
+        enc = np.array(sub._type_map_base, dtype=np.uint32)
+        assert np.array_equal(enc, G[k + 'encoded_map']), \
+            '%d differing node codes' % np.count_nonzero(enc != G[k + 'encoded_map'])
+        assert sub.num_fluid_nodes == int(G[k + 'num_fluid_nodes'])
+        assert np.array_equal(runner.field_base(runner._sim.rho), G[k + 'rho'])
+        for d, c in enumerate(runner._sim.v):
+            assert np.array_equal(runner.field_base(c), G[k + 'v%d' % d])
+
+
+def test_padded_sizes_known_answers():
+    """reference tests/subdomain_runner.py:54-77: (10,3) -> [3,16] and (3,5,7) -> [7,5,8] at alignment 8."""
+    from sailfish_amd.lb_single import LBFluidSim
+    from sailfish_amd.subdomain import SubdomainSpec2D, SubdomainSpec3D
+    from sailfish_amd.subdomain_runner import SubdomainRunner
+    cfg = _host.make_config(2, mem_alignment=8, lat_nx=64, lat_ny=64)
+    spec = SubdomainSpec2D((0, 0), (10, 3))
+    spec.set_actual_size(0)
+    r = SubdomainRunner(LBFluidSim(cfg), spec, None, _host.HostOnlyBackend())
+    r._init_shape()
+    assert r._physical_size == [3, 16] and r.num_phys_nodes == 48
+    cfg = _host.make_config(3, mem_alignment=8, lat_nx=64, lat_ny=64, lat_nz=64)
+    spec = SubdomainSpec3D((0, 0, 0), (3, 5, 7))
+    spec.set_actual_size(0)
+    r = SubdomainRunner(LBFluidSim(cfg), spec, None, _host.HostOnlyBackend())
+    r._init_shape()
+    assert r._physical_size == [7, 5, 8] and r.num_phys_nodes == 280
