@@ -99,22 +99,33 @@ class TorchDistConnector(object):
     def tensor(self, ptr):
         return self._tensors[ptr]
 
+    @staticmethod
+    def exchange_tensors(sends, recvs):
+        """sends / recvs: lists of (tensor, peer rank), each ordered by neighbour subdomain id.  One
+        batched group of point-to-point operations (no collective); returns after the operations have
+        been *enqueued* for CUDA tensors (stream-ordered) and completed for CPU tensors."""
+        import torch.distributed as dist
+        ops = [dist.P2POp(dist.isend, t, peer) for t, peer in sends]
+        ops += [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
+        if not ops:
+            return
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+
     def exchange(self, runner):
         import torch
-        import torch.distributed as dist
-        ops = []
+        sends, recvs = [], []
         for nid in sorted(runner._links):
             link = runner._links[nid]
             n_send, n_recv = runner.halo_counts(nid)
             peer = self.id_to_rank[nid]
             if n_send:
-                ops.append(dist.P2POp(dist.isend, self.tensor(link.send_buf)[:n_send], peer))
+                sends.append((self.tensor(link.send_buf)[:n_send], peer))
             if n_recv:
-                ops.append(dist.P2POp(dist.irecv, self.tensor(link.recv_buf)[:n_recv], peer))
-        if not ops:
+                recvs.append((self.tensor(link.recv_buf)[:n_recv], peer))
+        if not sends and not recvs:
             return
         if self._stream is None:
             self._stream = torch.cuda.ExternalStream(runner._data_stream.native)
         with torch.cuda.stream(self._stream):
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
+            self.exchange_tensors(sends, recvs)

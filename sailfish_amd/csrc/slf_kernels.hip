@@ -285,8 +285,14 @@ __global__ void __launch_bounds__(256) sparse_kernel(const unsigned long long* _
   if (i >= n) return;
   const unsigned long long gi = idx[i];
   if (gi == ~0ull) return;
-  if constexpr (COLLECT) buffer[i] = dist[gi];
-  else dist[gi] = buffer[i];
+  if constexpr (COLLECT) {
+    buffer[i] = dist[gi];
+  } else {
+    // never-written ghost slots (pushed from excluded nodes) stay non-finite sentinels and are not
+    // delivered -- the same policy as the periodic-boundary kernels (reference kernel_utils.mako:196,229)
+    const R val = buffer[i];
+    if (slf_isfinite(val)) dist[gi] = val;
+  }
 }
 
 // PrepareMacroFields-style pass: density/velocity of every wet node without

@@ -1,0 +1,41 @@
+"""Worker of the world_size-2 gloo test: one subdomain per process, halo buffers exchanged with the
+product's TorchDistConnector (CPU tensors over gloo); arithmetic by the oracle."""
+import os
+import sys
+
+import numpy as np
+
+
+def worker(rank, world, port, case, steps, outdir):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank)})
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from sailfish_amd.connector import TorchDistConnector, init_distributed
+    from tests import _host
+    from tests._oracle_group import OracleSubdomain
+    r, w = init_distributed('gloo')
+    assert (r, w) == (rank, world)
+    module, sim, dim, geo, cfg = case
+    sim_cls = _host.load_sim_class(module, sim)
+    cfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, cfg)
+    assert len(specs) == world
+    sub = OracleSubdomain(runners[rank])
+    conn = TorchDistConnector(dict((s.id, s.id) for s in specs), device=torch.device('cpu'))
+    for i in range(steps):
+        sends = sub.compute(save=(i == steps - 1))
+        counts = sub.recv_counts()
+        nids = sorted(sub.links)
+        tdt = torch.float32 if sub.o.dtype == np.float32 else torch.float64
+        s_list = [(torch.from_numpy(sends[n]), conn.id_to_rank[n]) for n in nids if len(sends[n])]
+        r_bufs = dict((n, torch.empty(counts[n], dtype=tdt)) for n in nids)
+        r_list = [(r_bufs[n], conn.id_to_rank[n]) for n in nids if counts[n]]
+        conn.exchange_tensors(s_list, r_list)
+        sub.finish(dict((n, r_bufs[n].numpy()) for n in nids))
+    cur = sub.dist[0] if sub.aa else sub.dist[sub.iteration & 1]
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), dist=np.ascontiguousarray(sub.real(cur)),
+             rho=np.ascontiguousarray(sub.real(sub.rho)), location=np.array(specs[rank].location),
+             size=np.array(specs[rank].size))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,128 @@
+"""Oracle twin of the multi-subdomain runner: geometry, descriptors and halo index lists come from
+the product's host layer (sailfish_amd), every numerical operation (sweep, periodic boundaries,
+pack / unpack) is executed by the CPU oracle.  Test-only."""
+import numpy as np
+
+from oracle.oracle import OracleSim
+from sailfish_amd import hipabi, subdomain_connection
+from tests import _host
+
+
+class OracleSubdomain(object):
+    def __init__(self, runner):
+        r = self.runner = runner
+        r._init_geometry()
+        r._sim.init_fields(r)
+        r._subdomain.init_fields(r._sim)
+        self.desc = r._module_desc()
+        self.o = OracleSim(self.desc)
+        self.dim = r.dim
+        self.aa = self.desc.access_pattern == hipabi.SLF_AA
+        self.node_map = np.ascontiguousarray(r._subdomain._type_map_base, dtype=np.uint32).reshape(self.o.shape)
+        dt = self.o.dtype
+        self.rho = np.ascontiguousarray(r.field_base(r._sim.rho), dtype=dt).reshape(self.o.shape)
+        self.v = [np.ascontiguousarray(r.field_base(c), dtype=dt).reshape(self.o.shape) for c in r._sim.v]
+        while len(self.v) < 3:
+            self.v.append(np.zeros(self.o.shape, dtype=dt))
+        self.dist = [self.o.new_dist()] + ([] if self.aa else [self.o.new_dist()])
+        with np.errstate(all='ignore'):
+            for d in self.dist:
+                self.o.init(d, self.rho, self.v[0], self.v[1], self.v[2])
+        local = r._local_periodic()
+        self.pbc_axes = [a for a in range(self.dim) if local[a] and not r._fused[a]]
+        self.iteration = 0
+        self.links = {}
+        if len(r._all_specs) > 1:
+            arr = list(reversed(r._physical_size))
+            self.links = subdomain_connection.build_halo_links(
+                r._spec, r._all_specs, r._global_size, r._global_periodic, r._sim.grid, arr,
+                hipabi.dist_stride(self.desc), fused=r._fused)
+
+    def raw(self, dist):
+        """Flat view of the whole strided distribution buffer."""
+        base = dist.base
+        while base.base is not None:
+            base = base.base
+        return base.reshape(-1)
+
+    def compute(self, save=False):
+        it = self.iteration
+        opts = 1 if save else 0
+        m = self.node_map
+        if self.aa:
+            prop = 2 if (it & 1) else 1
+            self.o.step(prop, m, self.dist[0], self.dist[0], self.rho, *self.v, options=opts)
+            out, swap = 0, (it & 1) == 0
+        else:
+            i = it & 1
+            self.o.step(0, m, self.dist[i], self.dist[1 - i], self.rho, *self.v, options=opts)
+            out, swap = 1 - i, False
+        for axis in self.pbc_axes:
+            self.o.pbc(self.dist[out], axis, swap)
+        self.mode = 'pull' if (self.aa and (it & 1) == 0) else 'push'
+        self.out = out
+        self.iteration += 1
+        sends = {}
+        for nid, link in self.links.items():
+            idx = getattr(link, self.mode + '_send')
+            buf = np.zeros(len(idx), dtype=self.o.dtype)
+            if len(idx):
+                self.o.sparse(True, idx, self.raw(self.dist[out]), buf)
+            sends[nid] = buf
+        return sends
+
+    def recv_counts(self):
+        return dict((nid, len(getattr(l, self.mode + '_recv'))) for nid, l in self.links.items())
+
+    def finish(self, recvs):
+        for nid, buf in recvs.items():
+            idx = getattr(self.links[nid], self.mode + '_recv')
+            assert len(idx) == len(buf)
+            if len(idx):
+                self.o.sparse(False, idx, self.raw(self.dist[self.out]), np.ascontiguousarray(buf))
+
+    def real(self, arr):
+        """Real-node view of a field / distribution array stored as [..., arr_nz, arr_ny, arr_nx]."""
+        ng = self.runner._spec._nonghost_slice
+        if self.dim == 2:
+            return arr[(Ellipsis, 0) + tuple(ng)]
+        return arr[(Ellipsis,) + tuple(ng)]
+
+
+class OracleGroup(object):
+    """All subdomains in one process, stepped in lock-step (the oracle twin of controller.LocalGroup)."""
+
+    def __init__(self, sim_cls, dim, geo_name, cfg_kw):
+        self.cfg, self.specs, runners = _host.build_runners(sim_cls, dim, geo_name, cfg_kw)
+        self.subs = [OracleSubdomain(r) for r in runners]
+
+    def step(self, save=False):
+        sends = [s.compute(save) for s in self.subs]
+        for s in self.subs:
+            recvs = dict((nid, sends[nid][s.runner._spec.id]) for nid in s.links)
+            s.finish(recvs)
+
+    def run(self, n, save_last=True):
+        for i in range(n):
+            self.step(save_last and i == n - 1)
+
+    def merged(self, what):
+        """Global (real nodes only) array assembled from the subdomains: what = 'rho' | 'v0'.. | 'dist'."""
+        dim = self.subs[0].dim
+        gshape = tuple(reversed(self.subs[0].runner._global_size))
+        if what == 'dist':
+            Q = self.subs[0].o.Q
+            out = np.zeros((Q,) + gshape, dtype=self.subs[0].o.dtype)
+        else:
+            out = np.zeros(gshape, dtype=self.subs[0].o.dtype)
+        for s in self.subs:
+            sp = s.runner._spec
+            sl = tuple(slice(o, o + n) for o, n in zip(reversed(sp.location), reversed(sp.size)))
+            if what == 'dist':
+                cur = s.dist[0] if s.aa else s.dist[s.iteration & 1]
+                out[(slice(None),) + sl] = s.real(cur)
+            elif what == 'rho':
+                out[sl] = s.real(s.rho)
+            else:
+                out[sl] = s.real(s.v[int(what[1])])
+        return out
