@@ -149,10 +149,10 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* desc, slf_module** ou
 int slf_module_destroy(slf_module* m);
 /* Kernel names are the reference's: "CollideAndPropagate",
  * "SetInitialConditions", "ApplyPeriodicBoundaryConditions",
- * "ApplyPeriodicBoundaryConditionsWithSwap", "ApplyMacroPeriodicBoundaryConditions",
- * "CollectContinuousData[WithSwap]", "DistributeContinuousData[WithSwap]",
- * "CollectSparseData", "DistributeSparseData",
- * "CollectContinuousMacroData", "DistributeContinuousMacroData". */
+ * "ApplyPeriodicBoundaryConditionsWithSwap" (AA modules only),
+ * "ApplyMacroPeriodicBoundaryConditions", "CollectSparseData", "DistributeSparseData"
+ * (index lists are uint64: q * dist_stride + node index), plus "ComputeMacroFields"
+ * (rho / v of the current state, arguments as CollideAndPropagate). */
 int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out);
 int slf_kernel_destroy(slf_kernel* k);
 /* fmt: one char per argument, 'P' = device pointer (8 bytes), 'i' = int32,

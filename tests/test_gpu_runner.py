@@ -1,0 +1,142 @@
+"""GPU tests of the full stack: examples -> LBSimulationController -> SubdomainRunner(s) ->
+backend_hip -> libsailfish_hip.so, compared with the oracle twin (tests/_oracle_group.py) that uses
+the same geometry, descriptors and halo lists.  Includes the reference's 1-vs-N subdomain
+equivalence (regtest/subdomains/*.py), here with all subdomains on the one GPU of the test box, its
+AB == AA check (tests/gpu/access_pattern.sh) and its checkpoint round trip (tests/gpu/checkpoint.sh).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _host
+from tests._oracle_group import OracleGroup
+
+pytestmark = pytest.mark.gpu
+
+GEO = {2: 'EqualSubdomainsGeometry2D', 3: 'EqualSubdomainsGeometry3D'}
+
+
+def run_gpu(module, sim, dim, cfg, steps, extra=None):
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls = _host.load_sim_class(module, sim)
+    defaults = dict(cfg)
+    defaults.update(max_iters=steps, quiet=True, perf_stats_every=0)
+    if extra:
+        defaults.update(extra)
+    ctrl = LBSimulationController(sim_cls, getattr(geo_mod, GEO[dim]), default_config=defaults)
+    ctrl.run(ignore_cmdline=True)
+    return ctrl
+
+
+def merged_gpu(ctrl, what):
+    r0 = ctrl.runners[0]
+    gshape = tuple(reversed(r0._global_size))
+    if what == 'dist':
+        out = np.zeros((r0._sim.grid.Q,) + gshape, dtype=r0.float)
+    else:
+        out = np.zeros(gshape, dtype=r0.float)
+    for r in ctrl.runners:
+        sp = r._spec
+        sl = tuple(slice(o, o + n) for o, n in zip(reversed(sp.location), reversed(sp.size)))
+        if what == 'dist':
+            d = r._debug_get_dist()
+            out[(slice(None),) + sl] = d[(slice(None),) + tuple(sp._nonghost_slice)]
+        elif what == 'rho':
+            out[sl] = r._sim.rho
+        else:
+            out[sl] = r._sim.v[int(what[1])]
+    return out
+
+
+def check_against_oracle(module, sim, dim, cfg, steps, u_scale):
+    ctrl = run_gpu(module, sim, dim, cfg, steps)
+    og = OracleGroup(_host.load_sim_class(module, sim), dim, GEO[dim], cfg)
+    og.run(steps, save_last=True)
+    rho_g, rho_o = merged_gpu(ctrl, 'rho'), og.merged('rho')
+    wet = np.isfinite(rho_o) & (rho_o != 0)
+    assert np.max(np.abs(rho_g[wet] - rho_o[wet]) / np.abs(rho_o[wet])) < 1e-6
+    for d in range(dim):
+        a, b = merged_gpu(ctrl, 'v%d' % d), og.merged('v%d' % d)
+        assert np.max(np.abs(a[wet] - b[wet])) / u_scale < 1e-6
+    fg, fo = merged_gpu(ctrl, 'dist'), og.merged('dist')
+    m = np.isfinite(fo)
+    assert np.array_equal(np.isfinite(fg), m)
+    assert np.max(np.abs(fg[m] - fo[m])) < 1e-7
+    return ctrl, np.array_equal(fg[m], fo[m])
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('nsub,axis', [(1, 'x'), (3, 'x'), (2, 'y')])
+def test_ldc_2d(pattern, nsub, axis):
+    cfg = dict(lat_nx=66, lat_ny=40, visc=0.0254, access_pattern=pattern, subdomains=nsub, conn_axis=axis)
+    check_against_oracle('ldc_2d', 'LDCSim', 2, cfg, 40, 0.1)
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('nsub,axis,model', [(1, 'x', 'bgk'), (2, 'z', 'mrt'), (2, 'y', 'bgk'), (2, 'x', 'bgk')])
+def test_ldc_3d(pattern, nsub, axis, model):
+    cfg = dict(lat_nx=24, lat_ny=18, lat_nz=16, visc=0.03, model=model, access_pattern=pattern,
+               subdomains=nsub, conn_axis=axis)
+    check_against_oracle('ldc_3d', 'LDCSim', 3, cfg, 30, 0.05)
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('wall,fused,nsub,axis', [('fullbb', True, 1, 'x'), ('halfbb', False, 1, 'x'),
+                                                  ('halfbb', True, 2, 'y'), ('fullbb', False, 2, 'x')])
+def test_poiseuille_force(pattern, wall, fused, nsub, axis):
+    cfg = dict(lat_nx=24, lat_ny=40, visc=0.1, horizontal=False, stationary=False, drive='force', wall=wall,
+               force_implementation='guo', access_pattern=pattern, hip_fused_periodic=fused,
+               subdomains=nsub, conn_axis=axis)
+    check_against_oracle('poiseuille', 'PoiseuilleSim', 2, cfg, 50, 0.02)
+
+
+def test_poiseuille_pressure_mrt():
+    cfg = dict(lat_nx=24, lat_ny=40, visc=0.1, horizontal=False, stationary=True, drive='pressure', wall='fullbb',
+               force_implementation='guo', access_pattern='AB', model='mrt')
+    check_against_oracle('poiseuille', 'PoiseuilleSim', 2, cfg, 50, 0.02)
+
+
+@pytest.mark.parametrize('nsub,axis', [(1, 'z'), (2, 'z'), (2, 'x')])
+def test_pipe_3d(nsub, axis):
+    cfg = dict(lat_nx=18, lat_ny=18, lat_nz=16, visc=0.1, flow_direction='z', stationary=False, drive='force',
+               force_implementation='guo', access_pattern='AA', subdomains=nsub, conn_axis=axis)
+    check_against_oracle('poiseuille_3d', 'PoiseuilleSim', 3, cfg, 30, 0.02)
+
+
+def test_poiseuille_converges_to_parabola():
+    """Physics known answer (reference examples/poiseuille.py:73-83, regtest/poiseuille.py): the steady
+    force-driven profile between half-way bounce-back walls is the parabola with u_max = max_v."""
+    cfg = dict(lat_nx=8, lat_ny=34, visc=0.1, horizontal=True, stationary=True, drive='force', wall='halfbb',
+               force_implementation='guo', access_pattern='AA')
+    ctrl = run_gpu('poiseuille', 'PoiseuilleSim', 2, cfg, 3000)
+    r = ctrl.runners[0]
+    vx = r._sim.vx[:, 3]
+    sub = r._subdomain
+    hy = np.arange(34)
+    ref = sub.velocity_profile(r.config, hy)
+    err = np.max(np.abs(vx - ref)) / ref.max()
+    assert err < 5e-3, err
+
+
+def test_output_files_and_checkpoint_roundtrip(tmp_path):
+    """103 steps + checkpoint, restore, continue to 200 == straight 200 (reference tests/gpu/checkpoint.sh),
+    and the NPY output naming / masking (reference io.py:170-191, 53-59)."""
+    base = dict(lat_nx=34, lat_ny=26, visc=0.02, access_pattern='AA')
+    out = str(tmp_path / 'ldc')
+    ctrl = run_gpu('ldc_2d', 'LDCSim', 2, base, 200, extra=dict(output=out, every=100))
+    f200 = np.load(out + '.0.200.npz')
+    assert set(f200.files) == {'rho', 'v'} and f200['v'].shape == (2, 26, 34)
+    assert np.isnan(f200['rho'][0, 5])          # full-BB wall node is masked
+    assert np.array_equal(f200['rho'][1:-1, 1:-1], ctrl.runners[0]._sim.rho[1:-1, 1:-1])
+    ck = str(tmp_path / 'ck')
+    run_gpu('ldc_2d', 'LDCSim', 2, base, 103, extra=dict(checkpoint_file=ck, final_checkpoint=True))
+    cp = [f for f in os.listdir(str(tmp_path)) if f.startswith('ck') and f.endswith('.cpoint.npz')]
+    assert len(cp) == 1
+    restored = run_gpu('ldc_2d', 'LDCSim', 2, base, 200,
+                       extra=dict(restore_from=os.path.join(str(tmp_path), cp[0][:-len('.0.cpoint.npz')])))
+    assert restored.runners[0]._sim.iteration == 200
+    # (the run with --output masked its non-fluid nodes with NaN; compare the wet interior)
+    assert np.array_equal(restored.runners[0]._sim.rho[1:-1, 1:-1], ctrl.runners[0]._sim.rho[1:-1, 1:-1])
+    assert np.array_equal(restored.runners[0]._debug_get_dist(), ctrl.runners[0]._debug_get_dist(), equal_nan=True)

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_runner.py -m gpu -x -q 2>&1 | tail -30 | tee gpurun_out/pytest_runner.log
