@@ -92,7 +92,10 @@ def build_runners(sim_cls, dim, geo_name, cfg_kw, backend_factory=None):
     from sailfish_amd.io import LBOutput
     cfg = make_config(dim, **cfg_kw)
     sim_cls.modify_config(cfg)
-    geo = getattr(geo_mod, geo_name or ('LBGeometry2D' if dim == 2 else 'LBGeometry3D'))(cfg)
+    if isinstance(geo_name, type):
+        geo = geo_name(cfg)
+    else:
+        geo = getattr(geo_mod, geo_name or ('LBGeometry2D' if dim == 2 else 'LBGeometry3D'))(cfg)
     specs = geo.subdomains()
     for s in specs:
         s.set_actual_size(1)
