@@ -161,6 +161,15 @@ class BoxSim(object):
     def sync(self):
         self.stream.synchronize()
 
+    def release(self):
+        """Frees the device memory of this simulation."""
+        self.sync()
+        b = self.backend
+        for addr in list(self.gpu_dist) + [self.gpu_rho] + list(self.gpu_v) + ([self.gpu_map] if self.gpu_map else []):
+            b.free_buf(addr)
+        self.gpu_dist = []
+        b._iteration_kernels = []
+
     def fetch_fields(self):
         self.sync()
         self.backend.from_buf(self.gpu_rho)

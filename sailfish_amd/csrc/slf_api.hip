@@ -12,7 +12,7 @@
 #include "slf_node.h"
 
 #ifndef SLF_DEFAULT_VARIANT
-#define SLF_DEFAULT_VARIANT 9
+#define SLF_DEFAULT_VARIANT 11
 #endif
 
 namespace {

@@ -45,7 +45,7 @@ __device__ __forceinline__ void vset(typename VecT<VEC>::type& v, int k, float x
 
 // Even AA step (own node, opposite slot), VEC nodes per thread.
 template <int MODEL, int VEC, int NT>
-__global__ void __launch_bounds__(1024) fast_even_kernel(const SweepParams<D3Q19, float> p) {
+__global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   typedef typename VecT<VEC>::type V;
   const Geometry& g = p.g;
@@ -261,6 +261,7 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
     const int threads_needed = (g.lat_nx + vec - 1) / vec;
     int bx = ((threads_needed + 63) / 64) * 64;
     if (bx > block_x) bx = block_x;
+    if (bx > (vec == 4 ? 256 : 512)) bx = (vec == 4 ? 256 : 512);
     dim3 block(bx, 1, 1);
     dim3 grid((threads_needed + bx - 1) / bx, ny, nz);
     if (vec == 4) hipLaunchKernelGGL((fast_even_kernel<MODEL, 4, NT>), grid, block, 0, s, p);
