@@ -183,6 +183,7 @@ class HIPBackend(object):
         self.gpu_id = gpu_id
         self.buffers = {}   # device address -> host mirror
         self._sizes = {}
+        self._raw = {}
         self._iteration_kernels = []
         self._total_memory_bytes = 0
         ctx = ctypes.c_void_p()
@@ -227,29 +228,42 @@ class HIPBackend(object):
     def _host_base(arr):
         return arr.base if (arr.base is not None and isinstance(arr.base, np.ndarray)) else arr
 
-    def alloc_buf(self, size=None, like=None, wrap_in_array=False):
+    def alloc_buf(self, size=None, like=None, wrap_in_array=False, align_offset=0):
         """Allocates a device buffer; with ``like`` the host array (or its base)
         becomes the buffer's mirror and is copied to the device immediately
-        (reference backend_cuda.py:132-154)."""
+        (reference backend_cuda.py:132-154).
+
+        align_offset (extension): the returned address is a 256-byte aligned address plus this many
+        bytes.  The runner uses it for the distribution arrays so that the first *real* node of every
+        row (x = 1, behind the ghost column) starts a 128-byte line."""
         if like is not None:
             host = self._host_base(like)
             if not host.flags['C_CONTIGUOUS']:
                 raise ValueError('host mirror must be C-contiguous')
             size = host.nbytes
         ptr = ctypes.c_void_p()
-        _check(self._lib, self._lib.slf_malloc(self._ctx, int(size), ctypes.byref(ptr)), 'slf_malloc')
-        addr = ptr.value
-        self._total_memory_bytes += int(size)
-        self._sizes[addr] = int(size)
+        pad = 256 if align_offset else 0
+        _check(self._lib, self._lib.slf_malloc(self._ctx, int(size) + pad, ctypes.byref(ptr)), 'slf_malloc')
+        raw = ptr.value
+        addr = raw + int(align_offset)
+        self._total_memory_bytes += int(size) + pad
+        self._sizes[addr] = int(size) + pad
+        self._raw[addr] = raw
         if like is not None:
             self.buffers[addr] = self._host_base(like)
             self.to_buf(addr)
         return addr
 
     def free_buf(self, addr):
-        _check(self._lib, self._lib.slf_free(self._ctx, ctypes.c_void_p(addr)), 'slf_free')
+        raw = self._raw.pop(addr, addr)
+        _check(self._lib, self._lib.slf_free(self._ctx, ctypes.c_void_p(raw)), 'slf_free')
         self.buffers.pop(addr, None)
         self._total_memory_bytes -= self._sizes.pop(addr, 0)
+
+    @staticmethod
+    def dist_align_offset(itemsize, envelope=1):
+        """Byte offset that puts node index `envelope` (the first real x of row 0) on a 128-byte line."""
+        return (128 - envelope * itemsize) % 128
 
     def alloc_async_host_buf(self, shape, dtype):
         """Page-locked host array (reference backend_cuda.py:156-159)."""

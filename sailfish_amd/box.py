@@ -75,9 +75,10 @@ class BoxSim(object):
         self.stride = hipabi.dist_stride(desc)
         fbytes = self.stride * self.dtype().itemsize
         self.module = b.build(desc)
-        self.gpu_dist = [b.alloc_buf(size=self.Q * fbytes)]
+        off = b.dist_align_offset(self.dtype().itemsize)
+        self.gpu_dist = [b.alloc_buf(size=self.Q * fbytes, align_offset=off)]
         if not self.aa:
-            self.gpu_dist.append(b.alloc_buf(size=self.Q * fbytes))
+            self.gpu_dist.append(b.alloc_buf(size=self.Q * fbytes, align_offset=off))
         # host mirrors of the macroscopic fields (ghost = +inf sentinel, reference
         # subdomain_runner.py:278-297)
         self.rho = np.full(self.shape, np.inf, dtype=self.dtype)

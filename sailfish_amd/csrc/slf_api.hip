@@ -342,7 +342,7 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   ph.relaxation_enabled = d->relaxation_enabled;
   // Workgroup = an x-chunk of one row.  Whole rows up to 1024 nodes are one
   // workgroup; longer rows are cut into 256-thread chunks.
-  int bx = ((d->lat_nx + 63) / 64) * 64;
+  int bx = ((d->lat_nx - 2 + 63) / 64) * 64;
   if (bx > 1024) bx = 256;
   const char* env = getenv("SLF_BLOCK_X");
   if (env && atoi(env) >= 64 && atoi(env) <= 1024 && atoi(env) % 64 == 0) bx = atoi(env);

@@ -43,7 +43,9 @@ __device__ __forceinline__ void vset(typename VecT<VEC>::type& v, int k, float x
   else v[k] = x;
 }
 
-// Even AA step (own node, opposite slot), VEC nodes per thread.
+// Even AA step (own node, opposite slot), VEC nodes per thread.  Thread 0 of a row starts at the first
+// real node x = 1; the launcher only selects VEC > 1 when x = 1 is VEC-element aligned in memory (the
+// backend allocates distribution arrays with that offset), so every access is an aligned 8 / 16-byte one.
 template <int MODEL, int VEC, int NT>
 __global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const S
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = p.z0 + (int)blockIdx.z;
-  const int gx0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  const int gx0 = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (gx0 > g.lat_nx - 2) return;
   const uint32_t gi = (uint32_t)gx0 + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
   const size_t ds = g.dist_size;
@@ -75,12 +77,18 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const S
     vset<VEC>(ovz, k, v[2]);
   }
   if (p.options & 1u) {
-    // ghost / padding nodes of the group receive garbage in fields nobody reads (x is wrapped in-sweep)
-    *(V*)(p.rho + gi) = orho;
-    *(V*)(p.vx + gi) = ovx;
-    *(V*)(p.vy + gi) = ovy;
-    *(V*)(p.vz + gi) = ovz;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      if (gx0 + k <= g.lat_nx - 2) {
+        p.rho[gi + k] = vget<VEC>(orho, k);
+        p.vx[gi + k] = vget<VEC>(ovx, k);
+        p.vy[gi + k] = vget<VEC>(ovy, k);
+        p.vz[gi + k] = vget<VEC>(ovz, k);
+      }
+    }
   }
+  // nodes of the last group beyond x = nx are the high ghost / padding: their own slots are never read
+  // when x is wrapped in-sweep
   static_for<0, L::Q>([&](auto I) { st<NT>((V*)(p.dout + ds * (size_t)L::opp(I) + gi), fv[I]); });
 }
 
@@ -91,8 +99,8 @@ __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = p.z0 + (int)blockIdx.z;
-  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (gx < 1 || gx > g.lat_nx - 2) return;
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
   const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
   const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
@@ -131,32 +139,28 @@ __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q
 
 
 // Whole-row workgroup, aligned global accesses for the steps that stream along x
-// (odd AA step: pull + push; AB: push).  Every population row segment is loaded
-// and stored at the thread's own x (one aligned 256-byte request per wave and
-// direction); the +-1 x shift happens in registers (cross-lane shuffle inside a
-// wave, a few LDS words between the waves of the row, the periodic wrap through
-// the two mirror lanes x = 0 and x = nx + 1).  This is the MI355X counterpart of
-// the reference's shuffle / shared-memory propagation (propagation.mako:180-382).
-// Requires blockDim.x >= lat_nx (the row fits one workgroup) and x wrapped in-sweep.
+// (odd AA step: pull + push; AB: push).  Thread t owns the real node x = t + 1; every population row
+// segment is loaded and stored at the thread's own x (one aligned 256-byte request per wave and
+// direction); the +-1 x shift happens in registers: cross-lane shuffle inside a wave, a few LDS words
+// between the waves of the row, and the periodic wrap as the cyclic continuation of the same exchange
+// (x = 1 <-> x = nx).  This is the MI355X counterpart of the reference's shuffle / shared-memory
+// propagation (propagation.mako:180-382).  Requires blockDim.x >= nx (the row fits one workgroup) and
+// x wrapped in-sweep.
 template <int MODEL, int PROP, int NT>
 __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   constexpr int NW = 16;
-  __shared__ float s_in_p[NW][5], s_in_m[NW][5], s_out_p[NW][5], s_out_m[NW][5], s_wrap_p[5], s_wrap_m[5];
+  __shared__ float s_in_p[NW][5], s_in_m[NW][5], s_out_p[NW][5], s_out_m[NW][5];
+  __shared__ float s_inw_p[5], s_inw_m[5], s_wrap_p[5], s_wrap_m[5];
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = p.z0 + (int)blockIdx.z;
-  const int x = (int)threadIdx.x;
   const int nx = g.lat_nx - 2;
-  const int lane = x & 63, w = x >> 6;
-  const bool live = (x >= 1 && x <= nx);
-  int xs = x;
-  if (x == 0) xs = nx;
-  else if (x == nx + 1) xs = 1;
-  else if (x > nx + 1) xs = nx + 1;  // idle lanes: any in-row address
+  const int x = (int)threadIdx.x + 1;
+  const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+  const bool live = x <= nx;
   const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
-  const uint32_t gi = row + (uint32_t)(x <= nx + 1 ? x : nx + 1);
-  const uint32_t gis = row + (uint32_t)xs;
+  const uint32_t gi = row + (uint32_t)(live ? x : nx);  // idle lanes: any in-row address, never stored
   const AxisOff ox0 = {0, 0};
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
   const AxisOff oz = axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]);
@@ -167,13 +171,21 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
     // raw_i(x) = slot opp(i) at (x, y - e_y, z - e_z): the value node x + e_x will use as f_i
     static_for<0, L::Q>([&](auto I) {
       const int off = dir_offset<L, I>(ox0, oy, oz, false);
-      f[I] = ld<NT>(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gis + off));
+      f[I] = ld<NT>(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gi + off));
     });
     {
       int kp = 0, km = 0;
       static_for<1, L::Q>([&](auto I) {
-        if constexpr (L::ex(I) > 0) { if (lane == 63) s_in_p[w][kp] = f[I]; kp++; }
-        if constexpr (L::ex(I) < 0) { if (lane == 0) s_in_m[w][km] = f[I]; km++; }
+        if constexpr (L::ex(I) > 0) {
+          if (lane == 63) s_in_p[w][kp] = f[I];
+          if (x == nx) s_inw_p[kp] = f[I];
+          kp++;
+        }
+        if constexpr (L::ex(I) < 0) {
+          if (lane == 0) s_in_m[w][km] = f[I];
+          if (x == 1) s_inw_m[km] = f[I];
+          km++;
+        }
       });
     }
     __syncthreads();
@@ -183,12 +195,14 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
         if constexpr (L::ex(I) > 0) {
           float t = __shfl_up(f[I], 1);
           if (lane == 0 && w > 0) t = s_in_p[w - 1][kp];
+          if (x == 1) t = s_inw_p[kp];
           f[I] = t;
           kp++;
         }
         if constexpr (L::ex(I) < 0) {
           float t = __shfl_down(f[I], 1);
           if (lane == 63) t = s_in_m[(w + 1) & (NW - 1)][km];
+          if (x == nx) t = s_inw_m[km];
           f[I] = t;
           km++;
         }
@@ -257,8 +271,13 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
                            int block_x, hipStream_t s) {
   const int variant = g.variant;
   const int vec = (variant & 4) ? 4 : ((variant & 2) ? 2 : 1);
-  if (prop == PROP_AA_EVEN && vec > 1) {
-    const int threads_needed = (g.lat_nx + vec - 1) / vec;
+  const int nx = g.lat_nx - 2;
+  // vector accesses need x = 1 on a vec-element boundary of both arrays
+  const bool vec_ok = (((uintptr_t)(p.din + 1)) % (sizeof(float) * vec) == 0) &&
+                      (((uintptr_t)(p.dout + 1)) % (sizeof(float) * vec) == 0) && (g.arr_nx % vec == 0) &&
+                      (g.dist_size % vec == 0);
+  if (prop == PROP_AA_EVEN && vec > 1 && vec_ok) {
+    const int threads_needed = (nx + vec - 1) / vec;
     int bx = ((threads_needed + 63) / 64) * 64;
     if (bx > block_x) bx = block_x;
     if (bx > (vec == 4 ? 256 : 512)) bx = (vec == 4 ? 256 : 512);
@@ -269,7 +288,7 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
     return true;
   }
   if ((variant & 8) && prop != PROP_AA_EVEN) {
-    const int bx = ((g.lat_nx + 63) / 64) * 64;
+    const int bx = ((nx + 63) / 64) * 64;
     if (bx <= 1024) {
       dim3 block(bx, 1, 1);
       dim3 grid(1, ny, nz);
@@ -280,7 +299,7 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
   }
   if (NT == 0) return false;  // plain scalar: the general kernel already does that
   dim3 block(block_x, 1, 1);
-  dim3 grid((g.lat_nx + block_x - 1) / block_x, ny, nz);
+  dim3 grid((nx + block_x - 1) / block_x, ny, nz);
   switch (prop) {
     case PROP_AB: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AB, NT>), grid, block, 0, s, p); break;
     case PROP_AA_EVEN: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_EVEN, NT>), grid, block, 0, s, p); break;

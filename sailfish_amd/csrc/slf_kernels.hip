@@ -26,8 +26,11 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
-  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (gx < 1 || gx > g.lat_nx - 2) return;
+  // thread 0 of a row owns the first *real* node (x = 1): with the distribution arrays allocated so that
+  // x = 1 sits on a 128-byte boundary (backend alloc_buf(align_offset=...)), every wave's row segment
+  // is line aligned
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
 
   const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
 
@@ -303,8 +306,8 @@ __global__ void __launch_bounds__(1024) macro_kernel(const SweepParams<L, R> p) 
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
-  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (gx < 1 || gx > g.lat_nx - 2) return;
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
   const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
   int kind = NK_FLUID;
   if constexpr (GENERAL) {
@@ -342,7 +345,7 @@ static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& 
                                 int z0, int z1, int block_x, hipStream_t s) {
   const SweepParams<L, R> p = make_params<L, R>(g, ph, a, y0, z0);
   dim3 block(block_x, 1, 1);
-  dim3 grid((g.lat_nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
+  dim3 grid((g.lat_nx - 2 + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
   if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false>), grid, block, 0, s, p);
@@ -455,7 +458,7 @@ static hipError_t launch_macro2(Prop prop, bool general, const Geometry& g, cons
   const SweepParams<L, R> p = make_params<L, R>(g, ph, a, 1, L::dim == 3 ? 1 : 0);
   const int bx = 256;
   dim3 block(bx, 1, 1);
-  dim3 grid((g.lat_nx + bx - 1) / bx, g.lat_ny - 2, L::dim == 3 ? g.lat_nz - 2 : 1);
+  dim3 grid((g.lat_nx - 2 + bx - 1) / bx, g.lat_ny - 2, L::dim == 3 ? g.lat_nz - 2 : 1);
   if (prop == PROP_AA_ODD) {
     if (general) hipLaunchKernelGGL((macro_kernel<L, R, PROP_AA_ODD, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((macro_kernel<L, R, PROP_AA_ODD, false>), grid, block, 0, s, p);

@@ -211,9 +211,10 @@ class SubdomainRunner(object):
                 self._gpu_field_map[id(comp)] = b.alloc_buf(like=self._host_base[id(comp)])
         self._gpu_geo_map = b.alloc_buf(like=self._host_base[id(self._subdomain._type_map_ghost)])
         nbytes = self._sim.grid.Q * self._dist_stride * self.float().itemsize
-        self._gpu_grids_primary.append(b.alloc_buf(size=nbytes))
+        off = b.dist_align_offset(self.float().itemsize)
+        self._gpu_grids_primary.append(b.alloc_buf(size=nbytes, align_offset=off))
         if self.config.access_pattern == 'AB':
-            self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes))
+            self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes, align_offset=off))
         self.config.logger.debug('distributions: %d MiB' % (nbytes * (2 if self._gpu_grids_secondary else 1) >> 20))
 
     def gpu_field(self, field):

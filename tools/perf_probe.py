@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--model', default='bgk')
     ap.add_argument('--modes', default='even,odd,aa,ab')
     ap.add_argument('--norelax', action='store_true')
+    ap.add_argument('--noalign', action='store_true')
     ap.add_argument('--pads', default='0', help='comma list of dist_stride paddings (elements)')
     ap.add_argument('--trace', type=int, default=0, help='also print the time of every batch of N launches')
     args = ap.parse_args()
@@ -40,8 +41,9 @@ def main():
     nodes = desc0.arr_nx * desc0.arr_ny * desc0.arr_nz
     pads = [int(x) for x in args.pads.split(',')]
     maxstride = nodes + max(pads)
-    dist_a = b.alloc_buf(size=19 * maxstride * 4)
-    dist_b = b.alloc_buf(size=19 * maxstride * 4) if 'ab' in args.modes else 0
+    off = b.dist_align_offset(4) if not args.noalign else 0
+    dist_a = b.alloc_buf(size=19 * maxstride * 4, align_offset=off)
+    dist_b = b.alloc_buf(size=19 * maxstride * 4, align_offset=off) if 'ab' in args.modes else 0
     shape = (desc0.arr_nz, desc0.arr_ny, desc0.arr_nx)
     rho = np.ones(shape, dtype=np.float32)
     rho += (1e-3 * np.random.RandomState(1).rand(*shape)).astype(np.float32)
