@@ -5,6 +5,11 @@ walls on three sides, a regularized-velocity lid moving in +x on the top row).
     python examples/ldc_2d.py --lat_nx=256 --lat_ny=256 --visc=0.0254 --max_iters=10000 --every=1000 \\
         --output=/tmp/ldc
 """
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root (the `sailfish` alias)
+
 from sailfish.controller import LBSimulationController
 from sailfish.lb_single import LBFluidSim
 from sailfish.node_type import NTFullBBWall, NTRegularizedVelocity

@@ -1,6 +1,11 @@
 #!/usr/bin/env python
 """Lid-driven cavity, D3Q19 (the geometry of sailfish's examples/ldc_3d.py: the z = max plane is the
 lid, moving in +x; every other face is a full-way bounce-back wall)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root (the `sailfish` alias)
+
 from sailfish.controller import LBSimulationController
 from sailfish.lb_single import LBFluidSim
 from sailfish.node_type import NTFullBBWall, NTRegularizedVelocity

@@ -2,6 +2,11 @@
 """Plane Poiseuille flow, D2Q9: body-force driven (periodic along the flow) or pressure driven
 (equilibrium-density inlet / outlet), full-way or half-way bounce-back walls.  Option names follow
 sailfish's examples/poiseuille.py (--horizontal, --drive, --wall, --stationary)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root (the `sailfish` alias)
+
 import numpy as np
 
 from sailfish.controller import LBSimulationController

@@ -2,6 +2,11 @@
 """Hagen-Poiseuille flow in a circular pipe, D3Q19, body-force or pressure driven; the pipe wall is a
 staircase of full-way bounce-back nodes (cf. sailfish's examples/poiseuille_3d.py; same option names:
 --flow_direction, --drive, --stationary)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root (the `sailfish` alias)
+
 import numpy as np
 
 from sailfish.controller import LBSimulationController

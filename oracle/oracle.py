@@ -42,6 +42,12 @@ def lib(precision=4):
     L.orc_macro_pbc.argtypes = [P(SlfModuleDesc), vp, ctypes.c_int]
     L.orc_sparse.argtypes = [ctypes.c_int, vp, vp, vp, ctypes.c_int]
     L.orc_compute_macro.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp, vp, vp, vp]
+    L.orc_sc_init.argtypes = [P(SlfModuleDesc), vp, vp, vp, vp, vp, vp, vp]
+    L.orc_sc_macro.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_sc_step.argtypes = [P(SlfModuleDesc), ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_sc_force_node.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp, dp]
+    for fn in (L.orc_sc_init, L.orc_sc_macro, L.orc_sc_step, L.orc_sc_force_node):
+        fn.restype = None
     for fn in (L.orc_node_feq, L.orc_node_macro, L.orc_node_update, L.orc_init, L.orc_step, L.orc_pbc,
                L.orc_macro_pbc, L.orc_sparse, L.orc_compute_macro):
         fn.restype = None
@@ -83,6 +89,13 @@ def node_update(desc, kind, orientation, par, f, precision=8):
         pp[:len(par)] = par
     lib(precision).orc_node_update(ctypes.byref(desc), kind, orientation, _dp(pp), _dp(f), _dp(rho), _dp(v))
     return f, rho[0], v
+
+
+def sc_force_node(lattice, potential, cc, rho_local, neigh, precision=8):
+    out = np.zeros(3)
+    n = np.ascontiguousarray(neigh, dtype=np.float64)
+    lib(precision).orc_sc_force_node(lattice, potential, float(cc), float(rho_local), _dp(n), _dp(out))
+    return out
 
 
 class OracleSim(object):
@@ -128,6 +141,17 @@ class OracleSim(object):
 
     def sparse(self, collect, idx, dist, buf):
         self.L.orc_sparse(int(collect), _vp(idx), _vp(dist), _vp(buf), len(idx))
+
+    def sc_init(self, d1, d2, rho, phi, vx, vy, vz):
+        self.L.orc_sc_init(ctypes.byref(self.desc), _vp(d1), _vp(d2), _vp(rho), _vp(phi), _vp(vx), _vp(vy), _vp(vz))
+
+    def sc_macro(self, prop, nmap, d1, d2, rho, phi, vx, vy, vz):
+        self.L.orc_sc_macro(ctypes.byref(self.desc), prop, _vp(nmap), _vp(d1), _vp(d2), _vp(rho), _vp(phi), _vp(vx),
+                            _vp(vy), _vp(vz))
+
+    def sc_step(self, grid_idx, prop, nmap, din, dout, rho, phi, vx, vy, vz):
+        self.L.orc_sc_step(ctypes.byref(self.desc), grid_idx, prop, _vp(nmap), _vp(din), _vp(dout), _vp(rho),
+                           _vp(phi), _vp(vx), _vp(vy), _vp(vz))
 
     def compute_macro(self, prop, nmap, din, rho, vx, vy, vz):
         self.L.orc_compute_macro(ctypes.byref(self.desc), prop, _vp(nmap), _vp(din), _vp(rho), _vp(vx), _vp(vy),

@@ -7,7 +7,7 @@ import sys
 import sailfish_amd
 
 _MODULES = ['sym', 'util', 'config', 'node_type', 'geo_encoder', 'subdomain_connection', 'subdomain', 'geo',
-            'io', 'lb_base', 'subdomain_runner', 'lb_single', 'connector', 'controller', 'backend_hip', 'hipabi']
+            'io', 'lb_base', 'subdomain_runner', 'lb_single', 'lb_binary', 'connector', 'controller', 'backend_hip', 'hipabi']
 
 __version__ = sailfish_amd.__version__
 

@@ -36,11 +36,19 @@ struct Physics {
   int relaxation_enabled;
 };
 
+struct ShanChen {
+  int enabled;
+  double tau_phi;
+  double G[4];      // G11 G12 G21 G22
+  int potential;    // 0 linear, 1 classic
+};
+
 struct SweepArgs {
   const void* map;
   void* dist_in;
   void* dist_out;
   void* rho;
+  void* phi;        // second density field (binary Shan-Chen), else unused
   void* v[3];
   const void* node_params;
   uint32_t options;
@@ -68,5 +76,16 @@ hipError_t launch_sparse(const KernelSelector& sel, bool collect, const unsigned
 
 hipError_t launch_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
                         const SweepArgs& a, hipStream_t s);
+
+// ---- binary Shan-Chen (slf_sc.hip) ----
+// macro pass: a.dist_in = lattice 0, a.dist_out = lattice 1 (both read), writes rho, phi, v
+hipError_t launch_sc_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                           const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, hipStream_t s);
+// collide-and-stream of lattice `grid_idx`: reads rho, phi, v
+hipError_t launch_sc_sweep(const KernelSelector& sel, int grid_idx, Prop prop, const Geometry& g, const Physics& ph,
+                           const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
+                           hipStream_t s);
+hipError_t launch_sc_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist1, void* dist2,
+                          const void* rho, const void* phi, const void* const v[3], hipStream_t s);
 
 }  // namespace slf

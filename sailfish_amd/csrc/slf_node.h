@@ -120,30 +120,36 @@ struct CollideParams {
   int has_force;
 };
 
-// C5 + C6: BGK relaxation with optional Guo forcing.  v is updated to the
-// output velocity (u + a/2) when a force is present.
+// C5 + C6: BGK relaxation with optional Guo forcing by the acceleration a.  v is updated to the
+// velocity used for the equilibrium (u + a/2), which is also the reference's output velocity.
 template <class L, class R>
-SLF_D void bgk_relax(R (&f)[L::Q], R rho, R (&v)[3], const CollideParams<L, R>& cp) {
-  const R rho0 = cp.incompressible ? (R)1 : rho;
-  if (cp.has_force) {
-    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * cp.accel[D]; });
+SLF_D void bgk_relax_accel(R (&f)[L::Q], R rho, R (&v)[3], R omega, R guo_pref, bool incompressible, bool has_force,
+                           const R (&a)[3]) {
+  const R rho0 = incompressible ? (R)1 : rho;
+  if (has_force) {
+    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * a[D]; });
   }
   const R u15 = usq15<L, R>(v);
   static_for<0, L::Q>([&](auto I) {
     const R fe = feq<L, R, I>(rho, rho0, v, u15);
-    f[I] = f[I] + cp.omega * (fe - f[I]);
+    f[I] = f[I] + omega * (fe - f[I]);
   });
-  if (cp.has_force) {
-    const R pref = rho * cp.guo_pref;
-    R va = v[0] * cp.accel[0] + v[1] * cp.accel[1];
-    if constexpr (L::dim == 3) va = va + v[2] * cp.accel[2];
+  if (has_force) {
+    const R pref = rho * guo_pref;
+    R va = v[0] * a[0] + v[1] * a[1];
+    if constexpr (L::dim == 3) va = va + v[2] * a[2];
     static_for<0, L::Q>([&](auto I) {
       const R eu = edotv<L, R, I>(v);
-      const R ea = edotv<L, R, I>(cp.accel);
+      const R ea = edotv<L, R, I>(a);
       const R t = (ea - va) + (R)3 * eu * ea;
       f[I] = f[I] + pref * Weights<L, R>::w(I) * t;
     });
   }
+}
+
+template <class L, class R>
+SLF_D void bgk_relax(R (&f)[L::Q], R rho, R (&v)[3], const CollideParams<L, R>& cp) {
+  bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, cp.has_force != 0, cp.accel);
 }
 
 // C7 helpers: one row of the integer moment matrix applied to a vector.

@@ -1,0 +1,312 @@
+// Binary-fluid Shan-Chen model (two lattices coupled by a pseudopotential force) for gfx950.
+//
+//   sc_macro_kernel     ShanChenPrepareMacroFields      (reference templates/models/binary_shan_chen.mako:19-87)
+//   sc_sweep_kernel<K>  ShanChenCollideAndPropagate{0,1} (binary_shan_chen.mako:89-141, shan_chen.mako:9-84)
+//   sc_init_kernel      SetInitialConditions (binary)    (templates/models/lb_binary_fluid.mako:87-127)
+//
+// Same layout, streaming modes and launch shape as the single-fluid sweep (slf_kernels.hip).  The force
+//   F_k(x) = - sum_j G_kj psi(rho_k(x)) sum_i w_i e_i psi(rho_j(x + e_i))
+// reads the 18 neighbour densities of the *other* field through the cache hierarchy (each value is
+// reused by 18 nodes; rows of a workgroup are contiguous), the acceleration F_k / rho_k enters the BGK
+// collision through Guo forcing exactly like a body force (relaxation_common.mako:56-64,110-149).
+#include "slf_sweep.h"
+
+namespace slf {
+
+template <class L, class R>
+struct ScParams {
+  const uint32_t* __restrict__ map;
+  const R* d_in;     // sweep: lattice in      | macro: lattice 0
+  R* d_out;          // sweep: lattice out     | macro: lattice 1 (read)
+  R* rho0;
+  R* rho1;
+  R* vx;
+  R* vy;
+  R* vz;
+  uint32_t options;
+  int y0, z0;
+  Geometry g;
+  R omega[2];        // 1/tau, 1/tau_phi
+  R guo_pref[2];
+  R G[2];            // couplings of this lattice with field 0 and field 1 (sweep only)
+  R accel[3];        // additional body-force acceleration
+  int has_body_force;
+  int potential;
+};
+
+template <class R>
+__device__ __forceinline__ R sc_psi(R rho, int potential) {
+  // sym.py:896-908: linear psi = rho; classic psi = 1 - exp(-rho)
+  if (potential == 0) return rho;
+  return (R)1 - (R)exp((double)((R)0 - rho));
+}
+
+template <class L, class R, int PROP>
+__device__ __forceinline__ void sc_load(R (&f)[L::Q], const R* din, size_t ds, uint32_t gi, const AxisOff& ox,
+                                        const AxisOff& oy, const AxisOff& oz) {
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_ODD) {
+      const int off = dir_offset<L, I>(ox, oy, oz, false);
+      f[I] = (din + ds * (size_t)L::opp(I))[(uint32_t)((int)gi + off)];
+    } else {
+      f[I] = (din + ds * (size_t)I)[gi];
+    }
+  });
+}
+
+template <class L, class R, int PROP, bool GENERAL>
+__global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  if constexpr (GENERAL) {
+    const uint32_t code = p.map[gi];
+    const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if (!kind_is_wet(kind)) return;
+  }
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  const size_t ds = g.dist_size;
+  R f[L::Q];
+  // lattice 0
+  sc_load<L, R, PROP>(f, p.d_in, ds, gi, ox, oy, oz);
+  const R rho0 = density<L, R>(f);
+  R v[3];
+  v[0] = p.omega[0] * momentum<L, R, 0>(f);
+  v[1] = p.omega[0] * momentum<L, R, 1>(f);
+  v[2] = (R)0;
+  if constexpr (L::dim == 3) v[2] = p.omega[0] * momentum<L, R, 2>(f);
+  // lattice 1
+  sc_load<L, R, PROP>(f, (const R*)p.d_out, ds, gi, ox, oy, oz);
+  const R rho1 = density<L, R>(f);
+  v[0] = v[0] + p.omega[1] * momentum<L, R, 0>(f);
+  v[1] = v[1] + p.omega[1] * momentum<L, R, 1>(f);
+  if constexpr (L::dim == 3) v[2] = v[2] + p.omega[1] * momentum<L, R, 2>(f);
+  // common velocity: sum_k j_k / tau_k over sum_k rho_k / tau_k (binary_shan_chen.mako:69-83)
+  const R total = p.omega[0] * rho0 + p.omega[1] * rho1;
+  p.rho0[gi] = rho0;
+  p.rho1[gi] = rho1;
+  p.vx[gi] = v[0] / total;
+  p.vy[gi] = v[1] / total;
+  if constexpr (L::dim == 3) p.vz[gi] = v[2] / total;
+}
+
+template <class L, class R, int K, int PROP, bool GENERAL>
+__global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  int kind = NK_FLUID;
+  if constexpr (GENERAL) {
+    const uint32_t code = p.map[gi];
+    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if (kind_is_excluded(kind)) return;
+  }
+  const bool wet = kind_is_wet(kind);
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  const size_t ds = g.dist_size;
+
+  const R* own = (K == 0) ? p.rho0 : p.rho1;
+  const R rho = own[gi];
+  // ---- Shan-Chen acceleration (sc_calculate_force, shan_chen.mako:9-27)
+  R a[3] = {(R)0, (R)0, (R)0};
+  if (wet) {
+    static_for<0, 2>([&](auto J) {
+      const R cc = p.G[J];
+      if (cc != (R)0) {
+        const R* field = (J == 0) ? p.rho0 : p.rho1;
+        R force[3] = {(R)0, (R)0, (R)0};
+        static_for<1, L::Q>([&](auto I) {
+          const int off = dir_offset<L, I>(ox, oy, oz, true);
+          const R psi = sc_psi<R>(field[(uint32_t)((int)gi + off)], p.potential);
+          static_for<0, L::dim>([&](auto D) {
+            constexpr int e = e_comp<L>(I, D);
+            if constexpr (e > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
+            if constexpr (e < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
+          });
+        });
+        const R psi_loc = sc_psi<R>(rho, p.potential);
+        static_for<0, L::dim>([&](auto D) {
+          force[D] = force[D] * (((R)0 - psi_loc) * cc);
+          a[D] = a[D] + force[D];
+        });
+      }
+    });
+    static_for<0, L::dim>([&](auto D) { a[D] = a[D] / rho; });
+    if (p.has_body_force) {
+      static_for<0, L::dim>([&](auto D) { a[D] = a[D] + p.accel[D]; });
+    }
+  }
+
+  R f[L::Q];
+  sc_load<L, R, PROP>(f, p.d_in, ds, gi, ox, oy, oz);
+  R v[3];
+  v[0] = p.vx[gi];
+  v[1] = p.vy[gi];
+  v[2] = (R)0;
+  if constexpr (L::dim == 3) v[2] = p.vz[gi];
+  if constexpr (GENERAL) {
+    if (kind == NK_FULL_BB) bounce_back<L, R>(f);
+  }
+  if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[K], p.guo_pref[K], false, true, a);
+
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_EVEN) {
+      (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
+    } else {
+      const int off = dir_offset<L, I>(ox, oy, oz, true);
+      (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+    }
+  });
+}
+
+// f1 = feq(rho, v), f2 = feq(phi, v) on every node (no type test)
+template <class L, class R>
+__global__ void __launch_bounds__(256) sc_init_kernel(R* d1, R* d2, const R* __restrict__ irho, const R* __restrict__ iphi,
+                                                     const R* __restrict__ ivx, const R* __restrict__ ivy,
+                                                     const R* __restrict__ ivz, Geometry g) {
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int gy = (int)blockIdx.y;
+  const int gz = (int)blockIdx.z;
+  if (gx > g.lat_nx - 1) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  R v[3];
+  v[0] = ivx[gi];
+  v[1] = ivy[gi];
+  v[2] = (R)0;
+  if constexpr (L::dim == 3) v[2] = ivz[gi];
+  const R u15 = usq15<L, R>(v);
+  const R r0 = irho[gi], r1 = iphi[gi];
+  static_for<0, L::Q>([&](auto I) {
+    (d1 + (size_t)g.dist_size * (size_t)I)[gi] = feq<L, R, I>(r0, r0, v, u15);
+    (d2 + (size_t)g.dist_size * (size_t)I)[gi] = feq<L, R, I>(r1, r1, v, u15);
+  });
+}
+
+// ---------------------------------------------------------------------------
+template <class L, class R>
+static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanChen& sc, const SweepArgs& a, int grid_idx,
+                              int y0, int z0) {
+  ScParams<L, R> p;
+  p.map = (const uint32_t*)a.map;
+  p.d_in = (const R*)a.dist_in;
+  p.d_out = (R*)a.dist_out;
+  p.rho0 = (R*)a.rho;
+  p.rho1 = (R*)a.phi;
+  p.vx = (R*)a.v[0];
+  p.vy = (R*)a.v[1];
+  p.vz = (R*)a.v[2];
+  p.options = a.options;
+  p.y0 = y0;
+  p.z0 = z0;
+  p.g = g;
+  p.omega[0] = (R)(1.0 / ph.tau);
+  p.omega[1] = (R)(1.0 / sc.tau_phi);
+  p.guo_pref[0] = (R)(3.0 * (1.0 - 0.5 / ph.tau));
+  p.guo_pref[1] = (R)(3.0 * (1.0 - 0.5 / sc.tau_phi));
+  p.G[0] = (R)sc.G[2 * grid_idx + 0];
+  p.G[1] = (R)sc.G[2 * grid_idx + 1];
+  for (int d = 0; d < 3; d++) p.accel[d] = (R)ph.accel[d];
+  p.has_body_force = ph.has_force;
+  p.potential = sc.potential;
+  return p;
+}
+
+template <class L, class R>
+static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Physics& ph, const ShanChen& sc,
+                            const SweepArgs& a, int y0, int y1, int z0, int z1, hipStream_t s) {
+  const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
+  const int nx = g.lat_nx - 2;
+  int bx = ((nx + 63) / 64) * 64;
+  if (bx > 1024) bx = 256;
+  dim3 block(bx, 1, 1);
+  dim3 grid((nx + bx - 1) / bx, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
+  if (grid.y == 0 || grid.z == 0) return hipSuccess;
+#define SLF_SCM(P)                                                                        \
+  do {                                                                                    \
+    if (general) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((sc_macro_kernel<L, R, P, false>), grid, block, 0, s, p);        \
+  } while (0)
+  if (prop == PROP_AA_ODD) SLF_SCM(PROP_AA_ODD);
+  else SLF_SCM(PROP_AB);
+#undef SLF_SCM
+  return hipGetLastError();
+}
+
+template <class L, class R, int K>
+static hipError_t sc_sweep3(Prop prop, bool general, const ScParams<L, R>& p, dim3 grid, dim3 block, hipStream_t s) {
+#define SLF_SCS(P)                                                                           \
+  do {                                                                                       \
+    if (general) hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, P, true>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, P, false>), grid, block, 0, s, p);        \
+  } while (0)
+  if (prop == PROP_AB) SLF_SCS(PROP_AB);
+  else if (prop == PROP_AA_EVEN) SLF_SCS(PROP_AA_EVEN);
+  else SLF_SCS(PROP_AA_ODD);
+#undef SLF_SCS
+  return hipGetLastError();
+}
+
+template <class L, class R>
+static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometry& g, const Physics& ph,
+                            const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
+                            hipStream_t s) {
+  const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, grid_idx, y0, z0);
+  const int nx = g.lat_nx - 2;
+  dim3 block(block_x, 1, 1);
+  dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
+  if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  if (grid_idx == 0) return sc_sweep3<L, R, 0>(prop, general, p, grid, block, s);
+  return sc_sweep3<L, R, 1>(prop, general, p, grid, block, s);
+}
+
+#define SLF_DISPATCH_LR(sel, CALL)                                   \
+  do {                                                               \
+    if ((sel).lattice == 0) {                                        \
+      if ((sel).precision == 4) { using L = D2Q9; using R = float; CALL; }  \
+      else { using L = D2Q9; using R = double; CALL; }               \
+    } else {                                                         \
+      if ((sel).precision == 4) { using L = D3Q19; using R = float; CALL; } \
+      else { using L = D3Q19; using R = double; CALL; }              \
+    }                                                                \
+  } while (0)
+
+hipError_t launch_sc_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                           const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (sc_macro2<L, R>(prop, sel.general, g, ph, sc, a, y0, y1, z0, z1, s)));
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_sc_sweep(const KernelSelector& sel, int grid_idx, Prop prop, const Geometry& g, const Physics& ph,
+                           const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
+                           hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (sc_sweep2<L, R>(grid_idx, prop, sel.general, g, ph, sc, a, y0, y1, z0, z1, block_x, s)));
+  return hipErrorInvalidValue;
+}
+
+template <class L, class R>
+static hipError_t sc_init2(const Geometry& g, void* d1, void* d2, const void* rho, const void* phi,
+                           const void* const v[3], hipStream_t s) {
+  dim3 block(256, 1, 1);
+  dim3 grid((g.lat_nx + 255) / 256, g.lat_ny, g.lat_nz);
+  hipLaunchKernelGGL((sc_init_kernel<L, R>), grid, block, 0, s, (R*)d1, (R*)d2, (const R*)rho, (const R*)phi,
+                     (const R*)v[0], (const R*)v[1], (const R*)v[2], g);
+  return hipGetLastError();
+}
+
+hipError_t launch_sc_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist1, void* dist2,
+                          const void* rho, const void* phi, const void* const v[3], hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (sc_init2<L, R>(g, dist1, dist2, rho, phi, v, s)));
+  return hipErrorInvalidValue;
+}
+
+}  // namespace slf

@@ -14,6 +14,7 @@ SLF_MAX_Q = 27
 SLF_D2Q9, SLF_D3Q19 = 0, 1
 SLF_BGK, SLF_MRT = 0, 1
 SLF_AB, SLF_AA = 0, 1
+SLF_SIM_LBM, SLF_SIM_SHAN_CHEN_BINARY = 0, 1
 (SLF_NK_FLUID, SLF_NK_GHOST, SLF_NK_UNUSED, SLF_NK_PROPAGATION_ONLY, SLF_NK_FULL_BB, SLF_NK_HALF_BB,
  SLF_NK_REGULARIZED_VELOCITY, SLF_NK_EQUILIBRIUM_DENSITY, SLF_NK_EQUILIBRIUM_VELOCITY) = range(9)
 
@@ -43,7 +44,11 @@ class SlfModuleDesc(Structure):
         ('node_params', POINTER(c_double)),
         ('dist_stride', ctypes.c_uint64),
         ('periodic_local', c_int32 * 3),
-        ('reserved0', c_int32),
+        ('simtype', c_int32),
+        ('tau_phi', c_double),
+        ('sc_G', c_double * 4),
+        ('sc_potential', c_int32),
+        ('reserved1', c_int32),
     ]
 
 
@@ -134,7 +139,7 @@ def make_desc(**kw):
     d.arr_nz = 1
     keep = []
     for k, v in kw.items():
-        if k in ('periodic_fused', 'accel', 'periodic_local'):
+        if k in ('periodic_fused', 'accel', 'periodic_local', 'sc_G'):
             for i, x in enumerate(v):
                 getattr(d, k)[i] = x
         elif k == 'mrt_rates':

@@ -212,9 +212,10 @@ class SubdomainRunner(object):
         self._gpu_geo_map = b.alloc_buf(like=self._host_base[id(self._subdomain._type_map_ghost)])
         nbytes = self._sim.grid.Q * self._dist_stride * self.float().itemsize
         off = b.dist_align_offset(self.float().itemsize)
-        self._gpu_grids_primary.append(b.alloc_buf(size=nbytes, align_offset=off))
-        if self.config.access_pattern == 'AB':
-            self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes, align_offset=off))
+        for _ in self._sim.grids:
+            self._gpu_grids_primary.append(b.alloc_buf(size=nbytes, align_offset=off))
+            if self.config.access_pattern == 'AB':
+                self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes, align_offset=off))
         self.config.logger.debug('distributions: %d MiB' % (nbytes * (2 if self._gpu_grids_secondary else 1) >> 20))
 
     def gpu_field(self, field):
@@ -223,6 +224,7 @@ class SubdomainRunner(object):
         return self._gpu_field_map[id(field)]
 
     def gpu_dist(self, num, copy):
+        """Device address of lattice `num`, copy 0 (A) or 1 (B; the same buffer as A in the AA pattern)."""
         if copy == 0:
             return self._gpu_grids_primary[num]
         if self._gpu_grids_secondary:
@@ -534,3 +536,49 @@ class SubdomainRunner(object):
         it0 = self._sim.iteration
         self.main()
         self.timing = {'steps': self._sim.iteration - it0, 'wall': time.time() - t0}
+
+
+class NNSubdomainRunner(SubdomainRunner):
+    """Runner for models with non-local interactions (reference subdomain_runner.py:1840-2197): every
+    step first computes the macroscopic fields of all nodes, makes them available on the ghost layer
+    (periodic boundaries), and only then collides and streams:
+
+        ShanChenPrepareMacroFields -> ApplyMacroPeriodicBoundaryConditions (rho, phi)
+        -> ShanChenCollideAndPropagate0, 1 -> ApplyPeriodicBoundaryConditions (both lattices)
+
+    Axes wrapped inside the kernels need no ghost fill.  Exchange of the macroscopic fields between
+    *different* subdomains (reference _send_macro/_recv_macro) is not implemented yet: one subdomain."""
+
+    def _init_halo(self):
+        if self._all_specs is not None and len(self._all_specs) > 1:
+            raise NotImplementedError('non-local (Shan-Chen) models run on a single subdomain in this version')
+        self._links = {}
+
+    def _prepare_compute_kernels(self):
+        self._kernels_full = self._sim.get_compute_kernels(self, True, True)
+        self._kernels_none = self._sim.get_compute_kernels(self, False, True)
+        self._pbc_kernels = self._sim.get_pbc_kernels(self)
+        self._pbc_axes = [a for a in range(self.dim) if self._local_periodic()[a] and not self._fused[a]]
+        self._regions = self._make_regions()
+        self._kernels_prepared = True
+
+    def step_compute(self, sync_req=False):
+        b = self.backend
+        it = self._sim.iteration
+        kernels = self._kernels_full if sync_req else self._kernels_none
+        macro_kernel, sim_kernels = kernels[it & 1]
+        b.run_kernel(macro_kernel, None, self._calc_stream)
+        base = 1 - (it & 1)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels.macro[base][axis]:
+                b.run_kernel(k, None, self._calc_stream)
+        for k in sim_kernels:
+            b.run_kernel(k, None, self._calc_stream)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels.distributions[base][axis]:
+                b.run_kernel(k, None, self._calc_stream)
+        self._sim.iteration += 1
+        b.set_iteration(self._sim.iteration)
+
+    def _debug_get_dist(self, output=True, grid_num=0, copy=None):
+        return SubdomainRunner._debug_get_dist(self, output, grid_num, copy)

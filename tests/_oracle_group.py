@@ -126,3 +126,69 @@ class OracleGroup(object):
             else:
                 out[sl] = s.real(s.v[int(what[1])])
         return out
+
+
+class OracleSCSubdomain(object):
+    """Oracle twin of NNSubdomainRunner for the binary Shan-Chen model (single subdomain)."""
+
+    def __init__(self, runner):
+        r = self.runner = runner
+        r._init_geometry()
+        r._sim.init_fields(r)
+        r._subdomain.init_fields(r._sim)
+        self.desc = r._module_desc()
+        self.o = OracleSim(self.desc)
+        self.dim = r.dim
+        self.aa = self.desc.access_pattern == hipabi.SLF_AA
+        dt = self.o.dtype
+        self.node_map = np.ascontiguousarray(r._subdomain._type_map_base, dtype=np.uint32).reshape(self.o.shape)
+        self.rho = np.ascontiguousarray(r.field_base(r._sim.rho), dtype=dt).reshape(self.o.shape)
+        self.phi = np.ascontiguousarray(r.field_base(r._sim.phi), dtype=dt).reshape(self.o.shape)
+        self.v = [np.ascontiguousarray(r.field_base(c), dtype=dt).reshape(self.o.shape) for c in r._sim.v]
+        while len(self.v) < 3:
+            self.v.append(np.zeros(self.o.shape, dtype=dt))
+        ncopy = 1 if self.aa else 2
+        self.d1 = [self.o.new_dist() for _ in range(ncopy)]
+        self.d2 = [self.o.new_dist() for _ in range(ncopy)]
+        with np.errstate(all='ignore'):
+            for a, b in zip(self.d1, self.d2):
+                self.o.sc_init(a, b, self.rho, self.phi, *self.v)
+        local = r._local_periodic()
+        self.pbc_axes = [a for a in range(self.dim) if local[a] and not r._fused[a]]
+        self.iteration = 0
+
+    def step(self):
+        it = self.iteration
+        m = self.node_map
+        if self.aa:
+            i = o = 0
+            prop = 2 if (it & 1) else 1
+            macro_prop, swap = prop, (it & 1) == 0
+        else:
+            i, o = it & 1, 1 - (it & 1)
+            prop = macro_prop = 0
+            swap = False
+        self.o.sc_macro(macro_prop, m, self.d1[i], self.d2[i], self.rho, self.phi, *self.v)
+        for axis in self.pbc_axes:
+            self.o.macro_pbc(self.rho, axis)
+            self.o.macro_pbc(self.phi, axis)
+        self.o.sc_step(0, prop, m, self.d1[i], self.d1[o], self.rho, self.phi, *self.v)
+        self.o.sc_step(1, prop, m, self.d2[i], self.d2[o], self.rho, self.phi, *self.v)
+        for axis in self.pbc_axes:
+            self.o.pbc(self.d1[o], axis, swap)
+            self.o.pbc(self.d2[o], axis, swap)
+        self.iteration += 1
+
+    def run(self, n):
+        for _ in range(n):
+            self.step()
+
+    def current(self):
+        k = 0 if self.aa else (self.iteration & 1)
+        return self.d1[k], self.d2[k]
+
+    def real(self, arr):
+        ng = self.runner._spec._nonghost_slice
+        if self.dim == 2:
+            return arr[(Ellipsis, 0) + tuple(ng)]
+        return arr[(Ellipsis,) + tuple(ng)]

@@ -1,0 +1,34 @@
+"""Shared set-up of the binary Shan-Chen tests."""
+import numpy as np
+
+from sailfish_amd.geo import LBGeometry2D, LBGeometry3D
+from sailfish_amd.lb_binary import LBBinaryFluidShanChen
+from sailfish_amd.subdomain import Subdomain2D, Subdomain3D
+
+
+def make_sim(dim, seed=7, amplitude=1e-3):
+    base = Subdomain2D if dim == 2 else Subdomain3D
+
+    class Mixture(base):
+        def boundary_conditions(self, *h):
+            pass
+
+        def initial_conditions(self, sim, *h):
+            rng = np.random.RandomState(seed)
+            sim.rho[:] = 1.0 + amplitude * rng.rand(*sim.rho.shape)
+            sim.phi[:] = 1.0 + amplitude * rng.rand(*sim.phi.shape)
+
+    class Sim(LBBinaryFluidShanChen):
+        subdomain = Mixture
+
+    return Sim, (LBGeometry2D if dim == 2 else LBGeometry3D)
+
+
+def config(dim, size, pattern='AB', fused=True, G12=1.2, G11=0.0, G22=0.0, visc=1.0 / 6.0, tau_phi=1.0,
+           precision='single', potential='linear'):
+    cfg = dict(lat_nx=size[0], lat_ny=size[1], periodic_x=True, periodic_y=True, access_pattern=pattern,
+               hip_fused_periodic=fused, G11=G11, G12=G12, G22=G22, visc=visc, tau_phi=tau_phi, precision=precision,
+               sc_potential=potential, force_implementation='guo', grid='D2Q9' if dim == 2 else 'D3Q19')
+    if dim == 3:
+        cfg.update(lat_nz=size[2], periodic_z=True)
+    return cfg

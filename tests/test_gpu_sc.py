@@ -1,0 +1,63 @@
+"""Binary Shan-Chen model on the GPU (config 5 of BASELINE.json, examples/binary_fluid/sc_separation_3d.py)
+against the oracle twin: rho, phi, u within 1e-6 relative; populations bit-identical for the linear
+pseudopotential."""
+import numpy as np
+import pytest
+
+from tests import _host, _sc
+from tests._oracle_group import OracleSCSubdomain
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(dim, size, steps, **kw):
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls, geo = _sc.make_sim(dim)
+    cfg = _sc.config(dim, size, **kw)
+    cfg.update(max_iters=steps, quiet=True, perf_stats_every=0)
+    ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
+    ctrl.run(ignore_cmdline=True)
+    return ctrl.runners[0]
+
+
+def run_oracle(dim, size, steps, **kw):
+    sim_cls, geo = _sc.make_sim(dim)
+    cfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, _sc.config(dim, size, **kw))
+    s = OracleSCSubdomain(runners[0])
+    s.run(steps)
+    return s
+
+
+@pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (70, 9, 8))])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_sc_vs_oracle(dim, size, pattern, fused):
+    steps = 21
+    r = run_gpu(dim, size, steps, pattern=pattern, fused=fused)
+    o = run_oracle(dim, size, steps, pattern=pattern, fused=fused)
+    for g_field, o_field in ((r._sim.rho, o.real(o.rho)), (r._sim.phi, o.real(o.phi))):
+        assert np.max(np.abs(g_field - o_field) / np.abs(o_field)) < 1e-6
+    for d in range(dim):
+        assert np.max(np.abs(r._sim.v[d] - o.real(o.v[d]))) < 1e-6 * 0.01 + 1e-9
+    for grid_num, od in enumerate(o.current()):
+        gd = r._debug_get_dist(grid_num=grid_num)
+        gd = gd[(slice(None),) + tuple(r._spec._nonghost_slice)]
+        assert np.array_equal(gd, o.real(od)), 'lattice %d populations differ' % grid_num
+
+
+def test_sc_classic_potential_and_self_coupling():
+    """exp() differs in the last bits between libm and the GPU: tolerance instead of bit equality."""
+    kw = dict(pattern='AA', fused=True, G12=0.9, G11=-0.3, G22=-0.2, potential='classic', tau_phi=0.8)
+    r = run_gpu(3, (40, 8, 6), 15, **kw)
+    o = run_oracle(3, (40, 8, 6), 15, **kw)
+    assert np.max(np.abs(r._sim.rho - o.real(o.rho))) < 1e-6
+    assert np.max(np.abs(r._sim.phi - o.real(o.phi))) < 1e-6
+
+
+def test_sc_phase_separation_and_mass():
+    """Physics: the mixture de-mixes at G12 = 1.2 (reference example set-up), each component keeps its mass."""
+    r = run_gpu(2, (64, 64), 1500, pattern='AA')
+    rho, phi = r._sim.rho.astype(np.float64), r._sim.phi.astype(np.float64)
+    assert abs(rho.mean() - 1.0005) < 2e-4 and abs(phi.mean() - 1.0005) < 2e-4
+    assert np.abs(rho - phi).max() > 0.5          # separated domains
+    assert np.isfinite(rho).all() and np.isfinite(phi).all()

@@ -1,0 +1,74 @@
+"""Binary Shan-Chen model, CPU side: the oracle's force against the template formula
+(reference templates/shan_chen.mako:29-84 with the pseudopotentials of sym.py:896-908) and the
+model-level invariants (per-component mass, total momentum, AB == AA, ghost-PBC == in-sweep wrap)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from sailfish_amd import sym
+from tests import _host, _sc
+from tests._oracle_group import OracleSCSubdomain
+
+
+@pytest.mark.parametrize('grid', [sym.D2Q9, sym.D3Q19])
+@pytest.mark.parametrize('potential', [0, 1])
+def test_force_formula(grid, potential):
+    rng = np.random.RandomState(3)
+    e = grid.basis_array
+    w = grid.weights_float
+    psi = (lambda r: r) if potential == 0 else (lambda r: 1.0 - np.exp(-r))
+    for _ in range(20):
+        neigh = rng.uniform(0.5, 1.5, grid.Q)
+        rho = rng.uniform(0.5, 1.5)
+        G = rng.uniform(0.5, 2.0)
+        ref = np.zeros(3)
+        for i in range(1, grid.Q):
+            ref[:grid.dim] += w[i] * e[i] * psi(neigh[i])
+        ref *= -G * psi(rho)
+        got = oracle.sc_force_node(grid.slf_id, potential, G, rho, neigh, precision=8)
+        assert np.max(np.abs(got - ref)) < 1e-14
+        got32 = oracle.sc_force_node(grid.slf_id, potential, G, rho, neigh, precision=4)
+        assert np.max(np.abs(got32 - ref)) < 2e-6
+
+
+def _run(dim, size, steps, **kw):
+    sim_cls, geo = _sc.make_sim(dim)
+    cfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, _sc.config(dim, size, **kw))
+    s = OracleSCSubdomain(runners[0])
+    f0 = [s.real(d).astype(np.float64).copy() for d in s.current()]
+    s.run(steps)
+    return s, f0
+
+
+@pytest.mark.parametrize('dim,size', [(2, (18, 14)), (3, (10, 8, 7))])
+def test_conservation(dim, size):
+    s, f0 = _run(dim, size, 20, pattern='AB', precision='double')
+    f1 = [s.real(d) for d in s.current()]
+    grid = s.runner._sim.grid
+    for a, b in zip(f0, f1):        # each component keeps its mass
+        assert abs(a.sum() - b.sum()) < 1e-10
+    e = grid.basis_array
+    for d in range(dim):            # the coupling is momentum conserving (G12 = G21)
+        m0 = sum(e[i][d] * (f0[0][i].sum() + f0[1][i].sum()) for i in range(grid.Q))
+        m1 = sum(e[i][d] * (f1[0][i].sum() + f1[1][i].sum()) for i in range(grid.Q))
+        assert abs(m0 - m1) < 1e-9
+
+
+@pytest.mark.parametrize('dim,size', [(2, (18, 14)), (3, (10, 8, 7))])
+def test_ab_aa_and_fused_equivalence(dim, size):
+    res = {}
+    for pattern in ('AB', 'AA'):
+        for fused in (True, False):
+            s, _ = _run(dim, size, 10, pattern=pattern, fused=fused)
+            res[(pattern, fused)] = [s.real(d).copy() for d in s.current()] + [s.real(s.rho).copy()]
+    ref = res[('AB', True)]
+    for k, v in res.items():
+        for a, b in zip(ref, v):
+            assert np.array_equal(a, b), k
+
+
+def test_phase_separation_starts():
+    """G12 = 1.2 is above the spinodal threshold: the contrast of the initial noise grows."""
+    s, _ = _run(2, (32, 32), 400, pattern='AA')
+    d = s.real(s.rho) - s.real(s.phi)
+    assert np.abs(d).max() > 0.05
