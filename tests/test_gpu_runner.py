@@ -140,3 +140,31 @@ def test_output_files_and_checkpoint_roundtrip(tmp_path):
     # (the run with --output masked its non-fluid nodes with NaN; compare the wet interior)
     assert np.array_equal(restored.runners[0]._sim.rho[1:-1, 1:-1], ctrl.runners[0]._sim.rho[1:-1, 1:-1])
     assert np.array_equal(restored.runners[0]._debug_get_dist(), ctrl.runners[0]._debug_get_dist(), equal_nan=True)
+
+
+def test_ldc_2d_re1000_matches_erturk(golden_dir):
+    """Physics regression of BASELINE config 1 (examples/ldc_2d.py, D2Q9 BGK 256x256, Re = 1000,
+    visc = 0.0254): steady centre-line velocities against Erturk et al. (reference regtest/ldc_2d.py,
+    regtest/ldc_golden/vx2d, vy2d)."""
+    n = 256
+    cfg = dict(lat_nx=n, lat_ny=n, visc=(n - 2) * 0.1 / 1000.0, access_pattern='AA')
+    ctrl = run_gpu('ldc_2d', 'LDCSim', 2, cfg, 160000)
+    sim = ctrl.runners[0]._sim
+    u_lid = 0.1
+    # u along the vertical centre line, v along the horizontal centre line (mean of the two middle columns/rows)
+    u_c = 0.5 * (sim.vx[:, n // 2] + sim.vx[:, n // 2 - 1]) / u_lid
+    v_c = 0.5 * (sim.vy[n // 2, :] + sim.vy[n // 2 - 1, :]) / u_lid
+    # the walls sit half-way between the wall node and the first fluid node (full-way bounce-back); the lid
+    # is on the last row
+    pos = (np.arange(n) - 0.5) / (n - 2)
+    vy2d = np.loadtxt(os.path.join(golden_dir, 'ldc_golden', 'vy2d'), skiprows=4)   # y, u(x=0.5, y)
+    vx2d = np.loadtxt(os.path.join(golden_dir, 'ldc_golden', 'vx2d'), skiprows=4)   # x, v(x, y=0.5)
+    ok = np.isfinite(u_c)
+    u_ref = np.interp(vy2d[:, 0], pos[ok], u_c[ok])
+    sel = (vy2d[:, 0] > 0.02) & (vy2d[:, 0] < 0.98)
+    err_u = np.max(np.abs(u_ref[sel] - vy2d[sel, 1]))
+    ok = np.isfinite(v_c)
+    v_ref = np.interp(vx2d[:, 0], pos[ok], v_c[ok])
+    sel = (vx2d[:, 0] > 0.02) & (vx2d[:, 0] < 0.98)
+    err_v = np.max(np.abs(v_ref[sel] - vx2d[sel, 1]))
+    assert err_u < 0.03 and err_v < 0.03, (err_u, err_v)
