@@ -39,7 +39,7 @@ enum { SLF_OK = 0, SLF_ERR_INVALID = 1, SLF_ERR_HIP = 2, SLF_ERR_UNSUPPORTED = 3
 enum { SLF_D2Q9 = 0, SLF_D3Q19 = 1 };
 enum { SLF_BGK = 0, SLF_MRT = 1 };
 enum { SLF_AB = 0, SLF_AA = 1 };
-enum { SLF_SIM_LBM = 0, SLF_SIM_SHAN_CHEN_BINARY = 1 };
+enum { SLF_SIM_LBM = 0, SLF_SIM_SHAN_CHEN_BINARY = 1, SLF_SIM_SHAN_CHEN_SINGLE = 2 };
 
 /* Canonical node kinds understood by the kernels (reference node_type.py:86-109,
  * 115-168, 198-, 269-; wet/excluded semantics from templates/geo_helpers.mako:42-84). */
@@ -98,7 +98,8 @@ typedef struct slf_module_desc {
   int32_t periodic_local[3];   /* 1: the subdomain spans this (globally periodic) axis, i.e. it is its own periodic
                                   neighbour there (SubdomainSpec.enable_local_periodicity, subdomain.py:122-127);
                                   0: the faces of this axis are walls / open / connected to other subdomains */
-  int32_t simtype;             /* SLF_SIM_LBM | SLF_SIM_SHAN_CHEN_BINARY (lb_binary.py:375-517) */
+  int32_t simtype;             /* SLF_SIM_LBM | SLF_SIM_SHAN_CHEN_BINARY (lb_binary.py:375-517) |
+                                  SLF_SIM_SHAN_CHEN_SINGLE (lb_single.py:242-347; coupling constant in sc_G[0]) */
   /* binary Shan-Chen: relaxation time of the second lattice (--tau_phi), coupling constants
    * G11, G12, G21, G22 (lb_binary.py:388-394) and pseudopotential (sym.py:896-908: 0 linear, 1 classic) */
   double tau_phi;
@@ -164,7 +165,10 @@ int slf_module_destroy(slf_module* m);
  * "ShanChenPrepareMacroFields"(map, dist1, dist2, rho, phi, vx, vy[, vz], options),
  * "ShanChenCollideAndPropagate0|1"(map, dist_in, dist_out, rho, phi, vx, vy[, vz], options) and the
  * two-lattice "SetInitialConditions"(map, dist1, dist2, vx, vy[, vz], rho, phi)
- * (reference templates/models/binary_shan_chen.mako:19-141, lb_binary_fluid.mako:87-127). */
+ * (reference templates/models/binary_shan_chen.mako:19-141, lb_binary_fluid.mako:87-127).
+ * Single-component Shan-Chen modules (SLF_SIM_SHAN_CHEN_SINGLE) keep the single-fluid kernel names; their
+ * "CollideAndPropagate" adds the pseudopotential force, and "PrepareMacroFields"(map, dist, rho, options)
+ * computes the density field it reads (reference templates/models/lb_single_fluid.mako:129-229). */
 int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out);
 int slf_kernel_destroy(slf_kernel* k);
 /* fmt: one char per argument, 'P' = device pointer (8 bytes), 'i' = int32,

@@ -46,7 +46,9 @@ def lib(precision=4):
     L.orc_sc_macro.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_sc_step.argtypes = [P(SlfModuleDesc), ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_sc_force_node.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp, dp]
-    for fn in (L.orc_sc_init, L.orc_sc_macro, L.orc_sc_step, L.orc_sc_force_node):
+    L.orc_scs_macro.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp]
+    L.orc_scs_step.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32]
+    for fn in (L.orc_sc_init, L.orc_sc_macro, L.orc_sc_step, L.orc_sc_force_node, L.orc_scs_macro, L.orc_scs_step):
         fn.restype = None
     for fn in (L.orc_node_feq, L.orc_node_macro, L.orc_node_update, L.orc_init, L.orc_step, L.orc_pbc,
                L.orc_macro_pbc, L.orc_sparse, L.orc_compute_macro):
@@ -152,6 +154,13 @@ class OracleSim(object):
     def sc_step(self, grid_idx, prop, nmap, din, dout, rho, phi, vx, vy, vz):
         self.L.orc_sc_step(ctypes.byref(self.desc), grid_idx, prop, _vp(nmap), _vp(din), _vp(dout), _vp(rho),
                            _vp(phi), _vp(vx), _vp(vy), _vp(vz))
+
+    def scs_macro(self, prop, nmap, din, rho):
+        self.L.orc_scs_macro(ctypes.byref(self.desc), prop, _vp(nmap), _vp(din), _vp(rho))
+
+    def scs_step(self, prop, nmap, din, dout, rho, vx, vy, vz, options=0):
+        self.L.orc_scs_step(ctypes.byref(self.desc), prop, _vp(nmap), _vp(din), _vp(dout), _vp(rho), _vp(vx),
+                            _vp(vy), _vp(vz), options)
 
     def compute_macro(self, prop, nmap, din, rho, vx, vy, vz):
         self.L.orc_compute_macro(ctypes.byref(self.desc), prop, _vp(nmap), _vp(din), _vp(rho), _vp(vx), _vp(vy),

@@ -47,6 +47,8 @@ enum KernelKind {
   KK_SC_SWEEP0,
   KK_SC_SWEEP1,
   KK_SC_INIT,
+  KK_SCS_MACRO,
+  KK_SCS_SWEEP,
 };
 
 }  // namespace
@@ -345,13 +347,14 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   ph.incompressible = d->incompressible;
   ph.has_force = d->has_force;
   ph.relaxation_enabled = d->relaxation_enabled;
-  m->sc.enabled = (d->simtype == SLF_SIM_SHAN_CHEN_BINARY);
+  m->sc.enabled = (d->simtype == SLF_SIM_SHAN_CHEN_BINARY) ? 1 : ((d->simtype == SLF_SIM_SHAN_CHEN_SINGLE) ? 2 : 0);
   m->sc.tau_phi = d->tau_phi;
   for (int i = 0; i < 4; i++) m->sc.G[i] = d->sc_G[i];
   m->sc.potential = d->sc_potential;
   if (m->sc.enabled) {
     if (d->model != SLF_BGK) { delete m; return fail(SLF_ERR_UNSUPPORTED, "Shan-Chen modules use the BGK collision"); }
-    if (d->tau_phi <= 0.5) { delete m; return fail(SLF_ERR_INVALID, "tau_phi must be > 0.5"); }
+    if (m->sc.enabled == 1 && d->tau_phi <= 0.5) { delete m; return fail(SLF_ERR_INVALID, "tau_phi must be > 0.5"); }
+    if (m->sc.enabled == 2) m->sc.tau_phi = d->tau;
     for (int i = 0; i < d->n_types; i++) {
       const int k = d->type_kind[i];
       if (!(k == SLF_NK_FLUID || k == SLF_NK_GHOST || k == SLF_NK_UNUSED || k == SLF_NK_PROPAGATION_ONLY ||
@@ -411,8 +414,9 @@ int slf_module_block_size(slf_module* m, int* threads) {
 int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   if (!m || !name || !out) return fail(SLF_ERR_INVALID, "NULL argument");
   KernelKind kk;
-  if (!strcmp(name, "CollideAndPropagate")) kk = KK_COLLIDE_AND_PROPAGATE;
-  else if (!strcmp(name, "SetInitialConditions")) kk = m->sc.enabled ? KK_SC_INIT : KK_SET_INITIAL_CONDITIONS;
+  if (!strcmp(name, "CollideAndPropagate")) kk = (m->sc.enabled == 2) ? KK_SCS_SWEEP : KK_COLLIDE_AND_PROPAGATE;
+  else if (!strcmp(name, "PrepareMacroFields")) kk = KK_SCS_MACRO;
+  else if (!strcmp(name, "SetInitialConditions")) kk = (m->sc.enabled == 1) ? KK_SC_INIT : KK_SET_INITIAL_CONDITIONS;
   else if (!strcmp(name, "ShanChenPrepareMacroFields")) kk = KK_SC_MACRO;
   else if (!strcmp(name, "ShanChenCollideAndPropagate0")) kk = KK_SC_SWEEP0;
   else if (!strcmp(name, "ShanChenCollideAndPropagate1")) kk = KK_SC_SWEEP1;
@@ -423,9 +427,11 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   else if (!strcmp(name, "DistributeSparseData")) kk = KK_DISTRIBUTE_SPARSE;
   else if (!strcmp(name, "ComputeMacroFields")) kk = KK_COMPUTE_MACRO;
   else return fail(SLF_ERR_NOT_FOUND, std::string("unknown kernel: ") + name);
-  if ((kk == KK_SC_MACRO || kk == KK_SC_SWEEP0 || kk == KK_SC_SWEEP1) && !m->sc.enabled)
+  if (kk == KK_SCS_MACRO && m->sc.enabled != 2)
+    return fail(SLF_ERR_NOT_FOUND, "PrepareMacroFields only exists in single-component Shan-Chen modules");
+  if ((kk == KK_SC_MACRO || kk == KK_SC_SWEEP0 || kk == KK_SC_SWEEP1) && m->sc.enabled != 1)
     return fail(SLF_ERR_NOT_FOUND, "Shan-Chen kernels only exist in modules built with simtype = SLF_SIM_SHAN_CHEN_BINARY");
-  if ((kk == KK_COLLIDE_AND_PROPAGATE || kk == KK_COMPUTE_MACRO) && m->sc.enabled)
+  if ((kk == KK_COLLIDE_AND_PROPAGATE || kk == KK_COMPUTE_MACRO) && m->sc.enabled == 1)
     return fail(SLF_ERR_NOT_FOUND, "single-fluid kernels do not exist in a Shan-Chen module");
   if (kk == KK_PBC_SWAP && m->access_pattern != SLF_AA)
     return fail(SLF_ERR_NOT_FOUND, "ApplyPeriodicBoundaryConditionsWithSwap only exists for the AA access pattern");
@@ -471,6 +477,8 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_SC_SWEEP0:
     case KK_SC_SWEEP1: want_p = 5 + dim; want_i = 1; break;       // map, dist, dist, rho, phi, v.., options
     case KK_SC_INIT: want_p = 5 + dim; want_i = 0; break;         // map, dist1, dist2, v.., rho, phi
+    case KK_SCS_MACRO: want_p = 3; want_i = 1; break;             // map, dist, rho, options
+    case KK_SCS_SWEEP: want_p = 4 + dim; want_i = 1; break;       // as CollideAndPropagate
   }
   if (k->ptrs.size() != want_p || k->ints.size() != want_i)
     return fail(SLF_ERR_INVALID, "argument list does not match the kernel's signature");
@@ -558,6 +566,46 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       if (k->kind == KK_SC_MACRO) e = slf::launch_sc_macro(m->sel, prop, g, m->phys, m->sc, a, y0, y1, z0, z1, s);
       else e = slf::launch_sc_sweep(m->sel, k->kind == KK_SC_SWEEP0 ? 0 : 1, prop, g, m->phys, m->sc, a, y0, y1, z0, z1,
                                     m->block_x, s);
+      break;
+    }
+    case KK_SCS_MACRO:
+    case KK_SCS_SWEEP: {
+      slf::SweepArgs a;
+      a.map = (const void*)k->ptrs[0];
+      a.dist_in = (void*)k->ptrs[1];
+      a.phi = nullptr;
+      a.node_params = m->node_params;
+      a.options = (uint32_t)k->ints[0];
+      if (k->kind == KK_SCS_MACRO) {
+        a.dist_out = nullptr;
+        a.rho = (void*)k->ptrs[2];
+        a.v[0] = a.v[1] = a.v[2] = nullptr;
+      } else {
+        a.dist_out = (void*)k->ptrs[2];
+        a.rho = (void*)k->ptrs[3];
+        a.v[0] = (void*)k->ptrs[4];
+        a.v[1] = (void*)k->ptrs[5];
+        a.v[2] = g.dim == 3 ? (void*)k->ptrs[6] : nullptr;
+      }
+      if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
+      slf::Prop prop = slf::PROP_AB;
+      if (m->access_pattern == SLF_AA) {
+        if (!k->needs_iteration) return fail(SLF_ERR_INVALID, "AA kernels need the iteration argument");
+        prop = (k->iteration & 1u) ? slf::PROP_AA_ODD : slf::PROP_AA_EVEN;
+      }
+      if (k->kind == KK_SCS_MACRO) {
+        e = slf::launch_scs_macro(m->sel, prop, g, m->phys, m->sc, a, s);
+        break;
+      }
+      int y0 = 1, y1 = g.lat_ny - 1, z0 = 1, z1 = g.lat_nz - 1;
+      if (g.dim == 2) { z0 = 0; z1 = 1; }
+      if (region) {
+        y0 = region->y0; y1 = region->y1;
+        if (g.dim == 3) { z0 = region->z0; z1 = region->z1; }
+        if (y0 < 1 || y1 > g.lat_ny - 1 || y0 > y1 || (g.dim == 3 && (z0 < 1 || z1 > g.lat_nz - 1 || z0 > z1)))
+          return fail(SLF_ERR_INVALID, "region outside the real nodes of the subdomain");
+      }
+      e = slf::launch_scs_sweep(m->sel, prop, g, m->phys, m->sc, a, y0, y1, z0, z1, m->block_x, s);
       break;
     }
     case KK_SC_INIT: {

@@ -37,7 +37,7 @@ struct Physics {
 };
 
 struct ShanChen {
-  int enabled;
+  int enabled;      // 0 off, 1 binary mixture, 2 single component
   double tau_phi;
   double G[4];      // G11 G12 G21 G22
   int potential;    // 0 linear, 1 classic
@@ -85,6 +85,12 @@ hipError_t launch_sc_macro(const KernelSelector& sel, Prop prop, const Geometry&
 hipError_t launch_sc_sweep(const KernelSelector& sel, int grid_idx, Prop prop, const Geometry& g, const Physics& ph,
                            const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                            hipStream_t s);
+// single-component Shan-Chen: density pass (a.dist_in -> a.rho) and the sweep with the force
+hipError_t launch_scs_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                            const ShanChen& sc, const SweepArgs& a, hipStream_t s);
+hipError_t launch_scs_sweep(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                            const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
+                            hipStream_t s);
 hipError_t launch_sc_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist1, void* dist2,
                           const void* rho, const void* phi, const void* const v[3], hipStream_t s);
 

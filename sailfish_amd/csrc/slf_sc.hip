@@ -169,6 +169,98 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
   });
 }
 
+// ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
+// PrepareMacroFields: density of every wet node
+template <class L, class R, int PROP, bool GENERAL>
+__global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  if constexpr (GENERAL) {
+    const uint32_t code = p.map[gi];
+    const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if (kind_is_excluded(kind)) return;
+  }
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  R f[L::Q];
+  sc_load<L, R, PROP>(f, p.d_in, g.dist_size, gi, ox, oy, oz);
+  p.rho0[gi] = density<L, R>(f);
+}
+
+// CollideAndPropagate with the self-interaction force F = -G psi(rho(x)) sum_i w_i e_i psi(rho(x + e_i))
+template <class L, class R, int PROP, bool GENERAL>
+__global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  int kind = NK_FLUID;
+  if constexpr (GENERAL) {
+    const uint32_t code = p.map[gi];
+    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if (kind_is_excluded(kind)) return;
+  }
+  const bool wet = kind_is_wet(kind);
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  const size_t ds = g.dist_size;
+  R f[L::Q];
+  sc_load<L, R, PROP>(f, p.d_in, ds, gi, ox, oy, oz);
+  R rho, v[3];
+  macro_standard<L, R>(f, false, rho, v);
+  R a[3] = {(R)0, (R)0, (R)0};
+  if (wet) {
+    const R cc = p.G[0];
+    if (cc != (R)0) {
+      R force[3] = {(R)0, (R)0, (R)0};
+      static_for<1, L::Q>([&](auto I) {
+        const int off = dir_offset<L, I>(ox, oy, oz, true);
+        const R psi = sc_psi<R>(p.rho0[(uint32_t)((int)gi + off)], p.potential);
+        static_for<0, L::dim>([&](auto D) {
+          constexpr int e = e_comp<L>(I, D);
+          if constexpr (e > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
+          if constexpr (e < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
+        });
+      });
+      const R psi_loc = sc_psi<R>(rho, p.potential);
+      static_for<0, L::dim>([&](auto D) {
+        force[D] = force[D] * (((R)0 - psi_loc) * cc);
+        a[D] = a[D] + force[D];
+      });
+    }
+    static_for<0, L::dim>([&](auto D) { a[D] = a[D] / rho; });
+    if (p.has_body_force) {
+      static_for<0, L::dim>([&](auto D) { a[D] = a[D] + p.accel[D]; });
+    }
+  }
+  if constexpr (GENERAL) {
+    if (kind == NK_FULL_BB) bounce_back<L, R>(f);
+  }
+  if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[0], p.guo_pref[0], false, true, a);
+  if ((p.options & 1u) && wet) {
+    // the density field itself is written by PrepareMacroFields; v is the force-shifted output velocity
+    p.vx[gi] = v[0];
+    p.vy[gi] = v[1];
+    if constexpr (L::dim == 3) p.vz[gi] = v[2];
+  }
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_EVEN) {
+      (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
+    } else {
+      const int off = dir_offset<L, I>(ox, oy, oz, true);
+      (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+    }
+  });
+}
+
 // f1 = feq(rho, v), f2 = feq(phi, v) on every node (no type test)
 template <class L, class R>
 __global__ void __launch_bounds__(256) sc_init_kernel(R* d1, R* d2, const R* __restrict__ irho, const R* __restrict__ iphi,
@@ -290,6 +382,50 @@ hipError_t launch_sc_sweep(const KernelSelector& sel, int grid_idx, Prop prop, c
                            const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                            hipStream_t s) {
   SLF_DISPATCH_LR(sel, return (sc_sweep2<L, R>(grid_idx, prop, sel.general, g, ph, sc, a, y0, y1, z0, z1, block_x, s)));
+  return hipErrorInvalidValue;
+}
+
+template <class L, class R>
+static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometry& g, const Physics& ph,
+                              const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
+                              hipStream_t s) {
+  ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
+  p.G[0] = (R)sc.G[0];
+  p.G[1] = (R)0;
+  const int nx = g.lat_nx - 2;
+  dim3 block(block_x, 1, 1);
+  dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
+  if (grid.y == 0 || grid.z == 0) return hipSuccess;
+#define SLF_SCS1(KERN, P)                                                       \
+  do {                                                                          \
+    if (general) hipLaunchKernelGGL((KERN<L, R, P, true>), grid, block, 0, s, p);  \
+    else hipLaunchKernelGGL((KERN<L, R, P, false>), grid, block, 0, s, p);         \
+  } while (0)
+  if (macro) {
+    if (prop == PROP_AA_ODD) SLF_SCS1(scs_macro_kernel, PROP_AA_ODD);
+    else SLF_SCS1(scs_macro_kernel, PROP_AB);
+  } else {
+    if (prop == PROP_AB) SLF_SCS1(scs_sweep_kernel, PROP_AB);
+    else if (prop == PROP_AA_EVEN) SLF_SCS1(scs_sweep_kernel, PROP_AA_EVEN);
+    else SLF_SCS1(scs_sweep_kernel, PROP_AA_ODD);
+  }
+#undef SLF_SCS1
+  return hipGetLastError();
+}
+
+hipError_t launch_scs_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                            const ShanChen& sc, const SweepArgs& a, hipStream_t s) {
+  const int z0 = g.dim == 3 ? 1 : 0, z1 = g.dim == 3 ? g.lat_nz - 1 : 1;
+  int bx = ((g.lat_nx - 2 + 63) / 64) * 64;
+  if (bx > 1024) bx = 256;
+  SLF_DISPATCH_LR(sel, return (scs_launch2<L, R>(true, prop, sel.general, g, ph, sc, a, 1, g.lat_ny - 1, z0, z1, bx, s)));
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_scs_sweep(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
+                            const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
+                            hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (scs_launch2<L, R>(false, prop, sel.general, g, ph, sc, a, y0, y1, z0, z1, block_x, s)));
   return hipErrorInvalidValue;
 }
 

@@ -4,7 +4,7 @@ from collections import defaultdict
 import numpy as np
 
 from sailfish_amd import hipabi, subdomain_runner, sym
-from sailfish_amd.lb_base import KernelPair, LBSim, ScalarField, VectorField
+from sailfish_amd.lb_base import KernelPair, LBForcedSim, LBSim, ScalarField, VectorField
 
 
 class LBFluidSim(LBSim):
@@ -89,3 +89,51 @@ class LBFluidSim(LBSim):
         for i in range(0, self.dim):
             kernels[1][i] = [runner.get_kernel(kernel, [gpu_dist, np.uint32(i)], 'Pi')]
         return kernels
+
+
+class LBSingleFluidShanChen(LBFluidSim, LBForcedSim):
+    """Single-component Shan-Chen model (reference lb_single.py:242-347): every step computes the density
+    field first (PrepareMacroFields), then collides with the pseudopotential force added by Guo forcing."""
+    nonlocality = 1
+    subdomain_runner = subdomain_runner.NNSubdomainRunner
+
+    @classmethod
+    def add_options(cls, group, dim):
+        group.add_argument('--G', type=float, default=1.0, help='Shan-Chen interaction strength constant')
+        group.add_argument('--sc_potential', type=str, choices=['classic', 'linear'], default='linear',
+                           help='Shan-Chen pseudopotential function to use')
+
+    @classmethod
+    def fields(cls):
+        return [ScalarField('rho', need_nn=True), VectorField('v')]
+
+    def constants(self):
+        return {'SCG': self.config.G}
+
+    def fill_module_desc(self, kw):
+        super(LBSingleFluidShanChen, self).fill_module_desc(kw)
+        if self.config.model != 'bgk':
+            raise ValueError('the Shan-Chen model uses the BGK collision operator')
+        kw.update(simtype=hipabi.SLF_SIM_SHAN_CHEN_SINGLE, sc_G=[self.config.G, 0.0, 0.0, 0.0],
+                  sc_potential={'linear': 0, 'classic': 1}[self.config.sc_potential], tau_phi=kw['tau'])
+
+    def get_pbc_kernels(self, runner):
+        from sailfish_amd.lb_binary import MacroKernels
+        dist_kernels = super(LBSingleFluidShanChen, self).get_pbc_kernels(runner)
+        macro_kernels = defaultdict(lambda: defaultdict(list))
+        for copy in (0, 1):
+            for i in range(0, self.dim):
+                macro_kernels[copy][i] = [runner.get_kernel('ApplyMacroPeriodicBoundaryConditions',
+                                                            [runner.gpu_field(fp.buffer), np.uint32(i)], 'Pi')
+                                          for fp in self._scalar_fields if fp.abstract.need_nn]
+        return MacroKernels(macro=macro_kernels, distributions=dist_kernels)
+
+    def get_compute_kernels(self, runner, full_output, bulk):
+        gpu_rho = runner.gpu_field(self.rho)
+        gpu_map = runner.gpu_geo_map()
+        options = np.uint32((1 if full_output else 0) | (2 if bulk else 0))
+        ni = self.config.needs_iteration_num
+        macro_kernels = [runner.get_kernel('PrepareMacroFields', [gpu_map, runner.gpu_dist(0, c), gpu_rho, options],
+                                           'PPPi', needs_iteration=ni) for c in (0, 1)]
+        sim_kernels = super(LBSingleFluidShanChen, self).get_compute_kernels(runner, full_output, bulk)
+        return list(zip(macro_kernels, sim_kernels))

@@ -192,3 +192,58 @@ class OracleSCSubdomain(object):
         if self.dim == 2:
             return arr[(Ellipsis, 0) + tuple(ng)]
         return arr[(Ellipsis,) + tuple(ng)]
+
+
+class OracleSCSingle(object):
+    """Oracle twin of NNSubdomainRunner for the single-component Shan-Chen model."""
+
+    def __init__(self, runner):
+        r = self.runner = runner
+        r._init_geometry()
+        r._sim.init_fields(r)
+        r._subdomain.init_fields(r._sim)
+        self.desc = r._module_desc()
+        self.o = OracleSim(self.desc)
+        self.dim = r.dim
+        self.aa = self.desc.access_pattern == hipabi.SLF_AA
+        dt = self.o.dtype
+        self.node_map = np.ascontiguousarray(r._subdomain._type_map_base, dtype=np.uint32).reshape(self.o.shape)
+        self.rho = np.ascontiguousarray(r.field_base(r._sim.rho), dtype=dt).reshape(self.o.shape)
+        self.v = [np.ascontiguousarray(r.field_base(c), dtype=dt).reshape(self.o.shape) for c in r._sim.v]
+        while len(self.v) < 3:
+            self.v.append(np.zeros(self.o.shape, dtype=dt))
+        self.d = [self.o.new_dist() for _ in range(1 if self.aa else 2)]
+        with np.errstate(all='ignore'):
+            for a in self.d:
+                self.o.init(a, self.rho, *self.v)
+        local = r._local_periodic()
+        self.pbc_axes = [a for a in range(self.dim) if local[a] and not r._fused[a]]
+        self.iteration = 0
+
+    def step(self, save=False):
+        it = self.iteration
+        if self.aa:
+            i = o = 0
+            prop, swap = (2 if (it & 1) else 1), (it & 1) == 0
+        else:
+            i, o, prop, swap = it & 1, 1 - (it & 1), 0, False
+        self.o.scs_macro(prop, self.node_map, self.d[i], self.rho)
+        for axis in self.pbc_axes:
+            self.o.macro_pbc(self.rho, axis)
+        self.o.scs_step(prop, self.node_map, self.d[i], self.d[o], self.rho, *self.v, options=1 if save else 0)
+        for axis in self.pbc_axes:
+            self.o.pbc(self.d[o], axis, swap)
+        self.iteration += 1
+
+    def run(self, n):
+        for k in range(n):
+            self.step(save=(k == n - 1))
+
+    def current(self):
+        return self.d[0] if self.aa else self.d[self.iteration & 1]
+
+    def real(self, arr):
+        ng = self.runner._spec._nonghost_slice
+        if self.dim == 2:
+            return arr[(Ellipsis, 0) + tuple(ng)]
+        return arr[(Ellipsis,) + tuple(ng)]

@@ -32,3 +32,31 @@ def config(dim, size, pattern='AB', fused=True, G12=1.2, G11=0.0, G22=0.0, visc=
     if dim == 3:
         cfg.update(lat_nz=size[2], periodic_z=True)
     return cfg
+
+
+def make_single_sim(dim, seed=2348, rho0=0.693, amplitude=0.01):
+    from sailfish_amd.lb_single import LBSingleFluidShanChen
+    base = Subdomain2D if dim == 2 else Subdomain3D
+
+    class Vapour(base):
+        def boundary_conditions(self, *h):
+            pass
+
+        def initial_conditions(self, sim, *h):
+            rng = np.random.RandomState(seed)
+            sim.rho[:] = rho0 + amplitude * rng.rand(*sim.rho.shape)
+
+    class Sim(LBSingleFluidShanChen):
+        subdomain = Vapour
+
+    return Sim, (LBGeometry2D if dim == 2 else LBGeometry3D)
+
+
+def single_config(dim, size, pattern='AB', fused=True, G=-5.0, visc=1.0 / 6.0, precision='single',
+                  potential='classic'):
+    cfg = dict(lat_nx=size[0], lat_ny=size[1], periodic_x=True, periodic_y=True, access_pattern=pattern,
+               hip_fused_periodic=fused, G=G, visc=visc, precision=precision, sc_potential=potential,
+               force_implementation='guo', grid='D2Q9' if dim == 2 else 'D3Q19')
+    if dim == 3:
+        cfg.update(lat_nz=size[2], periodic_z=True)
+    return cfg

@@ -61,3 +61,52 @@ def test_sc_phase_separation_and_mass():
     assert abs(rho.mean() - 1.0005) < 2e-4 and abs(phi.mean() - 1.0005) < 2e-4
     assert np.abs(rho - phi).max() > 0.5          # separated domains
     assert np.isfinite(rho).all() and np.isfinite(phi).all()
+
+
+def run_gpu_single(dim, size, steps, **kw):
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls, geo = _sc.make_single_sim(dim)
+    cfg = _sc.single_config(dim, size, **kw)
+    cfg.update(max_iters=steps, quiet=True, perf_stats_every=0)
+    ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
+    ctrl.run(ignore_cmdline=True)
+    return ctrl.runners[0]
+
+
+@pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (70, 9, 8))])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_single_component_vs_oracle(dim, size, pattern, fused):
+    from tests._oracle_group import OracleSCSingle
+    steps = 21
+    kw = dict(pattern=pattern, fused=fused, potential='linear', G=-1.2)
+    r = run_gpu_single(dim, size, steps, **kw)
+    sim_cls, geo = _sc.make_single_sim(dim)
+    cfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, _sc.single_config(dim, size, **kw))
+    o = OracleSCSingle(runners[0])
+    o.run(steps)
+    assert np.array_equal(r._sim.rho, o.real(o.rho))
+    for d in range(dim):
+        assert np.array_equal(r._sim.v[d], o.real(o.v[d]))
+    gd = r._debug_get_dist()[(slice(None),) + tuple(r._spec._nonghost_slice)]
+    assert np.array_equal(gd, o.real(o.current()))
+
+
+@pytest.mark.parametrize('G', [3.5, 4.5, 5.0, 5.5])
+def test_phase_separation_matches_reference_record(G, golden_dir):
+    """The reference's recorded regression data for this very set-up (regtest/sc_phase_sep.py ->
+    regtest/results/sc_phase_separation/single.dat: coupling G, min rho, max rho, order parameter after
+    50000 steps of examples/sc_phase_separation.py, seed 2348).  Below the spinodal point (|G| < ~4) the
+    fluid stays homogeneous, above it separates into coexisting liquid / vapour densities."""
+    import os
+    data = np.loadtxt(os.path.join(golden_dir, 'sc_phase_separation_single.dat'))
+    row = data[np.argmin(np.abs(data[:, 0] - G))]
+    assert abs(row[0] - G) < 1e-6
+    r = run_gpu_single(2, (256, 256), 50000, pattern='AB', G=-G, potential='classic')
+    rho = r._sim.rho
+    lo, hi = float(rho.min()), float(rho.max())
+    if row[2] - row[1] < 1e-3:           # homogeneous state
+        assert hi - lo < 1e-3 and abs(0.5 * (lo + hi) - 0.5 * (row[1] + row[2])) < 2e-3
+    else:                                 # coexistence densities (droplet curvature / coarsening stage: few %)
+        assert abs(hi - row[2]) / row[2] < 0.03, (lo, hi, row)
+        assert abs(lo - row[1]) < 0.02, (lo, hi, row)

@@ -72,3 +72,27 @@ def test_phase_separation_starts():
     s, _ = _run(2, (32, 32), 400, pattern='AA')
     d = s.real(s.rho) - s.real(s.phi)
     assert np.abs(d).max() > 0.05
+
+
+def _run_single(dim, size, steps, **kw):
+    from tests._oracle_group import OracleSCSingle
+    sim_cls, geo = _sc.make_single_sim(dim)
+    cfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, _sc.single_config(dim, size, **kw))
+    s = OracleSCSingle(runners[0])
+    m0 = s.real(s.current()).astype(np.float64).sum()
+    s.run(steps)
+    return s, m0
+
+
+@pytest.mark.parametrize('dim,size', [(2, (18, 14)), (3, (10, 8, 7))])
+def test_single_component_invariants(dim, size):
+    res = {}
+    for pattern in ('AB', 'AA'):
+        for fused in (True, False):
+            s, m0 = _run_single(dim, size, 12, pattern=pattern, fused=fused, potential='linear', G=-1.0)
+            res[(pattern, fused)] = (s.real(s.current()).copy(), s.real(s.rho).copy(), s.real(s.v[0]).copy())
+            assert abs(s.real(s.current()).astype(np.float64).sum() - m0) / m0 < 1e-6
+    ref = res[('AB', True)]
+    for k, v in res.items():
+        for a, b in zip(ref, v):
+            assert np.array_equal(a, b), k
