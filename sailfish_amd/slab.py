@@ -107,10 +107,8 @@ class SlabSim(BoxSim):
         self.reg_low, self.reg_high = (1, ny + 1, 1, 2), (1, ny + 1, nz, nz + 1)
         self.reg_bulk = (1, ny + 1, 2, nz)
 
-    def step(self, save_macro=False, region=None):
-        if self.world == 1:
-            return BoxSim.step(self, save_macro)
-        import torch
+    def step_compute(self, save_macro=False):
+        """Boundary planes, event, bulk planes on the calc stream; halo pack on the halo stream."""
         b = self.backend
         it = self.iteration
         if self.aa:
@@ -123,18 +121,30 @@ class SlabSim(BoxSim):
         b.run_kernel(k, self.reg_high, self.calc_stream)
         ev_bnd = b.make_event(self.calc_stream)
         b.run_kernel(k, self.reg_bulk, self.calc_stream)
-        # halo stream
         self.halo_stream.wait_for_event(ev_bnd)
-        ks = self.k_halo[(swap, out)]
-        b.run_kernel(ks[0], None, self.halo_stream)
-        b.run_kernel(ks[1], None, self.halo_stream)
-        with torch.cuda.stream(self.t_halo_stream):
-            self.exchanger.exchange(*self.t_bufs)
-        b.run_kernel(ks[2], None, self.halo_stream)
-        b.run_kernel(ks[3], None, self.halo_stream)
-        self.ev_halo = b.make_event(self.halo_stream)
+        self._ks = self.k_halo[(swap, out)]
+        b.run_kernel(self._ks[0], None, self.halo_stream)
+        b.run_kernel(self._ks[1], None, self.halo_stream)
         self.iteration += 1
         b.set_iteration(self.iteration)
+
+    def step_exchange(self):
+        import torch
+        with torch.cuda.stream(self.t_halo_stream):
+            self.exchanger.exchange(*self.t_bufs)
+
+    def step_finish(self):
+        b = self.backend
+        b.run_kernel(self._ks[2], None, self.halo_stream)
+        b.run_kernel(self._ks[3], None, self.halo_stream)
+        self.ev_halo = b.make_event(self.halo_stream)
+
+    def step(self, save_macro=False, region=None):
+        if self.world == 1:
+            return BoxSim.step(self, save_macro)
+        self.step_compute(save_macro)
+        self.step_exchange()
+        self.step_finish()
 
     def sync(self):
         self.stream.synchronize()
