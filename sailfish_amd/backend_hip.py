@@ -252,6 +252,11 @@ class HIPBackend(object):
         if like is not None:
             self.buffers[addr] = self._host_base(like)
             self.to_buf(addr)
+        else:
+            # padding columns / strides are never written by the kernels: start from zeros so that raw
+            # dumps (checkpoints, _debug_get_dist) are reproducible whatever the allocator hands back
+            _check(self._lib, self._lib.slf_memset(self._ctx, ctypes.c_void_p(raw), 0, int(size) + pad, None),
+                   'slf_memset')
         return addr
 
     def free_buf(self, addr):

@@ -112,17 +112,15 @@ class TorchDistConnector(object):
         for r in dist.batch_isend_irecv(ops):
             r.wait()
 
-    def exchange(self, runner):
+    def exchange(self, runner, kind='dist'):
         import torch
         sends, recvs = [], []
-        for nid in sorted(runner._links):
-            link = runner._links[nid]
-            n_send, n_recv = runner.halo_counts(nid)
+        for nid, send_buf, n_send, recv_buf, n_recv in runner.halo_messages(kind):
             peer = self.id_to_rank[nid]
             if n_send:
-                sends.append((self.tensor(link.send_buf)[:n_send], peer))
+                sends.append((self.tensor(send_buf)[:n_send], peer))
             if n_recv:
-                recvs.append((self.tensor(link.recv_buf)[:n_recv], peer))
+                recvs.append((self.tensor(recv_buf)[:n_recv], peer))
         if not sends and not recvs:
             return
         if self._stream is None:

@@ -13,6 +13,7 @@ Process model (MI355X-first, one node):
     is out of scope.
 """
 import logging
+import math
 import os
 import pickle
 import sys
@@ -57,28 +58,28 @@ class LocalGroup(object):
         self.runners = runners
         self.by_id = dict((r._spec.id, r) for r in runners)
 
-    def exchange(self):
-        """Copies every packed send buffer into the matching receive buffer of the neighbour."""
-        events = {}
+    def exchange(self, kind='dist'):
+        """Copies every packed send buffer into the matching receive buffer of the neighbour
+        (kind: 'dist' populations, 'macro' fields of non-local models)."""
+        events, msgs = {}, {}
         for r in self.runners:
-            if r._links:
+            msgs[r._spec.id] = dict((m[0], m) for m in r.halo_messages(kind))
+            if msgs[r._spec.id]:
                 events[r._spec.id] = r.backend.make_event(r._data_stream)
         for r in self.runners:
-            for nid, link in r._links.items():
+            for nid, (_, _, _, recv_buf, n_recv) in sorted(msgs[r._spec.id].items()):
                 src = self.by_id[nid]
-                src_link = src._links[r._spec.id]
-                n_send, _ = src.halo_counts(r._spec.id)
-                _, n_recv = r.halo_counts(nid)
+                _, send_buf, n_send, _, _ = msgs[nid][r._spec.id]
                 assert n_send == n_recv, 'halo size mismatch between subdomains %d and %d' % (nid, r._spec.id)
                 if n_recv == 0:
                     continue
                 r._data_stream.wait_for_event(events[nid])
                 nbytes = n_recv * r.float().itemsize
                 if src.backend.gpu_id == r.backend.gpu_id:
-                    r.backend.copy_buf_async(link.recv_buf, src_link.send_buf, nbytes, r._data_stream)
+                    r.backend.copy_buf_async(recv_buf, send_buf, nbytes, r._data_stream)
                 else:
-                    r.backend.copy_peer_async(link.recv_buf, r.backend.gpu_id, src_link.send_buf,
-                                              src.backend.gpu_id, nbytes, r._data_stream)
+                    r.backend.copy_peer_async(recv_buf, r.backend.gpu_id, send_buf, src.backend.gpu_id, nbytes,
+                                              r._data_stream)
 
     def run(self):
         runners = self.runners
@@ -87,8 +88,18 @@ class LocalGroup(object):
         cfg = runners[0].config
         t_prev, it_prev = time.time(), runners[0]._sim.iteration
         t0, it0 = t_prev, it_prev
+        for r in runners:
+            r._profile.record_start()
         while not any(r.need_quit() for r in runners):
             reqs = [r.pre_step() for r in runners]
+            for r in runners:
+                r._profile.start_step()
+            if len(runners) > 1 and runners[0].has_macro_exchange:
+                for r in runners:
+                    r.step_macro()
+                self.exchange('macro')
+                for r in runners:
+                    r.step_macro_finish()
             for r, (sync_req, fields_req, output_req) in zip(runners, reqs):
                 r.step_compute(fields_req)
             if len(runners) > 1:
@@ -97,6 +108,8 @@ class LocalGroup(object):
                 r.step_finish()
             for r, (sync_req, fields_req, output_req) in zip(runners, reqs):
                 r.post_step(sync_req, output_req)
+            for r in runners:
+                r._profile.end_step()
             it = runners[0]._sim.iteration
             if cfg.perf_stats_every > 0 and it % cfg.perf_stats_every == 0:
                 for r in runners:
@@ -106,6 +119,8 @@ class LocalGroup(object):
                 cfg.logger.info('iteration:{0}  speed:{1:.2f} MLUPS'.format(
                     it, nodes * (it - it_prev) / (now - t_prev) * 1e-6))
                 t_prev, it_prev = now, it
+        for r in runners:
+            r.summary = r._profile.record_end()
         for r in runners:
             r.finish()
         wall = time.time() - t0
@@ -219,12 +234,18 @@ class LBSimulationController(object):
             s.set_actual_size(envelope_size)
 
     def save_subdomain_config(self, subdomains):
+        """<output>.subdomains: pickled list of the subdomain specs (reference controller.py:769-775); read by
+        utils/merge_subdomains.py."""
         if self.config.output:
-            with open(io.subdomains_filename(self.config.output), 'wb') as f:
-                pickle.dump([(s.location, s.size, s.id) for s in subdomains], f)
+            dname = os.path.dirname(self.config.output)
+            if dname and not os.path.exists(dname):
+                os.makedirs(dname)
+            if int(os.environ.get('RANK', '0')) == 0:
+                with open(io.subdomains_filename(self.config.output), 'wb') as f:
+                    pickle.dump(subdomains, f)
 
     def run(self, ignore_cmdline=False):
-        """Parses options, builds the subdomains and runs the simulation.  Returns self (the runners are
+        """Parses options, builds the subdomains and runs the simulation (the runners are afterwards
         available as .runners, the parsed options as .config)."""
         args = sys.argv[1:] if not ignore_cmdline else []
         self.config = self._config_parser.parse(args)
@@ -287,10 +308,38 @@ class LBSimulationController(object):
             LocalGroup(self.runners).run()
         wall = time.time() - t0
         if cfg.mode == 'benchmark':
-            steps = self.runners[0].timing['steps']
-            nodes = sum(r.num_fluid_nodes for r in self.runners)
-            run_wall = self.runners[0].timing['wall']
-            if steps and run_wall > 0:
-                cfg.logger.info('Total MLUPS: eff:{0:.2f}  (wall incl. setup {1:.2f} s)'.format(
-                    nodes * steps / run_wall * 1e-6, wall))
-        return self
+            # reference return value in benchmark mode (controller.py:765): timing_infos, min_timings,
+            # max_timings, subdomains; (None, None) otherwise
+            self.timing_infos = self._benchmark_summary(world)
+            return ([s[0] for s in self.timing_infos], [s[1] for s in self.timing_infos],
+                    [s[2] for s in self.timing_infos], subdomains)
+        return None, None
+
+    def _benchmark_summary(self, world):
+        """Per-subdomain and total MLUPS, printed the reference's way (controller.py:740-765): eff = active
+        nodes / mean step wall time, comp = active nodes / mean sweep kernel time."""
+        cfg = self.config
+        summaries = [r.summary for r in self.runners if getattr(r, 'summary', None) is not None]
+        if world > 1:
+            import torch.distributed as dist
+            gathered = [None] * world
+            dist.all_gather_object(gathered, summaries)
+            summaries = [s for part in gathered for s in part]
+            if dist.get_rank() != 0:
+                return summaries
+        mlups_total = mlups_comp = 0.0
+        for ti, min_ti, max_ti, nodes in sorted(summaries, key=lambda s: s[0].subdomain_id):
+            total = nodes / ti.total * 1e-6
+            comp = nodes / ti.comp * 1e-6 if ti.comp > 0 else float('nan')
+            mlups_total += total
+            mlups_comp += comp
+            stdev = math.sqrt(max(ti.total_sq - ti.total ** 2, 0.0))
+            low = nodes / max(ti.total - stdev, 1e-12) * 1e-6 - total
+            high = nodes / (ti.total + stdev) * 1e-6 - total
+            if not cfg.quiet:
+                print('Subdomain {0}: MLUPS eff:{1:.2f} +{2:.2f} -{3:.2f}  comp:{4:.2f}'.format(
+                    ti.subdomain_id, total, abs(low), abs(high), comp))
+        if not cfg.quiet:
+            print('Total MLUPS: eff:{0:.2f}  comp:{1:.2f}'.format(mlups_total, mlups_comp))
+        self.mlups_total, self.mlups_comp = mlups_total, mlups_comp
+        return summaries

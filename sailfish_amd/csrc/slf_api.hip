@@ -155,6 +155,7 @@ int slf_free(slf_ctx* ctx, void* dptr) {
 int slf_memset(slf_ctx* ctx, void* dptr, int value, size_t bytes, slf_stream* stream) {
   if (!ctx || !dptr) return fail(SLF_ERR_INVALID, "NULL argument");
   SLF_HIP(hipMemsetAsync(dptr, value, bytes, native(stream)));
+  if (!stream) SLF_HIP(hipStreamSynchronize(nullptr));   // no stream given: complete before returning
   return SLF_OK;
 }
 

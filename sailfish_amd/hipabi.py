@@ -108,6 +108,26 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (+ HSA runtime)
+    and always load that copy (NEEDED "libamdhip64.so", RPATH $ORIGIN); libsailfish_hip.so asks for the
+    soname libamdhip64.so.7 and would pull in /opt/rocm's copy if it is loaded first.  Two runtimes in
+    one process cannot share streams (TorchDistConnector hands our halo stream to torch / RCCL) and the
+    second one does not even see the GPU.  So, if torch is installed, map its copy first: the dynamic
+    loader then resolves our dependency to the already-loaded soname.  torch itself is not imported."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if not os.path.exists(cand):
+        return None
+    return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load(path=None):
     """Load libsailfish_hip.so and attach the signatures.  Raises if absent."""
     global _lib
@@ -118,6 +138,7 @@ def load(path=None):
         raise HipLibraryMissing(
             'libsailfish_hip.so not found at %s -- run `python -m sailfish_amd.build` '
             '(there is no CPU fallback for the HIP backend)' % p)
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

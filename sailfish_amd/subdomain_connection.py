@@ -245,3 +245,57 @@ def ghost_owned_by_others(spec, specs, gsize, periodic):
     sel = ghosts[(owner >= 0) & (owner != spec.id)]
     out[tuple(sel[:, a] for a in reversed(range(dim)))] = True
     return out
+
+
+class MacroLink(object):
+    """Node index lists (uint64) of one neighbour relation for macroscopic fields."""
+
+    def __init__(self, neighbour_id):
+        self.neighbour_id = neighbour_id
+        self.send = np.zeros(0, dtype=np.uint64)
+        self.recv = np.zeros(0, dtype=np.uint64)
+
+
+def _foreign_ghosts(spec, specs, gsize, periodic, fused):
+    """Ghost nodes of `spec` whose global position is a real node of another subdomain:
+    (local coords, owner ids, wrapped global positions), in a canonical order (local z, y, x)."""
+    dim = spec.dim
+    n = list(spec.size)
+    coords = _shell_coords_fast(n).astype(np.int64)
+    is_real = np.all((coords >= 1) & (coords <= np.array(n)), axis=1)
+    ghosts = coords[~is_real]
+    for a in range(dim):
+        if fused[a]:
+            ghosts = ghosts[(ghosts[:, a] >= 1) & (ghosts[:, a] <= n[a])]
+    owner, pos = _owner_of(ghosts + np.array(spec.location, dtype=np.int64) - 1, specs, gsize, periodic)
+    keep = (owner >= 0) & (owner != spec.id)
+    ghosts, owner, pos = ghosts[keep], owner[keep], pos[keep]
+    order = np.lexsort(ghosts.T)
+    return ghosts[order], owner[order], pos[order]
+
+
+def build_macro_links(spec, specs, gsize, periodic, arr_shape, fused_of):
+    """{neighbour_id: MacroLink} for the exchange of macroscopic fields read by non-local models
+    (Shan-Chen: psi(rho) of the 18 neighbours; reference _send_macro/_recv_macro, subdomain_runner.py:
+    2033-2100): every ghost node of a subdomain receives the value of the real node that owns its global
+    position.  Message order = canonical order of the *receiver's* ghost nodes; the sender derives the
+    same list from the receiver's spec.  fused_of(s) -> per-axis flags "s wraps this axis in its kernels"."""
+    dim = spec.dim
+    stride = np.array([1, arr_shape[0], arr_shape[0] * arr_shape[1]][:dim], dtype=np.int64)
+    origin = np.array(spec.location, dtype=np.int64)
+
+    def lin(c):
+        return np.ascontiguousarray((c * stride).sum(axis=1), dtype=np.uint64)
+
+    links = {}
+    g, owner, _ = _foreign_ghosts(spec, specs, gsize, periodic, fused_of(spec))
+    for nid in np.unique(owner):
+        links.setdefault(int(nid), MacroLink(int(nid))).recv = lin(g[owner == nid])
+    for t in specs:
+        if t.id == spec.id:
+            continue
+        g, owner, pos = _foreign_ghosts(t, specs, gsize, periodic, fused_of(t))
+        m = owner == spec.id
+        if m.any():
+            links.setdefault(int(t.id), MacroLink(int(t.id))).send = lin(pos[m] - origin + 1)
+    return links

@@ -25,6 +25,7 @@ import numpy as np
 
 from sailfish_amd import hipabi, io, subdomain_connection, util
 from sailfish_amd.lb_base import LBSim  # noqa: F401  (type reference)
+from sailfish_amd.profile import TimeProfile
 
 
 class GPUBuffer(object):
@@ -61,6 +62,7 @@ class SubdomainRunner(object):
         self._global_size = None
         self._global_periodic = None
         self.timing = {'steps': 0, 'wall': 0.0}
+        self._profile = TimeProfile(self)
         self._init_geometry_done = False
         if not hasattr(self.config, 'logger'):
             self.config.logger = util.setup_logger(self.config)
@@ -250,9 +252,12 @@ class SubdomainRunner(object):
 
     # ------------------------------------------------------------------ halo
     def _init_halo(self):
-        """Index lists, device buffers and pack / unpack kernels for every neighbour."""
+        """Index lists, device buffers and pack / unpack kernels for every neighbour.  A model with
+        several lattices (binary fluids) sends them back to back in one message per neighbour."""
         self._links = {}
-        if len(self._all_specs) < 2:
+        self._macro_links = {}
+        self._ev_halo = None
+        if self._all_specs is None or len(self._all_specs) < 2:
             return
         arr = list(reversed(self._physical_size))
         links = subdomain_connection.build_halo_links(self._spec, self._all_specs, self._global_size,
@@ -263,14 +268,16 @@ class SubdomainRunner(object):
             from sailfish_amd.connector import LocalConnector
             self._connector = LocalConnector()
         modes = ('push', 'pull') if self.config.access_pattern == 'AA' else ('push',)
+        n_grids = len(self._gpu_grids_primary)
+        isz = np.dtype(self.float).itemsize
         for nid in sorted(links):
             link = links[nid]
             n_send = max(len(link.push_send), len(link.pull_send))
             n_recv = max(len(link.push_recv), len(link.pull_recv))
             if n_send == 0 and n_recv == 0:
                 continue
-            link.send_buf = self._connector.alloc_buffer(self, n_send, self.float)
-            link.recv_buf = self._connector.alloc_buffer(self, n_recv, self.float)
+            link.send_buf = self._connector.alloc_buffer(self, n_send * n_grids, self.float)
+            link.recv_buf = self._connector.alloc_buffer(self, n_recv * n_grids, self.float)
             link.kernels = {}
             for mode in modes:
                 s_idx = getattr(link, mode + '_send')
@@ -278,14 +285,33 @@ class SubdomainRunner(object):
                 g_s = b.alloc_buf(like=s_idx) if len(s_idx) else 0
                 g_r = b.alloc_buf(like=r_idx) if len(r_idx) else 0
                 for copy in range(1 if not self._gpu_grids_secondary else 2):
-                    dist = self.gpu_dist(0, copy)
-                    pack = self.get_kernel('CollectSparseData', [g_s, dist, link.send_buf, len(s_idx)], 'PPPi') \
-                        if len(s_idx) else None
-                    unpack = self.get_kernel('DistributeSparseData', [g_r, dist, link.recv_buf, len(r_idx)],
-                                             'PPPi') if len(r_idx) else None
-                    link.kernels[(mode, copy)] = (pack, unpack, len(s_idx), len(r_idx))
+                    packs, unpacks = [], []
+                    for g in range(n_grids):
+                        dist = self.gpu_dist(g, copy)
+                        if len(s_idx):
+                            packs.append(self.get_kernel('CollectSparseData', [
+                                g_s, dist, link.send_buf + g * len(s_idx) * isz, len(s_idx)], 'PPPi'))
+                        if len(r_idx):
+                            unpacks.append(self.get_kernel('DistributeSparseData', [
+                                g_r, dist, link.recv_buf + g * len(r_idx) * isz, len(r_idx)], 'PPPi'))
+                    link.kernels[(mode, copy)] = (packs, unpacks, len(s_idx) * n_grids, len(r_idx) * n_grids)
             self._links[nid] = link
-        self._ev_halo = None
+
+    def halo_messages(self, kind='dist'):
+        """[(neighbour id, send buffer, #send, receive buffer, #recv)] of the exchange that is due now,
+        ordered by neighbour id: 'dist' = populations of the step just computed, 'macro' = fields read
+        by non-local models."""
+        out = []
+        if kind == 'dist':
+            for nid in sorted(self._links):
+                link = self._links[nid]
+                k = link.kernels[(self._halo_mode, self._halo_copy)]
+                out.append((nid, link.send_buf, k[2], link.recv_buf, k[3]))
+        else:
+            for nid in sorted(self._macro_links):
+                link = self._macro_links[nid]
+                out.append((nid, link.send_buf, link.n_send, link.recv_buf, link.n_recv))
+        return out
 
     # ------------------------------------------------------------------ kernels
     def _prepare_compute_kernels(self):
@@ -337,12 +363,18 @@ class SubdomainRunner(object):
         bnd, bulk = regions_bulk
         if self._links and self._ev_halo is not None:
             self._calc_stream.wait_for_event(self._ev_halo)
-        for reg in bnd:
-            for k in kernels:
-                b.run_kernel(k, reg, self._calc_stream)
-        ev = b.make_event(self._calc_stream) if bnd else None
+        prof = self._profile
+        ev = None
+        if bnd:
+            prof.record_gpu_start(TimeProfile.BOUNDARY, self._calc_stream)
+            for reg in bnd:
+                for k in kernels:
+                    b.run_kernel(k, reg, self._calc_stream)
+            ev = prof.record_gpu_end(TimeProfile.BOUNDARY, self._calc_stream, need_event=True)
+        prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
         for k in kernels:
             b.run_kernel(k, bulk, self._calc_stream)
+        prof.record_gpu_end(TimeProfile.BULK, self._calc_stream)
         return ev
 
     def step_compute(self, sync_req=False):
@@ -356,6 +388,14 @@ class SubdomainRunner(object):
         for axis in self._pbc_axes:
             for k in self._pbc_kernels[base][axis]:
                 b.run_kernel(k, None, self._calc_stream)
+        self._pack_halo(it, ev_bnd)
+        self._sim.iteration += 1
+        b.set_iteration(self._sim.iteration)
+
+    def _pack_halo(self, it, ev_bnd=None):
+        """Packs the populations that leave the subdomain after the step of iteration `it` (on the data
+        stream, as soon as the boundary regions / the whole sweep are done)."""
+        b = self.backend
         aa = self.config.access_pattern == 'AA'
         self._halo_mode = 'pull' if (aa and (it & 1) == 0) else 'push'
         self._halo_copy = 0 if aa else 1 - (it & 1)
@@ -363,33 +403,37 @@ class SubdomainRunner(object):
             # x-connected or unsplit subdomains: the whole sweep (and the local PBC) must be done first
             ev = ev_bnd if (ev_bnd is not None and not self._pbc_axes) else b.make_event(self._calc_stream)
             self._data_stream.wait_for_event(ev)
+            self._profile.record_gpu_start(TimeProfile.COLLECTION, self._data_stream)
             for nid, link in self._links.items():
-                pack = link.kernels[(self._halo_mode, self._halo_copy)][0]
-                if pack is not None:
+                for pack in link.kernels[(self._halo_mode, self._halo_copy)][0]:
                     b.run_kernel(pack, None, self._data_stream)
-        self._sim.iteration += 1
-        b.set_iteration(self._sim.iteration)
-
-    def halo_counts(self, nid):
-        k = self._links[nid].kernels[(self._halo_mode, self._halo_copy)]
-        return k[2], k[3]
+            self._profile.record_gpu_end(TimeProfile.COLLECTION, self._data_stream)
 
     def step_finish(self):
         """Unpack the received halos (the exchange has been enqueued on the data stream)."""
         b = self.backend
         if not self._links:
             return
+        self._profile.record_gpu_start(TimeProfile.DISTRIB, self._data_stream)
         for nid, link in self._links.items():
-            unpack = link.kernels[(self._halo_mode, self._halo_copy)][1]
-            if unpack is not None:
+            for unpack in link.kernels[(self._halo_mode, self._halo_copy)][1]:
                 b.run_kernel(unpack, None, self._data_stream)
+        self._profile.record_gpu_end(TimeProfile.DISTRIB, self._data_stream)
         self._ev_halo = b.make_event(self._data_stream)
+
+    has_macro_exchange = False
 
     def step(self, sync_req=False):
         """One time step of a runner whose neighbours live in other processes."""
+        if self.has_macro_exchange and self._macro_links:
+            self.step_macro()
+            self._connector.exchange(self, 'macro')
+            self.step_macro_finish()
         self.step_compute(sync_req)
         if self._links:
+            self._profile.record_cpu_start(TimeProfile.RECV_DISTS)
             self._connector.exchange(self)
+            self._profile.record_cpu_end(TimeProfile.RECV_DISTS)
         self.step_finish()
 
     # ------------------------------------------------------------------ data movement
@@ -518,16 +562,20 @@ class SubdomainRunner(object):
         cfg = self.config
         t_prev = time.time()
         it_prev = self._sim.iteration
+        self._profile.record_start()
         while not self.need_quit():
             sync_req, fields_req, output_req = self.pre_step()
+            self._profile.start_step()
             self.step(fields_req)
             self.post_step(sync_req, output_req)
+            self._profile.end_step()
             if cfg.perf_stats_every > 0 and self._sim.iteration % cfg.perf_stats_every == 0:
                 self.backend.sync_stream(self._calc_stream, self._data_stream)
                 now = time.time()
                 mlups = self.num_fluid_nodes * (self._sim.iteration - it_prev) / (now - t_prev) * 1e-6
                 cfg.logger.info('iteration:{0}  speed:{1:.2f} MLUPS'.format(self._sim.iteration, mlups))
                 t_prev, it_prev = now, self._sim.iteration
+        self.summary = self._profile.record_end()
         self.finish()
 
     def run(self):
@@ -549,10 +597,42 @@ class NNSubdomainRunner(SubdomainRunner):
     Axes wrapped inside the kernels need no ghost fill.  Exchange of the macroscopic fields between
     *different* subdomains (reference _send_macro/_recv_macro) is not implemented yet: one subdomain."""
 
+    has_macro_exchange = True
+
     def _init_halo(self):
-        if self._all_specs is not None and len(self._all_specs) > 1:
-            raise NotImplementedError('non-local (Shan-Chen) models run on a single subdomain in this version')
-        self._links = {}
+        """Population halo as in the base class (all lattices), plus the exchange of the macroscopic
+        fields the non-local force reads at neighbouring nodes (reference _init_interblock_kernels /
+        _send_macro / _recv_macro, subdomain_runner.py:1907-2100)."""
+        SubdomainRunner._init_halo(self)
+        if not self._links:
+            return
+        cfg = self.config
+        arr = list(reversed(self._physical_size))
+        dim = self.dim
+
+        def fused_of(spec):
+            return [int(bool(spec._periodicity[a]) and getattr(cfg, 'hip_fused_periodic', True)) for a in range(dim)]
+
+        links = subdomain_connection.build_macro_links(self._spec, self._all_specs, self._global_size,
+                                                       self._global_periodic, arr, fused_of)
+        b = self.backend
+        fields = [self.gpu_field(fp.buffer) for fp in self._sim._scalar_fields if fp.abstract.need_nn]
+        isz = np.dtype(self.float).itemsize
+        for nid in sorted(links):
+            link = links[nid]
+            ns, nr = len(link.send), len(link.recv)
+            if ns == 0 and nr == 0:
+                continue
+            link.n_send, link.n_recv = ns * len(fields), nr * len(fields)
+            link.send_buf = self._connector.alloc_buffer(self, link.n_send, self.float)
+            link.recv_buf = self._connector.alloc_buffer(self, link.n_recv, self.float)
+            g_s = b.alloc_buf(like=link.send) if ns else 0
+            g_r = b.alloc_buf(like=link.recv) if nr else 0
+            link.packs = [self.get_kernel('CollectSparseData', [g_s, f, link.send_buf + i * ns * isz, ns], 'PPPi')
+                          for i, f in enumerate(fields)] if ns else []
+            link.unpacks = [self.get_kernel('DistributeSparseData', [g_r, f, link.recv_buf + i * nr * isz, nr], 'PPPi')
+                            for i, f in enumerate(fields)] if nr else []
+            self._macro_links[nid] = link
 
     def _prepare_compute_kernels(self):
         self._kernels_full = self._sim.get_compute_kernels(self, True, True)
@@ -562,21 +642,65 @@ class NNSubdomainRunner(SubdomainRunner):
         self._regions = self._make_regions()
         self._kernels_prepared = True
 
-    def step_compute(self, sync_req=False):
+    def _run_macro(self):
+        """Macroscopic fields of every real node, then their local periodic images."""
         b = self.backend
         it = self._sim.iteration
-        kernels = self._kernels_full if sync_req else self._kernels_none
-        macro_kernel, sim_kernels = kernels[it & 1]
+        macro_kernel = self._kernels_none[it & 1][0]
+        prof = self._profile
+        if self._links and self._ev_halo is not None:
+            self._calc_stream.wait_for_event(self._ev_halo)      # populations received after the last step
+        prof.record_gpu_start(TimeProfile.MACRO_BULK, self._calc_stream)
         b.run_kernel(macro_kernel, None, self._calc_stream)
+        prof.record_gpu_end(TimeProfile.MACRO_BULK, self._calc_stream)
         base = 1 - (it & 1)
         for axis in self._pbc_axes:
             for k in self._pbc_kernels.macro[base][axis]:
                 b.run_kernel(k, None, self._calc_stream)
+
+    def step_macro(self):
+        """First half of a step with neighbours: macro fields + pack of the boundary values."""
+        b = self.backend
+        self._run_macro()
+        self._macro_done = True
+        if self._macro_links:
+            self._data_stream.wait_for_event(b.make_event(self._calc_stream))
+            self._profile.record_gpu_start(TimeProfile.MACRO_COLLECTION, self._data_stream)
+            for nid, link in self._macro_links.items():
+                for k in link.packs:
+                    b.run_kernel(k, None, self._data_stream)
+            self._profile.record_gpu_end(TimeProfile.MACRO_COLLECTION, self._data_stream)
+
+    def step_macro_finish(self):
+        """Unpack the neighbours' values into the ghost nodes; the sweep waits for it."""
+        b = self.backend
+        if not self._macro_links:
+            return
+        self._profile.record_gpu_start(TimeProfile.MACRO_DISTRIB, self._data_stream)
+        for nid, link in self._macro_links.items():
+            for k in link.unpacks:
+                b.run_kernel(k, None, self._data_stream)
+        self._profile.record_gpu_end(TimeProfile.MACRO_DISTRIB, self._data_stream)
+        self._calc_stream.wait_for_event(b.make_event(self._data_stream))
+
+    def step_compute(self, sync_req=False):
+        b = self.backend
+        it = self._sim.iteration
+        if not getattr(self, '_macro_done', False):
+            self._run_macro()
+        self._macro_done = False
+        kernels = self._kernels_full if sync_req else self._kernels_none
+        sim_kernels = kernels[it & 1][1]
+        prof = self._profile
+        base = 1 - (it & 1)
+        prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
         for k in sim_kernels:
             b.run_kernel(k, None, self._calc_stream)
+        prof.record_gpu_end(TimeProfile.BULK, self._calc_stream)
         for axis in self._pbc_axes:
             for k in self._pbc_kernels.distributions[base][axis]:
                 b.run_kernel(k, None, self._calc_stream)
+        self._pack_halo(it)
         self._sim.iteration += 1
         b.set_iteration(self._sim.iteration)
 

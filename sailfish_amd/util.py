@@ -8,7 +8,7 @@ import numpy as np
 
 from sailfish_amd import sym
 
-TimingInfo = namedtuple('TimingInfo', 'comp bulk bnd coll net_wait recv send total subdomain_id')
+TimingInfo = namedtuple('TimingInfo', 'comp bulk bnd coll net_wait recv send total total_sq subdomain_id')
 
 
 class GridError(Exception):

@@ -128,10 +128,18 @@ class OracleGroup(object):
         return out
 
 
-class OracleSCSubdomain(object):
-    """Oracle twin of NNSubdomainRunner for the binary Shan-Chen model (single subdomain)."""
+def _flat(arr):
+    base = arr
+    while base.base is not None:
+        base = base.base
+    return base.reshape(-1)
 
-    def __init__(self, runner):
+
+class _OracleNN(object):
+    """Shared part of the oracle twins of NNSubdomainRunner: a step is  macro fields -> local macro PBC
+    -> [macro halo] -> sweep(s) -> local PBC -> [population halo]."""
+
+    def _setup(self, runner):
         r = self.runner = runner
         r._init_geometry()
         r._sim.init_fields(r)
@@ -143,40 +151,131 @@ class OracleSCSubdomain(object):
         dt = self.o.dtype
         self.node_map = np.ascontiguousarray(r._subdomain._type_map_base, dtype=np.uint32).reshape(self.o.shape)
         self.rho = np.ascontiguousarray(r.field_base(r._sim.rho), dtype=dt).reshape(self.o.shape)
-        self.phi = np.ascontiguousarray(r.field_base(r._sim.phi), dtype=dt).reshape(self.o.shape)
         self.v = [np.ascontiguousarray(r.field_base(c), dtype=dt).reshape(self.o.shape) for c in r._sim.v]
         while len(self.v) < 3:
             self.v.append(np.zeros(self.o.shape, dtype=dt))
+        local = r._local_periodic()
+        self.pbc_axes = [a for a in range(self.dim) if local[a] and not r._fused[a]]
+        self.iteration = 0
+        self.links, self.macro_links = {}, {}
+        if r._all_specs is not None and len(r._all_specs) > 1:
+            arr = list(reversed(r._physical_size))
+            cfg = r.config
+
+            def fused_of(spec):
+                return [int(bool(spec._periodicity[a]) and getattr(cfg, 'hip_fused_periodic', True))
+                        for a in range(self.dim)]
+
+            self.links = subdomain_connection.build_halo_links(
+                r._spec, r._all_specs, r._global_size, r._global_periodic, r._sim.grid, arr,
+                hipabi.dist_stride(self.desc), fused=r._fused)
+            self.macro_links = subdomain_connection.build_macro_links(
+                r._spec, r._all_specs, r._global_size, r._global_periodic, arr, fused_of)
+
+    def _props(self):
+        it = self.iteration
+        if self.aa:
+            return 0, 0, (2 if (it & 1) else 1), (it & 1) == 0
+        return it & 1, 1 - (it & 1), 0, False
+
+    # -- phases
+    def macro_send(self):
+        self.macro()
+        sends = {}
+        for nid, link in self.macro_links.items():
+            parts = []
+            for f in self.nn_fields():
+                buf = np.zeros(len(link.send), dtype=self.o.dtype)
+                if len(link.send):
+                    self.o.sparse(True, link.send, _flat(f), buf)
+                parts.append(buf)
+            sends[nid] = np.concatenate(parts)
+        return sends
+
+    def macro_recv(self, recvs):
+        for nid, buf in recvs.items():
+            link = self.macro_links[nid]
+            n = len(link.recv)
+            fields = self.nn_fields()
+            assert len(buf) == n * len(fields)
+            for i, f in enumerate(fields):
+                if n:
+                    self.o.sparse(False, link.recv, _flat(f), np.ascontiguousarray(buf[i * n:(i + 1) * n]))
+
+    def dist_send(self, save=False):
+        self.sweep(save)
+        it = self.iteration - 1
+        mode = 'pull' if (self.aa and (it & 1) == 0) else 'push'
+        self._mode = mode
+        sends = {}
+        for nid, link in self.links.items():
+            idx = getattr(link, mode + '_send')
+            parts = []
+            for d in self.lattices_out():
+                buf = np.zeros(len(idx), dtype=self.o.dtype)
+                if len(idx):
+                    self.o.sparse(True, idx, _flat(d), buf)
+                parts.append(buf)
+            sends[nid] = np.concatenate(parts)
+        return sends
+
+    def dist_recv(self, recvs):
+        for nid, buf in recvs.items():
+            idx = getattr(self.links[nid], self._mode + '_recv')
+            n = len(idx)
+            lat = self.lattices_out()
+            assert len(buf) == n * len(lat)
+            for i, d in enumerate(lat):
+                if n:
+                    self.o.sparse(False, idx, _flat(d), np.ascontiguousarray(buf[i * n:(i + 1) * n]))
+
+    def step(self, save=False):
+        self.macro()
+        self.sweep(save)
+
+    def real(self, arr):
+        ng = self.runner._spec._nonghost_slice
+        if self.dim == 2:
+            return arr[(Ellipsis, 0) + tuple(ng)]
+        return arr[(Ellipsis,) + tuple(ng)]
+
+
+class OracleSCSubdomain(_OracleNN):
+    """Oracle twin of NNSubdomainRunner for the binary Shan-Chen model."""
+
+    def __init__(self, runner):
+        self._setup(runner)
+        r, dt = runner, self.o.dtype
+        self.phi = np.ascontiguousarray(r.field_base(r._sim.phi), dtype=dt).reshape(self.o.shape)
         ncopy = 1 if self.aa else 2
         self.d1 = [self.o.new_dist() for _ in range(ncopy)]
         self.d2 = [self.o.new_dist() for _ in range(ncopy)]
         with np.errstate(all='ignore'):
             for a, b in zip(self.d1, self.d2):
                 self.o.sc_init(a, b, self.rho, self.phi, *self.v)
-        local = r._local_periodic()
-        self.pbc_axes = [a for a in range(self.dim) if local[a] and not r._fused[a]]
-        self.iteration = 0
 
-    def step(self):
-        it = self.iteration
-        m = self.node_map
-        if self.aa:
-            i = o = 0
-            prop = 2 if (it & 1) else 1
-            macro_prop, swap = prop, (it & 1) == 0
-        else:
-            i, o = it & 1, 1 - (it & 1)
-            prop = macro_prop = 0
-            swap = False
-        self.o.sc_macro(macro_prop, m, self.d1[i], self.d2[i], self.rho, self.phi, *self.v)
+    def nn_fields(self):
+        return [self.rho, self.phi]
+
+    def lattices_out(self):
+        return [self.d1[self._out], self.d2[self._out]]
+
+    def macro(self):
+        i, o, prop, swap = self._props()
+        self.o.sc_macro(prop, self.node_map, self.d1[i], self.d2[i], self.rho, self.phi, *self.v)
         for axis in self.pbc_axes:
             self.o.macro_pbc(self.rho, axis)
             self.o.macro_pbc(self.phi, axis)
+
+    def sweep(self, save=False):
+        i, o, prop, swap = self._props()
+        m = self.node_map
         self.o.sc_step(0, prop, m, self.d1[i], self.d1[o], self.rho, self.phi, *self.v)
         self.o.sc_step(1, prop, m, self.d2[i], self.d2[o], self.rho, self.phi, *self.v)
         for axis in self.pbc_axes:
             self.o.pbc(self.d1[o], axis, swap)
             self.o.pbc(self.d2[o], axis, swap)
+        self._out = o
         self.iteration += 1
 
     def run(self, n):
@@ -187,52 +286,35 @@ class OracleSCSubdomain(object):
         k = 0 if self.aa else (self.iteration & 1)
         return self.d1[k], self.d2[k]
 
-    def real(self, arr):
-        ng = self.runner._spec._nonghost_slice
-        if self.dim == 2:
-            return arr[(Ellipsis, 0) + tuple(ng)]
-        return arr[(Ellipsis,) + tuple(ng)]
 
-
-class OracleSCSingle(object):
+class OracleSCSingle(_OracleNN):
     """Oracle twin of NNSubdomainRunner for the single-component Shan-Chen model."""
 
     def __init__(self, runner):
-        r = self.runner = runner
-        r._init_geometry()
-        r._sim.init_fields(r)
-        r._subdomain.init_fields(r._sim)
-        self.desc = r._module_desc()
-        self.o = OracleSim(self.desc)
-        self.dim = r.dim
-        self.aa = self.desc.access_pattern == hipabi.SLF_AA
-        dt = self.o.dtype
-        self.node_map = np.ascontiguousarray(r._subdomain._type_map_base, dtype=np.uint32).reshape(self.o.shape)
-        self.rho = np.ascontiguousarray(r.field_base(r._sim.rho), dtype=dt).reshape(self.o.shape)
-        self.v = [np.ascontiguousarray(r.field_base(c), dtype=dt).reshape(self.o.shape) for c in r._sim.v]
-        while len(self.v) < 3:
-            self.v.append(np.zeros(self.o.shape, dtype=dt))
+        self._setup(runner)
         self.d = [self.o.new_dist() for _ in range(1 if self.aa else 2)]
         with np.errstate(all='ignore'):
             for a in self.d:
                 self.o.init(a, self.rho, *self.v)
-        local = r._local_periodic()
-        self.pbc_axes = [a for a in range(self.dim) if local[a] and not r._fused[a]]
-        self.iteration = 0
 
-    def step(self, save=False):
-        it = self.iteration
-        if self.aa:
-            i = o = 0
-            prop, swap = (2 if (it & 1) else 1), (it & 1) == 0
-        else:
-            i, o, prop, swap = it & 1, 1 - (it & 1), 0, False
+    def nn_fields(self):
+        return [self.rho]
+
+    def lattices_out(self):
+        return [self.d[self._out]]
+
+    def macro(self):
+        i, o, prop, swap = self._props()
         self.o.scs_macro(prop, self.node_map, self.d[i], self.rho)
         for axis in self.pbc_axes:
             self.o.macro_pbc(self.rho, axis)
+
+    def sweep(self, save=False):
+        i, o, prop, swap = self._props()
         self.o.scs_step(prop, self.node_map, self.d[i], self.d[o], self.rho, *self.v, options=1 if save else 0)
         for axis in self.pbc_axes:
             self.o.pbc(self.d[o], axis, swap)
+        self._out = o
         self.iteration += 1
 
     def run(self, n):
@@ -242,8 +324,38 @@ class OracleSCSingle(object):
     def current(self):
         return self.d[0] if self.aa else self.d[self.iteration & 1]
 
-    def real(self, arr):
-        ng = self.runner._spec._nonghost_slice
-        if self.dim == 2:
-            return arr[(Ellipsis, 0) + tuple(ng)]
-        return arr[(Ellipsis,) + tuple(ng)]
+
+class OracleNNGroup(object):
+    """Several Shan-Chen subdomains in lock-step: two exchanges per step (macro fields, populations;
+    reference NNSubdomainRunner.step, subdomain_runner.py:2102-2197)."""
+
+    def __init__(self, sim_cls, dim, geo_name, cfg_kw, single=False):
+        self.cfg, self.specs, runners = _host.build_runners(sim_cls, dim, geo_name, cfg_kw)
+        cls = OracleSCSingle if single else OracleSCSubdomain
+        self.subs = [cls(r) for r in runners]
+
+    def step(self, save=False):
+        ids = [s.runner._spec.id for s in self.subs]
+        by_id = dict(zip(ids, range(len(ids))))
+        sends = [s.macro_send() for s in self.subs]
+        for s in self.subs:
+            s.macro_recv(dict((nid, sends[by_id[nid]][s.runner._spec.id]) for nid in s.macro_links))
+        sends = [s.dist_send(save) for s in self.subs]
+        for s in self.subs:
+            s.dist_recv(dict((nid, sends[by_id[nid]][s.runner._spec.id]) for nid in s.links))
+
+    def run(self, n):
+        for k in range(n):
+            self.step(save=(k == n - 1))
+
+    def merged(self, get):
+        """Global real-node array; get(sub) -> array stored as [..., arr_nz, arr_ny, arr_nx]."""
+        first = get(self.subs[0])
+        lead = first.shape[:first.ndim - 3]
+        gshape = tuple(reversed(self.subs[0].runner._global_size))
+        out = np.zeros(lead + gshape, dtype=first.dtype)
+        for s in self.subs:
+            sp = s.runner._spec
+            sl = tuple(slice(o, o + n) for o, n in zip(reversed(sp.location), reversed(sp.size)))
+            out[(Ellipsis,) + sl] = s.real(get(s))
+        return out

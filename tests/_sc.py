@@ -14,9 +14,12 @@ def make_sim(dim, seed=7, amplitude=1e-3):
             pass
 
         def initial_conditions(self, sim, *h):
+            # noise defined on the *global* grid so that any decomposition starts from the same state
             rng = np.random.RandomState(seed)
-            sim.rho[:] = 1.0 + amplitude * rng.rand(*sim.rho.shape)
-            sim.phi[:] = 1.0 + amplitude * rng.rand(*sim.phi.shape)
+            gshape = (self.gy, self.gx) if dim == 2 else (self.gz, self.gy, self.gx)
+            where = tuple(reversed(h))
+            sim.rho[:] = 1.0 + amplitude * rng.rand(*gshape)[where]
+            sim.phi[:] = 1.0 + amplitude * rng.rand(*gshape)[where]
 
     class Sim(LBBinaryFluidShanChen):
         subdomain = Mixture
@@ -44,7 +47,8 @@ def make_single_sim(dim, seed=2348, rho0=0.693, amplitude=0.01):
 
         def initial_conditions(self, sim, *h):
             rng = np.random.RandomState(seed)
-            sim.rho[:] = rho0 + amplitude * rng.rand(*sim.rho.shape)
+            gshape = (self.gy, self.gx) if dim == 2 else (self.gz, self.gy, self.gx)
+            sim.rho[:] = rho0 + amplitude * rng.rand(*gshape)[tuple(reversed(h))]
 
     class Sim(LBSingleFluidShanChen):
         subdomain = Vapour

@@ -168,3 +168,44 @@ def test_ldc_2d_re1000_matches_erturk(golden_dir):
     sel = (vx2d[:, 0] > 0.02) & (vx2d[:, 0] < 0.98)
     err_v = np.max(np.abs(v_ref[sel] - vx2d[sel, 1]))
     assert err_u < 0.03 and err_v < 0.03, (err_u, err_v)
+
+
+def test_benchmark_mode_summary(capsys):
+    """--mode=benchmark: TimeProfile accounting and the reference's summary lines (controller.py:740-765)."""
+    cfg = dict(lat_nx=64, lat_ny=48, lat_nz=40, visc=0.05, subdomains=2, conn_axis='z', access_pattern='AA')
+    ctrl = run_gpu('ldc_3d', 'LDCSim', 3, cfg, 260,
+                   extra=dict(mode='benchmark', quiet=False, benchmark_sample_from=100, benchmark_minibatch=50))
+    out = capsys.readouterr().out
+    assert 'Subdomain 0: MLUPS eff:' in out and 'Subdomain 1: MLUPS eff:' in out and 'Total MLUPS: eff:' in out
+    assert len(ctrl.timing_infos) == 2
+    for ti, min_ti, max_ti, nodes in ctrl.timing_infos:
+        assert ti.total > 0 and ti.comp > 0 and ti.bulk > 0 and ti.bnd > 0 and ti.coll > 0
+        assert ti.comp <= ti.total * 1.5
+        assert min_ti.total <= ti.total <= max_ti.total * (1 + 1e-9)
+        assert ti.total_sq >= ti.total ** 2 * (1 - 1e-9)
+    assert ctrl.runners[0]._profile.samples == 160
+    assert ctrl.mlups_total > 0 and ctrl.mlups_comp >= ctrl.mlups_total * 0.5
+
+
+def test_tools_merge_and_compare(tmp_path):
+    """The reference's file-level checks run with its own tools: 2 subdomains merged == 1 subdomain, and
+    AA == AB (tests/gpu/access_pattern.sh:12-29 + utils/compare_results.py), bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from utils.compare_results import compare
+    from utils.merge_subdomains import merge_subdomains
+    from sailfish_amd import io
+    cfg = dict(lat_nx=40, lat_ny=24, lat_nz=20, visc=0.03)
+    one = str(tmp_path / 'one')
+    two = str(tmp_path / 'two')
+    ab = str(tmp_path / 'ab')
+    run_gpu('ldc_3d', 'LDCSim', 3, dict(cfg, access_pattern='AA'), 60, extra=dict(output=one, every=30))
+    run_gpu('ldc_3d', 'LDCSim', 3, dict(cfg, access_pattern='AA', subdomains=2, conn_axis='y'), 60,
+            extra=dict(output=two, every=30))
+    run_gpu('ldc_3d', 'LDCSim', 3, dict(cfg, access_pattern='AB'), 60, extra=dict(output=ab, every=30))
+    digits = io.filename_iter_digits(60)
+    for it in (30, 60):
+        merge_subdomains(two, digits, it)
+        merge_subdomains(one, digits, it)
+        assert compare(io.merged_filename(one, digits, it), io.merged_filename(two, digits, it)) == 0
+        assert compare(io.filename(one, digits, 0, it), io.filename(ab, digits, 0, it)) == 0

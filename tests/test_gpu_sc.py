@@ -110,3 +110,35 @@ def test_phase_separation_matches_reference_record(G, golden_dir):
     else:                                 # coexistence densities (droplet curvature / coarsening stage: few %)
         assert abs(hi - row[2]) / row[2] < 0.03, (lo, hi, row)
         assert abs(lo - row[1]) < 0.02, (lo, hi, row)
+
+
+@pytest.mark.parametrize('single', [False, True])
+@pytest.mark.parametrize('dim,size,nsub,axis', [(2, (70, 20), 2, 'x'), (3, (40, 9, 8), 2, 'z'), (3, (40, 12, 8), 3, 'y')])
+@pytest.mark.parametrize('pattern,fused', [('AB', True), ('AA', True), ('AA', False)])
+def test_sc_multi_subdomain(single, dim, size, nsub, axis, pattern, fused):
+    """Non-local models on several subdomains (macro-field halo + population halo of every lattice;
+    reference NNSubdomainRunner, regtest/subdomains/binary_pbc.py): equal to the oracle group, which the
+    CPU suite shows to be bit-identical to a single subdomain."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from tests._oracle_group import OracleNNGroup
+    steps = 11
+    sim_cls, _ = (_sc.make_single_sim if single else _sc.make_sim)(dim)
+    cfg = (_sc.single_config if single else _sc.config)(dim, size, pattern=pattern, fused=fused)
+    if single:
+        cfg.update(G=-1.2, sc_potential='linear')
+    cfg.update(subdomains=nsub, conn_axis=axis)
+    geo_name = 'EqualSubdomainsGeometry%dD' % dim
+    og = OracleNNGroup(sim_cls, dim, geo_name, dict(cfg), single=single)
+    og.run(steps)
+    gcfg = dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0)
+    ctrl = LBSimulationController(sim_cls, getattr(geo_mod, geo_name), default_config=gcfg)
+    ctrl.run(ignore_cmdline=True)
+    assert len(ctrl.runners) == nsub
+    for r, o in zip(ctrl.runners, og.subs):
+        assert r._spec.id == o.runner._spec.id
+        assert np.array_equal(r._sim.rho, o.real(o.rho))
+        lattices = [o.current()] if single else list(o.current())
+        for grid_num, od in enumerate(lattices):
+            gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+            assert np.array_equal(gd, o.real(od)), 'subdomain %d lattice %d' % (r._spec.id, grid_num)

@@ -96,3 +96,34 @@ def test_single_component_invariants(dim, size):
     for k, v in res.items():
         for a, b in zip(ref, v):
             assert np.array_equal(a, b), k
+
+
+def _group(dim, size, steps, single, nsub, axis, **kw):
+    from tests._oracle_group import OracleNNGroup
+    sim_cls, _ = (_sc.make_single_sim if single else _sc.make_sim)(dim)
+    cfg = (_sc.single_config if single else _sc.config)(dim, size, **kw)
+    if single:
+        cfg.update(G=-1.2, sc_potential='linear')
+    cfg.update(subdomains=nsub, conn_axis=axis)
+    g = OracleNNGroup(sim_cls, dim, 'EqualSubdomainsGeometry%dD' % dim, cfg, single=single)
+    g.run(steps)
+    return g
+
+
+@pytest.mark.parametrize('single', [False, True])
+@pytest.mark.parametrize('dim,size,nsub,axis', [(2, (18, 12), 2, 'x'), (2, (18, 12), 3, 'y'), (3, (10, 8, 6), 2, 'z'),
+                                                (3, (10, 8, 6), 2, 'x')])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_one_vs_n_subdomains(single, dim, size, nsub, axis, pattern):
+    """Macro-field halo + population halo of the non-local models: N subdomains == 1 subdomain, bit for bit
+    (reference regtest/subdomains/binary_pbc.py checks 6 decimals)."""
+    ref = _group(dim, size, 9, single, 1, axis, pattern=pattern)
+    for fused in (True, False):
+        g = _group(dim, size, 9, single, nsub, axis, pattern=pattern, fused=fused)
+        assert np.array_equal(g.merged(lambda s: s.rho), ref.merged(lambda s: s.rho))
+        if single:
+            assert np.array_equal(g.merged(lambda s: s.current()), ref.merged(lambda s: s.current()))
+        else:
+            assert np.array_equal(g.merged(lambda s: s.phi), ref.merged(lambda s: s.phi))
+            for k in (0, 1):
+                assert np.array_equal(g.merged(lambda s: s.current()[k]), ref.merged(lambda s: s.current()[k]))
