@@ -20,18 +20,6 @@ template <> struct VecT<1> { typedef float type; };
 template <> struct VecT<2> { typedef float2v type; };
 template <> struct VecT<4> { typedef float4v type; };
 
-// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores
-template <int NT, class T>
-__device__ __forceinline__ T ld(const T* p) {
-  if constexpr (NT & 1) return __builtin_nontemporal_load(p);
-  else return *p;
-}
-template <int NT, class T>
-__device__ __forceinline__ void st(T* p, T v) {
-  if constexpr (NT & 2) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
-
 template <int VEC>
 __device__ __forceinline__ float vget(const typename VecT<VEC>::type& v, int k) {
   if constexpr (VEC == 1) return v;
@@ -327,6 +315,7 @@ static bool launch_fast_model(Prop prop, const Geometry& g, const SweepParams<D3
 bool launch_sweep_fast(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const SweepArgs& a,
                        int y0, int y1, int z0, int z1, int block_x, hipStream_t s, hipError_t* err) {
   if (sel.general || sel.lattice != 1 || sel.precision != 4 || !g.wrap[0] || g.variant == 0) return false;
+  if (g.variant & 256) return false;   // experiments: use the generic row kernels (slf_row.hip) instead
   if (y1 <= y0 || z1 <= z0) return false;
   const SweepParams<D3Q19, float> p = make_params<D3Q19, float>(g, ph, a, y0, z0);
   bool done = sel.model == 0 ? launch_fast_model<0>(prop, g, p, y1 - y0, z1 - z0, block_x, s)

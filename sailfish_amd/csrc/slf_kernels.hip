@@ -60,73 +60,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
 
   R rho, v[3];
   bool wet = true;
-  if constexpr (GENERAL) {
-    wet = kind_is_wet(kind);
-    const int orientation = (int)(code >> g.orient_shift);
-    const int pidx = (int)((code >> g.param_shift) & g.param_mask);
-    const bool inc = p.cp.incompressible != 0;
-    // ---- macroscopic quantities (getMacro, boundary.mako:465-507)
-    const bool bc_macro = (kind == NK_REGULARIZED_VELOCITY || kind == NK_EQUILIBRIUM_VELOCITY ||
-                           kind == NK_EQUILIBRIUM_DENSITY) && orientation != 0;
-    if (!bc_macro) {
-      macro_standard<L, R>(f, inc, rho, v);
-    } else if (kind == NK_EQUILIBRIUM_DENSITY) {
-      with_orientation<L>(orientation, [&](auto O) { macro_density_bc<L, R, O>(f, p.node_params[pidx], rho, v); });
-    } else {
-      with_orientation<L>(orientation,
-                          [&](auto O) { macro_velocity_bc<L, R, O>(f, p.node_params + pidx, inc, rho, v); });
-    }
-    // ---- pre-collision boundary conditions (boundary.mako:784-878)
-    const R rho0 = inc ? (R)1 : rho;
-    if (kind == NK_FULL_BB) {
-      bounce_back<L, R>(f);
-    } else if (kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY) {
-      set_equilibrium<L, R>(f, rho, rho0, v);
-    } else if (kind == NK_REGULARIZED_VELOCITY) {
-      if (orientation == 0) {
-        bounce_back<L, R>(f);  // nt_dir_other fallback, boundary.mako:336-338
-      } else {
-        with_orientation<L>(orientation, [&](auto O) { regularized_bc<L, R, O>(f, rho, rho0, v); });
-      }
-    }
-    // ---- collision (relaxate, relaxation.mako:196-202: wet nodes only)
-    if (wet && p.relaxation_enabled) {
-      if constexpr (MODEL == 0) {
-        bgk_relax<L, R>(f, rho, v, p.cp);
-      } else {
-        mrt_relax<L, R>(f, v, p.cp, kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY);
-      }
-    }
-    // ---- post-collision: half-way bounce-back (boundary.mako:653-683)
-    if (kind == NK_HALF_BB) {
-      static_for<1, L::Q>([&](auto I) {
-        bool missing;
-        if (g.use_link_tags) {
-          missing = ((orientation >> (I - 1)) & 1) == 0;  // direction I points to a non-fluid node
-        } else {
-          missing = false;
-          with_orientation<L>(orientation, [&](auto O) {
-            if constexpr (is_missing<L, L::opp(I), O>()) missing = true;
-          });
-        }
-        if (missing) {
-          // population opp(I) is undefined here: feed it with the reflected f_I.
-          if constexpr (PROP == PROP_AA_EVEN) {
-            const int off = dir_offset<L, I>(ox, oy, oz, true);
-            (p.dout + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
-          } else {
-            (p.dout + ds * (size_t)L::opp(I))[gi] = f[I];
-          }
-        }
-      });
-    }
-  } else {
-    macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
-    if (p.relaxation_enabled) {
-      if constexpr (MODEL == 0) bgk_relax<L, R>(f, rho, v, p.cp);
-      else mrt_relax<L, R>(f, v, p.cp, false);
-    }
-  }
+  node_update<L, R, MODEL, PROP, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
 
   // ---- macroscopic output (save_macro_fields, kernel_common.mako:213-240)
   if ((p.options & 1u) && wet) {
@@ -385,6 +319,7 @@ hipError_t launch_sweep(const KernelSelector& sel, Prop prop, const Geometry& g,
   {
     hipError_t fe = hipSuccess;
     if (launch_sweep_fast(sel, prop, g, ph, a, y0, y1, z0, z1, block_x, s, &fe)) return fe;
+    if (launch_sweep_row(sel, prop, g, ph, a, y0, y1, z0, z1, s, &fe)) return fe;
   }
   SLF_DISPATCH_LR(sel, return (launch_sweep2<L, R>(sel.model, prop, sel.general, g, ph, a, y0, y1, z0, z1, block_x, s)));
   return hipErrorInvalidValue;

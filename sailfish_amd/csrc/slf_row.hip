@@ -1,0 +1,243 @@
+// Whole-row sweep kernels: the aligned-streaming scheme of the tuned north-star kernel
+// (slf_fast.hip: fast_row_kernel) for every D3Q19 configuration -- f32 / f64, BGK / MRT, with or without
+// the node map (walls, boundary conditions, unused nodes), x wrapped in-sweep or not.
+//
+//   * one workgroup = one (y, z) row, thread t owns node x = t + 1; the distribution arrays are
+//     allocated so that x = 1 starts a 128-byte line  =>  every global access of a wave is line aligned;
+//   * the +-1 x shift of the push (AB and odd AA step) happens in registers: __shfl_up/down inside a
+//     wave64, one LDS word per direction between neighbouring waves, the periodic wrap as the cyclic
+//     continuation (x = nx <-> x = 1)  =>  every *store* is aligned (partial-line writes are what hurts
+//     HBM); the pull of the odd AA step uses plain shifted loads (misaligned reads are served from cache);
+//   * without in-sweep wrap the ghost columns x = 0 and x = nx + 1 are written by the two edge lanes of
+//     the row only;
+//   * a population is stored by the thread that owns its *target* x, if and only if its *source* node
+//     takes part in the sweep (the reference pushes from every non-excluded node, whatever the target
+//     is: propagation.mako:384-421) -- the 'active' flag travels with the value;
+//   * populations are streamed once per step: non-temporal loads and stores.
+//
+// Arithmetic is node_update() of slf_sweep.h, shared with the per-node kernel in slf_kernels.hip: the
+// results are bit-identical.  Replaces the reference's shared-memory propagation
+// (templates/propagation.mako:180-288) on MI355X.
+#include "slf_sweep.h"
+
+namespace slf {
+
+template <class L>
+constexpr int count_x_dirs() {
+  int n = 0;
+  for (int i = 0; i < L::Q; i++) n += (L::ex(i) > 0) ? 1 : 0;
+  return n;
+}
+
+template <class R>
+__device__ __forceinline__ R shfl_up1(R v) { return __shfl_up(v, 1); }
+template <class R>
+__device__ __forceinline__ R shfl_down1(R v) { return __shfl_down(v, 1); }
+
+template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT>
+__global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
+  static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
+  constexpr int NW = 16;
+  constexpr int NXD = count_x_dirs<L>();
+  __shared__ R s_out_p[NW][NXD], s_out_m[NW][NXD], s_wrap_p[NXD], s_wrap_m[NXD];
+  __shared__ int s_act_p[NW], s_act_m[NW], s_actw_p, s_actw_m;
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int nx = g.lat_nx - 2;
+  const int x = (int)threadIdx.x + 1;
+  const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+  const bool live = x <= nx;
+  const bool wrapx = g.wrap[0] != 0;
+  const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const uint32_t gi = row + (uint32_t)(live ? x : nx);  // idle lanes: an in-row address, never stored
+  const AxisOff ox0 = {0, 0};
+  const AxisOff ox = axis_off(x, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  const size_t ds = g.dist_size;
+
+  int kind = NK_FLUID;
+  uint32_t code = 0;
+  bool active = live;
+  if constexpr (GENERAL) {
+    code = p.map[gi];
+    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    active = live && !kind_is_excluded(kind);
+  }
+  // ---- load.  Odd AA step: pull with plain x-shifted loads -- misaligned *reads* cost little (the
+  // neighbouring wave uses the rest of the line; measured equal to an LDS exchange of aligned loads,
+  // profiles/r01/row_probe4.log) and save a barrier; the push below is what must be aligned.
+  // (Issuing the loads before the node map has arrived was tried and does not pay: row_probe5.log.)
+  R f[L::Q];
+  static_for<0, L::Q>([&](auto I) {
+    const R* src;
+    if constexpr (PROP == PROP_AA_ODD) {
+      const int off = dir_offset<L, I>(ox, oy, oz, false);
+      src = p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gi + off);
+    } else {
+      src = p.din + ds * (size_t)I + gi;
+    }
+    f[I] = active ? ld<NT>(src) : (R)0;
+  });
+
+  R rho, v[3];
+  bool wet = true;
+  if (active) {
+    node_update<L, R, MODEL, PROP, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+    if ((p.options & 1u) && wet) {
+      p.rho[gi] = rho;
+      p.vx[gi] = v[0];
+      p.vy[gi] = v[1];
+      if constexpr (L::dim == 3) p.vz[gi] = v[2];
+    }
+  }
+
+  // push: the value of node x travels to x + e_x and is stored by the thread that owns the target x
+  {
+    int kp = 0, km = 0;
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) > 0) {
+        if (lane == 63) s_out_p[w][kp] = f[I];
+        if (x == nx) s_wrap_p[kp] = f[I];
+        kp++;
+      }
+      if constexpr (L::ex(I) < 0) {
+        if (lane == 0) s_out_m[w][km] = f[I];
+        if (x == 1) s_wrap_m[km] = f[I];
+        km++;
+      }
+    });
+    if constexpr (GENERAL) {
+      if (lane == 63) s_act_p[w] = (int)active;
+      if (lane == 0) s_act_m[w] = (int)active;
+      if (x == nx) s_actw_p = (int)active;
+      if (x == 1) s_actw_m = (int)active;
+    }
+  }
+  __syncthreads();
+  bool from_left = live, from_right = live;   // is the node at x - 1 / x + 1 a source?
+  if constexpr (GENERAL) {
+    int a = __shfl_up((int)active, 1);
+    if (lane == 0 && w > 0) a = s_act_p[w - 1];
+    if (x == 1) a = wrapx ? s_actw_p : 0;
+    from_left = a != 0;
+    a = __shfl_down((int)active, 1);
+    if (lane == 63) a = s_act_m[(w + 1) & (NW - 1)];
+    if (x == nx) a = wrapx ? s_actw_m : 0;
+    from_right = a != 0;
+  } else {
+    if (!wrapx) {
+      if (x == 1) from_left = false;
+      if (x == nx) from_right = false;
+    }
+  }
+  {
+    int kp = 0, km = 0;
+    static_for<0, L::Q>([&](auto I) {
+      const int off = dir_offset<L, I>(ox0, oy, oz, true);
+      R* dst = p.dout + ds * (size_t)I + (uint32_t)((int)gi + off);
+      R t = f[I];
+      bool src_ok = active;
+      if constexpr (L::ex(I) > 0) {
+        // edge lane, no wrap: the value leaves the row into the ghost column x = nx + 1
+        if (!wrapx && x == nx && active) st<0>(dst + 1, f[I]);
+        t = shfl_up1<R>(f[I]);
+        if (lane == 0 && w > 0) t = s_out_p[w - 1][kp];
+        if (x == 1) t = s_wrap_p[kp];
+        src_ok = from_left;
+        kp++;
+      }
+      if constexpr (L::ex(I) < 0) {
+        if (!wrapx && x == 1 && active) st<0>(dst - 1, f[I]);
+        t = shfl_down1<R>(f[I]);
+        if (lane == 63) t = s_out_m[(w + 1) & (NW - 1)][km];
+        if (x == nx) t = s_wrap_m[km];
+        src_ok = from_right;
+        km++;
+      }
+      if (live && src_ok) st<NT>(dst, t);
+    });
+  }
+}
+
+// Even AA step: every access is to the node's own slots (aligned); per-node kernel with cache hints.
+template <class L, class R, int MODEL, bool GENERAL, int NT>
+__global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int gy = p.y0 + (int)blockIdx.y;
+  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (gx > g.lat_nx - 2) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const size_t ds = g.dist_size;
+  R f[L::Q];
+  int kind = NK_FLUID;
+  uint32_t code = 0;
+  if constexpr (GENERAL) {
+    code = p.map[gi];
+    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if (kind_is_excluded(kind)) return;
+  }
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  static_for<0, L::Q>([&](auto I) { f[I] = ld<NT>(p.din + ds * (size_t)I + gi); });
+  R rho, v[3];
+  bool wet = true;
+  node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+  if ((p.options & 1u) && wet) {
+    p.rho[gi] = rho;
+    p.vx[gi] = v[0];
+    p.vy[gi] = v[1];
+    if constexpr (L::dim == 3) p.vz[gi] = v[2];
+  }
+  static_for<0, L::Q>([&](auto I) { st<NT>(p.dout + ds * (size_t)L::opp(I) + gi, f[I]); });
+}
+
+template <class L, class R, int MODEL, bool GENERAL, int NT>
+static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
+  const int bx = ((nx + 63) / 64) * 64;
+  dim3 block(bx, 1, 1);
+  dim3 grid(1, ny, nz);
+  switch (prop) {
+    case PROP_AB: hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT>), grid, block, 0, s, p); break;
+    case PROP_AA_ODD: hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT>), grid, block, 0, s, p); break;
+  }
+}
+
+template <class L, class R, int MODEL, bool GENERAL>
+static void launch_row4(Prop prop, int nt, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
+  if (nt == 3) launch_row5<L, R, MODEL, GENERAL, 3>(prop, p, nx, ny, nz, s);
+  else launch_row5<L, R, MODEL, GENERAL, 0>(prop, p, nx, ny, nz, s);
+}
+
+template <class L, class R>
+static void launch_row2(const KernelSelector& sel, Prop prop, int nt, const SweepParams<L, R>& p, int nx, int ny,
+                        int nz, hipStream_t s) {
+  if (sel.model == 0) {
+    if (sel.general) launch_row4<L, R, 0, true>(prop, nt, p, nx, ny, nz, s);
+    else launch_row4<L, R, 0, false>(prop, nt, p, nx, ny, nz, s);
+  } else {
+    if (sel.general) launch_row4<L, R, 1, true>(prop, nt, p, nx, ny, nz, s);
+    else launch_row4<L, R, 1, false>(prop, nt, p, nx, ny, nz, s);
+  }
+}
+
+bool launch_sweep_row(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const SweepArgs& a,
+                      int y0, int y1, int z0, int z1, hipStream_t s, hipError_t* err) {
+  const int nx = g.lat_nx - 2;
+  // 3-D only: in 2-D (D2Q9, a few thousand rows, ~20 us per sweep) the per-node kernel with its smaller
+  // workgroups is 7-15 % faster (profiles/r01/row_general2.log)
+  if (!(g.variant & 8) || sel.lattice != 1 || nx > 1024 || nx < 1) return false;
+  const int ny = y1 - y0, nz = (g.dim == 3) ? z1 - z0 : 1;
+  if (ny <= 0 || nz <= 0) return false;
+  const int nt = (g.variant & 1) ? 3 : 0;
+  if (sel.precision == 4) launch_row2<D3Q19, float>(sel, prop, nt, make_params<D3Q19, float>(g, ph, a, y0, z0), nx, ny, nz, s);
+  else launch_row2<D3Q19, double>(sel, prop, nt, make_params<D3Q19, double>(g, ph, a, y0, z0), nx, ny, nz, s);
+  *err = hipGetLastError();
+  return true;
+}
+
+}  // namespace slf

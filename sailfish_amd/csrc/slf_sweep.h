@@ -51,6 +51,98 @@ __device__ __forceinline__ int dir_offset(const AxisOff& ox, const AxisOff& oy, 
   return off;
 }
 
+// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (populations are streamed exactly once per step)
+template <int NT, class T>
+__device__ __forceinline__ T ld(const T* p) {
+  if constexpr (NT & 1) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int NT, class T>
+__device__ __forceinline__ void st(T* p, T v) {
+  if constexpr (NT & 2) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// Everything between loading the populations of a node and streaming them: macroscopic quantities,
+// pre-collision boundary conditions, collision, half-way bounce-back stores (reference
+// lb_single_fluid.mako:175-228).  Shared by all sweep kernels so that they differ only in access shape.
+template <class L, class R, int MODEL, int PROP, bool GENERAL>
+__device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L::Q], uint32_t code, int kind,
+                                            uint32_t gi, const AxisOff& ox, const AxisOff& oy, const AxisOff& oz,
+                                            R& rho, R (&v)[3], bool& wet) {
+  const Geometry& g = p.g;
+  const size_t ds = g.dist_size;
+  (void)ds;
+  if constexpr (GENERAL) {
+    wet = kind_is_wet(kind);
+    const int orientation = (int)(code >> g.orient_shift);
+    const int pidx = (int)((code >> g.param_shift) & g.param_mask);
+    const bool inc = p.cp.incompressible != 0;
+    // ---- macroscopic quantities (getMacro, boundary.mako:465-507)
+    const bool bc_macro = (kind == NK_REGULARIZED_VELOCITY || kind == NK_EQUILIBRIUM_VELOCITY ||
+                           kind == NK_EQUILIBRIUM_DENSITY) && orientation != 0;
+    if (!bc_macro) {
+      macro_standard<L, R>(f, inc, rho, v);
+    } else if (kind == NK_EQUILIBRIUM_DENSITY) {
+      with_orientation<L>(orientation, [&](auto O) { macro_density_bc<L, R, O>(f, p.node_params[pidx], rho, v); });
+    } else {
+      with_orientation<L>(orientation,
+                          [&](auto O) { macro_velocity_bc<L, R, O>(f, p.node_params + pidx, inc, rho, v); });
+    }
+    // ---- pre-collision boundary conditions (boundary.mako:784-878)
+    const R rho0 = inc ? (R)1 : rho;
+    if (kind == NK_FULL_BB) {
+      bounce_back<L, R>(f);
+    } else if (kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY) {
+      set_equilibrium<L, R>(f, rho, rho0, v);
+    } else if (kind == NK_REGULARIZED_VELOCITY) {
+      if (orientation == 0) {
+        bounce_back<L, R>(f);  // nt_dir_other fallback, boundary.mako:336-338
+      } else {
+        with_orientation<L>(orientation, [&](auto O) { regularized_bc<L, R, O>(f, rho, rho0, v); });
+      }
+    }
+    // ---- collision (relaxate, relaxation.mako:196-202: wet nodes only)
+    if (wet && p.relaxation_enabled) {
+      if constexpr (MODEL == 0) {
+        bgk_relax<L, R>(f, rho, v, p.cp);
+      } else {
+        mrt_relax<L, R>(f, v, p.cp, kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY);
+      }
+    }
+    // ---- post-collision: half-way bounce-back (boundary.mako:653-683)
+    if (kind == NK_HALF_BB) {
+      static_for<1, L::Q>([&](auto I) {
+        bool missing;
+        if (g.use_link_tags) {
+          missing = ((orientation >> (I - 1)) & 1) == 0;  // direction I points to a non-fluid node
+        } else {
+          missing = false;
+          with_orientation<L>(orientation, [&](auto O) {
+            if constexpr (is_missing<L, L::opp(I), O>()) missing = true;
+          });
+        }
+        if (missing) {
+          // population opp(I) is undefined here: feed it with the reflected f_I.
+          if constexpr (PROP == PROP_AA_EVEN) {
+            const int off = dir_offset<L, I>(ox, oy, oz, true);
+            (p.dout + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+          } else {
+            (p.dout + ds * (size_t)L::opp(I))[gi] = f[I];
+          }
+        }
+      });
+    }
+  } else {
+    macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
+    if (p.relaxation_enabled) {
+      if constexpr (MODEL == 0) bgk_relax<L, R>(f, rho, v, p.cp);
+      else mrt_relax<L, R>(f, v, p.cp, false);
+    }
+  }
+
+}
+
 template <class L, class R>
 inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const SweepArgs& a, int y0, int z0) {
   SweepParams<L, R> p;
@@ -80,5 +172,8 @@ inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const
 // Returns true when the launch was handled by a tuned kernel (status in *err).
 bool launch_sweep_fast(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const SweepArgs& a,
                        int y0, int y1, int z0, int z1, int block_x, hipStream_t s, hipError_t* err);
+// Whole-row kernels for every lattice / precision / model, with or without the node map (slf_row.hip).
+bool launch_sweep_row(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const SweepArgs& a,
+                      int y0, int y1, int z0, int z1, hipStream_t s, hipError_t* err);
 
 }  // namespace slf

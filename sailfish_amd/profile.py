@@ -95,7 +95,14 @@ class TimeProfile(object):
         r.backend.sync_stream(r._calc_stream, r._data_stream)
 
     def start_step(self):
-        self._active = self._is_benchmark and self._runner._sim.iteration >= self._sample_from
+        it = self._runner._sim.iteration
+        max_iters = self._runner.config.max_iters
+        self._active = self._is_benchmark and it >= self._sample_from
+        if self._active and max_iters > 0 and it + 1 >= max_iters:
+            # the final step carries the end-of-run transfer of all fields to the host and their
+            # verification (seconds of host work for a 512^3 subdomain): not part of the sample
+            self._close_batch()
+            self._active = False
         if not self._active:
             return
         if self._in_batch == 0:

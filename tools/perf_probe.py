@@ -27,6 +27,9 @@ def main():
     ap.add_argument('--norelax', action='store_true')
     ap.add_argument('--noalign', action='store_true')
     ap.add_argument('--pads', default='0', help='comma list of dist_stride paddings (elements)')
+    ap.add_argument('--general', default='', choices=['', 'fluid', 'walls', 'pipe'],
+                    help='run the node-map (general) kernels: all-fluid periodic box / closed box of full-BB walls / '
+                         'circular pipe along z (unused nodes outside)')
     ap.add_argument('--trace', type=int, default=0, help='also print the time of every batch of N launches')
     args = ap.parse_args()
 
@@ -52,6 +55,33 @@ def main():
     g_v = [b.alloc_buf(like=v) for _ in range(3)]
     stream = b.make_stream()
     mod0 = b.build(desc0)
+    gkw, g_map, fused = {}, 0, [1, 1, 1]
+    if args.general:
+        from tests import _geometry as geo
+        m = geo.empty_map(desc0)
+        if args.general == 'walls':
+            fused = [0, 0, 0]
+            w = geo.encode(geo.T_FULLBB)
+            m[1, 1:n + 1, 1:n + 1] = w
+            m[n, 1:n + 1, 1:n + 1] = w
+            m[1:n + 1, 1, 1:n + 1] = w
+            m[1:n + 1, n, 1:n + 1] = w
+            m[1:n + 1, 1:n + 1, 1] = w
+            m[1:n + 1, 1:n + 1, n] = w
+        elif args.general == 'pipe':
+            fused = [0, 0, 1]
+            yy, xx = np.mgrid[0:desc0.arr_ny, 0:desc0.arr_nx]
+            r2 = (yy - (n + 1) / 2.0) ** 2 + (xx - (n + 1) / 2.0) ** 2
+            inside = r2 < (n / 2.0 - 1) ** 2
+            ring = (~inside) & (r2 < (n / 2.0 + 0.5) ** 2)
+            real = np.zeros_like(inside)
+            real[1:n + 1, 1:n + 1] = True
+            m[1:n + 1, (~inside & ~ring) & real] = geo.encode(geo.T_UNUSED)
+            m[1:n + 1, ring & real] = geo.encode(geo.T_FULLBB)
+        g_map = b.alloc_buf(like=np.ascontiguousarray(m))
+        gkw = dict(fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS)
+        print('general map %s: %.1f%% of the real nodes excluded' % (
+            args.general, 100.0 * np.mean((m[1:n + 1, 1:n + 1, 1:n + 1] & 7) == geo.T_UNUSED)))
     for d in ([dist_a, dist_b] if dist_b else [dist_a]):
         k = b.get_kernel(mod0, 'SetInitialConditions', (64,), [d] + g_v + [g_rho, 0], 'PPPPPP')
         b.run_kernel(k, None, stream)
@@ -67,18 +97,18 @@ def main():
             for mode in args.modes.split(','):
                 ap_ = 'AB' if mode == 'ab' else 'AA'
                 desc = make_box_desc(grid, size, model=args.model, precision='single', access_pattern=ap_,
-                                     visc=1.0 / 6.0, periodic_fused=[1, 1, 1],
-                                     relaxation_enabled=not args.norelax, dist_pad=pad)
+                                     visc=1.0 / 6.0, periodic_fused=fused,
+                                     relaxation_enabled=not args.norelax, dist_pad=pad, **gkw)
                 mod = b.build(desc)
                 sig = 'PPPPPPPi'
                 for dd in ([dist_a, dist_b] if dist_b else [dist_a]):
                     kk = b.get_kernel(mod, 'SetInitialConditions', (64,), [dd] + g_v + [g_rho, 0], 'PPPPPP')
                     b.run_kernel(kk, None, stream)
                 if mode == 'ab':
-                    ks = [b.get_kernel(mod, 'CollideAndPropagate', (64,), [0, dist_a, dist_b, g_rho] + g_v + [0], sig),
-                          b.get_kernel(mod, 'CollideAndPropagate', (64,), [0, dist_b, dist_a, g_rho] + g_v + [0], sig)]
+                    ks = [b.get_kernel(mod, 'CollideAndPropagate', (64,), [g_map, dist_a, dist_b, g_rho] + g_v + [0], sig),
+                          b.get_kernel(mod, 'CollideAndPropagate', (64,), [g_map, dist_b, dist_a, g_rho] + g_v + [0], sig)]
                 else:
-                    ks = [b.get_kernel(mod, 'CollideAndPropagate', (64,), [0, dist_a, dist_a, g_rho] + g_v + [0], sig,
+                    ks = [b.get_kernel(mod, 'CollideAndPropagate', (64,), [g_map, dist_a, dist_a, g_rho] + g_v + [0], sig,
                                        needs_iteration=True)]
 
                 def launch(i):
