@@ -475,20 +475,30 @@ class SubdomainRunner(object):
         return (dist_num,) + tuple(np.unravel_index(dist_idx, self._physical_size))
 
     def save_checkpoint(self):
-        """<base>.<iter>.<subdomain>.cpoint.npz with state + dist0a[/dist0b] (reference :1414-1431)."""
-        fname = io.checkpoint_filename(self.config.checkpoint_file, io.filename_iter_digits(self.config.max_iters),
-                                       self._spec.id, self._sim.iteration)
-        data = {'state': np.frombuffer(pickle.dumps(self._sim.get_state()), dtype=np.uint8),
-                'dist0a': self._debug_get_dist(copy=0)}
-        if self._gpu_grids_secondary:
-            data['dist0b'] = self._debug_get_dist(copy=1)
+        """<base>.<iter>.<subdomain>.cpoint.npz with the simulation state and dist<N>a[/dist<N>b] of every
+        lattice N (reference :1414-1431; --single_checkpoint keeps one file that is overwritten)."""
+        if getattr(self.config, 'single_checkpoint', False):
+            fname = io.checkpoint_filename(self.config.checkpoint_file, 1, self._spec.id, 0)
+        else:
+            fname = io.checkpoint_filename(self.config.checkpoint_file, io.filename_iter_digits(self.config.max_iters),
+                                           self._spec.id, self._sim.iteration)
+        data = {'state': np.frombuffer(pickle.dumps(self._sim.get_state()), dtype=np.uint8)}
+        for n in range(len(self._gpu_grids_primary)):
+            data['dist%da' % n] = self._debug_get_dist(grid_num=n, copy=0)
+            if self._gpu_grids_secondary:
+                data['dist%db' % n] = self._debug_get_dist(grid_num=n, copy=1)
         np.savez(fname, **data)
 
     def restore_checkpoint(self, fname):
+        self.config.logger.info('Restoring checkpoint from {0}'.format(fname))
         cpoint = np.load(fname, allow_pickle=False)
-        self._debug_set_dist(cpoint['dist0a'], copy=0)
-        if self._gpu_grids_secondary and 'dist0b' in cpoint:
-            self._debug_set_dist(cpoint['dist0b'], copy=1)
+        for key in cpoint.files:
+            if not key.startswith('dist'):
+                continue
+            n, copy = int(key[4:-1]), (0 if key.endswith('a') else 1)
+            if n >= len(self._gpu_grids_primary) or (copy == 1 and not self._gpu_grids_secondary):
+                continue
+            self._debug_set_dist(cpoint[key], grid_num=n, copy=copy)
         if getattr(self.config, 'restore_time', True):
             self._sim.set_state(pickle.loads(cpoint['state'].tobytes()))
         self.backend.set_iteration(self._sim.iteration)

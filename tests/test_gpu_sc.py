@@ -142,3 +142,31 @@ def test_sc_multi_subdomain(single, dim, size, nsub, axis, pattern, fused):
         for grid_num, od in enumerate(lattices):
             gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
             assert np.array_equal(gd, o.real(od)), 'subdomain %d lattice %d' % (r._spec.id, grid_num)
+
+
+def test_sc_checkpoint_roundtrip(tmp_path):
+    """Both lattices of the binary model are checkpointed (dist0a, dist1a [, dist0b, dist1b], reference
+    subdomain_runner.py:1414-1449): 8 steps + restore + 7 steps == 15 steps, bit for bit."""
+    import os
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls, geo = _sc.make_sim(3)
+
+    def run(steps, pattern, **extra):
+        cfg = _sc.config(3, (24, 10, 8), pattern=pattern)
+        cfg.update(max_iters=steps, quiet=True, perf_stats_every=0, **extra)
+        ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
+        ctrl.run(ignore_cmdline=True)
+        return ctrl.runners[0]
+
+    for pattern in ('AB', 'AA'):
+        ck = str(tmp_path / ('ck' + pattern))
+        run(8, pattern, checkpoint_file=ck, final_checkpoint=True)
+        files = [f for f in os.listdir(str(tmp_path)) if f.startswith('ck' + pattern) and f.endswith('.cpoint.npz')]
+        assert len(files) == 1
+        keys = set(np.load(os.path.join(str(tmp_path), files[0])).files)
+        assert {'state', 'dist0a', 'dist1a'} <= keys and (('dist1b' in keys) == (pattern == 'AB'))
+        cont = run(15, pattern, restore_from=os.path.join(str(tmp_path), files[0][:-len('.0.cpoint.npz')]))
+        ref = run(15, pattern)
+        assert cont._sim.iteration == 15
+        for g in (0, 1):
+            assert np.array_equal(cont._debug_get_dist(grid_num=g), ref._debug_get_dist(grid_num=g), equal_nan=True)
