@@ -151,6 +151,17 @@ int slf_event_record(slf_event* ev, slf_stream* s);
 int slf_event_sync(slf_event* ev);
 int slf_event_elapsed_ms(slf_event* start, slf_event* end, float* ms); /* ev.time_since */
 
+/* ---- launch graphs (extension; no counterpart in the reference, which pays one Python-level launch per
+ *      kernel: subdomain_runner.py:960-974).  Everything enqueued on `s` between begin and end -- kernel
+ *      launches, copies, event waits -- is recorded instead of executed; the result replays with ONE
+ *      runtime call.  The runner uses it for launch-bound small subdomains (2-D cases): stretches of
+ *      steps without host interaction are replayed as graphs of 2..16 steps. ---- */
+typedef struct slf_graph slf_graph;
+int slf_graph_capture_begin(slf_stream* s);
+int slf_graph_capture_end(slf_stream* s, slf_graph** out);
+int slf_graph_launch(slf_graph* g, slf_stream* s);
+int slf_graph_destroy(slf_graph* g);
+
 /* ---- modules / kernels: build, get_kernel, set_iteration, run_kernel
  *      (backend_cuda.py:193-251, 128-130) ---- */
 int slf_module_create(slf_ctx* ctx, const slf_module_desc* desc, slf_module** out); /* build() */

@@ -65,6 +65,24 @@ class HIPStream(object):
             pass
 
 
+class HIPGraph(object):
+    """A recorded stretch of stream work that replays with one runtime call (slf_graph_*)."""
+
+    def __init__(self, backend, handle):
+        self._lib = backend._lib
+        self.handle = handle
+
+    def launch(self, stream):
+        _check(self._lib, self._lib.slf_graph_launch(self.handle, stream.handle if stream is not None else None),
+               'slf_graph_launch')
+
+    def __del__(self):
+        try:
+            self._lib.slf_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class HIPEvent(object):
     def __init__(self, backend, timing=False):
         self._lib = backend._lib
@@ -170,6 +188,8 @@ class HIPBackend(object):
     def add_options(cls, group):
         group.add_argument('--hip-kernel-stats', dest='hip_kernel_stats', action='store_true', default=False,
                            help='print the workgroup shape chosen for the sweep kernels')
+        group.add_argument('--nohip_graphs', dest='hip_graphs', action='store_false', default=True,
+                           help='do not replay stretches of steps without host interaction as HIP graphs')
         group.add_argument('--nohip_fused_periodic', dest='hip_fused_periodic', action='store_false',
                            default=True,
                            help='apply periodic boundary conditions with separate ghost-layer kernels '
@@ -355,6 +375,17 @@ class HIPBackend(object):
                'slf_kernel_launch(%s)' % kernel.name)
 
     # -- streams / events -----------------------------------------------------
+    def capture_graph(self, stream, enqueue):
+        """Records everything `enqueue()` puts on `stream` (nothing executes) and returns a HIPGraph."""
+        _check(self._lib, self._lib.slf_graph_capture_begin(stream.handle), 'slf_graph_capture_begin')
+        try:
+            enqueue()
+        finally:
+            h = ctypes.c_void_p()
+            rc = self._lib.slf_graph_capture_end(stream.handle, ctypes.byref(h))
+        _check(self._lib, rc, 'slf_graph_capture_end')
+        return HIPGraph(self, h)
+
     def make_stream(self):
         return HIPStream(self)
 

@@ -64,6 +64,10 @@ struct slf_event {
   slf_ctx* ctx;
   hipEvent_t e;
 };
+struct slf_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
 struct slf_module {
   slf_ctx* ctx;
   slf::KernelSelector sel;
@@ -237,6 +241,44 @@ int slf_stream_sync(slf_stream* s) {
 int slf_stream_native(slf_stream* s, void** hip_stream) {
   if (!hip_stream) return fail(SLF_ERR_INVALID, "hip_stream is NULL");
   *hip_stream = (void*)native(s);
+  return SLF_OK;
+}
+
+int slf_graph_capture_begin(slf_stream* s) {
+  if (!s) return fail(SLF_ERR_INVALID, "graph capture needs a stream created with slf_stream_create");
+  SLF_HIP(hipStreamBeginCapture(s->s, hipStreamCaptureModeThreadLocal));
+  return SLF_OK;
+}
+
+int slf_graph_capture_end(slf_stream* s, slf_graph** out) {
+  if (!s || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  hipGraph_t graph = nullptr;
+  SLF_HIP(hipStreamEndCapture(s->s, &graph));
+  if (!graph) return fail(SLF_ERR_HIP, "stream capture produced no graph");
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(graph);
+    return fail(SLF_ERR_HIP, hipGetErrorString(e));
+  }
+  slf_graph* g = new slf_graph;
+  g->graph = graph;
+  g->exec = exec;
+  *out = g;
+  return SLF_OK;
+}
+
+int slf_graph_launch(slf_graph* g, slf_stream* s) {
+  if (!g) return fail(SLF_ERR_INVALID, "graph is NULL");
+  SLF_HIP(hipGraphLaunch(g->exec, native(s)));
+  return SLF_OK;
+}
+
+int slf_graph_destroy(slf_graph* g) {
+  if (!g) return SLF_OK;
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
   return SLF_OK;
 }
 

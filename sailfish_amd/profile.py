@@ -113,10 +113,11 @@ class TimeProfile(object):
                 self._cpu_batch[i] = 0.0
         self._open.clear()
 
-    def end_step(self):
+    def end_step(self, n=1):
+        """n > 1: a graph replay of n steps."""
         if not self._active:
             return
-        self._in_batch += 1
+        self._in_batch += n
         if self._in_batch >= self._minibatch:
             self._close_batch()
 
@@ -135,11 +136,11 @@ class TimeProfile(object):
         self._account(self.STEP, dur, per)
         self._timings[self.STEP_SQ] += n * per * per
         sums = {}
-        for i, ev0, ev1 in self._events:
+        for i, ev0, ev1, steps in self._events:
             d = ev1.time_since(ev0) / 1e3
             sums[i] = sums.get(i, 0.0) + d
-            self._min_timings[i] = min(self._min_timings[i], d)
-            self._max_timings[i] = max(self._max_timings[i], d)
+            self._min_timings[i] = min(self._min_timings[i], d / steps)
+            self._max_timings[i] = max(self._max_timings[i], d / steps)
         for i, total in sums.items():
             self._timings[i] += total
         del self._events[:]
@@ -157,10 +158,10 @@ class TimeProfile(object):
         self._open[event] = ev
         return ev
 
-    def record_gpu_end(self, event, stream, need_event=False):
+    def record_gpu_end(self, event, stream, need_event=False, steps=1):
         if self._active and event in self._open:
             ev = self._runner.backend.make_event(stream, timing=True)
-            self._events.append((event, self._open.pop(event), ev))
+            self._events.append((event, self._open.pop(event), ev, steps))
             return ev
         if need_event:
             return self._runner.backend.make_event(stream)

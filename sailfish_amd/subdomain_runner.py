@@ -559,6 +559,82 @@ class SubdomainRunner(object):
             self.save_checkpoint()
         self._sim.after_step(self)
 
+    # ------------------------------------------------------------------ launch graphs
+    GRAPH_STEPS = (16, 2)      # graph sizes (steps per replay), largest first; even -> the AA parity repeats
+
+    def _enqueue_plain_step(self, it):
+        """The kernels of one step without output, halo or profiling (what a graph records)."""
+        b = self.backend
+        kernels = self._kernels_none.primary if (it & 1) == 0 else self._kernels_none.secondary
+        for k in kernels:
+            b.run_kernel(k, self._regions[1], self._calc_stream)
+        base = 1 - (it & 1)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels[base][axis]:
+                b.run_kernel(k, None, self._calc_stream)
+
+    def _steps_without_host(self):
+        """Number of coming steps that need no host involvement at all: no output, field transfer,
+        checkpoint, statistics line, user hook or end-of-run handling."""
+        cfg, sim = self.config, self._sim
+        it = sim.iteration
+        if type(sim).after_step is not LBSim.after_step or sim.need_sync_flag or sim.need_fields_flag:
+            return 0
+        lim = [1 << 30]
+        if cfg.max_iters > 0:
+            lim.append(cfg.max_iters - 1 - it)          # the final step transfers the fields
+        if cfg.output_required:
+            every = max(1, int(cfg.every))
+            first = max(it, int(getattr(cfg, 'from_', 0)))
+            nxt = first + ((every - 1 - first) % every)    # first s >= first with (s + 1) % every == 0
+            lim.append(nxt - it)
+        if getattr(cfg, 'checkpoint_every', 0) > 0 and cfg.checkpoint_file:
+            lim.append(cfg.checkpoint_every - 1 - (it % cfg.checkpoint_every))
+        if cfg.perf_stats_every > 0:
+            lim.append(cfg.perf_stats_every - 1 - (it % cfg.perf_stats_every))
+        prof = self._profile
+        if prof._is_benchmark and it < prof._sample_from:
+            lim.append(prof._sample_from - it)             # sampling starts exactly there
+        return max(0, min(lim))
+
+    def fast_forward(self):
+        """Replays as many of the coming steps as possible as HIP graphs (launch-bound small
+        subdomains: one runtime call per 2 / 16 steps instead of a Python-level launch per kernel).
+        Returns the number of steps done (0: take a normal step)."""
+        if not getattr(self.config, 'hip_graphs', True) or self._links or self._quit_requested():
+            return 0
+        n = self._steps_without_host()
+        if n < 2:
+            return 0
+        b = self.backend
+        it = self._sim.iteration
+        graphs = self.__dict__.setdefault('_graphs', {})
+        done = 0
+        prof = self._profile
+        for size in self.GRAPH_STEPS:
+            while n - done >= size:
+                key = (size, (it + done) & 1)
+                if key not in graphs:
+                    start = it + done
+
+                    def enqueue():
+                        for s_ in range(size):
+                            b.set_iteration(start + s_)
+                            self._enqueue_plain_step(start + s_)
+                    graphs[key] = b.capture_graph(self._calc_stream, enqueue)
+                prof.start_step()
+                prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
+                graphs[key].launch(self._calc_stream)
+                prof.record_gpu_end(TimeProfile.BULK, self._calc_stream, steps=size)
+                done += size
+                self._sim.iteration = it + done
+                prof.end_step(size)
+        b.set_iteration(self._sim.iteration)
+        return done
+
+    def _quit_requested(self):
+        return self._quit_event is not None and self._quit_event.is_set()
+
     def finish(self):
         self.backend.sync_stream(self._calc_stream, self._data_stream)
         if getattr(self.config, 'final_checkpoint', False) and self.config.checkpoint_file:
@@ -574,6 +650,8 @@ class SubdomainRunner(object):
         it_prev = self._sim.iteration
         self._profile.record_start()
         while not self.need_quit():
+            if self.fast_forward():
+                continue
             sync_req, fields_req, output_req = self.pre_step()
             self._profile.start_step()
             self.step(fields_req)
@@ -692,6 +770,20 @@ class NNSubdomainRunner(SubdomainRunner):
                 b.run_kernel(k, None, self._data_stream)
         self._profile.record_gpu_end(TimeProfile.MACRO_DISTRIB, self._data_stream)
         self._calc_stream.wait_for_event(b.make_event(self._data_stream))
+
+    def _enqueue_plain_step(self, it):
+        b = self.backend
+        macro_kernel, sim_kernels = self._kernels_none[it & 1]
+        base = 1 - (it & 1)
+        b.run_kernel(macro_kernel, None, self._calc_stream)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels.macro[base][axis]:
+                b.run_kernel(k, None, self._calc_stream)
+        for k in sim_kernels:
+            b.run_kernel(k, None, self._calc_stream)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels.distributions[base][axis]:
+                b.run_kernel(k, None, self._calc_stream)
 
     def step_compute(self, sync_req=False):
         b = self.backend

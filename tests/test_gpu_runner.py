@@ -209,3 +209,26 @@ def test_tools_merge_and_compare(tmp_path):
         merge_subdomains(one, digits, it)
         assert compare(io.merged_filename(one, digits, it), io.merged_filename(two, digits, it)) == 0
         assert compare(io.filename(one, digits, 0, it), io.filename(ab, digits, 0, it)) == 0
+
+
+@pytest.mark.parametrize('module,sim,dim,cfg', [
+    ('ldc_2d', 'LDCSim', 2, dict(lat_nx=48, lat_ny=40, visc=0.02)),
+    ('poiseuille', 'PoiseuilleSim', 2, dict(lat_nx=32, lat_ny=24, visc=0.05, hip_fused_periodic=False)),
+    ('ldc_3d', 'LDCSim', 3, dict(lat_nx=24, lat_ny=20, lat_nz=16, visc=0.03, model='mrt'))])
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+def test_launch_graphs_equal_plain_stepping(module, sim, dim, cfg, pattern, tmp_path):
+    """Stretches of steps without host interaction are replayed as HIP graphs of 16 / 2 steps
+    (SubdomainRunner.fast_forward); output steps, odd remainders and the final step are normal steps.
+    Same populations and the same output files as with --nohip_graphs."""
+    res = {}
+    for graphs in (True, False):
+        out = str(tmp_path / ('g%d' % graphs))
+        ctrl = run_gpu(module, sim, dim, dict(cfg, access_pattern=pattern), 75,
+                       extra=dict(hip_graphs=graphs, output=out, every=37))
+        r = ctrl.runners[0]
+        assert r._sim.iteration == 75
+        res[graphs] = (r._debug_get_dist(), np.load(out + '.0.37.npz')['rho'], np.load(out + '.0.74.npz')['rho'],
+                       len(r.__dict__.get('_graphs', {})))
+    assert res[True][3] >= 2 and res[False][3] == 0          # 16-step and 2-step graphs were built
+    for a, b in zip(res[True][:3], res[False][:3]):
+        assert np.array_equal(a, b, equal_nan=True)
