@@ -68,9 +68,18 @@ def cpu_baseline(args):
         steps += 2
     dt = time.time() - t0
     cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
+    cpu_model = 'unknown CPU'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    cpu_model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {'value': round(n ** 3 * steps / dt * 1e-6, 2), 'unit': 'MLUPS', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle/lbm_oracle.c (OpenMP), D3Q19 %s f%d AA periodic %d^3, %d steps in %.1f s'
-                      % (args.model.upper(), 32 if args.precision == 'single' else 64, n, steps, dt)}
+            'sample': 'oracle/lbm_oracle.c (OpenMP, %d threads on %s), D3Q19 %s f%d AA periodic %d^3, %d steps in %.1f s'
+                      % (cores, cpu_model, args.model.upper(), 32 if args.precision == 'single' else 64, n, steps, dt)}
 
 
 def load_traffic(workload_key):

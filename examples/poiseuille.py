@@ -20,6 +20,7 @@ from sailfish.subdomain import Subdomain2D
 class ChannelSubdomain(Subdomain2D):
     max_v = 0.02
     wall_bc = NTFullBBWall
+    pressure_bc = NTEquilibriumDensity      # any density node type: NTZouHeDensity, NTRegularizedDensity
 
     @classmethod
     def width(cls, config):
@@ -48,8 +49,8 @@ class ChannelSubdomain(Subdomain2D):
         if cfg.drive == 'pressure':
             dp = self._pressure_drop_per_node() * n_along
             inside = (across > 0) & (across < n_across - 1)
-            self.set_node(inside & (along == 0), NTEquilibriumDensity(1.0 + 1.5 * dp))
-            self.set_node(inside & (along == n_along - 1), NTEquilibriumDensity(1.0 - 1.5 * dp))
+            self.set_node(inside & (along == 0), self.pressure_bc(1.0 + 1.5 * dp))
+            self.set_node(inside & (along == n_along - 1), self.pressure_bc(1.0 - 1.5 * dp))
         self.set_node(across == 0, self.wall_bc)
         self.set_node(across == n_across - 1, self.wall_bc)
 

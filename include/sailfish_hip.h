@@ -52,7 +52,10 @@ enum {
   SLF_NK_HALF_BB = 5,
   SLF_NK_REGULARIZED_VELOCITY = 6,
   SLF_NK_EQUILIBRIUM_DENSITY = 7,
-  SLF_NK_EQUILIBRIUM_VELOCITY = 8
+  SLF_NK_EQUILIBRIUM_VELOCITY = 8,
+  SLF_NK_ZOUHE_VELOCITY = 9,      /* boundary.mako:343-382, 811-815 */
+  SLF_NK_ZOUHE_DENSITY = 10,      /* boundary.mako:487-494 */
+  SLF_NK_REGULARIZED_DENSITY = 11 /* boundary.mako:501-506, 817-835 */
 };
 
 #define SLF_MAX_NODE_TYPES 16

@@ -28,12 +28,16 @@ enum NodeKind : int {
   NK_REGULARIZED_VELOCITY = 6,
   NK_EQUILIBRIUM_DENSITY = 7,
   NK_EQUILIBRIUM_VELOCITY = 8,
-  NK_COUNT = 9
+  NK_ZOUHE_VELOCITY = 9,
+  NK_ZOUHE_DENSITY = 10,
+  NK_REGULARIZED_DENSITY = 11,
+  NK_COUNT = 12
 };
 
 SLF_HD bool kind_is_wet(int k) {
   return k == NK_FLUID || k == NK_HALF_BB || k == NK_REGULARIZED_VELOCITY || k == NK_EQUILIBRIUM_DENSITY ||
-         k == NK_EQUILIBRIUM_VELOCITY;
+         k == NK_EQUILIBRIUM_VELOCITY || k == NK_ZOUHE_VELOCITY || k == NK_ZOUHE_DENSITY ||
+         k == NK_REGULARIZED_DENSITY;
 }
 SLF_HD bool kind_is_excluded(int k) { return k == NK_GHOST || k == NK_UNUSED || k == NK_PROPAGATION_ONLY; }
 
@@ -365,6 +369,44 @@ SLF_D void regularized_bc(R (&f)[L::Q], R rho, R rho0, const R (&v)[3]) {
     });
     const R val = feq<L, R, I>(rho, rho0, v, u15) + Weights<L, R>::w45(I) * acc;
     f[I] = val > (R)1e-7 ? val : (R)1e-7;
+  });
+}
+
+// Number of unknown populations, other than the one along the normal n, with a component along axis d.
+template <class L>
+constexpr int zouhe_count(int n, int d) {
+  int c = 0;
+  for (int i = 1; i < L::Q; i++) {
+    const int sp = L::ex(i) * L::ex(n) + L::ey(i) * L::ey(n) + L::ez(i) * L::ez(n);
+    const int ed = (d == 0) ? L::ex(i) : ((d == 1) ? L::ey(i) : L::ez(i));
+    if (sp > 0 && i != n && ed != 0) c++;
+  }
+  return c;
+}
+
+// C11: Zou-He node (boundary.mako:343-382): bounce-back of the non-equilibrium part of the unknown
+// populations (sym.py:750-766), then the tangential momentum excess  rho v - sum e_i f_i  is spread over
+// the unknown populations that are not along the normal (sym.py:768-815).
+template <class L, class R, int O>
+SLF_D void zouhe_bb(R (&f)[L::Q], R rho, R rho0, const R (&v)[3]) {
+  static_for<1, L::Q>([&](auto I) {
+    if constexpr (is_missing<L, I, O>()) {
+      f[I] = f[L::opp(I)] + Weights<L, R>::w6(I) * (rho0 * edotv<L, R, I>(v));
+    }
+  });
+  constexpr int n = L::dir2vecidx(O);
+  static_for<0, L::dim>([&](auto D) {
+    if constexpr (e_comp<L>(n, D) == 0) {
+      constexpr int cnt = zouhe_count<L>(n, D);
+      const R md = (rho * v[D] - momentum<L, R, D>(f)) / (R)cnt;
+      static_for<1, L::Q>([&](auto I) {
+        if constexpr (is_missing<L, I, O>() && I != n) {
+          constexpr int e = e_comp<L>(I, D);
+          if constexpr (e > 0) f[I] = f[I] + md;
+          if constexpr (e < 0) f[I] = f[I] - md;
+        }
+      });
+    }
   });
 }
 

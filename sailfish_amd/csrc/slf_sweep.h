@@ -79,12 +79,20 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
     const int pidx = (int)((code >> g.param_shift) & g.param_mask);
     const bool inc = p.cp.incompressible != 0;
     // ---- macroscopic quantities (getMacro, boundary.mako:465-507)
+    const bool density_bc = kind == NK_EQUILIBRIUM_DENSITY || kind == NK_ZOUHE_DENSITY || kind == NK_REGULARIZED_DENSITY;
     const bool bc_macro = (kind == NK_REGULARIZED_VELOCITY || kind == NK_EQUILIBRIUM_VELOCITY ||
-                           kind == NK_EQUILIBRIUM_DENSITY) && orientation != 0;
+                           kind == NK_ZOUHE_VELOCITY || density_bc) && orientation != 0;
     if (!bc_macro) {
       macro_standard<L, R>(f, inc, rho, v);
-    } else if (kind == NK_EQUILIBRIUM_DENSITY) {
+    } else if (density_bc) {
       with_orientation<L>(orientation, [&](auto O) { macro_density_bc<L, R, O>(f, p.node_params[pidx], rho, v); });
+      if (kind == NK_ZOUHE_DENSITY) {
+        // boundary.mako:487-494: fix the populations, take u from them, keep the imposed density
+        const R par_rho = rho;
+        with_orientation<L>(orientation, [&](auto O) { zouhe_bb<L, R, O>(f, par_rho, inc ? (R)1 : par_rho, v); });
+        macro_standard<L, R>(f, inc, rho, v);
+        rho = par_rho;
+      }
     } else {
       with_orientation<L>(orientation,
                           [&](auto O) { macro_velocity_bc<L, R, O>(f, p.node_params + pidx, inc, rho, v); });
@@ -95,11 +103,17 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
       bounce_back<L, R>(f);
     } else if (kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY) {
       set_equilibrium<L, R>(f, rho, rho0, v);
-    } else if (kind == NK_REGULARIZED_VELOCITY) {
+    } else if (kind == NK_REGULARIZED_VELOCITY || kind == NK_REGULARIZED_DENSITY) {
       if (orientation == 0) {
         bounce_back<L, R>(f);  // nt_dir_other fallback, boundary.mako:336-338
       } else {
         with_orientation<L>(orientation, [&](auto O) { regularized_bc<L, R, O>(f, rho, rho0, v); });
+      }
+    } else if (kind == NK_ZOUHE_VELOCITY) {
+      if (orientation == 0) {
+        bounce_back<L, R>(f);
+      } else {
+        with_orientation<L>(orientation, [&](auto O) { zouhe_bb<L, R, O>(f, rho, rho0, v); });
       }
     }
     // ---- collision (relaxate, relaxation.mako:196-202: wet nodes only)

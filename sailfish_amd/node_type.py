@@ -278,4 +278,7 @@ HIP_KIND = {
     NTRegularizedVelocity: hipabi.SLF_NK_REGULARIZED_VELOCITY,
     NTEquilibriumDensity: hipabi.SLF_NK_EQUILIBRIUM_DENSITY,
     NTEquilibriumVelocity: hipabi.SLF_NK_EQUILIBRIUM_VELOCITY,
+    NTZouHeVelocity: hipabi.SLF_NK_ZOUHE_VELOCITY,
+    NTZouHeDensity: hipabi.SLF_NK_ZOUHE_DENSITY,
+    NTRegularizedDensity: hipabi.SLF_NK_REGULARIZED_DENSITY,
 }

@@ -7,10 +7,12 @@ import numpy as np
 from sailfish_amd import hipabi as h
 
 TYPE_KIND = [h.SLF_NK_FLUID, h.SLF_NK_GHOST, h.SLF_NK_FULL_BB, h.SLF_NK_REGULARIZED_VELOCITY, h.SLF_NK_HALF_BB,
-             h.SLF_NK_EQUILIBRIUM_DENSITY, h.SLF_NK_UNUSED]
-T_FLUID, T_GHOST, T_FULLBB, T_REGVEL, T_HALFBB, T_EQDENS, T_UNUSED = range(7)
-NT_BITS = (3, 3, 0)          # type bits, param bits, scratch bits
-ORIENT_SHIFT = 6
+             h.SLF_NK_EQUILIBRIUM_DENSITY, h.SLF_NK_UNUSED, h.SLF_NK_ZOUHE_VELOCITY, h.SLF_NK_ZOUHE_DENSITY,
+             h.SLF_NK_REGULARIZED_DENSITY, h.SLF_NK_EQUILIBRIUM_VELOCITY]
+(T_FLUID, T_GHOST, T_FULLBB, T_REGVEL, T_HALFBB, T_EQDENS, T_UNUSED, T_ZHVEL, T_ZHDENS, T_REGDENS,
+ T_EQVEL) = range(11)
+NT_BITS = (4, 3, 0)          # type bits, param bits, scratch bits
+ORIENT_SHIFT = 7
 
 
 def encode(type_id, orientation=0, param=0):
@@ -106,4 +108,19 @@ def channel_3d_fullbb(desc):
     ny = desc.lat_ny - 2
     m[1:desc.lat_nz - 1, 1, 1:desc.lat_nx - 1] = encode(T_FULLBB)
     m[1:desc.lat_nz - 1, ny, 1:desc.lat_nx - 1] = encode(T_FULLBB)
+    return m
+
+
+def channel_inlet_outlet(desc, t_in, t_out, dim):
+    """Open channel along x: inlet node type t_in on x = 1 (inward normal +x: orientation 1, parameter
+    slot 0), outlet t_out on x = max (normal -x: orientation 3 in D2Q9 / 2 in D3Q19, parameter slot 1 for
+    a density outlet, 0 for a velocity one is not used here), full-BB walls on y, z periodic."""
+    m = empty_map(desc)
+    ny, nx = desc.lat_ny - 2, desc.lat_nx - 2
+    o_out = 3 if dim == 2 else 2
+    zs = slice(0, 1) if dim == 2 else slice(1, desc.lat_nz - 1)
+    m[zs, 2:ny, 1] = encode(t_in, orientation=1, param=0)
+    m[zs, 2:ny, nx] = encode(t_out, orientation=o_out, param=3 if dim == 3 else 2)
+    m[zs, 1, 1:nx + 1] = encode(T_FULLBB)
+    m[zs, ny, 1:nx + 1] = encode(T_FULLBB)
     return m

@@ -123,7 +123,7 @@ def test_channel_2d_halfbb_force(backend, pattern, fused):
     r = _run_pair(backend, grid, (40, 18), 50, (True, False, False),
                   node_map_fn=lambda d: geo.channel_2d_halfbb(grid, d), u_scale=0.01, init='rest',
                   model='bgk', precision='single', access_pattern=pattern, visc=0.05, fluid_only=False,
-                  type_kind=geo.TYPE_KIND, nt_bits=(3, 3, 0), periodic_fused=[fused, 0, 0], accel=[1e-5, 0.0],
+                  type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS, periodic_fused=[fused, 0, 0], accel=[1e-5, 0.0],
                   use_link_tags=True)
     assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
 
@@ -207,3 +207,22 @@ def test_tuned_kernel_variants_bit_exact(backend, variant, pattern, size, monkey
         r = _run_pair(backend, sym.D3Q19, size, 9, (True, True, True), model=model, precision='single',
                       access_pattern=pattern, visc=0.01, periodic_fused=[1, 1, 1])
         assert r['dist_exact'] and r['rho_err'] == 0.0 and r['v_err'] == 0.0, (variant, pattern, size, model, r)
+
+
+@pytest.mark.parametrize('grid,size', [(sym.D2Q9, (40, 18)), (sym.D3Q19, (26, 12, 6))])
+@pytest.mark.parametrize('t_in,t_out,model,pattern', [
+    ('T_ZHVEL', 'T_ZHDENS', 'bgk', 'AB'), ('T_ZHVEL', 'T_ZHDENS', 'mrt', 'AA'),
+    ('T_REGVEL', 'T_REGDENS', 'bgk', 'AA'), ('T_EQVEL', 'T_ZHDENS', 'bgk', 'AB'),
+    ('T_ZHVEL', 'T_EQDENS', 'bgk', 'AA')])
+def test_open_channel_inlet_outlet(backend, grid, size, t_in, t_out, model, pattern):
+    """Zou-He velocity / density and regularized density nodes (reference boundary.mako:343-382, 487-506,
+    811-835) in an open channel: velocity inlet, density outlet, full-BB walls."""
+    dim = grid.dim
+    params = [0.03, 0.0] + ([0.0] if dim == 3 else []) + [1.0]
+    r = _run_pair(backend, grid, size, 60, (False, False, dim == 3),
+                  node_map_fn=lambda d: geo.channel_inlet_outlet(d, getattr(geo, t_in), getattr(geo, t_out), dim),
+                  u_scale=0.03, init='rest', model=model, precision='single', access_pattern=pattern, visc=0.05,
+                  fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS, node_params=params,
+                  periodic_fused=[0, 0, 1 if dim == 3 else 0])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    assert r['dist_exact'], r

@@ -137,3 +137,45 @@ def test_full_bounce_back(gold):
     f, rho, v = oracle.node_update(d, hipabi.SLF_NK_FULL_BB, 0, None, f0, 8)
     for i in range(grid.Q):
         assert f[i] == f0[grid.idx_opposite[i]]
+
+
+@pytest.mark.parametrize('precision', [8, 4])
+def test_zouhe_velocity_bc(gold, precision):
+    """NTZouHeVelocity: rho from the known populations, non-equilibrium bounce-back, tangential momentum
+    fix-up (reference boundary.mako:343-382, sym.zouhe_fixup) -- expected values from the reference's sympy."""
+    grid, G = gold
+    d = _no_relax(grid, precision)
+    for o in range(1, 2 * grid.dim + 1):
+        for k in range(len(G['rho'])):
+            f, rho, v = oracle.node_update(d, hipabi.SLF_NK_ZOUHE_VELOCITY, o, G['bc_v'][k], G['f'][k], precision)
+            _close(rho, G['regvel_rho'][o - 1, k], TOL[precision] * 2)
+            _close(f, G['zouhe_vel_post'][o - 1, k], TOL[precision] * 2)
+            # the node now carries exactly the imposed momentum
+            e = grid.basis_array
+            for a in range(grid.dim):
+                assert abs(sum(e[i][a] * f[i] for i in range(grid.Q)) - rho * G['bc_v'][k][a]) < TOL[precision] * 4
+
+
+@pytest.mark.parametrize('precision', [8, 4])
+def test_zouhe_density_bc(gold, precision):
+    grid, G = gold
+    d = _no_relax(grid, precision)
+    for o in range(1, 2 * grid.dim + 1):
+        for k in range(len(G['rho'])):
+            f, rho, v = oracle.node_update(d, hipabi.SLF_NK_ZOUHE_DENSITY, o, [G['bc_rho'][k]], G['f'][k], precision)
+            _close(rho, G['bc_rho'][k], 1e-7)
+            _close(f, G['zouhe_dens_post'][o - 1, k], TOL[precision] * 2)
+            _close(v[:grid.dim], G['zouhe_dens_v'][o - 1, k], TOL[precision] * 2)
+
+
+@pytest.mark.parametrize('precision', [8, 4])
+def test_regularized_density_bc(gold, precision):
+    grid, G = gold
+    d = _no_relax(grid, precision)
+    for o in range(1, 2 * grid.dim + 1):
+        for k in range(len(G['rho'])):
+            f, rho, v = oracle.node_update(d, hipabi.SLF_NK_REGULARIZED_DENSITY, o, [G['bc_rho'][k]], G['f'][k],
+                                           precision)
+            _close(rho, G['bc_rho'][k], 1e-7)
+            _close(v[:grid.dim], G['eqdens_v'][o - 1, k], TOL[precision] * 2)
+            _close(f, G['regdens_post'][o - 1, k], TOL[precision] * 2)

@@ -224,6 +224,27 @@ def arithmetic_goldens(grid, rng, n=48):
     regv_rho = np.zeros((2 * dim, n))
     eqd = np.zeros((2 * dim, n, Q))
     eqd_v = np.zeros((2 * dim, n, dim))
+    # --- Zou-He nodes: boundary.mako:343-382 (zouhe_bb), :487-494 (density variant), sym.py:768-815
+    # --- regularized density: boundary.mako:501-506 + the regularisation above
+    zhv = np.zeros((2 * dim, n, Q))
+    zhd = np.zeros((2 * dim, n, Q))
+    zhd_v = np.zeros((2 * dim, n, dim))
+    regd = np.zeros((2 * dim, n, Q))
+
+    def zouhe(o, g, rho_full, v, subs):
+        """zouhe_bb after the non-equilibrium bounce-back: momentum difference + fix-up."""
+        subs = dict(subs)
+        subs.update(_fi_subs(grid, g))
+        mom = [_evalf(sym.ex_velocity(grid, 'fi', d, cfg, momentum=True), subs) for d in range(dim)]
+        for d, name in enumerate(['nvx', 'nvy', 'nvz'][:dim]):
+            subs[name] = rho_full * v[d] - mom[d]
+        g = g.copy()
+        for lhs, rhs in sym.zouhe_fixup(grid, o):
+            val = _evalf(rhs, subs)
+            if lhs.name.startswith('fi->'):
+                g[grid.idx_name.index(lhs.name.split('->')[1])] = val
+            subs[lhs.name] = val
+        return g
     bc_v = rng.uniform(-0.08, 0.08, (n, dim))
     bc_rho = rng.uniform(0.95, 1.05, n)
     out['bc_v'], out['bc_rho'] = bc_v, bc_rho
@@ -254,6 +275,13 @@ def arithmetic_goldens(grid, rng, n=48):
             subs.update({'flux[%d]' % j: x for j, x in enumerate(fl)})
             for i in range(Q):
                 regv[o - 1, k, i] = max(1e-7, _evalf(eqx[i], subs) + _evalf(reg[i], subs))
+            # Zou-He velocity node: g holds the populations after noneq_bb with (r, bc_v)
+            subs_v = _macro_subs(grid, r, bc_v[k])
+            subs_v.update(_fi_subs(grid, fi))
+            g_v = fi.copy()
+            for lhs, rhs in sym.noneq_bb(grid, o, eqx):
+                g_v[grid.idx_name.index(lhs.name.split('->')[1])] = _evalf(rhs, subs_v)
+            zhv[o - 1, k] = zouhe(o, g_v, r, bc_v[k], subs_v)
             # density BC
             subs = {'g0m0': rs, 'rho': rs, 'par_rho': bc_rho[k]}
             vv = [_evalf(sym.ex_velocity(grid, 'fi', d, cfg, missing_dir=o, par_rho='par_rho'), subs)
@@ -262,9 +290,34 @@ def arithmetic_goldens(grid, rng, n=48):
             subs = _macro_subs(grid, bc_rho[k], vv)
             for i in range(Q):
                 eqd[o - 1, k, i] = _evalf(eqx[i], subs)
+            # Zou-He density node: noneq_bb with (par_rho, vv), fix-up, then the standard moments
+            subs_d = _macro_subs(grid, bc_rho[k], vv)
+            subs_d.update(_fi_subs(grid, fi))
+            g_d = fi.copy()
+            for lhs, rhs in sym.noneq_bb(grid, o, eqx):
+                g_d[grid.idx_name.index(lhs.name.split('->')[1])] = _evalf(rhs, subs_d)
+            g_z = zouhe(o, g_d, bc_rho[k], vv, subs_d)
+            zhd[o - 1, k] = g_z
+            rz = _evalf(ex_rho, _fi_subs(grid, g_z))
+            sz = _fi_subs(grid, g_z)
+            sz.update({'rho': rz, 'g0m0': rz, 'rho0': rz})
+            zhd_v[o - 1, k] = [_evalf(sym.ex_velocity(grid, 'fi', d, cfg), sz) for d in range(dim)]
+            # regularized density node: regularisation of g_d with (par_rho, vv)
+            subs_r = _macro_subs(grid, bc_rho[k], vv)
+            subs_r.update(_fi_subs(grid, g_d))
+            fl = []
+            for a in range(dim):
+                for b in range(a, dim):
+                    fl.append(_evalf(sym.ex_flux(grid, 'fi', a, b, cfg), subs_r)
+                              - _evalf(sym.ex_eq_flux(grid, a, b), subs_r))
+            subs_r.update({'flux[%d]' % j: x for j, x in enumerate(fl)})
+            for i in range(Q):
+                regd[o - 1, k, i] = max(1e-7, _evalf(eqx[i], subs_r) + _evalf(reg[i], subs_r))
             del nvec[:]
     out['regvel_rho'], out['regvel_post'] = regv_rho, regv
     out['eqdens_v'], out['eqdens_post'] = eqd_v, eqd
+    out['zouhe_vel_post'], out['zouhe_dens_post'], out['zouhe_dens_v'] = zhv, zhd, zhd_v
+    out['regdens_post'] = regd
     return out
 
 
