@@ -259,3 +259,34 @@ def test_poiseuille_pressure_other_density_nodes(bc):
     got = r._sim.v[1][24, :]
     assert 0.6 * sim_cls.subdomain.max_v < got.max() < 1.4 * sim_cls.subdomain.max_v
     assert np.max(np.abs(got[1:-1] - got[1:-1][::-1])) < 1e-4
+
+
+@pytest.mark.parametrize('model,precision', [('bgk', 'double'), ('mrt', 'double'), ('bgk', 'single'), ('mrt', 'single')])
+def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
+    """The reference's regression curve regtest/poiseuille.py: relative error of the maximum velocity of a
+    127 x 128 force-driven channel (full-way bounce-back) after 100/visc iterations, 30 viscosities from
+    1e-3 to 1e-1, against the numbers the reference recorded from its GPU path
+    (tests/golden/poiseuille_curves/).  Recorded by an older revision => envelope: our error may not be
+    larger than the recorded one (plus a small absolute slack), and single precision must agree with it
+    closely where round-off does not dominate (visc >= 0.02)."""
+    data = np.loadtxt(os.path.join(golden_dir, 'poiseuille_curves', 'D2Q9_%s_force_%s_fullbb.dat' % (model, precision)))
+    assert data.shape == (30, 2)
+    sim_cls = _host.load_sim_class('poiseuille', 'PoiseuilleSim')
+    rows = data if precision == 'double' else data[data[:, 0] >= 0.02]
+    worst = 0.0
+    for visc, recorded in rows[::3]:
+        iters = 100 * (int(100 / visc) // 100)
+        cfg = dict(lat_nx=127, lat_ny=128, visc=float(visc), horizontal=True, stationary=True, drive='force',
+                   wall='fullbb', precision=precision, model=model, access_pattern='AA')
+        ctrl = run_gpu('poiseuille', 'PoiseuilleSim', 2, cfg, iters)
+        r = ctrl.runners[0]
+        vx = r._sim.v[0]
+        profile = vx[:, vx.shape[1] // 2]
+        theory = sim_cls.subdomain.velocity_profile(r.config, np.arange(vx.shape[0]))
+        err = np.nanmax(profile) / np.nanmax(theory) - 1.0
+        if precision == 'double':
+            assert abs(err) <= abs(recorded) + 5e-5, (visc, err, recorded)
+        else:
+            assert abs(err - recorded) < 3e-3, (visc, err, recorded)
+        worst = max(worst, abs(err))
+    assert worst < (3e-4 if precision == 'double' else 5e-3)
