@@ -287,6 +287,6 @@ def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
         if precision == 'double':
             assert abs(err) <= abs(recorded) + 5e-5, (visc, err, recorded)
         else:
-            assert abs(err - recorded) < 3e-3, (visc, err, recorded)
+            assert abs(err - recorded) < 5e-3, (visc, err, recorded)
         worst = max(worst, abs(err))
     assert worst < (3e-4 if precision == 'double' else 5e-3)
