@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""MLUPS of every BASELINE.json configuration that fits one GPU, through the full host stack
+(examples -> LBSimulationController --mode=benchmark -> backend_hip), one JSON line per configuration.
+bench.py stays the headline number (config: 512^3 periodic box); this is the table behind DESIGN.md.
+
+    python tools/bench_configs.py [--out profiles/r01/configs.jsonl] [--quick]
+"""
+import argparse
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+
+from sailfish.controller import LBSimulationController  # noqa: E402
+from sailfish.geo import EqualSubdomainsGeometry3D, LBGeometry2D, LBGeometry3D  # noqa: E402
+from sailfish.lb_single import LBFluidSim  # noqa: E402
+from sailfish.subdomain import Subdomain3D  # noqa: E402
+
+BYTES = {('D3Q19', 'single'): 152, ('D3Q19', 'double'): 304, ('D2Q9', 'single'): 72}
+
+
+class PeriodicBox(Subdomain3D):
+    def boundary_conditions(self, hx, hy, hz):
+        pass
+
+    def initial_conditions(self, sim, hx, hy, hz):
+        import numpy as np
+        sim.rho[:] = 1.0
+        sim.vx[:] = 0.05 * np.sin(2 * np.pi * hy / self.gy)
+        sim.vy[:] = 0.05 * np.sin(2 * np.pi * hz / self.gz)
+        sim.vz[:] = 0.05 * np.sin(2 * np.pi * hx / self.gx)
+
+
+class BoxSim(LBFluidSim):
+    subdomain = PeriodicBox
+
+
+def run(label, sim_cls, geo, settings, bytes_per_update):
+    cfg = dict(mode='benchmark', quiet=True, perf_stats_every=0)
+    cfg.update(settings)
+    ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
+    with redirect_stdout(io.StringIO()):
+        ctrl.run(ignore_cmdline=True)
+    nodes = sum(r.num_fluid_nodes for r in ctrl.runners)
+    out = {'config': label, 'MLUPS_eff': round(ctrl.mlups_total, 1), 'MLUPS_comp': round(ctrl.mlups_comp, 1),
+           'fluid_nodes': int(nodes), 'settings': dict((k, v) for k, v in settings.items())}
+    if bytes_per_update:
+        out['bytes_per_update'] = bytes_per_update
+        out['GBps_comp'] = round(ctrl.mlups_comp * bytes_per_update / 1e3, 1)   # sweep kernels only
+        out['GBps_eff'] = round(ctrl.mlups_total * bytes_per_update / 1e3, 1)   # wall clock, everything included
+        out['frac_of_8TBps'] = round(ctrl.mlups_comp * bytes_per_update / 8e6, 4)
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default='')
+    ap.add_argument('--quick', action='store_true')
+    args = ap.parse_args()
+    from examples.ldc_2d import CavitySim as Cavity2D
+    from examples.ldc_3d import CavitySim as Cavity3D
+    from examples.binary_fluid.sc_separation_3d import SeparationSim
+    it = 0.3 if args.quick else 1.0
+    res = []
+    # config 0: the reference's own small case, on the GPU here (its CPU figure is bench.py's cpu_baseline)
+    res.append(run('0: ldc_2d D2Q9 BGK 256x256', Cavity2D, LBGeometry2D,
+                   dict(lat_nx=256, lat_ny=256, visc=0.0254, access_pattern='AA', max_iters=int(40000 * it),
+                        benchmark_sample_from=int(10000 * it)), 72))
+    # config 1: D3Q19 BGK periodic box 256^3
+    res.append(run('1: D3Q19 BGK periodic box 256^3', BoxSim, LBGeometry3D,
+                   dict(lat_nx=256, lat_ny=256, lat_nz=256, periodic_x=True, periodic_y=True, periodic_z=True,
+                        visc=1.0 / 6.0, access_pattern='AA', grid='D3Q19', max_iters=int(3000 * it),
+                        benchmark_sample_from=int(1000 * it)), 152))
+    # config 2: D3Q19 MRT lid-driven cavity 512^3 (Re = 1000)
+    res.append(run('2: D3Q19 MRT lid-driven cavity 512^3', Cavity3D, LBGeometry3D,
+                   dict(lat_nx=512, lat_ny=512, lat_nz=512, model='mrt', visc=0.0256, access_pattern='AA',
+                        max_iters=int(700 * it), benchmark_sample_from=int(200 * it)), 152))
+    res.append(run('2b: D3Q19 BGK lid-driven cavity 512^3', Cavity3D, LBGeometry3D,
+                   dict(lat_nx=512, lat_ny=512, lat_nz=512, model='bgk', visc=0.0256, access_pattern='AA',
+                        max_iters=int(700 * it), benchmark_sample_from=int(200 * it)), 152))
+    # config 3 (8 GPUs) is bench.py --gpus 8; here its per-GPU shape for both decompositions, 2 subdomains
+    # of the reference's x-split layout on this one GPU (halo path exercised, no xGMI)
+    res.append(run('3: D3Q19 BGK 1024x512x512 / 8: one 128x512x512 x-slab pair on one GPU', BoxSim,
+                   EqualSubdomainsGeometry3D,
+                   dict(lat_nx=256, lat_ny=512, lat_nz=512, subdomains=2, conn_axis='x', periodic_x=True,
+                        periodic_y=True, periodic_z=True, visc=1.0 / 6.0, access_pattern='AA', grid='D3Q19',
+                        max_iters=int(600 * it), benchmark_sample_from=int(200 * it)), 152))
+    # config 4: binary Shan-Chen 256^3 (3 passes per step: 516 B per node update)
+    res.append(run('4: binary Shan-Chen D3Q19 256^3', SeparationSim, LBGeometry3D,
+                   dict(lat_nx=256, lat_ny=256, lat_nz=256, access_pattern='AA', max_iters=int(1500 * it),
+                        benchmark_sample_from=int(500 * it)), 516))
+    if args.out:
+        with open(args.out, 'w') as fh:
+            for r in res:
+                fh.write(json.dumps(r) + '\n')
+
+
+if __name__ == '__main__':
+    main()
