@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libsailfish_hip.so')
 SOURCES = ['slf_kernels.hip', 'slf_fast.hip', 'slf_row.hip', 'slf_sc.hip', 'slf_api.hip']
-HEADERS = ['slf_kernels.h', 'slf_lattice.h', 'slf_node.h', 'slf_sweep.h', os.path.join('..', '..', 'include', 'sailfish_hip.h')]
+HEADERS = ['slf_kernels.h', 'slf_lattice.h', 'slf_node.h', 'slf_sweep.h', 'slf_rowpush.h', os.path.join('..', '..', 'include', 'sailfish_hip.h')]
 
 # -ffp-contract=off: fixed IEEE operation order (DESIGN.md "arithmetic contract");
 # the sweep is HBM-bound, the extra VALU issue slots are hidden.

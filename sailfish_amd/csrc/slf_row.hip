@@ -18,40 +18,21 @@
 // Arithmetic is node_update() of slf_sweep.h, shared with the per-node kernel in slf_kernels.hip: the
 // results are bit-identical.  Replaces the reference's shared-memory propagation
 // (templates/propagation.mako:180-288) on MI355X.
-#include "slf_sweep.h"
+#include "slf_rowpush.h"
 
 namespace slf {
-
-template <class L>
-constexpr int count_x_dirs() {
-  int n = 0;
-  for (int i = 0; i < L::Q; i++) n += (L::ex(i) > 0) ? 1 : 0;
-  return n;
-}
-
-template <class R>
-__device__ __forceinline__ R shfl_up1(R v) { return __shfl_up(v, 1); }
-template <class R>
-__device__ __forceinline__ R shfl_down1(R v) { return __shfl_down(v, 1); }
 
 template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT>
 __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
-  constexpr int NW = 16;
-  constexpr int NXD = count_x_dirs<L>();
-  __shared__ R s_out_p[NW][NXD], s_out_m[NW][NXD], s_wrap_p[NXD], s_wrap_m[NXD];
-  __shared__ int s_act_p[NW], s_act_m[NW], s_actw_p, s_actw_m;
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
   const int nx = g.lat_nx - 2;
   const int x = (int)threadIdx.x + 1;
-  const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
   const bool live = x <= nx;
-  const bool wrapx = g.wrap[0] != 0;
   const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
   const uint32_t gi = row + (uint32_t)(live ? x : nx);  // idle lanes: an in-row address, never stored
-  const AxisOff ox0 = {0, 0};
   const AxisOff ox = axis_off(x, g.lat_nx, 1, g.wrap[0]);
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
   const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
@@ -93,72 +74,7 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
     }
   }
 
-  // push: the value of node x travels to x + e_x and is stored by the thread that owns the target x
-  {
-    int kp = 0, km = 0;
-    static_for<1, L::Q>([&](auto I) {
-      if constexpr (L::ex(I) > 0) {
-        if (lane == 63) s_out_p[w][kp] = f[I];
-        if (x == nx) s_wrap_p[kp] = f[I];
-        kp++;
-      }
-      if constexpr (L::ex(I) < 0) {
-        if (lane == 0) s_out_m[w][km] = f[I];
-        if (x == 1) s_wrap_m[km] = f[I];
-        km++;
-      }
-    });
-    if constexpr (GENERAL) {
-      if (lane == 63) s_act_p[w] = (int)active;
-      if (lane == 0) s_act_m[w] = (int)active;
-      if (x == nx) s_actw_p = (int)active;
-      if (x == 1) s_actw_m = (int)active;
-    }
-  }
-  __syncthreads();
-  bool from_left = live, from_right = live;   // is the node at x - 1 / x + 1 a source?
-  if constexpr (GENERAL) {
-    int a = __shfl_up((int)active, 1);
-    if (lane == 0 && w > 0) a = s_act_p[w - 1];
-    if (x == 1) a = wrapx ? s_actw_p : 0;
-    from_left = a != 0;
-    a = __shfl_down((int)active, 1);
-    if (lane == 63) a = s_act_m[(w + 1) & (NW - 1)];
-    if (x == nx) a = wrapx ? s_actw_m : 0;
-    from_right = a != 0;
-  } else {
-    if (!wrapx) {
-      if (x == 1) from_left = false;
-      if (x == nx) from_right = false;
-    }
-  }
-  {
-    int kp = 0, km = 0;
-    static_for<0, L::Q>([&](auto I) {
-      const int off = dir_offset<L, I>(ox0, oy, oz, true);
-      R* dst = p.dout + ds * (size_t)I + (uint32_t)((int)gi + off);
-      R t = f[I];
-      bool src_ok = active;
-      if constexpr (L::ex(I) > 0) {
-        // edge lane, no wrap: the value leaves the row into the ghost column x = nx + 1
-        if (!wrapx && x == nx && active) st<0>(dst + 1, f[I]);
-        t = shfl_up1<R>(f[I]);
-        if (lane == 0 && w > 0) t = s_out_p[w - 1][kp];
-        if (x == 1) t = s_wrap_p[kp];
-        src_ok = from_left;
-        kp++;
-      }
-      if constexpr (L::ex(I) < 0) {
-        if (!wrapx && x == 1 && active) st<0>(dst - 1, f[I]);
-        t = shfl_down1<R>(f[I]);
-        if (lane == 63) t = s_out_m[(w + 1) & (NW - 1)][km];
-        if (x == nx) t = s_wrap_m[km];
-        src_ok = from_right;
-        km++;
-      }
-      if (live && src_ok) st<NT>(dst, t);
-    });
-  }
+  row_push<L, R, GENERAL, NT>(g, f, p.dout, ds, gi, x, nx, live, active, oy, oz);
 }
 
 // Even AA step: every access is to the node's own slots (aligned); per-node kernel with cache hints.

@@ -9,7 +9,7 @@
 // reads the 18 neighbour densities of the *other* field through the cache hierarchy (each value is
 // reused by 18 nodes; rows of a workgroup are contiguous), the acceleration F_k / rho_k enters the BGK
 // collision through Guo forcing exactly like a body force (relaxation_common.mako:56-64,110-149).
-#include "slf_sweep.h"
+#include "slf_rowpush.h"
 
 namespace slf {
 
@@ -95,21 +95,32 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   if constexpr (L::dim == 3) p.vz[gi] = v[2] / total;
 }
 
-template <class L, class R, int K, int PROP, bool GENERAL>
+// ROW: one workgroup = one whole row, streaming through row_push() (aligned stores, slf_rowpush.h); every
+// thread stays until the end (barrier inside), excluded nodes and idle lanes are merely inactive.
+template <class L, class R, int K, int PROP, bool GENERAL, bool ROW = false>
 __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
   const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (gx > g.lat_nx - 2) return;
-  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const int nx = g.lat_nx - 2;
+  const bool live = gx <= nx;
+  if constexpr (!ROW) {
+    if (!live) return;
+  }
+  const uint32_t gi = (uint32_t)(live ? gx : nx) + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
   int kind = NK_FLUID;
+  bool active = live;
   if constexpr (GENERAL) {
     const uint32_t code = p.map[gi];
     kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
-    if (kind_is_excluded(kind)) return;
+    if constexpr (!ROW) {
+      if (kind_is_excluded(kind)) return;
+    } else {
+      active = live && !kind_is_excluded(kind);
+    }
   }
-  const bool wet = kind_is_wet(kind);
+  const bool wet = kind_is_wet(kind) && active;
   const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
   const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
@@ -159,14 +170,18 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
   }
   if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[K], p.guo_pref[K], false, true, a);
 
-  static_for<0, L::Q>([&](auto I) {
-    if constexpr (PROP == PROP_AA_EVEN) {
-      (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
-    } else {
-      const int off = dir_offset<L, I>(ox, oy, oz, true);
-      (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
-    }
-  });
+  if constexpr (ROW && PROP != PROP_AA_EVEN) {
+    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, gi, gx, nx, live, active, oy, oz);
+  } else {
+    static_for<0, L::Q>([&](auto I) {
+      if constexpr (PROP == PROP_AA_EVEN) {
+        (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
+      } else {
+        const int off = dir_offset<L, I>(ox, oy, oz, true);
+        (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+      }
+    });
+  }
 }
 
 // ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
@@ -193,21 +208,30 @@ __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p)
 }
 
 // CollideAndPropagate with the self-interaction force F = -G psi(rho(x)) sum_i w_i e_i psi(rho(x + e_i))
-template <class L, class R, int PROP, bool GENERAL>
+template <class L, class R, int PROP, bool GENERAL, bool ROW = false>
 __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
   const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (gx > g.lat_nx - 2) return;
-  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const int nx = g.lat_nx - 2;
+  const bool live = gx <= nx;
+  if constexpr (!ROW) {
+    if (!live) return;
+  }
+  const uint32_t gi = (uint32_t)(live ? gx : nx) + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
   int kind = NK_FLUID;
+  bool active = live;
   if constexpr (GENERAL) {
     const uint32_t code = p.map[gi];
     kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
-    if (kind_is_excluded(kind)) return;
+    if constexpr (!ROW) {
+      if (kind_is_excluded(kind)) return;
+    } else {
+      active = live && !kind_is_excluded(kind);
+    }
   }
-  const bool wet = kind_is_wet(kind);
+  const bool wet = kind_is_wet(kind) && active;
   const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
   const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
@@ -251,14 +275,18 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
     p.vy[gi] = v[1];
     if constexpr (L::dim == 3) p.vz[gi] = v[2];
   }
-  static_for<0, L::Q>([&](auto I) {
-    if constexpr (PROP == PROP_AA_EVEN) {
-      (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
-    } else {
-      const int off = dir_offset<L, I>(ox, oy, oz, true);
-      (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
-    }
-  });
+  if constexpr (ROW && PROP != PROP_AA_EVEN) {
+    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, gi, gx, nx, live, active, oy, oz);
+  } else {
+    static_for<0, L::Q>([&](auto I) {
+      if constexpr (PROP == PROP_AA_EVEN) {
+        (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
+      } else {
+        const int off = dir_offset<L, I>(ox, oy, oz, true);
+        (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+      }
+    });
+  }
 }
 
 // f1 = feq(rho, v), f2 = feq(phi, v) on every node (no type test)
@@ -335,16 +363,27 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
 }
 
 template <class L, class R, int K>
-static hipError_t sc_sweep3(Prop prop, bool general, const ScParams<L, R>& p, dim3 grid, dim3 block, hipStream_t s) {
+static hipError_t sc_sweep3(Prop prop, bool general, bool row, const ScParams<L, R>& p, dim3 grid, dim3 block,
+                            hipStream_t s) {
 #define SLF_SCS(P)                                                                           \
   do {                                                                                       \
     if (general) hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, P, true>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, P, false>), grid, block, 0, s, p);        \
   } while (0)
+#define SLF_SCS_ROW(P)                                                                             \
+  do {                                                                                               \
+    if (general) hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, P, true, true>), grid, block, 0, s, p);   \
+    else hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, P, false, true>), grid, block, 0, s, p);          \
+  } while (0)
+  if constexpr (L::dim == 3) {
+    if (row && prop == PROP_AB) { SLF_SCS_ROW(PROP_AB); return hipGetLastError(); }
+    if (row && prop == PROP_AA_ODD) { SLF_SCS_ROW(PROP_AA_ODD); return hipGetLastError(); }
+  }
   if (prop == PROP_AB) SLF_SCS(PROP_AB);
   else if (prop == PROP_AA_EVEN) SLF_SCS(PROP_AA_EVEN);
   else SLF_SCS(PROP_AA_ODD);
 #undef SLF_SCS
+#undef SLF_SCS_ROW
   return hipGetLastError();
 }
 
@@ -354,11 +393,14 @@ static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometr
                             hipStream_t s) {
   const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, grid_idx, y0, z0);
   const int nx = g.lat_nx - 2;
+  // whole-row workgroups + aligned stores for the x-streaming steps in 3-D (as slf_row.hip)
+  const bool row = L::dim == 3 && (g.variant & 8) && nx <= 1024 && prop != PROP_AA_EVEN;
+  if (row) block_x = ((nx + 63) / 64) * 64;
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
-  if (grid_idx == 0) return sc_sweep3<L, R, 0>(prop, general, p, grid, block, s);
-  return sc_sweep3<L, R, 1>(prop, general, p, grid, block, s);
+  if (grid_idx == 0) return sc_sweep3<L, R, 0>(prop, general, row, p, grid, block, s);
+  return sc_sweep3<L, R, 1>(prop, general, row, p, grid, block, s);
 }
 
 #define SLF_DISPATCH_LR(sel, CALL)                                   \
@@ -393,9 +435,23 @@ static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometr
   p.G[0] = (R)sc.G[0];
   p.G[1] = (R)0;
   const int nx = g.lat_nx - 2;
+  const bool row = !macro && L::dim == 3 && (g.variant & 8) && nx <= 1024 && prop != PROP_AA_EVEN;
+  if (row) block_x = ((nx + 63) / 64) * 64;
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  if constexpr (L::dim == 3) {
+    if (row) {
+      if (prop == PROP_AB) {
+        if (general) hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AB, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AB, false, true>), grid, block, 0, s, p);
+      } else {
+        if (general) hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_ODD, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_ODD, false, true>), grid, block, 0, s, p);
+      }
+      return hipGetLastError();
+    }
+  }
 #define SLF_SCS1(KERN, P)                                                       \
   do {                                                                          \
     if (general) hipLaunchKernelGGL((KERN<L, R, P, true>), grid, block, 0, s, p);  \
