@@ -41,6 +41,15 @@ enum { SLF_BGK = 0, SLF_MRT = 1 };
 enum { SLF_AB = 0, SLF_AA = 1 };
 enum { SLF_SIM_LBM = 0, SLF_SIM_SHAN_CHEN_BINARY = 1, SLF_SIM_SHAN_CHEN_SINGLE = 2 };
 
+/* Node addressing (reference subdomain_runner.py:829-878, kernel_common.mako:140-167).  INDIRECT: the
+ * distribution arrays hold the *active* nodes only (dist_stride >= number of active nodes); a dense
+ * uint32 table `nodes` maps a node's dense index to its slot or SLF_INVALID_NODE.  Node map and
+ * macroscopic fields stay dense.  In an indirect module CollideAndPropagate, SetInitialConditions and
+ * ComputeMacroFields take that table as an additional FIRST pointer argument (as the reference's
+ * _add_indirect_args, subdomain_runner.py:1153-1157); periodic boundaries must be wrapped in-sweep. */
+enum { SLF_ADDR_DIRECT = 0, SLF_ADDR_INDIRECT = 1 };
+#define SLF_INVALID_NODE 0xffffffffu
+
 /* Canonical node kinds understood by the kernels (reference node_type.py:86-109,
  * 115-168, 198-, 269-; wet/excluded semantics from templates/geo_helpers.mako:42-84). */
 enum {
@@ -108,7 +117,7 @@ typedef struct slf_module_desc {
   double tau_phi;
   double sc_G[4];
   int32_t sc_potential;
-  int32_t reserved1;
+  int32_t node_addressing;       /* SLF_ADDR_DIRECT | SLF_ADDR_INDIRECT (--node_addressing, lb_base.py:66-71) */
 } slf_module_desc;
 
 /* Region of the lattice a sweep launch covers (replaces the reference's

@@ -50,6 +50,8 @@ def lib(precision=4):
     L.orc_scs_step.argtypes = [P(SlfModuleDesc), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32]
     for fn in (L.orc_sc_init, L.orc_sc_macro, L.orc_sc_step, L.orc_sc_force_node, L.orc_scs_macro, L.orc_scs_step):
         fn.restype = None
+    L.orc_set_nodes.argtypes = [vp]
+    L.orc_set_nodes.restype = None
     for fn in (L.orc_node_feq, L.orc_node_macro, L.orc_node_update, L.orc_init, L.orc_step, L.orc_pbc,
                L.orc_macro_pbc, L.orc_sparse, L.orc_compute_macro):
         fn.restype = None
@@ -124,16 +126,33 @@ class OracleSim(object):
     def new_field(self, fill=0.0):
         return np.full(self.shape, fill, dtype=self.dtype)
 
+    # -- indirect node addressing: distributions are [Q, stride] arrays of active-node slots ----------
+    nodes = None
+
+    def set_nodes(self, nodes):
+        """nodes: dense uint32 array (slot or 0xffffffff per node) or None for direct addressing."""
+        self.nodes = None if nodes is None else np.ascontiguousarray(nodes, dtype=np.uint32)
+
+    def new_sparse_dist(self):
+        return np.full((self.Q, self.stride), np.nan, dtype=self.dtype)
+
+    def _install_nodes(self):
+        self.L.orc_set_nodes(_vp(self.nodes) if self.nodes is not None else None)
+
     def init(self, dist, rho, vx, vy, vz=None):
+        self._install_nodes()
         self.L.orc_init(ctypes.byref(self.desc), _vp(dist), _vp(rho), _vp(vx), _vp(vy), _vp(vz))
+        self.L.orc_set_nodes(None)
 
     def step(self, prop, nmap, din, dout, rho, vx, vy, vz, options=0, region=None):
         d = self.desc
         y0, y1, z0, z1 = 1, d.lat_ny - 1, 1, d.lat_nz - 1
         if region is not None:
             y0, y1, z0, z1 = region
+        self._install_nodes()
         self.L.orc_step(ctypes.byref(d), prop, _vp(nmap), _vp(din), _vp(dout), _vp(rho), _vp(vx), _vp(vy),
                         _vp(vz), options, y0, y1, z0, z1)
+        self.L.orc_set_nodes(None)
 
     def pbc(self, dist, axis, with_swap=False):
         self.L.orc_pbc(ctypes.byref(self.desc), _vp(dist), axis, int(with_swap))

@@ -354,6 +354,14 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   m->sel.model = d->model;
   m->sel.precision = d->precision;
   m->sel.general = !d->fluid_only;
+  if (d->node_addressing != SLF_ADDR_DIRECT && d->node_addressing != SLF_ADDR_INDIRECT) {
+    delete m;
+    return fail(SLF_ERR_INVALID, "node_addressing must be SLF_ADDR_DIRECT or SLF_ADDR_INDIRECT");
+  }
+  if (d->node_addressing == SLF_ADDR_INDIRECT) {
+    if (d->fluid_only) { delete m; return fail(SLF_ERR_INVALID, "indirect addressing needs the node map (fluid_only = 0)"); }
+    if (d->simtype != SLF_SIM_LBM) { delete m; return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: single-fluid modules only"); }
+  }
   m->access_pattern = d->access_pattern;
   slf::Geometry& g = m->geo;
   g.dim = dim;
@@ -361,7 +369,13 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   g.arr_nx = d->arr_nx; g.arr_ny = d->arr_ny; g.arr_nz = d->arr_nz;
   g.arr_nxy = d->arr_nx * d->arr_ny;
   g.dist_size = (uint32_t)(d->dist_stride ? d->dist_stride : total);
-  if (g.dist_size < total) { delete m; return fail(SLF_ERR_INVALID, "dist_stride smaller than the subdomain"); }
+  if (d->node_addressing == SLF_ADDR_INDIRECT) {
+    // the stride is the number of active-node slots: the caller's business (it owns the address table)
+    if (d->dist_stride == 0) { delete m; return fail(SLF_ERR_INVALID, "indirect addressing: dist_stride (number of slots) must be given"); }
+  } else if (g.dist_size < total) {
+    delete m;
+    return fail(SLF_ERR_INVALID, "dist_stride smaller than the subdomain");
+  }
   for (int i = 0; i < 3; i++) {
     g.wrap[i] = (i < dim) ? (d->periodic_fused[i] != 0) : 0;
     g.axis_mode[i] = g.wrap[i] ? 2 : ((i < dim && d->periodic_local[i]) ? 1 : 0);
@@ -380,6 +394,7 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
     g.type_lut |= (unsigned long long)k << (4 * i);
   }
   g.use_link_tags = d->use_link_tags;
+  g.indirect = d->node_addressing == SLF_ADDR_INDIRECT;
   g.variant = SLF_DEFAULT_VARIANT;
   if (const char* ev = getenv("SLF_VARIANT")) g.variant = atoi(ev);
   slf::Physics& ph = m->phys;
@@ -476,6 +491,9 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
     return fail(SLF_ERR_NOT_FOUND, "Shan-Chen kernels only exist in modules built with simtype = SLF_SIM_SHAN_CHEN_BINARY");
   if ((kk == KK_COLLIDE_AND_PROPAGATE || kk == KK_COMPUTE_MACRO) && m->sc.enabled == 1)
     return fail(SLF_ERR_NOT_FOUND, "single-fluid kernels do not exist in a Shan-Chen module");
+  if ((kk == KK_PBC || kk == KK_PBC_SWAP) && m->geo.indirect)
+    return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: periodic boundaries are wrapped inside the sweep "
+                                     "(periodic_fused), there are no ghost-layer PBC kernels");
   if (kk == KK_PBC_SWAP && m->access_pattern != SLF_AA)
     return fail(SLF_ERR_NOT_FOUND, "ApplyPeriodicBoundaryConditionsWithSwap only exists for the AA access pattern");
   slf_kernel* k = new slf_kernel;
@@ -523,6 +541,9 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_SCS_MACRO: want_p = 3; want_i = 1; break;             // map, dist, rho, options
     case KK_SCS_SWEEP: want_p = 4 + dim; want_i = 1; break;       // as CollideAndPropagate
   }
+  if (k->mod->geo.indirect && (k->kind == KK_COLLIDE_AND_PROPAGATE || k->kind == KK_COMPUTE_MACRO ||
+                               k->kind == KK_SET_INITIAL_CONDITIONS))
+    want_p += 1;   // leading `nodes` table (reference _add_indirect_args, subdomain_runner.py:1153-1157)
   if (k->ptrs.size() != want_p || k->ints.size() != want_i)
     return fail(SLF_ERR_INVALID, "argument list does not match the kernel's signature");
   k->needs_iteration = needs_iteration;
@@ -547,17 +568,20 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     case KK_COLLIDE_AND_PROPAGATE:
     case KK_COMPUTE_MACRO: {
       slf::SweepArgs a;
-      a.map = (const void*)k->ptrs[0];
-      a.dist_in = (void*)k->ptrs[1];
-      a.dist_out = (void*)k->ptrs[2];
-      a.rho = (void*)k->ptrs[3];
+      const int b0 = g.indirect ? 1 : 0;
+      a.nodes = g.indirect ? (const void*)k->ptrs[0] : nullptr;
+      a.map = (const void*)k->ptrs[b0 + 0];
+      a.dist_in = (void*)k->ptrs[b0 + 1];
+      a.dist_out = (void*)k->ptrs[b0 + 2];
+      a.rho = (void*)k->ptrs[b0 + 3];
       a.phi = nullptr;
-      a.v[0] = (void*)k->ptrs[4];
-      a.v[1] = (void*)k->ptrs[5];
-      a.v[2] = g.dim == 3 ? (void*)k->ptrs[6] : nullptr;
+      a.v[0] = (void*)k->ptrs[b0 + 4];
+      a.v[1] = (void*)k->ptrs[b0 + 5];
+      a.v[2] = g.dim == 3 ? (void*)k->ptrs[b0 + 6] : nullptr;
       a.node_params = m->node_params;
       a.options = (uint32_t)k->ints[0];
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
+      if (g.indirect && !a.nodes) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
       slf::Prop prop = slf::PROP_AB;
       if (m->access_pattern == SLF_AA) {
         if (!k->needs_iteration) return fail(SLF_ERR_INVALID, "AA kernels need the iteration argument");
@@ -582,6 +606,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     case KK_SC_SWEEP0:
     case KK_SC_SWEEP1: {
       slf::SweepArgs a;
+      a.nodes = nullptr;
       a.map = (const void*)k->ptrs[0];
       a.dist_in = (void*)k->ptrs[1];
       a.dist_out = (void*)k->ptrs[2];
@@ -614,6 +639,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     case KK_SCS_MACRO:
     case KK_SCS_SWEEP: {
       slf::SweepArgs a;
+      a.nodes = nullptr;
       a.map = (const void*)k->ptrs[0];
       a.dist_in = (void*)k->ptrs[1];
       a.phi = nullptr;
@@ -661,9 +687,12 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     }
     case KK_SET_INITIAL_CONDITIONS: {
       // (dist, vx, vy[, vz], rho, map)  -- reference lb_single.py:72-94
-      const void* v[3] = {(const void*)k->ptrs[1], (const void*)k->ptrs[2],
-                          g.dim == 3 ? (const void*)k->ptrs[3] : nullptr};
-      e = slf::launch_init(m->sel, g, m->phys, (void*)k->ptrs[0], (const void*)k->ptrs[1 + g.dim], v, s);
+      const int b0 = g.indirect ? 1 : 0;   // indirect: (nodes, dist, v.., rho, map)
+      const void* v[3] = {(const void*)k->ptrs[b0 + 1], (const void*)k->ptrs[b0 + 2],
+                          g.dim == 3 ? (const void*)k->ptrs[b0 + 3] : nullptr};
+      if (g.indirect && !k->ptrs[0]) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
+      e = slf::launch_init(m->sel, g, m->phys, (void*)k->ptrs[b0 + 0], (const void*)k->ptrs[b0 + 1 + g.dim], v,
+                           g.indirect ? (const void*)k->ptrs[0] : nullptr, s);
       break;
     }
     case KK_PBC:

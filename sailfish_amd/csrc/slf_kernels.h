@@ -25,6 +25,7 @@ struct Geometry {
   unsigned long long type_lut; // 4 bits per dense type id -> NodeKind
   int use_link_tags;
   int variant;                 // tuned-kernel selection bits (SLF_VARIANT), see slf_fast.hip
+  int indirect;                // distributions hold active nodes only, addressed through SweepArgs::nodes
 };
 
 struct Physics {
@@ -44,6 +45,7 @@ struct ShanChen {
 };
 
 struct SweepArgs {
+  const void* nodes;   // indirect addressing: dense index -> slot table (uint32), else NULL
   const void* map;
   void* dist_in;
   void* dist_out;
@@ -64,7 +66,7 @@ hipError_t launch_sweep(const KernelSelector& sel, Prop prop, const Geometry& g,
                         const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s);
 
 hipError_t launch_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist,
-                       const void* rho, const void* const v[3], hipStream_t s);
+                       const void* rho, const void* const v[3], const void* nodes, hipStream_t s);
 
 hipError_t launch_pbc(const KernelSelector& sel, const Geometry& g, void* dist, int axis, bool with_swap,
                       hipStream_t s);

@@ -21,7 +21,7 @@
 
 namespace slf {
 
-template <class L, class R, int MODEL, int PROP, bool GENERAL>
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false>
 __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
@@ -34,6 +34,13 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
 
   const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
 
+  // indirect addressing (reference kernel_common.mako:140-167): the distribution arrays hold active
+  // nodes only; si = slot of this node, neighbours are translated through the same dense table
+  uint32_t si = gi;
+  if constexpr (INDIRECT) {
+    si = p.nodes[gi];
+    if (si == INVALID_NODE) return;
+  }
   int kind = NK_FLUID;
   uint32_t code = 0;
   if constexpr (GENERAL) {
@@ -52,15 +59,17 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
   static_for<0, L::Q>([&](auto I) {
     if constexpr (PROP == PROP_AA_ODD) {
       const int off = dir_offset<L, I>(ox, oy, oz, false);
-      f[I] = (p.din + ds * (size_t)L::opp(I))[(uint32_t)((int)gi + off)];
+      uint32_t sn = (uint32_t)((int)gi + off);
+      if constexpr (INDIRECT) sn = p.nodes[sn];
+      f[I] = (!INDIRECT || sn != INVALID_NODE) ? (p.din + ds * (size_t)L::opp(I))[sn] : (R)0;
     } else {
-      f[I] = (p.din + ds * (size_t)I)[gi];
+      f[I] = (p.din + ds * (size_t)I)[si];
     }
   });
 
   R rho, v[3];
   bool wet = true;
-  node_update<L, R, MODEL, PROP, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+  node_update<L, R, MODEL, PROP, GENERAL, INDIRECT>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
 
   // ---- macroscopic output (save_macro_fields, kernel_common.mako:213-240)
   if ((p.options & 1u) && wet) {
@@ -73,10 +82,12 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
   // ---- streaming (propagate, propagation.mako:384-421)
   static_for<0, L::Q>([&](auto I) {
     if constexpr (PROP == PROP_AA_EVEN) {
-      (p.dout + ds * (size_t)L::opp(I))[gi] = f[I];
+      (p.dout + ds * (size_t)L::opp(I))[si] = f[I];
     } else {
       const int off = dir_offset<L, I>(ox, oy, oz, true);
-      (p.dout + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+      uint32_t t = (uint32_t)((int)gi + off);
+      if constexpr (INDIRECT) t = p.nodes[t];
+      if (!INDIRECT || t != INVALID_NODE) (p.dout + ds * (size_t)I)[t] = f[I];
     }
   });
 }
@@ -86,12 +97,17 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
 template <class L, class R>
 __global__ void __launch_bounds__(256) init_kernel(R* dist, const R* __restrict__ irho, const R* __restrict__ ivx,
                                                    const R* __restrict__ ivy, const R* __restrict__ ivz, Geometry g,
-                                                   int incompressible) {
+                                                   int incompressible, const uint32_t* __restrict__ nodes) {
   const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int gy = (int)blockIdx.y;
   const int gz = (int)blockIdx.z;
   if (gx > g.lat_nx - 1) return;
   const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  uint32_t si = gi;   // indirect addressing: slot of this node, if it is active
+  if (nodes) {
+    si = nodes[gi];
+    if (si == INVALID_NODE) return;
+  }
   const R rho = irho[gi];
   R v[3];
   v[0] = ivx[gi];
@@ -100,7 +116,7 @@ __global__ void __launch_bounds__(256) init_kernel(R* dist, const R* __restrict_
   if constexpr (L::dim == 3) v[2] = ivz[gi];
   const R rho0 = incompressible ? (R)1 : rho;
   const R u15 = usq15<L, R>(v);
-  static_for<0, L::Q>([&](auto I) { (dist + (size_t)g.dist_size * (size_t)I)[gi] = feq<L, R, I>(rho, rho0, v, u15); });
+  static_for<0, L::Q>([&](auto I) { (dist + (size_t)g.dist_size * (size_t)I)[si] = feq<L, R, I>(rho, rho0, v, u15); });
 }
 
 __device__ __forceinline__ bool slf_isfinite(float x) { return __builtin_isfinite(x); }
@@ -253,13 +269,21 @@ __global__ void __launch_bounds__(1024) macro_kernel(const SweepParams<L, R> p) 
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
   const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
   const size_t ds = g.dist_size;
+  const uint32_t* nodes = p.nodes;
+  uint32_t si = gi;
+  if (nodes) {
+    si = nodes[gi];
+    if (si == INVALID_NODE) return;
+  }
   R f[L::Q];
   static_for<0, L::Q>([&](auto I) {
     if constexpr (PROP == PROP_AA_ODD) {
       const int off = dir_offset<L, I>(ox, oy, oz, false);
-      f[I] = (p.din + ds * (size_t)L::opp(I))[(uint32_t)((int)gi + off)];
+      uint32_t sn = (uint32_t)((int)gi + off);
+      if (nodes) sn = nodes[sn];
+      f[I] = (sn != INVALID_NODE) ? (p.din + ds * (size_t)L::opp(I))[sn] : (R)0;
     } else {
-      f[I] = (p.din + ds * (size_t)I)[gi];
+      f[I] = (p.din + ds * (size_t)I)[si];
     }
   });
   R rho, v[3];
@@ -281,7 +305,8 @@ static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& 
   dim3 block(block_x, 1, 1);
   dim3 grid((g.lat_nx - 2 + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
-  if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true>), grid, block, 0, s, p);
+  if (g.indirect) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, true>), grid, block, 0, s, p);
+  else if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false>), grid, block, 0, s, p);
   return hipGetLastError();
 }
@@ -316,7 +341,7 @@ static hipError_t launch_sweep2(int model, Prop prop, bool general, const Geomet
 
 hipError_t launch_sweep(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
                         const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s) {
-  {
+  if (!g.indirect) {   // the tuned kernels address the dense layout
     hipError_t fe = hipSuccess;
     if (launch_sweep_fast(sel, prop, g, ph, a, y0, y1, z0, z1, block_x, s, &fe)) return fe;
     if (launch_sweep_row(sel, prop, g, ph, a, y0, y1, z0, z1, s, &fe)) return fe;
@@ -327,17 +352,17 @@ hipError_t launch_sweep(const KernelSelector& sel, Prop prop, const Geometry& g,
 
 template <class L, class R>
 static hipError_t launch_init2(const Geometry& g, const Physics& ph, void* dist, const void* rho, const void* const v[3],
-                               hipStream_t s) {
+                               const void* nodes, hipStream_t s) {
   dim3 block(256, 1, 1);
   dim3 grid((g.lat_nx + 255) / 256, g.lat_ny, g.lat_nz);
   hipLaunchKernelGGL((init_kernel<L, R>), grid, block, 0, s, (R*)dist, (const R*)rho, (const R*)v[0], (const R*)v[1],
-                     (const R*)v[2], g, ph.incompressible);
+                     (const R*)v[2], g, ph.incompressible, (const uint32_t*)nodes);
   return hipGetLastError();
 }
 
 hipError_t launch_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist, const void* rho,
-                       const void* const v[3], hipStream_t s) {
-  SLF_DISPATCH_LR(sel, return (launch_init2<L, R>(g, ph, dist, rho, v, s)));
+                       const void* const v[3], const void* nodes, hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (launch_init2<L, R>(g, ph, dist, rho, v, nodes, s)));
   return hipErrorInvalidValue;
 }
 

@@ -9,6 +9,7 @@ namespace slf {
 
 template <class L, class R>
 struct SweepParams {
+  const uint32_t* __restrict__ nodes;   // indirect addressing table or NULL
   const uint32_t* __restrict__ map;
   const R* din;
   R* dout;
@@ -66,10 +67,14 @@ __device__ __forceinline__ void st(T* p, T v) {
 // Everything between loading the populations of a node and streaming them: macroscopic quantities,
 // pre-collision boundary conditions, collision, half-way bounce-back stores (reference
 // lb_single_fluid.mako:175-228).  Shared by all sweep kernels so that they differ only in access shape.
-template <class L, class R, int MODEL, int PROP, bool GENERAL>
+constexpr uint32_t INVALID_NODE = 0xffffffffu;
+
+// gi: dense node index; si: the node's slot in the distribution arrays (= gi unless INDIRECT).
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false>
 __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L::Q], uint32_t code, int kind,
                                             uint32_t gi, const AxisOff& ox, const AxisOff& oy, const AxisOff& oz,
-                                            R& rho, R (&v)[3], bool& wet) {
+                                            R& rho, R (&v)[3], bool& wet, uint32_t si = INVALID_NODE) {
+  if constexpr (!INDIRECT) si = gi;
   const Geometry& g = p.g;
   const size_t ds = g.dist_size;
   (void)ds;
@@ -140,9 +145,11 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
           // population opp(I) is undefined here: feed it with the reflected f_I.
           if constexpr (PROP == PROP_AA_EVEN) {
             const int off = dir_offset<L, I>(ox, oy, oz, true);
-            (p.dout + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
+            uint32_t t = (uint32_t)((int)gi + off);
+            if constexpr (INDIRECT) t = p.nodes[t];
+            if (!INDIRECT || t != INVALID_NODE) (p.dout + ds * (size_t)I)[t] = f[I];
           } else {
-            (p.dout + ds * (size_t)L::opp(I))[gi] = f[I];
+            (p.dout + ds * (size_t)L::opp(I))[si] = f[I];
           }
         }
       });
@@ -160,6 +167,7 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
 template <class L, class R>
 inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const SweepArgs& a, int y0, int z0) {
   SweepParams<L, R> p;
+  p.nodes = (const uint32_t*)a.nodes;
   p.map = (const uint32_t*)a.map;
   p.din = (const R*)a.dist_in;
   p.dout = (R*)a.dist_out;

@@ -49,7 +49,7 @@ class SlfModuleDesc(Structure):
         ('tau_phi', c_double),
         ('sc_G', c_double * 4),
         ('sc_potential', c_int32),
-        ('reserved1', c_int32),
+        ('node_addressing', c_int32),
     ]
 
 
@@ -105,6 +105,9 @@ SIGNATURES = {
     'slf_graph_destroy': (c_int, [c_void_p]),
     'slf_last_error': (c_char_p, []),
 }
+
+SLF_ADDR_DIRECT, SLF_ADDR_INDIRECT = 0, 1
+SLF_INVALID_NODE = 0xffffffff
 
 _lib = None
 

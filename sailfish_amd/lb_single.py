@@ -40,10 +40,10 @@ class LBFluidSim(LBSim):
         gpu_v = runner.gpu_field(self.v)
         gpu_map = runner.gpu_geo_map()
         args1 = [runner.gpu_dist(0, 0)] + gpu_v + [gpu_rho, gpu_map]
-        runner.exec_kernel('SetInitialConditions', args1, 'P' * len(args1))
+        runner.exec_kernel('SetInitialConditions', *runner.add_indirect_args(args1, 'P' * len(args1)))
         if self.config.access_pattern == 'AB':
             args2 = [runner.gpu_dist(0, 1)] + gpu_v + [gpu_rho, gpu_map]
-            runner.exec_kernel('SetInitialConditions', args2, 'P' * len(args2))
+            runner.exec_kernel('SetInitialConditions', *runner.add_indirect_args(args2, 'P' * len(args2)))
 
     def _compute_kernels_arguments(self, runner, full_output, bulk):
         gpu_rho = runner.gpu_field(self.rho)
@@ -62,7 +62,9 @@ class LBFluidSim(LBSim):
         args1.append(np.uint32(options))
         args2.append(np.uint32(options))
         signature = 'P' * (len(args1) - 1) + 'i'
-        return signature, args1, args2
+        args1, sig1 = runner.add_indirect_args(args1, signature)
+        args2, _ = runner.add_indirect_args(args2, signature)
+        return sig1, args1, args2
 
     def get_compute_kernels(self, runner, full_output, bulk):
         signature, args1, args2 = self._compute_kernels_arguments(runner, full_output, bulk)
@@ -76,6 +78,8 @@ class LBFluidSim(LBSim):
 
     def get_pbc_kernels(self, runner):
         """grid copy (0 primary, 1 secondary) -> axis -> kernels (reference lb_single.py:153-185)."""
+        if runner.indirect:      # periodic axes are wrapped inside the sweep; no ghost-layer kernels exist
+            return defaultdict(lambda: defaultdict(list))
         gpu_dist1a = runner.gpu_dist(0, 0)
         gpu_dist1b = runner.gpu_dist(0, 1)
         kernels = defaultdict(lambda: defaultdict(list))

@@ -218,9 +218,13 @@ class Subdomain(object):
         self._encoder = None
         self._seen_types = set([0])
         self._needs_orientation = False
+        # indirect addressing only: dense boolean array over all nodes incl. ghosts, True = the node takes
+        # part in the simulation and owns a slot in the distribution arrays (reference subdomain.py:385-394)
         self.active_node_mask = None
         if self.config.node_addressing == 'indirect':
-            raise NotImplementedError('--node_addressing=indirect is not implemented by the HIP backend')
+            self.load_active_node_map(*self._get_mgrid_base(self.config))
+            self.config.logger.info('Fill ratio is: %0.2f%%' %
+                                    (self.active_nodes / float(self.spec.num_actual_nodes) * 100))
 
     def allocate(self):
         runner = self.spec.runner
@@ -256,8 +260,29 @@ class Subdomain(object):
             return array[hy + es, hx + es]
         return array[args[0] + es, hy + es, hx + es]
 
+    def load_active_node_map(self, *args):
+        """Sets active_node_mask (indirect addressing); override in a subclass, typically through
+        set_active_node_map_from_wall_map().  Default: every node is active (reference subdomain.py:425-435)."""
+        self.active_node_mask = np.ones(self.full_lat_shape, dtype=bool)
+        self.config.logger.warning('Using indirect addressing with all nodes active. Consider '
+                                   '--node_addressing=direct for better performance.')
+
+    def set_active_node_map_from_wall_map(self, wall_map):
+        """wall_map: Boolean array over all nodes incl. ghosts, True = solid.  Fluid nodes and every node
+        with a fluid neighbour (one layer of wall / ghost nodes) are active (reference subdomain.py:452-474;
+        the neighbourhood wraps around the array like its scipy 'wrap' convolution)."""
+        fluid = np.logical_not(np.asarray(wall_map, dtype=bool))
+        near = np.zeros(fluid.shape, dtype=bool)
+        for off in self._neighbour_offsets():
+            if not any(off):
+                continue
+            near |= np.roll(fluid, shift=tuple(-o for o in off), axis=tuple(range(fluid.ndim)))
+        self.active_node_mask = fluid | near
+
     @property
     def active_nodes(self):
+        if self.active_node_mask is not None:
+            return int(np.sum(self.active_node_mask))
         return reduce(operator.mul, self.lat_shape)
 
     @util.lazy_property

@@ -189,7 +189,59 @@ class SubdomainRunner(object):
         vis = self._subdomain.visualization_map()
         kw['fluid_only'] = int(np.all(vis == 0) and all(fused[a] or not local[a] or True for a in range(self.dim))
                                and self._no_open_faces())
+        if self.indirect:
+            # distributions hold the active nodes only; everything else stays dense
+            if any(local[a] and not fused[a] for a in range(self.dim)):
+                raise ValueError('--node_addressing=indirect needs in-sweep periodic boundaries '
+                                 '(do not combine with --nohip_fused_periodic)')
+            kw['fluid_only'] = 0
+            kw['node_addressing'] = hipabi.SLF_ADDR_INDIRECT
+            kw['dist_stride'] = (self._subdomain.active_nodes + 1 + 31) // 32 * 32   # + one spare slot (halo lists)
         return hipabi.make_desc(**kw)
+
+    @property
+    def indirect(self):
+        return getattr(self.config, 'node_addressing', 'direct') == 'indirect'
+
+    def _indirect_address_host(self):
+        """Dense table node -> slot (or SLF_INVALID_NODE) over the padded arrays, slots numbered in memory
+        order of the active nodes so that neighbouring active nodes have neighbouring slots
+        (reference _build_indirect_address_map, :829-837)."""
+        addr, _ = self.make_scalar_field(np.uint32, register=False, nonghost_view=False)
+        base = self._host_base[id(addr)]
+        base[:] = hipabi.SLF_INVALID_NODE
+        mask = self._subdomain.active_node_mask
+        addr[mask] = np.arange(int(mask.sum()), dtype=np.uint32)
+        return base
+
+    def _build_indirect_address_map(self):
+        self._host_indirect_address = self._indirect_address_host()
+        self._gpu_indirect_address = self.backend.alloc_buf(like=self._host_indirect_address)
+
+    def _translate_halo_links(self, links, addr_base, dense_nodes, dist_stride):
+        """Halo index lists (population * dense_nodes + dense node) -> (population * dist_stride + slot).
+        Halo nodes next to solid regions own no slot: they are routed to the spare slot behind the last
+        active node, so that both sides of a link keep lists of the same length and order."""
+        addr = addr_base.reshape(-1).astype(np.uint64)
+        spare = np.uint64(self._subdomain.active_nodes)
+        for link in links.values():
+            for kind in ('push_send', 'push_recv', 'pull_send', 'pull_recv'):
+                idx = getattr(link, kind)
+                q, node = idx // np.uint64(dense_nodes), idx % np.uint64(dense_nodes)
+                slot = addr[node.astype(np.int64)]
+                slot[slot == np.uint64(hipabi.SLF_INVALID_NODE)] = spare
+                setattr(link, kind, np.ascontiguousarray(q * np.uint64(dist_stride) + slot, dtype=np.uint64))
+        return links
+
+    def gpu_indirect_address(self):
+        return self._gpu_indirect_address
+
+    def add_indirect_args(self, args, signature):
+        """Indirect modules take the address table as an additional first kernel argument
+        (reference _add_indirect_args, :1153-1157)."""
+        if self.indirect:
+            return [self.gpu_indirect_address()] + list(args), 'P' + signature
+        return list(args), signature
 
     def _no_open_faces(self):
         """A fluid-only subdomain may skip the node map only if no real node can be reached from an
@@ -212,6 +264,8 @@ class SubdomainRunner(object):
             for comp in vec:
                 self._gpu_field_map[id(comp)] = b.alloc_buf(like=self._host_base[id(comp)])
         self._gpu_geo_map = b.alloc_buf(like=self._host_base[id(self._subdomain._type_map_ghost)])
+        if self.indirect:
+            self._build_indirect_address_map()
         nbytes = self._sim.grid.Q * self._dist_stride * self.float().itemsize
         off = b.dist_align_offset(self.float().itemsize)
         for _ in self._sim.grids:
@@ -260,9 +314,13 @@ class SubdomainRunner(object):
         if self._all_specs is None or len(self._all_specs) < 2:
             return
         arr = list(reversed(self._physical_size))
+        dense_nodes = self._get_nodes()
         links = subdomain_connection.build_halo_links(self._spec, self._all_specs, self._global_size,
                                                       self._global_periodic, self._sim.grid, arr,
-                                                      self._dist_stride, fused=self._fused)
+                                                      dense_nodes if self.indirect else self._dist_stride,
+                                                      fused=self._fused)
+        if self.indirect:
+            self._translate_halo_links(links, self._host_indirect_address, dense_nodes, self._dist_stride)
         b = self.backend
         if self._connector is None:
             from sailfish_amd.connector import LocalConnector
@@ -454,19 +512,32 @@ class SubdomainRunner(object):
                 self.backend.to_buf(self.gpu_field(comp))
 
     def _debug_get_dist(self, output=True, grid_num=0, copy=None):
-        """Distributions as [Q, (nz,) ny, arr_nx] (reference subdomain_runner.py:1363-1381)."""
+        """Distributions as [Q, (nz,) ny, arr_nx] (reference subdomain_runner.py:1363-1381); with indirect
+        addressing the slots are scattered back to their nodes (inactive nodes: 0)."""
         self.backend.sync_stream(self._calc_stream, self._data_stream)
         if copy is None:
             copy = 0 if not self._gpu_grids_secondary else (self._sim.iteration & 1)
         raw = np.zeros((self._sim.grid.Q, self._dist_stride), dtype=self.float)
         self.backend.from_buf(self.gpu_dist(grid_num, copy), raw)
+        if self.indirect:
+            addr = self._host_indirect_address.reshape(-1)
+            act = addr != hipabi.SLF_INVALID_NODE
+            dense = np.zeros((self._sim.grid.Q, self._get_nodes()), dtype=self.float)
+            dense[:, act] = raw[:, addr[act]]
+            return dense.reshape([self._sim.grid.Q] + self._physical_size)
         return np.ascontiguousarray(raw[:, :self._get_nodes()]).reshape([self._sim.grid.Q] + self._physical_size)
 
     def _debug_set_dist(self, dbuf, output=True, grid_num=0, copy=None):
         if copy is None:
             copy = 0 if not self._gpu_grids_secondary else (self._sim.iteration & 1)
         raw = np.zeros((self._sim.grid.Q, self._dist_stride), dtype=self.float)
-        raw[:, :self._get_nodes()] = np.asarray(dbuf, dtype=self.float).reshape(self._sim.grid.Q, -1)
+        dense = np.asarray(dbuf, dtype=self.float).reshape(self._sim.grid.Q, -1)
+        if self.indirect:
+            addr = self._host_indirect_address.reshape(-1)
+            act = addr != hipabi.SLF_INVALID_NODE
+            raw[:, addr[act]] = dense[:, act]
+        else:
+            raw[:, :self._get_nodes()] = dense
         self.backend.to_buf(self.gpu_dist(grid_num, copy), raw)
 
     def _debug_global_idx_to_tuple(self, gi):

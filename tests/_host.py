@@ -64,6 +64,7 @@ EXAMPLE_MAP = {
     ('ldc_3d', 'LDCSim'): ('examples.ldc_3d', 'CavitySim'),
     ('poiseuille', 'PoiseuilleSim'): ('examples.poiseuille', 'ChannelSim'),
     ('poiseuille_3d', 'PoiseuilleSim'): ('examples.poiseuille_3d', 'PipeSim'),
+    ('external_geometry', 'ExternalSimulation'): ('examples.external_geometry', 'GeometrySim'),
 }
 
 

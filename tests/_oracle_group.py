@@ -24,7 +24,15 @@ class OracleSubdomain(object):
         self.v = [np.ascontiguousarray(r.field_base(c), dtype=dt).reshape(self.o.shape) for c in r._sim.v]
         while len(self.v) < 3:
             self.v.append(np.zeros(self.o.shape, dtype=dt))
-        self.dist = [self.o.new_dist()] + ([] if self.aa else [self.o.new_dist()])
+        self.indirect = r.indirect
+        self.addr = None
+        if self.indirect:          # distributions: [Q, stride] arrays of active-node slots
+            self.addr = r._indirect_address_host()
+            self.o.set_nodes(self.addr)
+            new = self.o.new_sparse_dist
+        else:
+            new = self.o.new_dist
+        self.dist = [new()] + ([] if self.aa else [new()])
         with np.errstate(all='ignore'):
             for d in self.dist:
                 self.o.init(d, self.rho, self.v[0], self.v[1], self.v[2])
@@ -34,16 +42,30 @@ class OracleSubdomain(object):
         self.links = {}
         if len(r._all_specs) > 1:
             arr = list(reversed(r._physical_size))
+            dense_nodes = int(np.prod(self.o.shape))
+            stride = hipabi.dist_stride(self.desc)
             self.links = subdomain_connection.build_halo_links(
                 r._spec, r._all_specs, r._global_size, r._global_periodic, r._sim.grid, arr,
-                hipabi.dist_stride(self.desc), fused=r._fused)
+                dense_nodes if self.indirect else stride, fused=r._fused)
+            if self.indirect:
+                r._translate_halo_links(self.links, self.addr, dense_nodes, stride)
 
     def raw(self, dist):
         """Flat view of the whole strided distribution buffer."""
-        base = dist.base
+        base = dist
         while base.base is not None:
             base = base.base
         return base.reshape(-1)
+
+    def dense(self, dist):
+        """[Q, nz, ny, nx] view / copy of a distribution array (indirect: slots scattered to their nodes)."""
+        if not self.indirect:
+            return dist
+        addr = self.addr.reshape(-1)
+        act = addr != hipabi.SLF_INVALID_NODE
+        out = np.zeros((self.o.Q, addr.size), dtype=self.o.dtype)
+        out[:, act] = dist[:, addr[act]]
+        return out.reshape((self.o.Q,) + self.o.shape)
 
     def compute(self, save=False):
         it = self.iteration
@@ -120,7 +142,7 @@ class OracleGroup(object):
             sl = tuple(slice(o, o + n) for o, n in zip(reversed(sp.location), reversed(sp.size)))
             if what == 'dist':
                 cur = s.dist[0] if s.aa else s.dist[s.iteration & 1]
-                out[(slice(None),) + sl] = s.real(cur)
+                out[(slice(None),) + sl] = s.real(s.dense(cur))
             elif what == 'rho':
                 out[sl] = s.real(s.rho)
             else:

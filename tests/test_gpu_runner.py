@@ -290,3 +290,21 @@ def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
             assert abs(err - recorded) < 5e-3, (visc, err, recorded)
         worst = max(worst, abs(err))
     assert worst < (3e-4 if precision == 'double' else 5e-3)
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('nsub,axis,model', [(1, 'x', 'bgk'), (2, 'x', 'mrt'), (2, 'y', 'bgk')])
+def test_indirect_addressing(pattern, nsub, axis, model):
+    """--node_addressing=indirect (reference subdomain_runner.py:829-878): distributions stored for the
+    active nodes only.  GPU == oracle twin (which tests/test_indirect_oracle.py shows to equal the dense
+    run on every fluid node), and the distribution buffers shrink with the fill ratio."""
+    cfg = dict(lat_nx=48, lat_ny=21, lat_nz=21, visc=0.05, periodic_x=True, grid='D3Q19', node_addressing='indirect',
+               access_pattern=pattern, model=model, subdomains=nsub, conn_axis=axis)
+    ctrl, exact = check_against_oracle('external_geometry', 'ExternalSimulation', 3, cfg, 25, 1e-4)
+    assert exact
+    for r in ctrl.runners:
+        dense = int(np.prod(r._physical_size))
+        assert r._dist_stride < 0.8 * dense and r._dist_stride >= r._subdomain.active_nodes + 1
+        assert r._desc.node_addressing == 1
+    v = merged_gpu(ctrl, 'v0')
+    assert np.nanmax(v) > 1e-6
