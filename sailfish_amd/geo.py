@@ -79,3 +79,44 @@ class EqualSubdomainsGeometry3D(LBGeometry3D):
         elif self.config.conn_axis == 'y':
             return [SubdomainSpec3D((0, o, 0), (self.gx, n, self.gz)) for o, n in _split(self.gy, s)]
         return [SubdomainSpec3D((0, 0, o), (self.gx, self.gy, n)) for o, n in _split(self.gz, s)]
+
+
+class WeightedSubdomainsGeometry3D(EqualSubdomainsGeometry3D):
+    """Slabs along --conn_axis holding (nearly) the same number of *active* nodes each, for sparse
+    geometries where equal-size slabs would leave some GPUs idle (reference geo.py:137-176).
+
+    --geometry_for_decomposition: .npy Boolean array [nz, ny, nx], True = inactive node.  The reference
+    builds the node count profile over the wrong array axis for conn_axis != y (its array is z, y, x but
+    it indexes the axes as x, y, z); here the profile is taken along the connection axis itself."""
+
+    @classmethod
+    def add_options(cls, group):
+        EqualSubdomainsGeometry3D.add_options(group)
+        group.add_argument('--geometry_for_decomposition', type=str, default='',
+                           help='Numpy boolean array with True entries indicating inactive nodes to use to '
+                                'decide where to split the domain.')
+
+    def subdomains(self):
+        src = getattr(self.config, 'geometry_for_decomposition', '')
+        if src is None or (isinstance(src, str) and not src):
+            return super(WeightedSubdomainsGeometry3D, self).subdomains()
+        import numpy as np
+        inactive = np.load(src) if isinstance(src, str) else np.asarray(src)
+        assert inactive.shape == (self.gz, self.gy, self.gx), 'decomposition geometry does not match the lattice'
+        axis = 'xyz'.index(self.config.conn_axis)
+        other = tuple(a for a in range(3) if a != 2 - axis)          # array axes are z, y, x
+        profile = np.cumsum(np.sum(np.logical_not(inactive), axis=other).astype(np.int64))
+        n, total = int(self.config.subdomains), int(profile[-1])
+        # cut after the first layer whose cumulative count reaches k / n of the total
+        cuts = [0]
+        for k in range(1, n):
+            c = int(np.searchsorted(profile, (total * k + n - 1) // n)) + 1
+            cuts.append(min(max(c, cuts[-1] + 1), len(profile) - (n - k)))
+        cuts.append(len(profile))
+        gsize = [self.gx, self.gy, self.gz]
+        ret = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            start, size = [0, 0, 0], list(gsize)
+            start[axis], size[axis] = lo, hi - lo
+            ret.append(SubdomainSpec3D(tuple(start), tuple(size)))
+        return ret

@@ -85,3 +85,31 @@ def test_padded_sizes_known_answers():
     r = SubdomainRunner(LBFluidSim(cfg), spec, None, _host.HostOnlyBackend())
     r._init_shape()
     assert r._physical_size == [7, 5, 8] and r.num_phys_nodes == 280
+
+
+def test_weighted_subdomains_balance_active_nodes(tmp_path):
+    """WeightedSubdomainsGeometry3D (reference geo.py:137-176): slabs with about the same number of active
+    nodes; falls back to equal slabs without a decomposition geometry."""
+    from sailfish_amd.geo import EqualSubdomainsGeometry3D, WeightedSubdomainsGeometry3D
+    from tests._host import make_config
+    nx, ny, nz = 40, 12, 10
+    inactive = np.ones((nz, ny, nx), dtype=bool)
+    # a cone-like channel: wide at low x, narrow at high x
+    for x in range(nx):
+        w = max(1, int(5 * (1.0 - x / float(nx)) ** 2) + 1)
+        inactive[nz // 2 - w:nz // 2 + w, ny // 2 - w:ny // 2 + w, x] = False
+    fn = str(tmp_path / 'geo.npy')
+    np.save(fn, inactive)
+    cfg = make_config(3, lat_nx=nx, lat_ny=ny, lat_nz=nz, subdomains=4, conn_axis='x', geometry_for_decomposition=fn)
+    specs = WeightedSubdomainsGeometry3D(cfg).subdomains()
+    assert len(specs) == 4 and specs[0].location[0] == 0 and specs[-1].end_location[0] == nx
+    for a, b in zip(specs[:-1], specs[1:]):
+        assert a.end_location[0] == b.location[0]            # contiguous, no overlap
+    counts = [int((~inactive[:, :, s.location[0]:s.end_location[0]]).sum()) for s in specs]
+    total = int((~inactive).sum())
+    assert sum(counts) == total
+    assert max(counts) - min(counts) <= 0.35 * total / 4       # balanced to within a layer of the wide end
+    equal = [s.size[0] for s in EqualSubdomainsGeometry3D(cfg).subdomains()]
+    assert [s.size[0] for s in specs] != equal and specs[0].size[0] < specs[-1].size[0]
+    cfg.geometry_for_decomposition = ''
+    assert [s.size[0] for s in WeightedSubdomainsGeometry3D(cfg).subdomains()] == equal
