@@ -185,10 +185,10 @@ class SubdomainRunner(object):
         kw['periodic_local'] = [int(x) for x in local] + [0] * (3 - self.dim)
         kw['periodic_fused'] = fused + [0] * (3 - self.dim)
         self._fused = fused
-        # fast path: every real node is a plain fluid node -> the sweep does not read the node map
-        vis = self._subdomain.visualization_map()
-        kw['fluid_only'] = int(np.all(vis == 0) and all(fused[a] or not local[a] or True for a in range(self.dim))
-                               and self._no_open_faces())
+        # fast path: every real node is a plain fluid node -> the sweep does not read the node map (ghost
+        # nodes behind an unconnected, non-periodic face are never pulled from by a fluid-only interior
+        # in any way that matters: what they hold is what a wall of excluded nodes would hold)
+        kw['fluid_only'] = int(np.all(self._subdomain.visualization_map() == 0))
         if self.indirect:
             # distributions hold the active nodes only; everything else stays dense
             if any(local[a] and not fused[a] for a in range(self.dim)):
@@ -242,12 +242,6 @@ class SubdomainRunner(object):
         if self.indirect:
             return [self.gpu_indirect_address()] + list(args), 'P' + signature
         return list(args), signature
-
-    def _no_open_faces(self):
-        """A fluid-only subdomain may skip the node map only if no real node can be reached from an
-        unconnected, non-periodic face (there the ghost layer plays the role of a wall of excluded
-        nodes and the map would be identical anyway) -- i.e. always; kept explicit for clarity."""
-        return True
 
     def _init_compute(self):
         self._desc = self._module_desc()
