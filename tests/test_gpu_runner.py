@@ -267,8 +267,8 @@ def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
     127 x 128 force-driven channel (full-way bounce-back) after 100/visc iterations, 30 viscosities from
     1e-3 to 1e-1, against the numbers the reference recorded from its GPU path
     (tests/golden/poiseuille_curves/).  Recorded by an older revision => envelope: our error may not be
-    larger than the recorded one (plus a small absolute slack), and single precision must agree with it
-    closely where round-off does not dominate (visc >= 0.02)."""
+    larger than the recorded one (plus a small absolute slack); single precision is compared where round-off
+    does not dominate the recorded values (visc >= 0.02; they scatter by several 1e-3 there)."""
     data = np.loadtxt(os.path.join(golden_dir, 'poiseuille_curves', 'D2Q9_%s_force_%s_fullbb.dat' % (model, precision)))
     assert data.shape == (30, 2)
     sim_cls = _host.load_sim_class('poiseuille', 'PoiseuilleSim')
@@ -287,7 +287,7 @@ def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
         if precision == 'double':
             assert abs(err) <= abs(recorded) + 5e-5, (visc, err, recorded)
         else:
-            assert abs(err - recorded) < 5e-3, (visc, err, recorded)
+            assert abs(err) <= abs(recorded) + 1e-3, (visc, err, recorded)
         worst = max(worst, abs(err))
     assert worst < (3e-4 if precision == 'double' else 5e-3)
 
