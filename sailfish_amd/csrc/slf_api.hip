@@ -396,6 +396,7 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   g.use_link_tags = d->use_link_tags;
   g.indirect = d->node_addressing == SLF_ADDR_INDIRECT;
   g.variant = SLF_DEFAULT_VARIANT;
+  if (d->sparse_geometry) g.variant |= 64;
   if (const char* ev = getenv("SLF_VARIANT")) g.variant = atoi(ev);
   slf::Physics& ph = m->phys;
   ph.tau = d->tau;

@@ -22,7 +22,11 @@
 
 namespace slf {
 
-template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT>
+// SPEC (node-map kernels): issue the population loads BEFORE the node map is read instead of predicating
+// them on it.  A workgroup advances at the pace of its slowest wave (barrier in row_push), so the extra
+// dependent round trip map -> loads costs 4-6 % of the odd step at 512^3 (profiles/r01/row_probe7.log, row_probe8.log); loading for excluded
+// nodes as well wastes their bytes, so the host asks for SPEC only when few nodes are excluded.
+template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool SPEC = false>
 __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
   const Geometry& g = p.g;
@@ -38,6 +42,21 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
   const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
   const size_t ds = g.dist_size;
 
+  // ---- load.  Odd AA step: pull with plain x-shifted loads -- misaligned *reads* cost little (the
+  // neighbouring wave uses the rest of the line; measured equal to an LDS exchange of aligned loads,
+  // profiles/r01/row_probe4.log) and save a barrier; the push below is what must be aligned.
+  R f[L::Q];
+  auto src_of = [&](auto I) -> const R* {
+    if constexpr (PROP == PROP_AA_ODD) {
+      const int off = dir_offset<L, I>(ox, oy, oz, false);
+      return p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gi + off);
+    } else {
+      return p.din + ds * (size_t)I + gi;
+    }
+  };
+  if constexpr (SPEC || !GENERAL) {
+    static_for<0, L::Q>([&](auto I) { f[I] = ld<NT>(src_of(I)); });
+  }
   int kind = NK_FLUID;
   uint32_t code = 0;
   bool active = live;
@@ -46,21 +65,9 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
     kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
     active = live && !kind_is_excluded(kind);
   }
-  // ---- load.  Odd AA step: pull with plain x-shifted loads -- misaligned *reads* cost little (the
-  // neighbouring wave uses the rest of the line; measured equal to an LDS exchange of aligned loads,
-  // profiles/r01/row_probe4.log) and save a barrier; the push below is what must be aligned.
-  // (Issuing the loads before the node map has arrived was tried and does not pay: row_probe5.log.)
-  R f[L::Q];
-  static_for<0, L::Q>([&](auto I) {
-    const R* src;
-    if constexpr (PROP == PROP_AA_ODD) {
-      const int off = dir_offset<L, I>(ox, oy, oz, false);
-      src = p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gi + off);
-    } else {
-      src = p.din + ds * (size_t)I + gi;
-    }
-    f[I] = active ? ld<NT>(src) : (R)0;
-  });
+  if constexpr (GENERAL && !SPEC) {
+    static_for<0, L::Q>([&](auto I) { f[I] = active ? ld<NT>(src_of(I)) : (R)0; });
+  }
 
   R rho, v[3];
   bool wet = true;
@@ -117,8 +124,14 @@ static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, i
   dim3 block(bx, 1, 1);
   dim3 grid(1, ny, nz);
   switch (prop) {
-    case PROP_AB: hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT>), grid, block, 0, s, p); break;
-    case PROP_AA_ODD: hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT>), grid, block, 0, s, p); break;
+    case PROP_AB:   // (no gain from SPEC here: row_probe8.log)
+      hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT>), grid, block, 0, s, p);
+      break;
+    case PROP_AA_ODD:
+      // variant bit 64 = the module descriptor says "sparse geometry" (many excluded nodes): predicate
+      if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, GENERAL>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT>), grid, block, 0, s, p);
+      break;
     default: hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT>), grid, block, 0, s, p); break;
   }
 }

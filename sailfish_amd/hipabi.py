@@ -50,6 +50,7 @@ class SlfModuleDesc(Structure):
         ('sc_G', c_double * 4),
         ('sc_potential', c_int32),
         ('node_addressing', c_int32),
+        ('sparse_geometry', c_int32),
     ]
 
 

@@ -24,6 +24,7 @@ import time
 import numpy as np
 
 from sailfish_amd import hipabi, io, subdomain_connection, util
+from sailfish_amd import node_type as nt
 from sailfish_amd.lb_base import LBSim  # noqa: F401  (type reference)
 from sailfish_amd.profile import TimeProfile
 
@@ -188,7 +189,10 @@ class SubdomainRunner(object):
         # fast path: every real node is a plain fluid node -> the sweep does not read the node map (ghost
         # nodes behind an unconnected, non-periodic face are never pulled from by a fluid-only interior
         # in any way that matters: what they hold is what a wall of excluded nodes would hold)
-        kw['fluid_only'] = int(np.all(self._subdomain.visualization_map() == 0))
+        vis = self._subdomain.visualization_map()
+        kw['fluid_only'] = int(np.all(vis == 0))
+        excluded = np.isin(vis, [nt._NTUnused.id, nt._NTGhost.id, nt._NTPropagationOnly.id])
+        kw['sparse_geometry'] = int(excluded.mean() > 0.05)
         if self.indirect:
             # distributions hold the active nodes only; everything else stays dense
             if any(local[a] and not fused[a] for a in range(self.dim)):
