@@ -113,3 +113,58 @@ def test_weighted_subdomains_balance_active_nodes(tmp_path):
     assert [s.size[0] for s in specs] != equal and specs[0].size[0] < specs[-1].size[0]
     cfg.geometry_for_decomposition = ''
     assert [s.size[0] for s in WeightedSubdomainsGeometry3D(cfg).subdomains()] == equal
+
+
+REF_EXAMPLES = [
+    ('sc_phase_separation', 'SCSim', 2, {}),
+    ('binary_fluid/sc_separation_2d', 'SeparationSCSim', 2, {}),
+    ('binary_fluid/sc_separation_3d', 'SeparationSCSim', 3, {'lat_nx': 24, 'lat_ny': 20, 'lat_nz': 16}),
+    ('external_geometry', 'ExternalSimulation', 3, {}),
+    ('external_geometry', 'ExternalSimulation', 3, {'node_addressing': 'indirect'}),
+]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='/root/reference not available on this machine')
+@pytest.mark.parametrize('module,sim,dim,extra', REF_EXAMPLES)
+def test_more_reference_examples_load_unchanged(module, sim, dim, extra):
+    """The reference's own example files (Shan-Chen models, external geometry incl. indirect addressing),
+    imported unchanged against the `sailfish` alias package: options parse, the subdomain geometry and the
+    initial fields build, and the module descriptor for the HIP backend comes out (no GPU involved)."""
+    import importlib.util
+    import sailfish  # noqa: F401
+    from sailfish_amd import hipabi
+    path = os.path.join('/root/reference/examples', module + '.py')
+    spec = importlib.util.spec_from_file_location('refexample_' + module.replace('/', '_'), path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sim_cls = getattr(mod, sim)
+    from sailfish_amd.lb_base import LBSim
+    assert issubclass(sim_cls, LBSim)
+    defaults = {}
+    sim_cls.update_defaults(defaults)
+    cfg = dict(defaults)
+    cfg.update(extra)
+    if module == 'external_geometry':
+        cfg['geometry'] = 'pipe.npy'
+    geo = 'LBGeometry%dD' % dim
+    # every option at its declared default (the example's own add_options included), as the command line
+    # parser of the controller would deliver them
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    ctrl = LBSimulationController(sim_cls, getattr(geo_mod, geo), default_config=cfg)
+    parsed = ctrl._config_parser.parse([])
+    full = dict((k, v) for k, v in vars(parsed).items() if not k.startswith('_'))
+    full.update(cfg)
+    cfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, full)
+    r = runners[0]
+    r._init_geometry()
+    r._sim.init_fields(r)
+    r._subdomain.init_fields(r._sim)
+    desc = r._module_desc()
+    assert desc.lat_nx == cfg_.lat_nx + 2
+    assert np.isfinite(r._sim.rho).all() and r._subdomain.num_fluid_nodes > 0
+    if extra.get('node_addressing') == 'indirect':
+        assert desc.node_addressing == hipabi.SLF_ADDR_INDIRECT
+        assert r._subdomain.active_nodes < 0.8 * np.prod(r._subdomain.full_lat_shape)
+    if 'sc_' in module:
+        assert desc.simtype in (hipabi.SLF_SIM_SHAN_CHEN_BINARY, hipabi.SLF_SIM_SHAN_CHEN_SINGLE)
