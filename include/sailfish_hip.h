@@ -180,6 +180,10 @@ int slf_graph_destroy(slf_graph* g);
  *      (backend_cuda.py:193-251, 128-130) ---- */
 int slf_module_create(slf_ctx* ctx, const slf_module_desc* desc, slf_module** out); /* build() */
 int slf_module_destroy(slf_module* m);
+/* On-GPU invalid value check (reference --check_invalid_results_gpu, geo_helpers.mako:193-213): sweep kernels
+ * launched with bit 2 (value 4) of their `options` argument set flag wet nodes whose density is not finite.
+ * Waits for `stream`, returns out = {flag, x, y, z} of the first such node and clears the flag. */
+int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]);
 /* Kernel names are the reference's: "CollideAndPropagate",
  * "SetInitialConditions", "ApplyPeriodicBoundaryConditions",
  * "ApplyPeriodicBoundaryConditionsWithSwap" (AA modules only),

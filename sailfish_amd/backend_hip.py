@@ -376,6 +376,14 @@ class HIPBackend(object):
                'slf_kernel_launch(%s)' % kernel.name)
 
     # -- streams / events -----------------------------------------------------
+    def poll_invalid(self, module, stream):
+        """(x, y, z) of a wet node with a non-finite density seen by a sweep since the last poll, or None
+        (on-GPU invalid value check; waits for `stream`)."""
+        out = (ctypes.c_int32 * 4)()
+        _check(self._lib, self._lib.slf_module_poll_invalid(module.handle, stream.handle if stream else None,
+                                                          ctypes.byref(out)), 'slf_module_poll_invalid')
+        return (out[1], out[2], out[3]) if out[0] else None
+
     def capture_graph(self, stream, enqueue):
         """Records everything `enqueue()` puts on `stream` (nothing executes) and returns a HIPGraph."""
         _check(self._lib, self._lib.slf_graph_capture_begin(stream.handle), 'slf_graph_capture_begin')

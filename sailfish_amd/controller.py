@@ -176,7 +176,9 @@ class LBSimulationController(object):
                            dest='check_invalid_results_host', default=True,
                            help='do not terminate when the host-side results contain inf / nan')
         group.add_argument('--nocheck_invalid_results_gpu', action='store_false',
-                           dest='check_invalid_results_gpu', default=True, help='(accepted for compatibility)')
+                           dest='check_invalid_results_gpu', default=True,
+                           help='If True, will terminate the simulation when invalid values (inf, nan) are detected '
+                                'in the domain during the simulation.')
         group.add_argument('--seed', type=int, default=int(time.time()), help='PRNG seed value')
 
         group = self._config_parser.add_group('Checkpointing')

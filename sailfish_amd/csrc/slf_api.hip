@@ -77,6 +77,7 @@ struct slf_module {
   int access_pattern;
   int block_x;
   void* node_params;  // device copy, in the module's precision
+  uint32_t* status;   // device {flag, x, y, z} of the on-GPU invalid value check
 };
 struct slf_kernel {
   slf_module* mod;
@@ -431,6 +432,7 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   if (env && atoi(env) >= 64 && atoi(env) <= 1024 && atoi(env) % 64 == 0) bx = atoi(env);
   m->block_x = bx;
   m->node_params = nullptr;
+  m->status = nullptr;
   const int np = d->n_node_params > 0 ? d->n_node_params : 1;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc(&m->node_params, (size_t)np * d->precision);
@@ -452,6 +454,14 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
     delete m;
     return hip_fail(e, "hipMemcpy(node_params)");
   }
+  e = hipMalloc((void**)&m->status, 4 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(m->status, 0, 4 * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    hipFree(m->node_params);
+    if (m->status) hipFree(m->status);
+    delete m;
+    return hip_fail(e, "hipMalloc(status)");
+  }
   *out = m;
   return SLF_OK;
 }
@@ -459,8 +469,20 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
 int slf_module_destroy(slf_module* m) {
   if (m) {
     if (m->node_params) hipFree(m->node_params);
+    if (m->status) hipFree(m->status);
     delete m;
   }
+  return SLF_OK;
+}
+
+int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]) {
+  if (!m || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  uint32_t h[4] = {0, 0, 0, 0};
+  SLF_HIP(hipSetDevice(m->ctx->device));
+  SLF_HIP(hipMemcpyAsync(h, m->status, sizeof(h), hipMemcpyDeviceToHost, native(stream)));
+  SLF_HIP(hipStreamSynchronize(native(stream)));
+  for (int i = 0; i < 4; i++) out[i] = (int32_t)h[i];
+  if (h[0]) SLF_HIP(hipMemsetAsync(m->status, 0, sizeof(h), native(stream)));
   return SLF_OK;
 }
 
@@ -580,6 +602,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.v[1] = (void*)k->ptrs[b0 + 5];
       a.v[2] = g.dim == 3 ? (void*)k->ptrs[b0 + 6] : nullptr;
       a.node_params = m->node_params;
+      a.status = m->status;
       a.options = (uint32_t)k->ints[0];
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       if (g.indirect && !a.nodes) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
@@ -617,6 +640,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.v[1] = (void*)k->ptrs[6];
       a.v[2] = g.dim == 3 ? (void*)k->ptrs[7] : nullptr;
       a.node_params = m->node_params;
+      a.status = m->status;
       a.options = (uint32_t)k->ints[0];
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       slf::Prop prop = slf::PROP_AB;
@@ -645,6 +669,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.dist_in = (void*)k->ptrs[1];
       a.phi = nullptr;
       a.node_params = m->node_params;
+      a.status = m->status;
       a.options = (uint32_t)k->ints[0];
       if (k->kind == KK_SCS_MACRO) {
         a.dist_out = nullptr;

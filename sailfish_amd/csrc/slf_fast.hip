@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const S
     static_for<0, L::Q>([&](auto I) { f[I] = vget<VEC>(fv[I], k); });
     float rho, v[3];
     macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
+    if (gx0 + k <= g.lat_nx - 2) check_invalid<float>(p.status, p.options, rho, gx0 + k, gy, gz);
     if (p.relaxation_enabled) {
       if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
       else mrt_relax<L, float>(f, v, p.cp, false);
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q
   });
   float rho, v[3];
   macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
+  check_invalid<float>(p.status, p.options, rho, gx, gy, gz);
   if (p.relaxation_enabled) {
     if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
     else mrt_relax<L, float>(f, v, p.cp, false);
@@ -202,6 +204,7 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
 
   float rho, v[3];
   macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
+  if (live) check_invalid<float>(p.status, p.options, rho, x, gy, gz);
   if (p.relaxation_enabled) {
     if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
     else mrt_relax<L, float>(f, v, p.cp, false);

@@ -53,6 +53,7 @@ struct SweepArgs {
   void* phi;        // second density field (binary Shan-Chen), else unused
   void* v[3];
   const void* node_params;
+  void* status;        // device uint32[4]: invalid-value flag + position
   uint32_t options;
 };
 

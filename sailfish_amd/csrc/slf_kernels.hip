@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
   bool wet = true;
   node_update<L, R, MODEL, PROP, GENERAL, INDIRECT>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
 
+  if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
   // ---- macroscopic output (save_macro_fields, kernel_common.mako:213-240)
   if ((p.options & 1u) && wet) {
     p.rho[gi] = rho;

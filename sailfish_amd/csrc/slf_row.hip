@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
   bool wet = true;
   if (active) {
     node_update<L, R, MODEL, PROP, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+    if (wet) check_invalid<R>(p.status, p.options, rho, x, gy, gz);
     if ((p.options & 1u) && wet) {
       p.rho[gi] = rho;
       p.vx[gi] = v[0];
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   R rho, v[3];
   bool wet = true;
   node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+  if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
   if ((p.options & 1u) && wet) {
     p.rho[gi] = rho;
     p.vx[gi] = v[0];

@@ -18,6 +18,7 @@ struct SweepParams {
   R* vy;
   R* vz;
   const R* __restrict__ node_params;
+  uint32_t* status;     // module-level {flag, x, y, z} for the on-GPU invalid value check (options bit 2)
   uint32_t options;
   int y0, z0;
   int relaxation_enabled;
@@ -68,6 +69,22 @@ __device__ __forceinline__ void st(T* p, T v) {
 // pre-collision boundary conditions, collision, half-way bounce-back stores (reference
 // lb_single_fluid.mako:175-228).  Shared by all sweep kernels so that they differ only in access shape.
 constexpr uint32_t INVALID_NODE = 0xffffffffu;
+constexpr uint32_t OPTION_CHECK_INVALID = 4u;   // kernel `options`: 1 save macro fields, 2 bulk (reference), 4 this
+
+// On-GPU invalid value check (reference checkInvalidValues, geo_helpers.mako:193-213, enabled by
+// --check_invalid_results_gpu): the reference prints and traps; here a wet node whose density is not
+// finite (any non-finite population makes it so) raises a flag and records the first position, and the
+// host polls it with slf_module_poll_invalid() -- the run ends with backend.FatalError instead of a dead GPU.
+template <class R>
+__device__ __forceinline__ void check_invalid(uint32_t* status, uint32_t options, R rho, int x, int y, int z) {
+  if ((options & OPTION_CHECK_INVALID) && !__builtin_isfinite(rho)) {
+    if (atomicOr(status, 1u) == 0u) {
+      status[1] = (uint32_t)x;
+      status[2] = (uint32_t)y;
+      status[3] = (uint32_t)z;
+    }
+  }
+}
 
 // gi: dense node index; si: the node's slot in the distribution arrays (= gi unless INDIRECT).
 template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false>
@@ -176,6 +193,7 @@ inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const
   p.vy = (R*)a.v[1];
   p.vz = (R*)a.v[2];
   p.node_params = (const R*)a.node_params;
+  p.status = (uint32_t*)a.status;
   p.options = a.options;
   p.y0 = y0;
   p.z0 = z0;

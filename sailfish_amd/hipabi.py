@@ -100,6 +100,7 @@ SIGNATURES = {
     'slf_kernel_set_args': (c_int, [c_void_p, c_char_p, POINTER(c_void_p), c_int, c_int]),
     'slf_kernel_set_iteration': (c_int, [c_void_p, c_uint32]),
     'slf_kernel_launch': (c_int, [c_void_p, POINTER(SlfRegion), c_void_p]),
+    'slf_module_poll_invalid': (c_int, [c_void_p, c_void_p, POINTER(c_int32 * 4)]),
     'slf_graph_capture_begin': (c_int, [c_void_p]),
     'slf_graph_capture_end': (c_int, [c_void_p, POINTER(c_void_p)]),
     'slf_graph_launch': (c_int, [c_void_p, c_void_p]),

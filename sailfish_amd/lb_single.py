@@ -59,6 +59,8 @@ class LBFluidSim(LBSim):
             options |= 1
         if bulk:
             options |= 2
+        if getattr(self.config, 'check_invalid_results_gpu', False):
+            options |= 4      # on-GPU invalid value check (slf_module_poll_invalid)
         args1.append(np.uint32(options))
         args2.append(np.uint32(options))
         signature = 'P' * (len(args1) - 1) + 'i'

@@ -612,9 +612,22 @@ class SubdomainRunner(object):
             sync_req = fields_req = True
         return sync_req, fields_req, output_req
 
+    def check_gpu_invalid(self):
+        """On-GPU invalid value check (reference --check_invalid_results_gpu): the sweeps flag wet nodes with
+        a non-finite density; polled whenever the host synchronises with the device anyway."""
+        if not getattr(self.config, 'check_invalid_results_gpu', False):
+            return
+        pos = self.backend.poll_invalid(self.module, self._calc_stream)
+        if pos is not None:
+            gpos = [int(p) - 1 + o for p, o in zip(pos, self._spec.location)]
+            raise self.backend.FatalError(
+                'Invalid value (inf / nan) detected on the GPU: subdomain %d, node %s (global position %s), '
+                'before iteration %d' % (self._spec.id, tuple(pos[:self.dim]), tuple(gpos), self._sim.iteration))
+
     def post_step(self, sync_req, output_req):
         cfg = self.config
         if sync_req:
+            self.check_gpu_invalid()
             self._fields_to_host(True)
             if getattr(cfg, 'check_invalid_results_host', True) and self._output is not None and \
                     self._output._fluid_map is not None and not self._output.verify():
@@ -706,6 +719,7 @@ class SubdomainRunner(object):
 
     def finish(self):
         self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self.check_gpu_invalid()
         if getattr(self.config, 'final_checkpoint', False) and self.config.checkpoint_file:
             self.save_checkpoint()
         self._sim.after_main_loop(self)

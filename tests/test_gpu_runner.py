@@ -308,3 +308,31 @@ def test_indirect_addressing(pattern, nsub, axis, model):
         assert r._desc.node_addressing == 1
     v = merged_gpu(ctrl, 'v0')
     assert np.nanmax(v) > 1e-6
+
+
+def test_gpu_invalid_value_check():
+    """--check_invalid_results_gpu (reference geo_helpers.mako:193-213, default on): a sweep that meets a wet
+    node with a non-finite density raises a flag on the device; the runner turns it into backend.FatalError with
+    the position instead of writing garbage.  Switched off, the host-side check of the output catches it."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.backend_hip import HIPFatalError
+    from sailfish_amd.controller import LBSimulationController
+    base = _host.load_sim_class('ldc_2d', 'LDCSim')
+
+    class Poisoned(base.subdomain):
+        def initial_conditions(self, sim, hx, hy):
+            base.subdomain.initial_conditions(self, sim, hx, hy)
+            sim.vx[12, 10] = 1e20              # feq overflows -> inf - inf -> nan in the first sweep
+
+    sim_cls = type('PoisonedSim', (base,), {'subdomain': Poisoned})
+    cfg = dict(lat_nx=32, lat_ny=24, visc=0.05, access_pattern='AA', max_iters=20, quiet=True, perf_stats_every=0)
+    with pytest.raises(HIPFatalError, match='Invalid value .*detected on the GPU: subdomain 0') as info:
+        LBSimulationController(sim_cls, getattr(geo_mod, GEO[2]), default_config=dict(cfg)).run(ignore_cmdline=True)
+    assert 'node (' in str(info.value)
+    with pytest.raises(RuntimeError, match='Invalid value detected in output'):
+        LBSimulationController(sim_cls, getattr(geo_mod, GEO[2]),
+                               default_config=dict(cfg, check_invalid_results_gpu=False, output='/tmp/slf_poisoned')
+                               ).run(ignore_cmdline=True)
+    # a healthy run is not affected
+    ctrl = run_gpu('ldc_2d', 'LDCSim', 2, dict(lat_nx=32, lat_ny=24, visc=0.05), 20)
+    assert np.isfinite(ctrl.runners[0]._sim.rho[1:-1, 1:-1]).all()
