@@ -21,7 +21,6 @@ generated CUDA/OpenCL text):
 Everything calls libsailfish_hip.so through ctypes; there is no CPU fallback.
 """
 import ctypes
-import os
 
 import numpy as np
 

@@ -6,7 +6,7 @@ exception is raised.
 import ctypes
 import os
 
-from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint32,
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint32,
                     c_void_p)
 
 SLF_MAX_NODE_TYPES = 16

@@ -2,7 +2,6 @@
 its regression tests rely on: <base>.<subdomain>.<iter>.npz with fields rho, v)."""
 import glob
 import math
-import os
 import re
 
 import numpy as np

@@ -4,7 +4,7 @@ from collections import defaultdict, namedtuple
 import numpy as np
 
 from sailfish_amd import hipabi, subdomain_runner, sym
-from sailfish_amd.lb_base import KernelPair, LBForcedSim, LBSim, ScalarField, VectorField
+from sailfish_amd.lb_base import LBForcedSim, LBSim, ScalarField, VectorField
 
 MacroKernels = namedtuple('MacroKernels', 'distributions macro')
 

@@ -166,6 +166,4 @@ class SlabSim(BoxSim):
         vz = np.broadcast_to((0.05 * np.sin(2 * np.pi * x / nx))[None, None, :], (nz, ny, nx))
         self.set_fields(rho, [vx.astype(self.dtype), vy.astype(self.dtype), vz.astype(self.dtype)])
         self.initial_conditions()
-        if self.world > 1 and self.aa is False:
-            pass
         self.sync()

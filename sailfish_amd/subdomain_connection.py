@@ -24,7 +24,6 @@ periodic-boundary kernels.
 """
 import numpy as np
 
-from sailfish_amd import hipabi
 
 
 class HaloLink(object):
