@@ -39,3 +39,26 @@ def worker(rank, world, port, case, steps, outdir):
              size=np.array(specs[rank].size))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def ring_worker(rank, world, port, outdir):
+    """RingExchanger (the exchange of bench.py --gpus N) on CPU tensors over gloo."""
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank)})
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from sailfish_amd.connector import RingExchanger, init_distributed
+    r, w = init_distributed('gloo')
+    ex = RingExchanger(r, w)
+    n = 1000
+    got = []
+    for step in range(3):
+        send_up = torch.full((n,), 100.0 * r + 10.0 * step + 1.0)       # -> rank + 1, its recv_low
+        send_down = torch.full((n,), 100.0 * r + 10.0 * step + 2.0)     # -> rank - 1, its recv_high
+        recv_low, recv_high = torch.zeros(n), torch.zeros(n)
+        ex.exchange(send_up, send_down, recv_low, recv_high)
+        got.append((float(recv_low[0]), float(recv_low[-1]), float(recv_high[0]), float(recv_high[-1])))
+    np.save(os.path.join(outdir, 'ring%d.npy' % rank), np.array(got))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -49,3 +49,21 @@ def test_two_ranks_equal_single_subdomain(case):
         got_rho[sl] = p['rho']
     assert np.array_equal(got_f, ref_f, equal_nan=True)
     assert np.array_equal(got_rho, ref_rho, equal_nan=True)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_ring_exchanger(world):
+    """The nearest-neighbour ring of bench.py --gpus N: what rank r sends up arrives in the recv_low buffer
+    of rank r + 1, what it sends down in the recv_high buffer of rank r - 1 -- including world = 2, where
+    both messages travel between the same pair of ranks and are told apart by posting order only."""
+    import torch.multiprocessing as mp
+    from tests._gloo_worker import ring_worker
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(ring_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        for r in range(world):
+            got = np.load(os.path.join(d, 'ring%d.npy' % r))
+            down, up = (r - 1) % world, (r + 1) % world
+            for step in range(3):
+                low0, low1, high0, high1 = got[step]
+                assert low0 == low1 == 100.0 * down + 10.0 * step + 1.0      # the lower neighbour's send_up
+                assert high0 == high1 == 100.0 * up + 10.0 * step + 2.0      # the upper neighbour's send_down
