@@ -118,6 +118,8 @@ typedef struct slf_module_desc {
   double sc_G[4];
   int32_t sc_potential;
   int32_t node_addressing;       /* SLF_ADDR_DIRECT | SLF_ADDR_INDIRECT (--node_addressing, lb_base.py:66-71) */
+  double accel1[3];              /* binary models: body-force acceleration acting on lattice 1 (accel[] acts on
+                                    lattice 0; reference add_body_force(..., grid=1), lb_base.py:331-359) */
   int32_t sparse_geometry;       /* hint: a sizeable fraction of the real nodes is excluded (unused / ghost-like):
                                     kernels predicate their loads on the node map instead of issuing them early */
 } slf_module_desc;

@@ -411,6 +411,7 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   m->sc.tau_phi = d->tau_phi;
   for (int i = 0; i < 4; i++) m->sc.G[i] = d->sc_G[i];
   m->sc.potential = d->sc_potential;
+  for (int i = 0; i < 3; i++) m->sc.accel1[i] = d->accel1[i];
   if (m->sc.enabled) {
     if (d->model != SLF_BGK) { delete m; return fail(SLF_ERR_UNSUPPORTED, "Shan-Chen modules use the BGK collision"); }
     if (m->sc.enabled == 1 && d->tau_phi <= 0.5) { delete m; return fail(SLF_ERR_INVALID, "tau_phi must be > 0.5"); }

@@ -42,6 +42,7 @@ struct ShanChen {
   double tau_phi;
   double G[4];      // G11 G12 G21 G22
   int potential;    // 0 linear, 1 classic
+  double accel1[3]; // body-force acceleration on lattice 1 (Physics::accel acts on lattice 0)
 };
 
 struct SweepArgs {

@@ -335,8 +335,12 @@ static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanCh
   p.guo_pref[1] = (R)(3.0 * (1.0 - 0.5 / sc.tau_phi));
   p.G[0] = (R)sc.G[2 * grid_idx + 0];
   p.G[1] = (R)sc.G[2 * grid_idx + 1];
-  for (int d = 0; d < 3; d++) p.accel[d] = (R)ph.accel[d];
-  p.has_body_force = ph.has_force;
+  // body forces act per lattice (reference add_body_force(force, grid=k), relaxation_common.mako:9-36)
+  p.has_body_force = 0;
+  for (int d = 0; d < 3; d++) {
+    p.accel[d] = (R)(grid_idx == 0 ? ph.accel[d] : sc.accel1[d]);
+    if (p.accel[d] != (R)0) p.has_body_force = 1;
+  }
   p.potential = sc.potential;
   return p;
 }

@@ -50,6 +50,7 @@ class SlfModuleDesc(Structure):
         ('sc_G', c_double * 4),
         ('sc_potential', c_int32),
         ('node_addressing', c_int32),
+        ('accel1', c_double * 3),
         ('sparse_geometry', c_int32),
     ]
 
@@ -170,7 +171,7 @@ def make_desc(**kw):
     d.arr_nz = 1
     keep = []
     for k, v in kw.items():
-        if k in ('periodic_fused', 'accel', 'periodic_local', 'sc_G'):
+        if k in ('periodic_fused', 'accel', 'periodic_local', 'sc_G', 'accel1'):
             for i, x in enumerate(v):
                 getattr(d, k)[i] = x
         elif k == 'mrt_rates':

@@ -196,8 +196,8 @@ class LBForcedSim(LBSim):
             raise NotImplementedError('time / space dependent forces are not supported by the HIP backend')
         if not accel:
             raise NotImplementedError('force (rather than acceleration) fields are not supported by the HIP backend')
-        if grid != 0:
-            raise NotImplementedError('multi-grid forces are not supported by the HIP backend')
+        if grid not in (0, 1):
+            raise NotImplementedError('the HIP backend handles body forces on lattices 0 and 1')
         self._forces.setdefault(grid, {}).setdefault(accel, np.zeros(dim, np.float64))
         self._forces[grid][accel] = self._forces[grid][accel] + np.float64(force)
 
@@ -207,3 +207,8 @@ class LBForcedSim(LBSim):
         if f is not None and np.any(f != 0.0):
             kw['has_force'] = 1
             kw['accel'] = list(f) + [0.0] * (3 - len(f))
+        f1 = self._forces.get(1, {}).get(True)
+        if f1 is not None and np.any(f1 != 0.0):
+            if len(self.grids) < 2:
+                raise ValueError('add_body_force(grid=1) on a model with a single lattice')
+            kw['accel1'] = list(f1) + [0.0] * (3 - len(f1))

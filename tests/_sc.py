@@ -64,3 +64,19 @@ def single_config(dim, size, pattern='AB', fused=True, G=-5.0, visc=1.0 / 6.0, p
     if dim == 3:
         cfg.update(lat_nz=size[2], periodic_z=True)
     return cfg
+
+
+def make_forced_sim(dim, a0, a1, seed=7):
+    """Binary mixture with a body-force acceleration a0 on lattice 0 and a1 on lattice 1
+    (reference add_body_force(..., grid=k); examples/binary_fluid/sc_poiseuille_2d.py, sc_rayleigh_taylor_2d.py)."""
+    base, geo = make_sim(dim, seed=seed)
+
+    class Forced(base):
+        def __init__(self, config):
+            super(Forced, self).__init__(config)
+            if a0 is not None:
+                self.add_body_force(tuple(a0))
+            if a1 is not None:
+                self.add_body_force(tuple(a1), grid=1)
+
+    return Forced, geo

@@ -170,3 +170,25 @@ def test_sc_checkpoint_roundtrip(tmp_path):
         assert cont._sim.iteration == 15
         for g in (0, 1):
             assert np.array_equal(cont._debug_get_dist(grid_num=g), ref._debug_get_dist(grid_num=g), equal_nan=True)
+
+
+@pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (40, 9, 8))])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_sc_per_lattice_body_force(dim, size, pattern):
+    """Body forces acting on one lattice each (reference add_body_force(..., grid=k),
+    examples/binary_fluid/sc_poiseuille_2d.py): GPU == oracle, populations bit-identical."""
+    from sailfish_amd.controller import LBSimulationController
+    a0, a1 = [2e-5, 0.0, -1e-5][:dim], [0.0, 3e-5, 1e-5][:dim]
+    sim_cls, geo = _sc.make_forced_sim(dim, a0, a1)
+    cfg = _sc.config(dim, size, pattern=pattern)
+    ocfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, dict(cfg))
+    o = OracleSCSubdomain(runners[0])
+    o.run(15)
+    gcfg = dict(cfg, max_iters=15, quiet=True, perf_stats_every=0)
+    ctrl = LBSimulationController(sim_cls, geo, default_config=gcfg)
+    ctrl.run(ignore_cmdline=True)
+    r = ctrl.runners[0]
+    assert list(r._desc.accel1)[:dim] == a1
+    for grid_num, od in enumerate(o.current()):
+        gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+        assert np.array_equal(gd, o.real(od)), 'lattice %d' % grid_num

@@ -127,3 +127,32 @@ def test_one_vs_n_subdomains(single, dim, size, nsub, axis, pattern):
             assert np.array_equal(g.merged(lambda s: s.phi), ref.merged(lambda s: s.phi))
             for k in (0, 1):
                 assert np.array_equal(g.merged(lambda s: s.current()[k]), ref.merged(lambda s: s.current()[k]))
+
+
+@pytest.mark.parametrize('dim,size', [(2, (16, 12)), (3, (8, 6, 6))])
+def test_per_lattice_body_force(dim, size):
+    """add_body_force(a, grid=k) accelerates lattice k only (reference relaxation_common.mako:9-36): in a
+    periodic box the momentum of the mixture grows by  sum_k mass_k a_k  per step (the Shan-Chen coupling is
+    momentum conserving), and a force on lattice 1 leaves the result unchanged when phi carries no mass...
+    here: compared against the unforced run for the expected difference."""
+    a0 = [2e-5, 0.0, -1e-5][:dim]
+    a1 = [0.0, 3e-5, 1e-5][:dim]
+    res = {}
+    for key, (f0, f1) in {'none': (None, None), 'both': (a0, a1), 'only1': (None, a1)}.items():
+        sim_cls, geo = _sc.make_forced_sim(dim, f0, f1)
+        cfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, _sc.config(dim, size, pattern='AB', precision='double'))
+        s = OracleSCSubdomain(runners[0])
+        assert list(s.desc.accel1)[:dim] == (list(f1) if f1 else [0.0] * dim)
+        steps = 6
+        s.run(steps)
+        grid = s.runner._sim.grid
+        e = grid.basis_array
+        f = [s.real(d).astype(np.float64) for d in s.current()]
+        mom = [[sum(e[i][d] * f[k][i].sum() for i in range(grid.Q)) for d in range(dim)] for k in (0, 1)]
+        mass = [f[k].sum() for k in (0, 1)]
+        res[key] = (np.array(mom[0]) + np.array(mom[1]), mass, steps)
+    m_none, mass, steps = res['none']
+    for key, (f0, f1) in (('both', (a0, a1)), ('only1', (None, a1))):
+        gain = res[key][0] - m_none
+        expect = steps * (mass[0] * np.array(f0 if f0 else [0.0] * dim) + mass[1] * np.array(f1))
+        assert np.allclose(gain, expect, rtol=1e-6, atol=1e-10), (key, gain, expect)
