@@ -48,6 +48,11 @@ enum { SLF_SIM_LBM = 0, SLF_SIM_SHAN_CHEN_BINARY = 1, SLF_SIM_SHAN_CHEN_SINGLE =
  * ComputeMacroFields take that table as an additional FIRST pointer argument (as the reference's
  * _add_indirect_args, subdomain_runner.py:1153-1157); periodic boundaries must be wrapped in-sweep. */
 enum { SLF_ADDR_DIRECT = 0, SLF_ADDR_INDIRECT = 1 };
+
+/* How a body-force / Shan-Chen acceleration a enters the BGK collision (relaxation_common.mako:56-99):
+ * GUO: feq at u + a/2 plus Guo's source term; EDM (exact difference method): feq at u, then
+ * f_i += feq_i(rho, u + a) - feq_i(rho, u).  The output velocity is u + a/2 in both. */
+enum { SLF_FORCE_GUO = 0, SLF_FORCE_EDM = 1 };
 #define SLF_INVALID_NODE 0xffffffffu
 
 /* Canonical node kinds understood by the kernels (reference node_type.py:86-109,
@@ -120,6 +125,7 @@ typedef struct slf_module_desc {
   int32_t node_addressing;       /* SLF_ADDR_DIRECT | SLF_ADDR_INDIRECT (--node_addressing, lb_base.py:66-71) */
   double accel1[3];              /* binary models: body-force acceleration acting on lattice 1 (accel[] acts on
                                     lattice 0; reference add_body_force(..., grid=1), lb_base.py:331-359) */
+  int32_t force_implementation;  /* SLF_FORCE_GUO | SLF_FORCE_EDM (--force_implementation, lb_base.py:325-330) */
   int32_t sparse_geometry;       /* hint: a sizeable fraction of the real nodes is excluded (unused / ghost-like):
                                     kernels predicate their loads on the node map instead of issuing them early */
 } slf_module_desc;

@@ -407,6 +407,11 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   ph.incompressible = d->incompressible;
   ph.has_force = d->has_force;
   ph.relaxation_enabled = d->relaxation_enabled;
+  ph.force_edm = d->force_implementation == SLF_FORCE_EDM;
+  if (ph.force_edm && d->model != SLF_BGK) {
+    delete m;
+    return fail(SLF_ERR_UNSUPPORTED, "the exact difference method (force_implementation = EDM) needs the BGK collision");
+  }
   m->sc.enabled = (d->simtype == SLF_SIM_SHAN_CHEN_BINARY) ? 1 : ((d->simtype == SLF_SIM_SHAN_CHEN_SINGLE) ? 2 : 0);
   m->sc.tau_phi = d->tau_phi;
   for (int i = 0; i < 4; i++) m->sc.G[i] = d->sc_G[i];

@@ -35,6 +35,7 @@ struct Physics {
   int incompressible;
   int has_force;
   int relaxation_enabled;
+  int force_edm;   // body / Shan-Chen forces by the exact difference method instead of Guo's
 };
 
 struct ShanChen {

@@ -122,14 +122,31 @@ struct CollideParams {
   R guo_pref;     // 3 (1 - 1/(2 tau))
   int incompressible;
   int has_force;
+  int force_edm;  // exact difference method instead of Guo forcing
 };
 
 // C5 + C6: BGK relaxation with optional Guo forcing by the acceleration a.  v is updated to the
 // velocity used for the equilibrium (u + a/2), which is also the reference's output velocity.
 template <class L, class R>
 SLF_D void bgk_relax_accel(R (&f)[L::Q], R rho, R (&v)[3], R omega, R guo_pref, bool incompressible, bool has_force,
-                           const R (&a)[3]) {
+                           const R (&a)[3], bool edm = false) {
   const R rho0 = incompressible ? (R)1 : rho;
+  if (has_force && edm) {
+    // exact difference method (relaxation_common.mako:66-73, sym_force.py:184-193): equilibrium at the
+    // unshifted velocity, then f_i += feq_i(rho, u + a) - feq_i(rho, u); output velocity u + a/2
+    R vs[3] = {v[0] + a[0], v[1] + a[1], (R)0};
+    if constexpr (L::dim == 3) vs[2] = v[2] + a[2];
+    const R u15 = usq15<L, R>(v);
+    const R u15s = usq15<L, R>(vs);
+    static_for<0, L::Q>([&](auto I) {
+      const R fe = feq<L, R, I>(rho, rho0, v, u15);
+      const R fs = feq<L, R, I>(rho, rho0, vs, u15s);
+      f[I] = f[I] + omega * (fe - f[I]);
+      f[I] = f[I] + (fs - fe);
+    });
+    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * a[D]; });
+    return;
+  }
   if (has_force) {
     static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * a[D]; });
   }
@@ -153,7 +170,8 @@ SLF_D void bgk_relax_accel(R (&f)[L::Q], R rho, R (&v)[3], R omega, R guo_pref, 
 
 template <class L, class R>
 SLF_D void bgk_relax(R (&f)[L::Q], R rho, R (&v)[3], const CollideParams<L, R>& cp) {
-  bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, cp.has_force != 0, cp.accel);
+  bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, cp.has_force != 0, cp.accel,
+                        cp.force_edm != 0);
 }
 
 // C7 helpers: one row of the integer moment matrix applied to a vector.

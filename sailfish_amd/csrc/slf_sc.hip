@@ -32,6 +32,7 @@ struct ScParams {
   R accel[3];        // additional body-force acceleration
   int has_body_force;
   int potential;
+  int force_edm;
 };
 
 template <class R>
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
   if constexpr (GENERAL) {
     if (kind == NK_FULL_BB) bounce_back<L, R>(f);
   }
-  if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[K], p.guo_pref[K], false, true, a);
+  if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
 
   if constexpr (ROW && PROP != PROP_AA_EVEN) {
     row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, gi, gx, nx, live, active, oy, oz);
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
   if constexpr (GENERAL) {
     if (kind == NK_FULL_BB) bounce_back<L, R>(f);
   }
-  if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[0], p.guo_pref[0], false, true, a);
+  if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[0], p.guo_pref[0], false, true, a, p.force_edm != 0);
   if ((p.options & 1u) && wet) {
     // the density field itself is written by PrepareMacroFields; v is the force-shifted output velocity
     p.vx[gi] = v[0];
@@ -335,6 +336,7 @@ static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanCh
   p.guo_pref[1] = (R)(3.0 * (1.0 - 0.5 / sc.tau_phi));
   p.G[0] = (R)sc.G[2 * grid_idx + 0];
   p.G[1] = (R)sc.G[2 * grid_idx + 1];
+  p.force_edm = ph.force_edm;
   // body forces act per lattice (reference add_body_force(force, grid=k), relaxation_common.mako:9-36)
   p.has_body_force = 0;
   for (int d = 0; d < 3; d++) {

@@ -205,6 +205,7 @@ inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const
   p.cp.guo_pref = (R)(3.0 * (1.0 - 0.5 / ph.tau));
   p.cp.incompressible = ph.incompressible;
   p.cp.has_force = ph.has_force;
+  p.cp.force_edm = ph.force_edm;
   return p;
 }
 

@@ -51,6 +51,7 @@ class SlfModuleDesc(Structure):
         ('sc_potential', c_int32),
         ('node_addressing', c_int32),
         ('accel1', c_double * 3),
+        ('force_implementation', c_int32),
         ('sparse_geometry', c_int32),
     ]
 
@@ -110,6 +111,7 @@ SIGNATURES = {
 }
 
 SLF_ADDR_DIRECT, SLF_ADDR_INDIRECT = 0, 1
+SLF_FORCE_GUO, SLF_FORCE_EDM = 0, 1
 SLF_INVALID_NODE = 0xffffffff
 
 _lib = None

@@ -4,6 +4,8 @@ from collections import namedtuple
 
 import numpy as np
 
+from sailfish_amd import hipabi
+
 from sailfish_amd import node_type as nt
 from sailfish_amd import sym, util
 
@@ -185,8 +187,9 @@ class LBForcedSim(LBSim):
 
     @classmethod
     def add_options(cls, group, dim):
-        group.add_argument('--force_implementation', type=str, choices=['guo'], default='guo',
-                           help='How body forces enter the collision (the HIP kernels implement Guo forcing).')
+        group.add_argument('--force_implementation', type=str, choices=['guo', 'edm'], default='guo',
+                           help='How body / Shan-Chen forces enter the collision: Guo forcing or the exact '
+                                'difference method (BGK only)')
 
     def add_body_force(self, force, grid=0, accel=True):
         """Adds a constant global acceleration (accel=True) acting on the fluid."""
@@ -207,6 +210,10 @@ class LBForcedSim(LBSim):
         if f is not None and np.any(f != 0.0):
             kw['has_force'] = 1
             kw['accel'] = list(f) + [0.0] * (3 - len(f))
+        impl = getattr(self.config, 'force_implementation', 'guo')
+        if impl not in ('guo', 'edm'):
+            raise NotImplementedError('force_implementation=%s is not supported by the HIP backend' % impl)
+        kw['force_implementation'] = hipabi.SLF_FORCE_EDM if impl == 'edm' else hipabi.SLF_FORCE_GUO
         f1 = self._forces.get(1, {}).get(True)
         if f1 is not None and np.any(f1 != 0.0):
             if len(self.grids) < 2:

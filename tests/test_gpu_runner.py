@@ -336,3 +336,13 @@ def test_gpu_invalid_value_check():
     # a healthy run is not affected
     ctrl = run_gpu('ldc_2d', 'LDCSim', 2, dict(lat_nx=32, lat_ny=24, visc=0.05), 20)
     assert np.isfinite(ctrl.runners[0]._sim.rho[1:-1, 1:-1]).all()
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_poiseuille_force_edm(pattern):
+    """--force_implementation=edm (exact difference method, reference relaxation_common.mako:66-99)."""
+    cfg = dict(lat_nx=24, lat_ny=40, visc=0.05, horizontal=False, stationary=False, drive='force', wall='fullbb',
+               force_implementation='edm', access_pattern=pattern)
+    ctrl, exact = check_against_oracle('poiseuille', 'PoiseuilleSim', 2, cfg, 60, 0.02)
+    assert exact
+    assert ctrl.runners[0]._desc.force_implementation == 1

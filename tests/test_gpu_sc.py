@@ -192,3 +192,29 @@ def test_sc_per_lattice_body_force(dim, size, pattern):
     for grid_num, od in enumerate(o.current()):
         gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
         assert np.array_equal(gd, o.real(od)), 'lattice %d' % grid_num
+
+
+@pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (40, 9, 8))])
+def test_sc_edm(dim, size):
+    """Shan-Chen force through the exact difference method (the setting of the reference's
+    examples/binary_fluid/sc_capillary_wave_2d.py, sc_laplace_2d.py, sc_poiseuille_2d.py)."""
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls, geo = _sc.make_forced_sim(dim, None, [0.0, 2e-5, 0.0][:dim])
+    cfg = _sc.config(dim, size, pattern='AA')
+    cfg['force_implementation'] = 'edm'
+    ocfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, dict(cfg))
+    o = OracleSCSubdomain(runners[0])
+    assert o.desc.force_implementation == 1
+    o.run(15)
+    ctrl = LBSimulationController(sim_cls, geo, default_config=dict(cfg, max_iters=15, quiet=True, perf_stats_every=0))
+    ctrl.run(ignore_cmdline=True)
+    r = ctrl.runners[0]
+    for grid_num, od in enumerate(o.current()):
+        gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+        assert np.array_equal(gd, o.real(od)), 'lattice %d' % grid_num
+    # and it is a different scheme from Guo's
+    cfg['force_implementation'] = 'guo'
+    ocfg_, specs, runners = _host.build_runners(sim_cls, dim, geo, dict(cfg))
+    g = OracleSCSubdomain(runners[0])
+    g.run(15)
+    assert not np.array_equal(g.real(g.current()[0]), o.real(o.current()[0]))

@@ -24,7 +24,7 @@ def gold(request, golden_dir):
     return g, np.load(os.path.join(golden_dir, 'arith_%s.npz' % request.param))
 
 
-def _desc(grid, precision, visc=1.0 / 6.0, model='bgk', accel=None, incompressible=False):
+def _desc(grid, precision, visc=1.0 / 6.0, model='bgk', accel=None, incompressible=False, edm=False):
     kw = dict(lattice=grid.slf_id, model=hipabi.SLF_MRT if model == 'mrt' else hipabi.SLF_BGK,
               precision=precision, access_pattern=hipabi.SLF_AB,
               lat_nx=4, lat_ny=4, lat_nz=4 if grid.dim == 3 else 1,
@@ -34,6 +34,8 @@ def _desc(grid, precision, visc=1.0 / 6.0, model='bgk', accel=None, incompressib
     if accel is not None:
         kw['has_force'] = 1
         kw['accel'] = list(accel) + [0.0] * (3 - len(accel))
+    if edm:
+        kw['force_implementation'] = hipabi.SLF_FORCE_EDM
     return hipabi.make_desc(**kw)
 
 
@@ -84,6 +86,19 @@ def test_bgk_guo_force(gold, precision):
         f, rho, v = oracle.node_update(d, hipabi.SLF_NK_FLUID, 0, None, G['f'][k], precision)
         _close(f, G['guo_post'][k], TOL[precision])
         _close(v[:grid.dim], G['guo_out_v'][k], TOL[precision])
+
+
+@pytest.mark.parametrize('precision', [8, 4])
+def test_bgk_edm_force(gold, precision):
+    """Exact difference method (reference relaxation_common.mako:66-73, sym_force.edm_shift_velocity)."""
+    grid, G = gold
+    nu = float(G['guo_visc'][0])
+    for k in range(len(G['rho'])):
+        d = _desc(grid, precision, visc=nu, accel=G['accel'][k], edm=True)
+        f, rho, v = oracle.node_update(d, hipabi.SLF_NK_FLUID, 0, None, G['f'][k], precision)
+        _close(f, G['edm_post'][k], TOL[precision])
+        _close(v[:grid.dim], G['guo_out_v'][k], TOL[precision])      # same output velocity u + a/2
+        assert np.max(np.abs(G['edm_post'][k] - G['guo_post'][k])) > 0   # the two schemes do differ
 
 
 @pytest.mark.parametrize('precision', [8, 4])

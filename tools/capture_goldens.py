@@ -189,6 +189,18 @@ def arithmetic_goldens(grid, rng, n=48):
         outv[k] = m_v[k] + 0.5 * accel[k]
     out['guo_post'], out['guo_out_v'] = postf, outv
 
+    # --- BGK + exact difference method: relaxation_common.mako:66-73,95-99, sym_force.py:184-193
+    #     (equilibrium at the unshifted velocity, f_i += feq_i(u + a) - feq_i(u))
+    edm = sym_force.edm_shift_velocity(eq.expression, grid, 0)
+    poste = np.zeros((n, Q))
+    for k in range(n):
+        subs = _macro_subs(grid, m_rho[k], m_v[k])
+        subs.update({'g0ea' + c: accel[k, j] for j, c in enumerate('xyz'[:dim])})
+        for i, e in enumerate(eq.expression):
+            feq = _evalf(e, subs)
+            poste[k, i] = f[k, i] + (1.0 / tau) * (feq - f[k, i]) + (_evalf(edm[i], subs) - feq)
+    out['edm_post'] = poste
+
     # --- MRT: relaxation_mrt.mako:31-97, sym.py:716-735 + grid.mrt_*
     if hasattr(grid, 'mrt_matrix'):
         M = np.array(grid.mrt_matrix.tolist(), dtype=np.float64)
