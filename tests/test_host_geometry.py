@@ -117,8 +117,19 @@ def test_weighted_subdomains_balance_active_nodes(tmp_path):
 
 REF_EXAMPLES = [
     ('sc_phase_separation', 'SCSim', 2, {}),
+    ('sc_drop', 'SCSim', 2, {}),
     ('binary_fluid/sc_separation_2d', 'SeparationSCSim', 2, {}),
     ('binary_fluid/sc_separation_3d', 'SeparationSCSim', 3, {'lat_nx': 24, 'lat_ny': 20, 'lat_nz': 16}),
+    ('binary_fluid/sc_capillary', None, 2, {}),                 # body forces on both lattices
+    ('binary_fluid/sc_capillary_wave_2d', None, 2, {}),         # force_implementation = edm
+    ('binary_fluid/sc_drop_2d', None, 2, {}),
+    ('binary_fluid/sc_laplace_2d', None, 2, {}),
+    ('binary_fluid/sc_poiseuille_2d', None, 2, {}),
+    ('binary_fluid/sc_rayleigh_taylor_2d', None, 2, {}),
+    ('cylinder', None, 2, {}),
+    ('duct_flow', None, 3, {'lat_nx': 32, 'lat_ny': 32, 'lat_nz': 32}),
+    ('sphere_3d', None, 3, {'lat_nx': 64, 'lat_ny': 32, 'lat_nz': 32}),
+    ('taylor_green_2d', None, 2, {}),
     ('external_geometry', 'ExternalSimulation', 3, {}),
     ('external_geometry', 'ExternalSimulation', 3, {'node_addressing': 'indirect'}),
 ]
@@ -137,8 +148,13 @@ def test_more_reference_examples_load_unchanged(module, sim, dim, extra):
     spec = importlib.util.spec_from_file_location('refexample_' + module.replace('/', '_'), path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    sim_cls = getattr(mod, sim)
     from sailfish_amd.lb_base import LBSim
+    if sim is None:      # the simulation class the example defines
+        import inspect
+        sim_cls = [c for c in vars(mod).values()
+                   if inspect.isclass(c) and issubclass(c, LBSim) and c.__module__ == mod.__name__][-1]
+    else:
+        sim_cls = getattr(mod, sim)
     assert issubclass(sim_cls, LBSim)
     defaults = {}
     sim_cls.update_defaults(defaults)
@@ -166,5 +182,5 @@ def test_more_reference_examples_load_unchanged(module, sim, dim, extra):
     if extra.get('node_addressing') == 'indirect':
         assert desc.node_addressing == hipabi.SLF_ADDR_INDIRECT
         assert r._subdomain.active_nodes < 0.8 * np.prod(r._subdomain.full_lat_shape)
-    if 'sc_' in module:
+    if 'sc_' in module and 'binary_fluid' not in module or sim in ('SeparationSCSim',):
         assert desc.simtype in (hipabi.SLF_SIM_SHAN_CHEN_BINARY, hipabi.SLF_SIM_SHAN_CHEN_SINGLE)
