@@ -62,3 +62,47 @@ def ring_worker(rank, world, port, outdir):
     np.save(os.path.join(outdir, 'ring%d.npy' % rank), np.array(got))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def nn_worker(rank, world, port, dim, size, nsub_axis, single, steps, outdir):
+    """Shan-Chen models, one subdomain per process: two exchanges per step (macroscopic fields, then the
+    populations of every lattice) through TorchDistConnector.exchange_tensors over gloo."""
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank)})
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from sailfish_amd.connector import TorchDistConnector, init_distributed
+    from tests import _host, _sc
+    from tests._oracle_group import OracleSCSingle, OracleSCSubdomain
+    init_distributed('gloo')
+    sim_cls, _ = (_sc.make_single_sim if single else _sc.make_sim)(dim)
+    cfg = (_sc.single_config if single else _sc.config)(dim, size, pattern='AA')
+    if single:
+        cfg.update(G=-1.2, sc_potential='linear')
+    cfg.update(subdomains=world, conn_axis=nsub_axis)
+    cfg_, specs, runners = _host.build_runners(sim_cls, dim, 'EqualSubdomainsGeometry%dD' % dim, cfg)
+    sub = (OracleSCSingle if single else OracleSCSubdomain)(runners[rank])
+    conn = TorchDistConnector(dict((s.id, s.id) for s in specs), device=torch.device('cpu'))
+    tdt = torch.float32 if sub.o.dtype == np.float32 else torch.float64
+
+    def swap(sends, counts):
+        nids = sorted(sends)
+        s_list = [(torch.from_numpy(np.ascontiguousarray(sends[n])), conn.id_to_rank[n]) for n in nids if len(sends[n])]
+        bufs = dict((n, torch.empty(counts[n], dtype=tdt)) for n in nids)
+        r_list = [(bufs[n], conn.id_to_rank[n]) for n in nids if counts[n]]
+        conn.exchange_tensors(s_list, r_list)
+        return dict((n, bufs[n].numpy()) for n in nids)
+
+    nf, nl = len(sub.nn_fields()), (1 if single else 2)
+    for i in range(steps):
+        sends = sub.macro_send()
+        sub.macro_recv(swap(sends, dict((n, len(l.recv) * nf) for n, l in sub.macro_links.items())))
+        sends = sub.dist_send(i == steps - 1)
+        sub.dist_recv(swap(sends, dict((n, len(getattr(l, sub._mode + '_recv')) * nl) for n, l in sub.links.items())))
+    cur = sub.current() if single else sub.current()[0]
+    np.savez(os.path.join(outdir, 'nn%d.npz' % rank), dist=np.ascontiguousarray(sub.real(cur)),
+             rho=np.ascontiguousarray(sub.real(sub.rho)), location=np.array(specs[rank].location),
+             size=np.array(specs[rank].size))
+    dist.barrier()
+    dist.destroy_process_group()

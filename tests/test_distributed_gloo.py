@@ -67,3 +67,32 @@ def test_ring_exchanger(world):
                 low0, low1, high0, high1 = got[step]
                 assert low0 == low1 == 100.0 * down + 10.0 * step + 1.0      # the lower neighbour's send_up
                 assert high0 == high1 == 100.0 * up + 10.0 * step + 2.0      # the upper neighbour's send_down
+
+
+@pytest.mark.parametrize('single', [False, True], ids=['binary', 'single_component'])
+def test_shan_chen_two_ranks(single):
+    """Non-local models across processes (config 5 on several GPUs): macro-field exchange + population exchange
+    per step over the product's connector; equal to the single-subdomain run bit for bit."""
+    import torch.multiprocessing as mp
+    from tests import _sc
+    from tests._gloo_worker import nn_worker
+    from tests._oracle_group import OracleNNGroup
+    dim, size, axis, steps = 3, (10, 8, 6), 'z', 6
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(nn_worker, args=(2, _free_port(), dim, size, axis, single, steps, d), nprocs=2, join=True)
+        parts = [np.load(os.path.join(d, 'nn%d.npz' % r)) for r in range(2)]
+    sim_cls, _ = (_sc.make_single_sim if single else _sc.make_sim)(dim)
+    cfg = (_sc.single_config if single else _sc.config)(dim, size, pattern='AA')
+    if single:
+        cfg.update(G=-1.2, sc_potential='linear')
+    cfg.update(subdomains=1, conn_axis=axis)
+    one = OracleNNGroup(sim_cls, dim, 'EqualSubdomainsGeometry3D', cfg, single=single)
+    one.run(steps)
+    ref_f = one.merged((lambda s: s.current()) if single else (lambda s: s.current()[0]))
+    ref_rho = one.merged(lambda s: s.rho)
+    got_f, got_rho = np.zeros_like(ref_f), np.zeros_like(ref_rho)
+    for p in parts:
+        sl = tuple(slice(int(o), int(o + n)) for o, n in zip(reversed(p['location']), reversed(p['size'])))
+        got_f[(slice(None),) + sl] = p['dist']
+        got_rho[sl] = p['rho']
+    assert np.array_equal(got_f, ref_f) and np.array_equal(got_rho, ref_rho)
