@@ -21,6 +21,7 @@ generated CUDA/OpenCL text):
 Everything calls libsailfish_hip.so through ctypes; there is no CPU fallback.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -204,7 +205,9 @@ class HIPBackend(object):
         self.buffers = {}   # device address -> host mirror
         self._sizes = {}
         self._raw = {}
-        self._iteration_kernels = []
+        # kernels whose trailing iteration argument set_iteration() rewrites; weak: a kernel that its owner
+        # dropped (a released simulation) must not be kept alive -- or updated -- by this registry
+        self._iteration_kernels = weakref.WeakSet()
         self._total_memory_bytes = 0
         ctx = ctypes.c_void_p()
         _check(self._lib, self._lib.slf_ctx_create(int(gpu_id), ctypes.byref(ctx)), 'slf_ctx_create')
@@ -358,11 +361,11 @@ class HIPBackend(object):
         kern = HIPKernel(self._lib, prog, name)
         kern.set_args(args, args_format, needs_iteration)
         if needs_iteration:
-            self._iteration_kernels.append(kern)
+            self._iteration_kernels.add(kern)
         return kern
 
     def set_iteration(self, it):
-        for kern in self._iteration_kernels:
+        for kern in list(self._iteration_kernels):
             _check(self._lib, self._lib.slf_kernel_set_iteration(kern.handle, int(it) & 0xFFFFFFFF),
                    'slf_kernel_set_iteration')
 

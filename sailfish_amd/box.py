@@ -169,7 +169,10 @@ class BoxSim(object):
         for addr in list(self.gpu_dist) + [self.gpu_rho] + list(self.gpu_v) + ([self.gpu_map] if self.gpu_map else []):
             b.free_buf(addr)
         self.gpu_dist = []
-        b._iteration_kernels = []
+        # drop the kernel objects: the backend's registry of iteration-dependent kernels holds them weakly
+        for name in ('k_init', 'k_sweep', 'k_pbc', 'k_macro', 'k_halo'):
+            if hasattr(self, name):
+                setattr(self, name, None)
 
     def fetch_fields(self):
         self.sync()
