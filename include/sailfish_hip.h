@@ -69,7 +69,10 @@ enum {
   SLF_NK_EQUILIBRIUM_VELOCITY = 8,
   SLF_NK_ZOUHE_VELOCITY = 9,      /* boundary.mako:343-382, 811-815 */
   SLF_NK_ZOUHE_DENSITY = 10,      /* boundary.mako:487-494 */
-  SLF_NK_REGULARIZED_DENSITY = 11 /* boundary.mako:501-506, 817-835 */
+  SLF_NK_REGULARIZED_DENSITY = 11, /* boundary.mako:501-506, 817-835 */
+  SLF_NK_COPY = 12,               /* NTCopy, boundary.mako:574-587: unknown populations copied from the node
+                                     one step along the inward normal (two-copy access pattern only) */
+  SLF_NK_YU_OUTFLOW = 13          /* NTYuOutflow, boundary.mako:589-603: 2 f(x + n) - f(x + 2 n) (AB only) */
 };
 
 #define SLF_MAX_NODE_TYPES 16

@@ -21,6 +21,7 @@ generated CUDA/OpenCL text):
 Everything calls libsailfish_hip.so through ctypes; there is no CPU fallback.
 """
 import ctypes
+import gc
 import weakref
 
 import numpy as np
@@ -388,12 +389,20 @@ class HIPBackend(object):
 
     def capture_graph(self, stream, enqueue):
         """Records everything `enqueue()` puts on `stream` (nothing executes) and returns a HIPGraph."""
-        _check(self._lib, self._lib.slf_graph_capture_begin(stream.handle), 'slf_graph_capture_begin')
+        # no garbage collection while recording: finalisers of dead HIP objects (events, modules, buffers of
+        # earlier simulations) would issue runtime calls in the middle of the capture
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
-            enqueue()
+            _check(self._lib, self._lib.slf_graph_capture_begin(stream.handle), 'slf_graph_capture_begin')
+            try:
+                enqueue()
+            finally:
+                h = ctypes.c_void_p()
+                rc = self._lib.slf_graph_capture_end(stream.handle, ctypes.byref(h))
         finally:
-            h = ctypes.c_void_p()
-            rc = self._lib.slf_graph_capture_end(stream.handle, ctypes.byref(h))
+            if gc_was_on:
+                gc.enable()
         _check(self._lib, rc, 'slf_graph_capture_end')
         return HIPGraph(self, h)
 

@@ -247,7 +247,9 @@ int slf_stream_native(slf_stream* s, void** hip_stream) {
 
 int slf_graph_capture_begin(slf_stream* s) {
   if (!s) return fail(SLF_ERR_INVALID, "graph capture needs a stream created with slf_stream_create");
-  SLF_HIP(hipStreamBeginCapture(s->s, hipStreamCaptureModeThreadLocal));
+  // relaxed: a destructor that frees device memory while we record (Python's garbage collector can run one at
+  // any time) must not invalidate the capture
+  SLF_HIP(hipStreamBeginCapture(s->s, hipStreamCaptureModeRelaxed));
   return SLF_OK;
 }
 
@@ -393,6 +395,14 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
       return fail(SLF_ERR_UNSUPPORTED, "node type kind not supported by the HIP backend");
     }
     g.type_lut |= (unsigned long long)k << (4 * i);
+  }
+  for (int i = 0; i < d->n_types; i++) {
+    const int k = d->type_kind[i];
+    if ((k == SLF_NK_COPY || k == SLF_NK_YU_OUTFLOW) && d->access_pattern != SLF_AB) {
+      delete m;
+      return fail(SLF_ERR_UNSUPPORTED, "NTCopy / NTYuOutflow nodes read neighbouring nodes of the input lattice: "
+                                       "two-copy (AB) access pattern only, as in the reference (boundary.mako:626-628)");
+    }
   }
   g.use_link_tags = d->use_link_tags;
   g.indirect = d->node_addressing == SLF_ADDR_INDIRECT;

@@ -31,13 +31,15 @@ enum NodeKind : int {
   NK_ZOUHE_VELOCITY = 9,
   NK_ZOUHE_DENSITY = 10,
   NK_REGULARIZED_DENSITY = 11,
-  NK_COUNT = 12
+  NK_COPY = 12,
+  NK_YU_OUTFLOW = 13,
+  NK_COUNT = 14
 };
 
 SLF_HD bool kind_is_wet(int k) {
   return k == NK_FLUID || k == NK_HALF_BB || k == NK_REGULARIZED_VELOCITY || k == NK_EQUILIBRIUM_DENSITY ||
          k == NK_EQUILIBRIUM_VELOCITY || k == NK_ZOUHE_VELOCITY || k == NK_ZOUHE_DENSITY ||
-         k == NK_REGULARIZED_DENSITY;
+         k == NK_REGULARIZED_DENSITY || k == NK_COPY || k == NK_YU_OUTFLOW;
 }
 SLF_HD bool kind_is_excluded(int k) { return k == NK_GHOST || k == NK_UNUSED || k == NK_PROPAGATION_ONLY; }
 

@@ -100,6 +100,32 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
     const int orientation = (int)(code >> g.orient_shift);
     const int pidx = (int)((code >> g.param_shift) & g.param_mask);
     const bool inc = p.cp.incompressible != 0;
+    // ---- fixMissingDistributions (boundary.mako:509-603): outflow nodes fill their unknown populations from
+    // the incoming state of the nodes one / two steps along the inward normal (two-copy pattern only)
+    if constexpr (PROP == PROP_AB) {
+      if ((kind == NK_COPY || kind == NK_YU_OUTFLOW) && orientation != 0) {
+        with_orientation<L>(orientation, [&](auto O) {
+          constexpr int n = L::dir2vecidx(O);
+          const int off1 = dir_offset<L, n>(ox, oy, oz, true);
+          const int off2 = 2 * (L::ex(n) + L::ey(n) * g.arr_nx + L::ez(n) * g.arr_nxy);
+          uint32_t s1 = (uint32_t)((int)gi + off1), s2 = (uint32_t)((int)gi + off2);
+          if constexpr (INDIRECT) {
+            s1 = p.nodes[s1];
+            s2 = p.nodes[s2];
+          }
+          static_for<1, L::Q>([&](auto I) {
+            if constexpr (is_missing<L, I, O>()) {
+              const R* d = p.din + ds * (size_t)I;
+              if (kind == NK_COPY) {
+                if (!INDIRECT || s1 != INVALID_NODE) f[I] = d[s1];
+              } else {
+                if (!INDIRECT || (s1 != INVALID_NODE && s2 != INVALID_NODE)) f[I] = (R)2 * d[s1] - d[s2];
+              }
+            }
+          });
+        });
+      }
+    }
     // ---- macroscopic quantities (getMacro, boundary.mako:465-507)
     const bool density_bc = kind == NK_EQUILIBRIUM_DENSITY || kind == NK_ZOUHE_DENSITY || kind == NK_REGULARIZED_DENSITY;
     const bool bc_macro = (kind == NK_REGULARIZED_VELOCITY || kind == NK_EQUILIBRIUM_VELOCITY ||

@@ -17,7 +17,7 @@ SLF_AB, SLF_AA = 0, 1
 SLF_SIM_LBM, SLF_SIM_SHAN_CHEN_BINARY, SLF_SIM_SHAN_CHEN_SINGLE = 0, 1, 2
 (SLF_NK_FLUID, SLF_NK_GHOST, SLF_NK_UNUSED, SLF_NK_PROPAGATION_ONLY, SLF_NK_FULL_BB, SLF_NK_HALF_BB,
  SLF_NK_REGULARIZED_VELOCITY, SLF_NK_EQUILIBRIUM_DENSITY, SLF_NK_EQUILIBRIUM_VELOCITY, SLF_NK_ZOUHE_VELOCITY,
- SLF_NK_ZOUHE_DENSITY, SLF_NK_REGULARIZED_DENSITY) = range(12)
+ SLF_NK_ZOUHE_DENSITY, SLF_NK_REGULARIZED_DENSITY, SLF_NK_COPY, SLF_NK_YU_OUTFLOW) = range(14)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsailfish_hip.so')
 

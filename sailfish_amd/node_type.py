@@ -281,4 +281,7 @@ HIP_KIND = {
     NTZouHeVelocity: hipabi.SLF_NK_ZOUHE_VELOCITY,
     NTZouHeDensity: hipabi.SLF_NK_ZOUHE_DENSITY,
     NTRegularizedDensity: hipabi.SLF_NK_REGULARIZED_DENSITY,
+    NTCopy: hipabi.SLF_NK_COPY,                 # two-copy (AB) access pattern only, like the reference
+    NTYuOutflow: hipabi.SLF_NK_YU_OUTFLOW,      # AB only
+    NTDoNothing: hipabi.SLF_NK_FLUID,           # AB: a plain fluid node (reference node_type.py:296-307); AA: unsupported
 }

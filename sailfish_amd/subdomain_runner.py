@@ -703,7 +703,14 @@ class SubdomainRunner(object):
                         for s_ in range(size):
                             b.set_iteration(start + s_)
                             self._enqueue_plain_step(start + s_)
-                    graphs[key] = b.capture_graph(self._calc_stream, enqueue)
+                    try:
+                        graphs[key] = b.capture_graph(self._calc_stream, enqueue)
+                    except b.FatalError as e:
+                        # nothing was executed; carry on with plain launches
+                        self.config.logger.warning('HIP graph capture failed (%s); continuing without graphs' % e)
+                        self.config.hip_graphs = False
+                        b.set_iteration(self._sim.iteration)
+                        return done
                 prof.start_step()
                 prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
                 graphs[key].launch(self._calc_stream)

@@ -9,8 +9,10 @@ from sailfish_amd import hipabi as h
 TYPE_KIND = [h.SLF_NK_FLUID, h.SLF_NK_GHOST, h.SLF_NK_FULL_BB, h.SLF_NK_REGULARIZED_VELOCITY, h.SLF_NK_HALF_BB,
              h.SLF_NK_EQUILIBRIUM_DENSITY, h.SLF_NK_UNUSED, h.SLF_NK_ZOUHE_VELOCITY, h.SLF_NK_ZOUHE_DENSITY,
              h.SLF_NK_REGULARIZED_DENSITY, h.SLF_NK_EQUILIBRIUM_VELOCITY]
+# with the outflow kinds, which exist for the two-copy access pattern only (a module with them refuses AA)
+TYPE_KIND_OUTFLOW = TYPE_KIND + [h.SLF_NK_COPY, h.SLF_NK_YU_OUTFLOW]
 (T_FLUID, T_GHOST, T_FULLBB, T_REGVEL, T_HALFBB, T_EQDENS, T_UNUSED, T_ZHVEL, T_ZHDENS, T_REGDENS,
- T_EQVEL) = range(11)
+ T_EQVEL, T_COPY, T_YU) = range(13)
 NT_BITS = (4, 3, 0)          # type bits, param bits, scratch bits
 ORIENT_SHIFT = 7
 

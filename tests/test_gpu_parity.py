@@ -226,3 +226,27 @@ def test_open_channel_inlet_outlet(backend, grid, size, t_in, t_out, model, patt
                   periodic_fused=[0, 0, 1 if dim == 3 else 0])
     assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
     assert r['dist_exact'], r
+
+
+@pytest.mark.parametrize('grid,size', [(sym.D2Q9, (40, 18)), (sym.D3Q19, (26, 12, 6))])
+@pytest.mark.parametrize('t_out,model', [('T_COPY', 'bgk'), ('T_YU', 'bgk'), ('T_COPY', 'mrt')])
+def test_open_channel_outflow_nodes(backend, grid, size, t_out, model):
+    """NTCopy / NTYuOutflow outlets (reference boundary.mako:574-603, two-copy access pattern): the unknown
+    populations of the outlet nodes come from the nodes one / two steps upstream."""
+    dim = grid.dim
+    params = [0.03, 0.0] + ([0.0] if dim == 3 else []) + [1.0]
+    r = _run_pair(backend, grid, size, 80, (False, False, dim == 3),
+                  node_map_fn=lambda d: geo.channel_inlet_outlet(d, geo.T_ZHVEL, getattr(geo, t_out), dim),
+                  u_scale=0.03, init='rest', model=model, precision='single', access_pattern='AB', visc=0.05,
+                  fluid_only=False, type_kind=geo.TYPE_KIND_OUTFLOW, nt_bits=geo.NT_BITS, node_params=params,
+                  periodic_fused=[0, 0, 1 if dim == 3 else 0])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    assert r['dist_exact'], r
+
+
+def test_outflow_nodes_need_the_two_copy_pattern(backend):
+    from sailfish_amd.backend_hip import HIPFatalError
+    desc = make_box_desc(sym.D2Q9, (16, 8), access_pattern="AA", fluid_only=False, type_kind=geo.TYPE_KIND_OUTFLOW,
+                         nt_bits=geo.NT_BITS, visc=0.05)
+    with pytest.raises(HIPFatalError, match='two-copy'):
+        backend.build(desc)
