@@ -26,7 +26,11 @@ def init_distributed(backend=None):
     os.environ.setdefault('MASTER_PORT', '29500')
     kw = {}
     if backend == 'nccl':
-        kw['device_id'] = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        # one process per GPU: make that GPU torch's current device too (streams handed to torch and RCCL's
+        # own stream must live on it)
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        kw['device_id'] = torch.device('cuda', local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world
 
@@ -124,6 +128,7 @@ class TorchDistConnector(object):
         if not sends and not recvs:
             return
         if self._stream is None:
-            self._stream = torch.cuda.ExternalStream(runner._data_stream.native)
+            self._stream = torch.cuda.ExternalStream(runner._data_stream.native,
+                                                     device=torch.device('cuda', runner.backend.gpu_id))
         with torch.cuda.stream(self._stream):
             self.exchange_tensors(sends, recvs)

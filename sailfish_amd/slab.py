@@ -80,7 +80,7 @@ class SlabSim(BoxSim):
         self.plan = SlabPlan(self.grid, self.desc)
         self.exchanger = exchanger or RingExchanger(self.rank, self.world)
         self.halo_stream = b.make_stream()
-        self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native)
+        self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
         tdtype = torch.float32 if self.desc.precision == 4 else torch.float64
         n = self.plan.count
         dev = torch.device('cuda', b.gpu_id)
