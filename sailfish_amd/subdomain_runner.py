@@ -64,6 +64,7 @@ class SubdomainRunner(object):
         self._global_periodic = None
         self.timing = {'steps': 0, 'wall': 0.0}
         self._profile = TimeProfile(self)
+        self._checkpoint_req = False      # set by SIGHUP (reference sighup_handler, :1528-1535)
         self._init_geometry_done = False
         if not hasattr(self.config, 'logger'):
             self.config.logger = util.setup_logger(self.config)
@@ -573,9 +574,26 @@ class SubdomainRunner(object):
         self.backend.set_iteration(self._sim.iteration)
 
     # ------------------------------------------------------------------ life cycle
+    def sighup_handler(self, signum, frame):
+        self.config.logger.info('Received HUP signal, will save checkpoint (it=%d).' % self._sim.iteration)
+        self._checkpoint_req = True
+
+    def _install_signal_handlers(self):
+        import signal
+        import threading
+        if hasattr(signal, 'SIGHUP') and threading.current_thread() is threading.main_thread():
+            previous = signal.getsignal(signal.SIGHUP)
+
+            def handler(signum, frame):
+                self.sighup_handler(signum, frame)
+                if callable(previous):          # several runners in one process: every one gets the request
+                    previous(signum, frame)
+            signal.signal(signal.SIGHUP, handler)
+
     def prepare(self):
         """Everything up to (not including) the main loop (reference run(), :1537-1602)."""
         cfg = self.config
+        self._install_signal_handlers()
         self._init_geometry()
         self._sim.init_fields(self)
         self._init_compute()
@@ -637,7 +655,8 @@ class SubdomainRunner(object):
                 self._output.save(self._sim.iteration)
             if getattr(cfg, 'debug_dump_dists', False):
                 self._output.dump_dists([self._debug_get_dist()], self._sim.iteration)
-        if self._sim.need_checkpoint() and cfg.checkpoint_file:
+        if (self._sim.need_checkpoint() or self._checkpoint_req) and cfg.checkpoint_file:
+            self._checkpoint_req = False
             self.save_checkpoint()
         self._sim.after_step(self)
 
@@ -660,7 +679,8 @@ class SubdomainRunner(object):
         checkpoint, statistics line, user hook or end-of-run handling."""
         cfg, sim = self.config, self._sim
         it = sim.iteration
-        if type(sim).after_step is not LBSim.after_step or sim.need_sync_flag or sim.need_fields_flag:
+        if type(sim).after_step is not LBSim.after_step or sim.need_sync_flag or sim.need_fields_flag or \
+                self._checkpoint_req:
             return 0
         lim = [1 << 30]
         if cfg.max_iters > 0:

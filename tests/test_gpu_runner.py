@@ -346,3 +346,28 @@ def test_poiseuille_force_edm(pattern):
     ctrl, exact = check_against_oracle('poiseuille', 'PoiseuilleSim', 2, cfg, 60, 0.02)
     assert exact
     assert ctrl.runners[0]._desc.force_implementation == 1
+
+
+def test_sighup_triggers_checkpoint(tmp_path):
+    """SIGHUP -> checkpoint at the next step (reference subdomain_runner.py:1528-1535)."""
+    import signal
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    base = _host.load_sim_class('ldc_2d', 'LDCSim')
+
+    class Hup(base):
+        def after_step(self, runner):
+            if self.iteration == 5:
+                os.kill(os.getpid(), signal.SIGHUP)
+
+    ck = str(tmp_path / 'hup')
+    cfg = dict(lat_nx=32, lat_ny=24, visc=0.05, access_pattern='AA', max_iters=12, quiet=True, perf_stats_every=0,
+               checkpoint_file=ck)
+    old = signal.getsignal(signal.SIGHUP)
+    try:
+        LBSimulationController(Hup, getattr(geo_mod, GEO[2]), default_config=cfg).run(ignore_cmdline=True)
+    finally:
+        signal.signal(signal.SIGHUP, old)
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.cpoint.npz'))
+    assert len(files) == 1 and '.06.' in files[0] or '.6.' in files[0], files
+    assert 'dist0a' in np.load(os.path.join(str(tmp_path), files[0])).files
