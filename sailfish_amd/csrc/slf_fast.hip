@@ -280,6 +280,7 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
   }
   if ((variant & 8) && prop != PROP_AA_EVEN) {
     const int bx = ((nx + 63) / 64) * 64;
+    if ((variant & 512) && bx != 64 && bx != 128 && bx != 256 && bx != 512) return false;  // segmented rows (slf_row.hip)
     if (bx <= 1024) {
       dim3 block(bx, 1, 1);
       dim3 grid(1, ny, nz);

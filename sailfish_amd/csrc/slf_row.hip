@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
   const int nx = g.lat_nx - 2;
-  const int x = (int)threadIdx.x + 1;
+  const int x = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const bool live = x <= nx;
   const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
   const uint32_t gi = row + (uint32_t)(live ? x : nx);  // idle lanes: an in-row address, never stored
@@ -120,11 +120,24 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   static_for<0, L::Q>([&](auto I) { st<NT>(p.dout + ds * (size_t)L::opp(I) + gi, f[I]); });
 }
 
+// Workgroup width for a row of nx nodes: the whole row.  Rows of 9-12 waves run 15-25 % below the 8-wave rows
+// of nx = 512, but cutting them into x-segments of 8 waves (row_push supports it: gridDim.x > 1, variant bit
+// 512) is slower still -- the partial-line stores of the segment edges cost more than the better fit buys
+// (profiles/r01/segmented_rows.log vs pad_rowshape.log).
+static inline int row_block_x(int nx, int variant) {
+  if (!(variant & 512)) return ((nx + 63) / 64) * 64;
+  const int waves = (nx + 63) / 64;
+  if (waves == 1 || waves == 2 || waves == 4 || waves == 8) return waves * 64;
+  int seg = 512;
+  while (seg >= nx) seg >>= 1;
+  return seg < 64 ? 64 : seg;
+}
+
 template <class L, class R, int MODEL, bool GENERAL, int NT>
 static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
-  const int bx = ((nx + 63) / 64) * 64;
+  const int bx = row_block_x(nx, p.g.variant);
   dim3 block(bx, 1, 1);
-  dim3 grid(1, ny, nz);
+  dim3 grid((nx + bx - 1) / bx, ny, nz);
   switch (prop) {
     case PROP_AB:   // (no gain from SPEC here: row_probe8.log)
       hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT>), grid, block, 0, s, p);
@@ -161,7 +174,8 @@ bool launch_sweep_row(const KernelSelector& sel, Prop prop, const Geometry& g, c
   const int nx = g.lat_nx - 2;
   // 3-D only: in 2-D (D2Q9, a few thousand rows, ~20 us per sweep) the per-node kernel with its smaller
   // workgroups is 7-15 % faster (profiles/r01/row_general2.log)
-  if (!(g.variant & 8) || sel.lattice != 1 || nx > 1024 || nx < 1) return false;
+  if (!(g.variant & 8) || sel.lattice != 1 || nx < 1) return false;
+  if (nx > 1024 && !(g.variant & 512)) return false;   // longer rows: per-node kernel (or segments, experimental)
   const int ny = y1 - y0, nz = (g.dim == 3) ? z1 - z0 : 1;
   if (ny <= 0 || nz <= 0) return false;
   const int nt = (g.variant & 1) ? 3 : 0;

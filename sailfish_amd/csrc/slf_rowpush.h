@@ -7,7 +7,8 @@
 // instruction of a wave covers whole 128-byte lines (the arrays are allocated with x = 1 on a line
 // boundary).  A value is stored iff its *source* node is active (takes part in the sweep), whatever the
 // target is; without in-sweep wrap along x the ghost columns are written by the two edge lanes.
-// Must be called by every thread of the workgroup (it contains a barrier).
+// Must be called by every thread of the workgroup (it contains a barrier); thread t of workgroup b owns
+// x = 1 + b * blockDim.x + t.
 #pragma once
 #include "slf_sweep.h"
 
@@ -36,26 +37,33 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
   const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
   const bool wrapx = g.wrap[0] != 0;
   const AxisOff ox0 = {0, 0};
+  // x-segment [xs, xe] of the row this workgroup owns.  One segment (the usual case): the wrap is part of the
+  // in-workgroup exchange.  Several segments (rows whose wave count does not tile a CU, nx > 1024): what
+  // leaves a segment is stored by its own edge lane, exactly like the ghost columns of a non-periodic row.
+  const int xs = 1 + (int)(blockIdx.x * blockDim.x);
+  const int xe = (xs + (int)blockDim.x - 1 < nx) ? xs + (int)blockDim.x - 1 : nx;
+  const bool multi = gridDim.x > 1;
+  const bool edge_stores = multi || !wrapx;
   // push: the value of node x travels to x + e_x and is stored by the thread that owns the target x
   {
     int kp = 0, km = 0;
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) > 0) {
         if (lane == 63) s_out_p[w][kp] = f[I];
-        if (x == nx) s_wrap_p[kp] = f[I];
+        if (x == xe) s_wrap_p[kp] = f[I];
         kp++;
       }
       if constexpr (L::ex(I) < 0) {
         if (lane == 0) s_out_m[w][km] = f[I];
-        if (x == 1) s_wrap_m[km] = f[I];
+        if (x == xs) s_wrap_m[km] = f[I];
         km++;
       }
     });
     if constexpr (GENERAL) {
       if (lane == 63) s_act_p[w] = (int)active;
       if (lane == 0) s_act_m[w] = (int)active;
-      if (x == nx) s_actw_p = (int)active;
-      if (x == 1) s_actw_m = (int)active;
+      if (x == xe) s_actw_p = (int)active;
+      if (x == xs) s_actw_m = (int)active;
     }
   }
   __syncthreads();
@@ -63,16 +71,16 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
   if constexpr (GENERAL) {
     int a = __shfl_up((int)active, 1);
     if (lane == 0 && w > 0) a = s_act_p[w - 1];
-    if (x == 1) a = wrapx ? s_actw_p : 0;
+    if (x == xs) a = edge_stores ? 0 : s_actw_p;
     from_left = a != 0;
     a = __shfl_down((int)active, 1);
     if (lane == 63) a = s_act_m[(w + 1) & (NW - 1)];
-    if (x == nx) a = wrapx ? s_actw_m : 0;
+    if (x == xe) a = edge_stores ? 0 : s_actw_m;
     from_right = a != 0;
   } else {
-    if (!wrapx) {
-      if (x == 1) from_left = false;
-      if (x == nx) from_right = false;
+    if (edge_stores) {
+      if (x == xs) from_left = false;
+      if (x == xe) from_right = false;
     }
   }
   {
@@ -83,19 +91,20 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
       R t = f[I];
       bool src_ok = active;
       if constexpr (L::ex(I) > 0) {
-        // edge lane, no wrap: the value leaves the row into the ghost column x = nx + 1
-        if (!wrapx && x == nx && active) st<0>(dst + 1, f[I]);
+        // edge lane: the value leaves the segment -- into the next segment, the ghost column x = nx + 1, or
+        // around the periodic seam to x = 1
+        if (edge_stores && x == xe && active) st<0>(dst + ((wrapx && x == nx) ? -(nx - 1) : 1), f[I]);
         t = shfl_up1<R>(f[I]);
         if (lane == 0 && w > 0) t = s_out_p[w - 1][kp];
-        if (x == 1) t = s_wrap_p[kp];
+        if (x == xs) t = s_wrap_p[kp];
         src_ok = from_left;
         kp++;
       }
       if constexpr (L::ex(I) < 0) {
-        if (!wrapx && x == 1 && active) st<0>(dst - 1, f[I]);
+        if (edge_stores && x == xs && active) st<0>(dst + ((wrapx && x == 1) ? (nx - 1) : -1), f[I]);
         t = shfl_down1<R>(f[I]);
         if (lane == 63) t = s_out_m[(w + 1) & (NW - 1)][km];
-        if (x == nx) t = s_wrap_m[km];
+        if (x == xe) t = s_wrap_m[km];
         src_ok = from_right;
         km++;
       }

@@ -250,3 +250,41 @@ def test_outflow_nodes_need_the_two_copy_pattern(backend):
                          nt_bits=geo.NT_BITS, visc=0.05)
     with pytest.raises(HIPFatalError, match='two-copy'):
         backend.build(desc)
+
+
+@pytest.mark.parametrize('nx', [150, 330])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('case', ['periodic_f32', 'periodic_f64_mrt', 'ghost_pbc_x', 'cavity', 'pipe_like'])
+@pytest.mark.parametrize('segmented', [False, True])
+def test_odd_row_lengths_and_segmented_rows(backend, nx, pattern, case, segmented, monkeypatch):
+    """Rows of 3 and 6 waves as whole-row workgroups (the default) and cut into x-segments (SLF_VARIANT bit 512,
+    slf_row.hip: row_block_x; 128 + 22 and 256 + 74 nodes): what leaves a segment is stored by its edge lane --
+    across segment boundaries, around the periodic seam and into the ghost columns.  Bit-identical to the oracle."""
+    if segmented:
+        monkeypatch.setenv('SLF_VARIANT', str(11 + 512))
+    size = (nx, 6, 5)
+    kw = dict(u_scale=0.05, access_pattern=pattern, visc=0.03)
+    if case == 'periodic_f32':
+        r = _run_pair(backend, sym.D3Q19, size, 13, (True, True, True), model='bgk', precision='single',
+                      periodic_fused=[1, 1, 1], **kw)
+    elif case == 'periodic_f64_mrt':
+        r = _run_pair(backend, sym.D3Q19, size, 13, (True, True, True), model='mrt', precision='double',
+                      periodic_fused=[1, 1, 1], **kw)
+    elif case == 'ghost_pbc_x':      # x periodic through the ghost-layer kernels: rows are not wrapped in-sweep
+        r = _run_pair(backend, sym.D3Q19, size, 13, (True, True, True), model='bgk', precision='single',
+                      periodic_fused=[0, 1, 1], **kw)
+    elif case == 'cavity':
+        r = _run_pair(backend, sym.D3Q19, size, 13, (False, False, False), node_map_fn=geo.cavity_3d, init='rest',
+                      model='bgk', precision='single', fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS,
+                      node_params=[0.05, 0.0, 0.0], **kw)
+    else:                            # unused nodes in the middle of rows, x wrapped in-sweep
+        def holes(desc):
+            m = geo.empty_map(desc)
+            m[2:4, 2:5, 60:140] = geo.encode(geo.T_FULLBB)
+            m[3, 3, 61:139] = geo.encode(geo.T_UNUSED)
+            return m
+        r = _run_pair(backend, sym.D3Q19, size, 13, (True, True, True), node_map_fn=holes, init='rest', model='bgk',
+                      precision='single', fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS,
+                      periodic_fused=[1, 1, 1], accel=[1e-5, 0.0, 0.0], **kw)
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    assert r['dist_exact'], r
