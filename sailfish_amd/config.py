@@ -33,8 +33,8 @@ class LBConfigParser(object):
         return self._parser.add_argument_group(name)
 
     def set_defaults(self, defaults):
-        for option in defaults.keys():
-            assert self._parser.get_default(option) is not None or True
+        """Values for declared options, and attributes for names no option declares (simulation scripts pass
+        private settings this way; the reference asserts that every key is a declared option, config.py:51-54)."""
         return self._parser.set_defaults(**defaults)
 
     def parse(self, args, internal_defaults=None):

@@ -1,0 +1,40 @@
+"""Option handling of the host layer (reference config.py:33-91, controller.py:441-455): options are
+collected from the simulation class, its subdomain, the geometry class and the backend; defaults come from
+update_defaults(), rc files, default_config and the command line, in that order of precedence."""
+import os
+
+from sailfish_amd import geo as geo_mod
+from sailfish_amd.controller import LBSimulationController
+from tests import _host
+
+
+def _ctrl(defaults=None):
+    sim_cls = _host.load_sim_class('poiseuille', 'PoiseuilleSim')
+    return LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry2D, default_config=defaults)
+
+
+def test_options_from_every_layer_and_precedence(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    cfg = _ctrl()._config_parser.parse([])
+    # model layer, example, geometry, backend, controller
+    assert cfg.visc == 0.1 and cfg.model == 'bgk' and cfg.grid == 'D2Q9'      # 0.1: the example's update_defaults
+    assert cfg.drive == 'force' and cfg.subdomains == 1 and cfg.conn_axis == 'x'
+    assert cfg.hip_fused_periodic is True and cfg.hip_graphs is True
+    assert cfg.access_pattern == 'AB' and cfg.node_addressing == 'direct' and cfg.precision == 'single'
+    assert cfg.check_invalid_results_gpu is True and cfg.force_implementation == 'guo'
+    # default_config beats update_defaults, the command line beats both
+    cfg = _ctrl({'visc': 0.05, 'lat_nx': 40})._config_parser.parse(['--visc=0.02', '--access_pattern=AA'])
+    assert cfg.visc == 0.02 and cfg.lat_nx == 40 and cfg.access_pattern == 'AA'
+    assert cfg.needs_iteration_num and not cfg.output_required
+    cfg = _ctrl()._config_parser.parse(['--output=/tmp/x', '--nohip_graphs', '--nocheck_invalid_results_gpu'])
+    assert cfg.output_required and cfg.hip_graphs is False and cfg.check_invalid_results_gpu is False
+
+
+def test_rc_file(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    with open(os.path.join(str(tmp_path), '.sailfishrc'), 'w') as f:
+        f.write('[main]\nprecision = double\n')
+    cfg = _ctrl()._config_parser.parse([])
+    assert cfg.precision == 'double'
+    cfg = _ctrl()._config_parser.parse(['--precision=single'])
+    assert cfg.precision == 'single'
