@@ -371,3 +371,41 @@ def test_sighup_triggers_checkpoint(tmp_path):
     files = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.cpoint.npz'))
     assert len(files) == 1 and '.06.' in files[0] or '.6.' in files[0], files
     assert 'dist0a' in np.load(os.path.join(str(tmp_path), files[0])).files
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('dim,cuts,size', [(2, [[9], [7]], (20, 16)), (3, [[5], [4], [3]], (11, 9, 7))])
+def test_block_decomposition_on_gpu(pattern, dim, cuts, size):
+    """2 x 2 (x 2) blocks of a periodic box, all on the one GPU: face, edge and corner halos and periodic images
+    between different subdomains through LocalGroup; equal to the oracle group (tests/test_halo_oracle.py shows
+    that one to equal the single-subdomain run)."""
+    from sailfish_amd.controller import LBSimulationController
+    from sailfish_amd.lb_single import LBFluidSim
+    from sailfish_amd.subdomain import Subdomain2D, Subdomain3D
+    from tests.test_halo_oracle import _block_geometry
+
+    class Box(Subdomain2D if dim == 2 else Subdomain3D):
+        def boundary_conditions(self, *h):
+            pass
+
+        def initial_conditions(self, sim, *h):
+            sim.rho[:] = 1.0 + 0.01 * np.sin(2 * np.pi * h[0] / self.gx) * np.cos(2 * np.pi * h[1] / self.gy)
+            sim.vx[:] = 0.03 * np.sin(2 * np.pi * h[1] / self.gy)
+            sim.vy[:] = 0.02 * np.cos(2 * np.pi * h[0] / self.gx)
+
+    class Sim(LBFluidSim):
+        subdomain = Box
+
+    cfg = dict(lat_nx=size[0], lat_ny=size[1], periodic_x=True, periodic_y=True, visc=0.02, model='mrt',
+               access_pattern=pattern, grid='D2Q9' if dim == 2 else 'D3Q19')
+    if dim == 3:
+        cfg.update(lat_nz=size[2], periodic_z=True)
+    geo_cls = _block_geometry(dim, cuts)
+    og = OracleGroup(Sim, dim, geo_cls, dict(cfg))
+    og.run(9, save_last=True)
+    ctrl = LBSimulationController(Sim, geo_cls, default_config=dict(cfg, max_iters=9, quiet=True, perf_stats_every=0))
+    ctrl.run(ignore_cmdline=True)
+    assert len(ctrl.runners) == 2 ** dim
+    fg, fo = merged_gpu(ctrl, 'dist'), og.merged('dist')
+    assert np.array_equal(fg, fo, equal_nan=True)
+    assert np.array_equal(merged_gpu(ctrl, 'rho'), og.merged('rho'))

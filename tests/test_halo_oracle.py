@@ -70,3 +70,62 @@ def test_pipe_3d_subdomains(pattern, nsub, axis):
     many = _run('poiseuille_3d', 'PoiseuilleSim', 3, 'EqualSubdomainsGeometry3D',
                 dict(cfg, subdomains=nsub, conn_axis=axis), steps=8)
     _compare(one, many)
+
+
+def _block_geometry(dim, cuts):
+    """Geometry class cutting the domain into a block grid: cuts = per-axis lists of cut positions (x first)."""
+    from sailfish_amd.geo import LBGeometry2D, LBGeometry3D
+    from sailfish_amd.subdomain import SubdomainSpec2D, SubdomainSpec3D
+    base = LBGeometry2D if dim == 2 else LBGeometry3D
+
+    class Blocks(base):
+        def subdomains(self):
+            g = [self.gx, self.gy] + ([self.gz] if dim == 3 else [])
+            edges = [[0] + list(c) + [g[a]] for a, c in enumerate(cuts)]
+            specs = []
+            import itertools
+            for idx in itertools.product(*[range(len(e) - 1) for e in edges]):
+                loc = tuple(edges[a][i] for a, i in enumerate(idx))
+                size = tuple(edges[a][i + 1] - edges[a][i] for a, i in enumerate(idx))
+                specs.append((SubdomainSpec2D if dim == 2 else SubdomainSpec3D)(loc, size))
+            return specs
+    return Blocks
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('dim,cuts,size', [
+    (2, [[9], [7]], (20, 16)),                    # 2 x 2 blocks of unequal size
+    (2, [[6, 13], [8]], (20, 16)),                # 3 x 2
+    (3, [[5], [4], [3]], (11, 9, 7)),             # 2 x 2 x 2: faces, edges and corners all cross subdomains
+])
+def test_block_decompositions_of_a_periodic_box(pattern, dim, cuts, size):
+    """Every face, edge and corner neighbour incl. the periodic images is a different subdomain (or the
+    subdomain itself across the seam): owner routing of the halo lists, 1 == N bit for bit, MRT."""
+    from tests import _sc  # noqa: F401  (only for the import side effects of the helpers)
+    from sailfish_amd.lb_single import LBFluidSim
+    from sailfish_amd.subdomain import Subdomain2D, Subdomain3D
+
+    class Box(Subdomain2D if dim == 2 else Subdomain3D):
+        def boundary_conditions(self, *h):
+            pass
+
+        def initial_conditions(self, sim, *h):
+            sim.rho[:] = 1.0 + 0.01 * np.sin(2 * np.pi * h[0] / self.gx) * np.cos(2 * np.pi * h[1] / self.gy)
+            sim.vx[:] = 0.03 * np.sin(2 * np.pi * h[1] / self.gy)
+            sim.vy[:] = 0.02 * np.cos(2 * np.pi * h[0] / self.gx)
+            if dim == 3:
+                sim.vz[:] = 0.01 * np.sin(2 * np.pi * (h[0] / self.gx + h[2] / self.gz))
+
+    class Sim(LBFluidSim):
+        subdomain = Box
+
+    cfg = dict(lat_nx=size[0], lat_ny=size[1], periodic_x=True, periodic_y=True, visc=0.02, model='mrt',
+               access_pattern=pattern, grid='D2Q9' if dim == 2 else 'D3Q19')
+    if dim == 3:
+        cfg.update(lat_nz=size[2], periodic_z=True)
+    one = OracleGroup(Sim, dim, 'LBGeometry%dD' % dim, dict(cfg))
+    many = OracleGroup(Sim, dim, _block_geometry(dim, cuts), dict(cfg))
+    assert len(many.subs) == np.prod([len(c) + 1 for c in cuts])
+    one.run(9, save_last=True)
+    many.run(9, save_last=True)
+    _compare(one, many)
