@@ -1,0 +1,1 @@
+"""Weak-scaling harness (one block per GPU)."""

@@ -1,0 +1,1 @@
+"""Simulation scripts written against the `sailfish` API, run through the HIP backend."""

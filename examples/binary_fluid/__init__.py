@@ -1,0 +1,1 @@
+"""Binary-fluid (Shan-Chen) simulation scripts."""

@@ -1,0 +1,1 @@
+"""Result tools with the command lines of the reference (merge_subdomains, compare_results)."""
