@@ -2,8 +2,9 @@
 // (slf_fast.hip: fast_row_kernel) for every D3Q19 configuration -- f32 / f64, BGK / MRT, with or without
 // the node map (walls, boundary conditions, unused nodes), x wrapped in-sweep or not.
 //
-//   * one workgroup = one (y, z) row, thread t owns node x = t + 1; the distribution arrays are
-//     allocated so that x = 1 starts a 128-byte line  =>  every global access of a wave is line aligned;
+//   * one workgroup = one (y, z) row (or, opt-in, an x-segment of it: row_block_x), thread t of workgroup b
+//     owns node x = 1 + b * blockDim.x + t; the distribution arrays are allocated so that x = 1 starts a
+//     128-byte line  =>  every global access of a wave is line aligned;
 //   * the +-1 x shift of the push (AB and odd AA step) happens in registers: __shfl_up/down inside a
 //     wave64, one LDS word per direction between neighbouring waves, the periodic wrap as the cyclic
 //     continuation (x = nx <-> x = 1)  =>  every *store* is aligned (partial-line writes are what hurts
@@ -24,8 +25,9 @@ namespace slf {
 
 // SPEC (node-map kernels): issue the population loads BEFORE the node map is read instead of predicating
 // them on it.  A workgroup advances at the pace of its slowest wave (barrier in row_push), so the extra
-// dependent round trip map -> loads costs 4-6 % of the odd step at 512^3 (profiles/r01/row_probe7.log, row_probe8.log); loading for excluded
-// nodes as well wastes their bytes, so the host asks for SPEC only when few nodes are excluded.
+// dependent round trip map -> loads costs 4-6 % of the odd step at 512^3 (profiles/r01/row_probe7.log,
+// row_probe8.log); loading for excluded nodes as well wastes their bytes, so the host asks for SPEC only when
+// few nodes are excluded.
 template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool SPEC = false>
 __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
