@@ -33,7 +33,8 @@ def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='A
               precision=4 if precision == 'single' else 8,
               access_pattern=hipabi.SLF_AA if access_pattern == 'AA' else hipabi.SLF_AB,
               lat_nx=lat[0], lat_ny=lat[1], lat_nz=lat[2] if dim == 3 else 1,
-              arr_nx=padded_nx(lat[0], alignment), arr_ny=lat[1], arr_nz=lat[2] if dim == 3 else 1,
+              arr_nx=padded_nx(lat[0], alignment) + int(os.environ.get('SLF_ARR_NX_PAD', '0')),   # experiments
+              arr_ny=lat[1] + int(os.environ.get('SLF_ARR_NY_PAD', '0')), arr_nz=lat[2] if dim == 3 else 1,
               periodic_fused=list(periodic_fused), fluid_only=int(fluid_only),
               tau=sym.relaxation_time(visc), visc=visc, mrt_rates=sym.mrt_rates(grid, visc),
               incompressible=int(incompressible), relaxation_enabled=int(relaxation_enabled),

@@ -409,6 +409,10 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   g.variant = SLF_DEFAULT_VARIANT;
   if (d->sparse_geometry) g.variant |= 64;
   if (const char* ev = getenv("SLF_VARIANT")) g.variant = atoi(ev);
+  g.row_order = 0;
+  g.lds_pad = 0;
+  if (const char* ev = getenv("SLF_ROW_ORDER")) g.row_order = atoi(ev);
+  if (const char* ev = getenv("SLF_LDS_PAD")) g.lds_pad = atoi(ev);
   slf::Physics& ph = m->phys;
   ph.tau = d->tau;
   ph.visc = d->visc;

@@ -34,19 +34,28 @@ __device__ __forceinline__ void vset(typename VecT<VEC>::type& v, int k, float x
 // Even AA step (own node, opposite slot), VEC nodes per thread.  Thread 0 of a row starts at the first
 // real node x = 1; the launcher only selects VEC > 1 when x = 1 is VEC-element aligned in memory (the
 // backend allocates distribution arrays with that offset), so every access is an aligned 8 / 16-byte one.
-template <int MODEL, int VEC, int NT>
-__global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const SweepParams<D3Q19, float> p) {
+template <int MODEL, int VEC, int NT, bool FORCE>
+// (second launch bound: minimum waves per SIMD.  The force-free BGK instantiation needs 82 VGPRs when left alone,
+// two more than six resident waves allow.)
+__global__ void __launch_bounds__(VEC == 4 ? 256 : 512, (VEC == 2 && MODEL == 0 && !FORCE) ? 6 : 2) fast_even_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   typedef typename VecT<VEC>::type V;
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = p.z0 + (int)blockIdx.z;
-  const int gx0 = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  int by = (int)blockIdx.y, bz = (int)blockIdx.z;
+  row_of_block(g.row_order, (int)gridDim.y, (int)gridDim.z, by, bz);
+  const int gy = sgpr(p.y0 + by);
+  const int gz = sgpr(p.z0 + bz);
+  const uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;   // index of this thread's VEC-node group in the row
+  const int gx0 = 1 + (int)vi * VEC;
   if (gx0 > g.lat_nx - 2) return;
-  const uint32_t gi = (uint32_t)gx0 + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
+  const uint32_t gi = row + (uint32_t)gx0;
+  const uint32_t vb = vi * (uint32_t)sizeof(V);                // ... and its byte offset from x = 1
   const size_t ds = g.dist_size;
   V fv[L::Q];
-  static_for<0, L::Q>([&](auto I) { fv[I] = ld<NT>((const V*)(p.din + ds * (size_t)I + gi)); });
+  static_for<0, L::Q>([&](auto I) {
+    fv[I] = ldg<NT>(at_byte(uniform_base((const V*)(p.din + ds * (size_t)I + row + 1)), vb));
+  });
   V orho, ovx, ovy, ovz;
 #pragma unroll
   for (int k = 0; k < VEC; k++) {
@@ -56,8 +65,8 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const S
     macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
     if (gx0 + k <= g.lat_nx - 2) check_invalid<float>(p.status, p.options, rho, gx0 + k, gy, gz);
     if (p.relaxation_enabled) {
-      if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
-      else mrt_relax<L, float>(f, v, p.cp, false);
+      if constexpr (MODEL == 0) bgk_relax<L, float, FORCE>(f, rho, v, p.cp);
+      else mrt_relax<L, float, FORCE>(f, v, p.cp, false);
     }
     static_for<0, L::Q>([&](auto I) { vset<VEC>(fv[I], k, f[I]); });
     vset<VEC>(orho, k, rho);
@@ -78,11 +87,13 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512) fast_even_kernel(const S
   }
   // nodes of the last group beyond x = nx are the high ghost / padding: their own slots are never read
   // when x is wrapped in-sweep
-  static_for<0, L::Q>([&](auto I) { st<NT>((V*)(p.dout + ds * (size_t)L::opp(I) + gi), fv[I]); });
+  static_for<0, L::Q>([&](auto I) {
+    stg<NT>(at_byte(uniform_base((V*)(p.dout + ds * (size_t)L::opp(I) + row + 1)), vb), fv[I]);
+  });
 }
 
 // One node per thread, any propagation mode (scalar accesses), optional non-temporal hint.
-template <int MODEL, int PROP, int NT>
+template <int MODEL, int PROP, int NT, bool FORCE>
 __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   const Geometry& g = p.g;
@@ -108,8 +119,8 @@ __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q
   macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
   check_invalid<float>(p.status, p.options, rho, gx, gy, gz);
   if (p.relaxation_enabled) {
-    if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
-    else mrt_relax<L, float>(f, v, p.cp, false);
+    if constexpr (MODEL == 0) bgk_relax<L, float, FORCE>(f, rho, v, p.cp);
+    else mrt_relax<L, float, FORCE>(f, v, p.cp, false);
   }
   if (p.options & 1u) {
     p.rho[gi] = rho;
@@ -136,24 +147,29 @@ __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q
 // (x = 1 <-> x = nx).  This is the MI355X counterpart of the reference's shuffle / shared-memory
 // propagation (propagation.mako:180-382).  Requires blockDim.x >= nx (the row fits one workgroup) and
 // x wrapped in-sweep.
-template <int MODEL, int PROP, int NT>
+template <int MODEL, int PROP, int NT, bool FORCE>
 __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   constexpr int NW = 16;
   __shared__ float s_in_p[NW][5], s_in_m[NW][5], s_out_p[NW][5], s_out_m[NW][5];
   __shared__ float s_inw_p[5], s_inw_m[5], s_wrap_p[5], s_wrap_m[5];
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = p.z0 + (int)blockIdx.z;
+  int by = (int)blockIdx.y, bz = (int)blockIdx.z;
+  row_of_block(g.row_order, (int)gridDim.y, (int)gridDim.z, by, bz);
+  const int gy = sgpr(p.y0 + by);
+  const int gz = sgpr(p.z0 + bz);
   const int nx = g.lat_nx - 2;
   const int x = (int)threadIdx.x + 1;
   const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
   const bool live = x <= nx;
-  const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
-  const uint32_t gi = row + (uint32_t)(live ? x : nx);  // idle lanes: any in-row address, never stored
+  const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
+  const uint32_t xi = (uint32_t)(live ? x : 1);  // idle lanes: an in-row address, never stored
+  const uint32_t xb = xi * 4u;                   // the ONE per-lane address register: byte offset of x in its row
+  const uint32_t gi = row + xi;
   const AxisOff ox0 = {0, 0};
-  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
-  const AxisOff oz = axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]);
+  AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  AxisOff oz = axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]);
+  oy.p = sgpr(oy.p); oy.m = sgpr(oy.m); oz.p = sgpr(oz.p); oz.m = sgpr(oz.m);
   const size_t ds = g.dist_size;
 
   float f[L::Q];
@@ -161,7 +177,7 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
     // raw_i(x) = slot opp(i) at (x, y - e_y, z - e_z): the value node x + e_x will use as f_i
     static_for<0, L::Q>([&](auto I) {
       const int off = dir_offset<L, I>(ox0, oy, oz, false);
-      f[I] = ld<NT>(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gi + off));
+      f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)row + off)), xb));
     });
     {
       int kp = 0, km = 0;
@@ -199,15 +215,15 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
       });
     }
   } else {
-    static_for<0, L::Q>([&](auto I) { f[I] = ld<NT>(p.din + ds * (size_t)I + gi); });
+    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
   }
 
   float rho, v[3];
   macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
   if (live) check_invalid<float>(p.status, p.options, rho, x, gy, gz);
   if (p.relaxation_enabled) {
-    if constexpr (MODEL == 0) bgk_relax<L, float>(f, rho, v, p.cp);
-    else mrt_relax<L, float>(f, v, p.cp, false);
+    if constexpr (MODEL == 0) bgk_relax<L, float, FORCE>(f, rho, v, p.cp);
+    else mrt_relax<L, float, FORCE>(f, v, p.cp, false);
   }
   if ((p.options & 1u) && live) {
     p.rho[gi] = rho;
@@ -251,13 +267,13 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
       }
       if (live) {
         const int off = dir_offset<L, I>(ox0, oy, oz, true);
-        st<NT>(p.dout + ds * (size_t)I + (uint32_t)((int)gi + off), t);
+        stg<NT>(at_byte(uniform_base(p.dout + ds * (size_t)I + (uint32_t)((int)row + off)), xb), t);
       }
     });
   }
 }
 
-template <int MODEL, int NT>
+template <int MODEL, int NT, bool FORCE>
 static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19, float>& p, int ny, int nz,
                            int block_x, hipStream_t s) {
   const int variant = g.variant;
@@ -274,8 +290,8 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
     if (bx > (vec == 4 ? 256 : 512)) bx = (vec == 4 ? 256 : 512);
     dim3 block(bx, 1, 1);
     dim3 grid((threads_needed + bx - 1) / bx, ny, nz);
-    if (vec == 4) hipLaunchKernelGGL((fast_even_kernel<MODEL, 4, NT>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, NT>), grid, block, 0, s, p);
+    if (vec == 4) hipLaunchKernelGGL((fast_even_kernel<MODEL, 4, NT, FORCE>), grid, block, g.lds_pad, s, p);
+    else hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, NT, FORCE>), grid, block, g.lds_pad, s, p);
     return true;
   }
   if ((variant & 8) && prop != PROP_AA_EVEN) {
@@ -284,8 +300,8 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
     if (bx <= 1024) {
       dim3 block(bx, 1, 1);
       dim3 grid(1, ny, nz);
-      if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT>), grid, block, 0, s, p);
+      if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT, FORCE>), grid, block, g.lds_pad, s, p);
+      else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT, FORCE>), grid, block, g.lds_pad, s, p);
       return true;
     }
   }
@@ -293,14 +309,14 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, ny, nz);
   switch (prop) {
-    case PROP_AB: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AB, NT>), grid, block, 0, s, p); break;
-    case PROP_AA_EVEN: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_EVEN, NT>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_ODD, NT>), grid, block, 0, s, p); break;
+    case PROP_AB: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AB, NT, FORCE>), grid, block, 0, s, p); break;
+    case PROP_AA_EVEN: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_EVEN, NT, FORCE>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_ODD, NT, FORCE>), grid, block, 0, s, p); break;
   }
   return true;
 }
 
-template <int MODEL>
+template <int MODEL, bool FORCE>
 static bool launch_fast_model(Prop prop, const Geometry& g, const SweepParams<D3Q19, float>& p, int ny, int nz,
                               int block_x, hipStream_t s) {
   // bit 1: NT loads + stores; bit 16: NT loads only; bit 32: NT stores only
@@ -309,10 +325,10 @@ static bool launch_fast_model(Prop prop, const Geometry& g, const SweepParams<D3
   if (g.variant & 16) nt |= 1;
   if (g.variant & 32) nt |= 2;
   switch (nt) {
-    case 0: return launch_fast_nt<MODEL, 0>(prop, g, p, ny, nz, block_x, s);
-    case 1: return launch_fast_nt<MODEL, 1>(prop, g, p, ny, nz, block_x, s);
-    case 2: return launch_fast_nt<MODEL, 2>(prop, g, p, ny, nz, block_x, s);
-    default: return launch_fast_nt<MODEL, 3>(prop, g, p, ny, nz, block_x, s);
+    case 0: return launch_fast_nt<MODEL, 0, FORCE>(prop, g, p, ny, nz, block_x, s);
+    case 1: return launch_fast_nt<MODEL, 1, FORCE>(prop, g, p, ny, nz, block_x, s);
+    case 2: return launch_fast_nt<MODEL, 2, FORCE>(prop, g, p, ny, nz, block_x, s);
+    default: return launch_fast_nt<MODEL, 3, FORCE>(prop, g, p, ny, nz, block_x, s);
   }
 }
 
@@ -322,8 +338,15 @@ bool launch_sweep_fast(const KernelSelector& sel, Prop prop, const Geometry& g, 
   if (g.variant & 256) return false;   // experiments: use the generic row kernels (slf_row.hip) instead
   if (y1 <= y0 || z1 <= z0) return false;
   const SweepParams<D3Q19, float> p = make_params<D3Q19, float>(g, ph, a, y0, z0);
-  bool done = sel.model == 0 ? launch_fast_model<0>(prop, g, p, y1 - y0, z1 - z0, block_x, s)
-                             : launch_fast_model<1>(prop, g, p, y1 - y0, z1 - z0, block_x, s);
+  const int ny = y1 - y0, nz = z1 - z0;
+  bool done;
+  if (ph.has_force) {
+    done = sel.model == 0 ? launch_fast_model<0, true>(prop, g, p, ny, nz, block_x, s)
+                          : launch_fast_model<1, true>(prop, g, p, ny, nz, block_x, s);
+  } else {   // no body force: straight-line collision, half the registers, twice the resident waves
+    done = sel.model == 0 ? launch_fast_model<0, false>(prop, g, p, ny, nz, block_x, s)
+                          : launch_fast_model<1, false>(prop, g, p, ny, nz, block_x, s);
+  }
   if (done) *err = hipGetLastError();
   return done;
 }

@@ -26,6 +26,8 @@ struct Geometry {
   int use_link_tags;
   int variant;                 // tuned-kernel selection bits (SLF_VARIANT), see slf_fast.hip
   int indirect;                // distributions hold active nodes only, addressed through SweepArgs::nodes
+  int row_order;               // workgroup -> row mapping of the whole-row kernels (SLF_ROW_ORDER), see row_of_block()
+  int lds_pad;                 // extra dynamic LDS bytes per workgroup (SLF_LDS_PAD): occupancy throttle, experiments
 };
 
 struct Physics {

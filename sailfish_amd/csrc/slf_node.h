@@ -170,10 +170,17 @@ SLF_D void bgk_relax_accel(R (&f)[L::Q], R rho, R (&v)[3], R omega, R guo_pref, 
   }
 }
 
-template <class L, class R>
+// FORCE = false: the module has no body force -- a compile-time fact for the kernel, so that the Guo / exact
+// difference branches (and the registers their merge points cost: 98 -> 48 VGPRs in the whole-row kernel, i.e.
+// 4 -> 8 resident waves per SIMD) do not exist in the instantiation the force-free configurations run.
+template <class L, class R, bool FORCE = true>
 SLF_D void bgk_relax(R (&f)[L::Q], R rho, R (&v)[3], const CollideParams<L, R>& cp) {
-  bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, cp.has_force != 0, cp.accel,
-                        cp.force_edm != 0);
+  if constexpr (FORCE) {
+    bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, cp.has_force != 0, cp.accel,
+                          cp.force_edm != 0);
+  } else {
+    bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, false, cp.accel, false);
+  }
 }
 
 // C7 helpers: one row of the integer moment matrix applied to a vector.
@@ -235,11 +242,12 @@ SLF_D void mrt_equilibrium(const R (&m)[L::Q], R inv_rho, R (&meq)[L::Q]) {
 
 // C7: relaxation in moment space.  force_eq: equilibrium-type node (moments
 // forced to equilibrium, relaxation_mrt.mako:58-77).
-template <class L, class R>
+template <class L, class R, bool FORCE = true>
 SLF_D void mrt_relax(R (&f)[L::Q], R (&v)[3], const CollideParams<L, R>& cp, bool force_eq) {
   R m[L::Q];
   static_for<0, L::Q>([&](auto K) { m[K] = mrt_row<L, R, K>(f); });
-  if (cp.has_force) {
+  const bool has_force = FORCE && cp.has_force;
+  if (has_force) {
     m[L::M_MX] = m[L::M_MX] + (R)0.5 * cp.accel[0];
     m[L::M_MY] = m[L::M_MY] + (R)0.5 * cp.accel[1];
     if constexpr (L::dim == 3) m[L::M_MZ] = m[L::M_MZ] + (R)0.5 * cp.accel[2];
@@ -255,14 +263,14 @@ SLF_D void mrt_relax(R (&f)[L::Q], R (&v)[3], const CollideParams<L, R>& cp, boo
       m[K] = m[K] - cp.mrt_s[K] * (m[K] - meq[K]);
     }
   });
-  if (cp.has_force) {
+  if (has_force) {
     m[L::M_MX] = m[L::M_MX] + (R)0.5 * cp.accel[0];
     m[L::M_MY] = m[L::M_MY] + (R)0.5 * cp.accel[1];
     if constexpr (L::dim == 3) m[L::M_MZ] = m[L::M_MZ] + (R)0.5 * cp.accel[2];
   }
   static_for<0, L::Q>([&](auto K) { m[K] = m[K] * (R)(1.0 / (double)L::mrt_norm(K)); });
   static_for<0, L::Q>([&](auto I) { f[I] = mrt_col<L, R, I>(m); });
-  if (cp.has_force) {
+  if (has_force) {
     static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * cp.accel[D]; });
   }
 }

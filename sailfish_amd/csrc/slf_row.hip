@@ -28,36 +28,43 @@ namespace slf {
 // dependent round trip map -> loads costs 4-6 % of the odd step at 512^3 (profiles/r01/row_probe7.log,
 // row_probe8.log); loading for excluded nodes as well wastes their bytes, so the host asks for SPEC only when
 // few nodes are excluded.
-template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool SPEC = false>
+template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool FORCE, bool SPEC = false>
 __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gy = sgpr(p.y0 + (int)blockIdx.y);
+  const int gz = (L::dim == 3) ? sgpr(p.z0 + (int)blockIdx.z) : 0;
   const int nx = g.lat_nx - 2;
   const int x = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const bool live = x <= nx;
-  const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
-  const uint32_t gi = row + (uint32_t)(live ? x : nx);  // idle lanes: an in-row address, never stored
+  const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
+  const uint32_t xi = (uint32_t)(live ? x : 1);  // idle lanes: an in-row address, never stored
+  const uint32_t gi = row + xi;
   const AxisOff ox = axis_off(x, g.lat_nx, 1, g.wrap[0]);
-  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
-  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  oy.p = sgpr(oy.p); oy.m = sgpr(oy.m); oz.p = sgpr(oz.p); oz.m = sgpr(oz.m);
+  const AxisOff ox0 = {0, 0};
   const size_t ds = g.dist_size;
 
-  // ---- load.  Odd AA step: pull with plain x-shifted loads -- misaligned *reads* cost little (the
-  // neighbouring wave uses the rest of the line; measured equal to an LDS exchange of aligned loads,
-  // profiles/r01/row_probe4.log) and save a barrier; the push below is what must be aligned.
+  // ---- load.  Every address = (wave-uniform row base of the direction, in SGPRs) + (this lane's byte offset in
+  // the row): uniform_base(), slf_sweep.h.  Odd AA step: pull with plain x-shifted loads -- misaligned *reads*
+  // cost little (the neighbouring wave uses the rest of the line; measured equal to an LDS exchange of aligned
+  // loads, profiles/r01/row_probe4.log) and save a barrier; the push below is what must be aligned.
   R f[L::Q];
-  auto src_of = [&](auto I) -> const R* {
+  auto src_of = [&](auto I) -> const SLF_GLOBAL R* {
     if constexpr (PROP == PROP_AA_ODD) {
-      const int off = dir_offset<L, I>(ox, oy, oz, false);
-      return p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)gi + off);
+      const int off = dir_offset<L, I>(ox0, oy, oz, false);                     // y, z part: uniform
+      constexpr int ex = L::ex(I);
+      const int xs = (ex == 0) ? 0 : ((ex > 0) ? ox.m : ox.p);                  // x part of x - e_i: per lane
+      return at_byte(uniform_base(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)row + off)),
+                     (uint32_t)((int)xi + xs) * (uint32_t)sizeof(R));
     } else {
-      return p.din + ds * (size_t)I + gi;
+      return at_byte(uniform_base(p.din + ds * (size_t)I + row), xi * (uint32_t)sizeof(R));
     }
   };
   if constexpr (SPEC || !GENERAL) {
-    static_for<0, L::Q>([&](auto I) { f[I] = ld<NT>(src_of(I)); });
+    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(src_of(I)); });
   }
   int kind = NK_FLUID;
   uint32_t code = 0;
@@ -68,13 +75,13 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
     active = live && !kind_is_excluded(kind);
   }
   if constexpr (GENERAL && !SPEC) {
-    static_for<0, L::Q>([&](auto I) { f[I] = active ? ld<NT>(src_of(I)) : (R)0; });
+    static_for<0, L::Q>([&](auto I) { f[I] = active ? ldg<NT>(src_of(I)) : (R)0; });
   }
 
   R rho, v[3];
   bool wet = true;
   if (active) {
-    node_update<L, R, MODEL, PROP, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+    node_update<L, R, MODEL, PROP, GENERAL, false, FORCE>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
     if (wet) check_invalid<R>(p.status, p.options, rho, x, gy, gz);
     if ((p.options & 1u) && wet) {
       p.rho[gi] = rho;
@@ -84,18 +91,20 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
     }
   }
 
-  row_push<L, R, GENERAL, NT>(g, f, p.dout, ds, gi, x, nx, live, active, oy, oz);
+  row_push<L, R, GENERAL, NT>(g, f, p.dout, ds, row, xi, x, nx, live, active, oy, oz);
 }
 
 // Even AA step: every access is to the node's own slots (aligned); per-node kernel with cache hints.
-template <class L, class R, int MODEL, bool GENERAL, int NT>
+template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE>
 __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+  const int gy = sgpr(p.y0 + (int)blockIdx.y);
+  const int gz = (L::dim == 3) ? sgpr(p.z0 + (int)blockIdx.z) : 0;
   const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (gx > g.lat_nx - 2) return;
-  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
+  const uint32_t gi = row + (uint32_t)gx;
+  const uint32_t xb = (uint32_t)gx * (uint32_t)sizeof(R);
   const size_t ds = g.dist_size;
   R f[L::Q];
   int kind = NK_FLUID;
@@ -108,10 +117,10 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
   const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
-  static_for<0, L::Q>([&](auto I) { f[I] = ld<NT>(p.din + ds * (size_t)I + gi); });
+  static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
   R rho, v[3];
   bool wet = true;
-  node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+  node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL, false, FORCE>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
   if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
   if ((p.options & 1u) && wet) {
     p.rho[gi] = rho;
@@ -119,7 +128,7 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
     p.vy[gi] = v[1];
     if constexpr (L::dim == 3) p.vz[gi] = v[2];
   }
-  static_for<0, L::Q>([&](auto I) { st<NT>(p.dout + ds * (size_t)L::opp(I) + gi, f[I]); });
+  static_for<0, L::Q>([&](auto I) { stg<NT>(at_byte(uniform_base(p.dout + ds * (size_t)L::opp(I) + row), xb), f[I]); });
 }
 
 // Workgroup width for a row of nx nodes: the whole row.  Rows of 9-12 waves run 15-25 % below the 8-wave rows
@@ -135,28 +144,34 @@ static inline int row_block_x(int nx, int variant) {
   return seg < 64 ? 64 : seg;
 }
 
-template <class L, class R, int MODEL, bool GENERAL, int NT>
+template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE>
 static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
   const int bx = row_block_x(nx, p.g.variant);
   dim3 block(bx, 1, 1);
   dim3 grid((nx + bx - 1) / bx, ny, nz);
   switch (prop) {
     case PROP_AB:   // (no gain from SPEC here: row_probe8.log)
-      hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT, FORCE>), grid, block, 0, s, p);
       break;
     case PROP_AA_ODD:
       // variant bit 64 = the module descriptor says "sparse geometry" (many excluded nodes): predicate
-      if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, GENERAL>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT>), grid, block, 0, s, p);
+      if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, GENERAL>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE>), grid, block, 0, s, p);
       break;
-    default: hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT, FORCE>), grid, block, 0, s, p); break;
   }
 }
 
 template <class L, class R, int MODEL, bool GENERAL>
 static void launch_row4(Prop prop, int nt, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
-  if (nt == 3) launch_row5<L, R, MODEL, GENERAL, 3>(prop, p, nx, ny, nz, s);
-  else launch_row5<L, R, MODEL, GENERAL, 0>(prop, p, nx, ny, nz, s);
+  const bool force = p.cp.has_force != 0;   // compile-time "no body force" instantiations: see bgk_relax, slf_node.h
+  if (nt == 3) {
+    if (force) launch_row5<L, R, MODEL, GENERAL, 3, true>(prop, p, nx, ny, nz, s);
+    else launch_row5<L, R, MODEL, GENERAL, 3, false>(prop, p, nx, ny, nz, s);
+  } else {
+    if (force) launch_row5<L, R, MODEL, GENERAL, 0, true>(prop, p, nx, ny, nz, s);
+    else launch_row5<L, R, MODEL, GENERAL, 0, false>(prop, p, nx, ny, nz, s);
+  }
 }
 
 template <class L, class R>

@@ -27,8 +27,8 @@ template <class R>
 __device__ __forceinline__ R shfl_down1(R v) { return __shfl_down(v, 1); }
 
 template <class L, class R, bool GENERAL, int NT>
-__device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], R* dout, size_t ds, uint32_t gi,
-                                         int x, int nx, bool live, bool active, const AxisOff& oy,
+__device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], R* dout, size_t ds, uint32_t row,
+                                         uint32_t xi, int x, int nx, bool live, bool active, const AxisOff& oy,
                                          const AxisOff& oz) {
   constexpr int NW = 16;
   constexpr int NXD = count_x_dirs<L>();
@@ -86,14 +86,15 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
   {
     int kp = 0, km = 0;
     static_for<0, L::Q>([&](auto I) {
-      const int off = dir_offset<L, I>(ox0, oy, oz, true);
-      R* dst = dout + ds * (size_t)I + (uint32_t)((int)gi + off);
+      const int off = dir_offset<L, I>(ox0, oy, oz, true);     // wave-uniform: base in SGPRs, lane offset = x
+      SLF_GLOBAL R* dst = at_byte(uniform_base(dout + ds * (size_t)I + (uint32_t)((int)row + off)),
+                                  xi * (uint32_t)sizeof(R));
       R t = f[I];
       bool src_ok = active;
       if constexpr (L::ex(I) > 0) {
         // edge lane: the value leaves the segment -- into the next segment, the ghost column x = nx + 1, or
         // around the periodic seam to x = 1
-        if (edge_stores && x == xe && active) st<0>(dst + ((wrapx && x == nx) ? -(nx - 1) : 1), f[I]);
+        if (edge_stores && x == xe && active) stg<0>(dst + ((wrapx && x == nx) ? -(nx - 1) : 1), f[I]);
         t = shfl_up1<R>(f[I]);
         if (lane == 0 && w > 0) t = s_out_p[w - 1][kp];
         if (x == xs) t = s_wrap_p[kp];
@@ -101,14 +102,14 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
         kp++;
       }
       if constexpr (L::ex(I) < 0) {
-        if (edge_stores && x == xs && active) st<0>(dst + ((wrapx && x == 1) ? (nx - 1) : -1), f[I]);
+        if (edge_stores && x == xs && active) stg<0>(dst + ((wrapx && x == 1) ? (nx - 1) : -1), f[I]);
         t = shfl_down1<R>(f[I]);
         if (lane == 63) t = s_out_m[(w + 1) & (NW - 1)][km];
         if (x == xe) t = s_wrap_m[km];
         src_ok = from_right;
         km++;
       }
-      if (live && src_ok) st<NT>(dst, t);
+      if (live && src_ok) stg<NT>(dst, t);
     });
   }
 }

@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
   if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
 
   if constexpr (ROW && PROP != PROP_AA_EVEN) {
-    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, gi, gx, nx, live, active, oy, oz);
+    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz,
+                               (uint32_t)(live ? gx : nx), gx, nx, live, active, oy, oz);
   } else {
     static_for<0, L::Q>([&](auto I) {
       if constexpr (PROP == PROP_AA_EVEN) {
@@ -277,7 +278,8 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
     if constexpr (L::dim == 3) p.vz[gi] = v[2];
   }
   if constexpr (ROW && PROP != PROP_AA_EVEN) {
-    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, gi, gx, nx, live, active, oy, oz);
+    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz,
+                               (uint32_t)(live ? gx : nx), gx, nx, live, active, oy, oz);
   } else {
     static_for<0, L::Q>([&](auto I) {
       if constexpr (PROP == PROP_AA_EVEN) {

@@ -65,6 +65,78 @@ __device__ __forceinline__ void st(T* p, T v) {
   else *p = v;
 }
 
+// Wave-uniform base address pinned to an SGPR pair.  The row kernels address every population as
+// (uniform row base of direction i) + (the thread's x): with the base in SGPRs the access is
+// `global_load/store v, v_x, s[base:base+1]` -- ONE shared 32-bit VGPR offset for all 19 + 19 streams instead of
+// a 64-bit VGPR address per direction (which is what the compiler generates on its own: it re-associates the
+// uniform and the per-lane parts).  That is ~40 VGPRs, i.e. the difference between 4 and 6-8 resident waves per
+// SIMD, and resident waves are what the sweep's HBM rate tracks (profiles/r02/occupancy.md).  The empty asm
+// keeps the compiler from folding the base back into per-lane arithmetic; the explicit global address space
+// keeps the access a global_ (not flat_) instruction.  p MUST be wave-uniform.
+#define SLF_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ SLF_GLOBAL T* uniform_base(T* p) {
+  const uint64_t a = (uint64_t)p;
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);          // no-ops when the value already
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));  // lives in SGPRs
+  asm("" : "+s"(lo), "+s"(hi));
+  return (SLF_GLOBAL T*)(((uint64_t)hi << 32) | lo);
+}
+// A wave-uniform 32-bit value pinned to an SGPR (same trick; keeps the scalar address arithmetic scalar).
+template <class T>
+__device__ __forceinline__ T sgpr(T v) {
+  static_assert(sizeof(T) == 4, "32-bit values only");
+  uint32_t u = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v));
+  asm("" : "+s"(u));
+  return __builtin_bit_cast(T, u);
+}
+// base + a per-lane BYTE offset kept in 32 bits (the saddr form takes a 32-bit VGPR offset).
+template <class T>
+__device__ __forceinline__ SLF_GLOBAL T* at_byte(SLF_GLOBAL T* base, uint32_t byte_off) {
+  return (SLF_GLOBAL T*)((SLF_GLOBAL char*)base + byte_off);
+}
+template <class T>
+__device__ __forceinline__ const SLF_GLOBAL T* at_byte(const SLF_GLOBAL T* base, uint32_t byte_off) {
+  return (const SLF_GLOBAL T*)((const SLF_GLOBAL char*)base + byte_off);
+}
+template <int NT, class T>
+__device__ __forceinline__ T ldg(const SLF_GLOBAL T* p) {
+  if constexpr (NT & 1) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int NT, class T>
+__device__ __forceinline__ void stg(SLF_GLOBAL T* p, T v) {
+  if constexpr (NT & 2) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// Which (y, z) row does workgroup (by, bz) of an (ny x nz)-row launch work on?  Workgroups are dispatched in
+// linear order and workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), so the mapping decides which rows are
+// in flight together and which XCD / L2 sees which addresses.
+//   0  row = block (y fastest): the 8 XCDs interleave row by row
+//   1  XCD-chunked: XCD k streams through its own contiguous eighth of the launch
+//   2  z fastest
+//   3  XCD-chunked in units of 8 consecutive rows per XCD (row-interleaved inside a 64-row tile)
+__device__ __forceinline__ void row_of_block(int order, int ny, int nz, int& y, int& z) {
+  if (order == 0) return;
+  const uint32_t n = (uint32_t)ny * (uint32_t)nz;
+  uint32_t l = (uint32_t)y + (uint32_t)ny * (uint32_t)z;
+  if (order == 1) {
+    if (n % 8u) return;
+    l = (l % 8u) * (n / 8u) + l / 8u;
+  } else if (order == 2) {
+    y = (int)(l / (uint32_t)nz);
+    z = (int)(l % (uint32_t)nz);
+    return;
+  } else if (order == 3) {
+    if (n % 64u) return;
+    const uint32_t tile = l / 64u, r = l % 64u;     // 64 consecutive blocks -> 8 rows on each of the 8 XCDs
+    l = tile * 64u + (r % 8u) * 8u + r / 8u;
+  }
+  y = (int)(l % (uint32_t)ny);
+  z = (int)(l / (uint32_t)ny);
+}
+
 // Everything between loading the populations of a node and streaming them: macroscopic quantities,
 // pre-collision boundary conditions, collision, half-way bounce-back stores (reference
 // lb_single_fluid.mako:175-228).  Shared by all sweep kernels so that they differ only in access shape.
@@ -87,7 +159,7 @@ __device__ __forceinline__ void check_invalid(uint32_t* status, uint32_t options
 }
 
 // gi: dense node index; si: the node's slot in the distribution arrays (= gi unless INDIRECT).
-template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false>
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool FORCE = true>
 __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L::Q], uint32_t code, int kind,
                                             uint32_t gi, const AxisOff& ox, const AxisOff& oy, const AxisOff& oz,
                                             R& rho, R (&v)[3], bool& wet, uint32_t si = INVALID_NODE) {
@@ -167,9 +239,9 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
     // ---- collision (relaxate, relaxation.mako:196-202: wet nodes only)
     if (wet && p.relaxation_enabled) {
       if constexpr (MODEL == 0) {
-        bgk_relax<L, R>(f, rho, v, p.cp);
+        bgk_relax<L, R, FORCE>(f, rho, v, p.cp);
       } else {
-        mrt_relax<L, R>(f, v, p.cp, kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY);
+        mrt_relax<L, R, FORCE>(f, v, p.cp, kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY);
       }
     }
     // ---- post-collision: half-way bounce-back (boundary.mako:653-683)
@@ -200,8 +272,8 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
   } else {
     macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
     if (p.relaxation_enabled) {
-      if constexpr (MODEL == 0) bgk_relax<L, R>(f, rho, v, p.cp);
-      else mrt_relax<L, R>(f, v, p.cp, false);
+      if constexpr (MODEL == 0) bgk_relax<L, R, FORCE>(f, rho, v, p.cp);
+      else mrt_relax<L, R, FORCE>(f, v, p.cp, false);
     }
   }
 

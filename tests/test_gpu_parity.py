@@ -288,3 +288,57 @@ def test_odd_row_lengths_and_segmented_rows(backend, nx, pattern, case, segmente
                       periodic_fused=[1, 1, 1], accel=[1e-5, 0.0, 0.0], **kw)
     assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
     assert r['dist_exact'], r
+
+
+FULL_WAVE_NX = [64, 128, 256, 512, 1024]
+
+
+@pytest.mark.parametrize('nx', FULL_WAVE_NX)
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+def test_full_wave_rows_headline_kernels(backend, nx, pattern, model):
+    """The headline shape: rows that fill their wavefronts exactly (nx = 64 k; 512 is the benchmark row).
+    x == nx is lane 63 of the last wave, the LDS slot of the wave 'after' the last one is read but never
+    written, the vec-2 even AA kernel has no tail -- none of which the idle-lane sizes exercise.  Fluid-only
+    periodic box with in-sweep wrap = fast_row_kernel / fast_even_kernel (slf_fast.hip), f32, bit-exact
+    against the oracle (reference propagation.mako:180-288; its warp-edge KATs: 2d_propagation.py:178-221)."""
+    r = _run_pair(backend, sym.D3Q19, (nx, 4, 3), 7, (True, True, True), model=model, precision='single',
+                  access_pattern=pattern, visc=0.01, periodic_fused=[1, 1, 1])
+    assert r['dist_exact'] and r['rho_err'] == 0.0 and r['v_err'] == 0.0, (nx, pattern, model, r)
+
+
+@pytest.mark.parametrize('nx', FULL_WAVE_NX)
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('case', ['generic_row_f32', 'generic_row_f64_mrt', 'ghost_pbc_x', 'cavity', 'holes'])
+def test_full_wave_rows_row_kernels(backend, nx, pattern, case, monkeypatch):
+    """Same row shapes through row_kernel / even_kernel (slf_row.hip): the generic fluid-only instantiation
+    (SLF_VARIANT bit 256 routes around slf_fast.hip), f64 MRT, rows that are not wrapped in-sweep (ghost
+    columns written by the edge lanes) and the GENERAL node-map instantiations (walls + lid; excluded nodes
+    in the middle of rows)."""
+    size = (nx, 4, 3)
+    kw = dict(u_scale=0.05, access_pattern=pattern, visc=0.03)
+    if case == 'generic_row_f32':
+        monkeypatch.setenv('SLF_VARIANT', str(11 + 256))
+        r = _run_pair(backend, sym.D3Q19, size, 7, (True, True, True), model='bgk', precision='single',
+                      periodic_fused=[1, 1, 1], **kw)
+    elif case == 'generic_row_f64_mrt':
+        r = _run_pair(backend, sym.D3Q19, size, 7, (True, True, True), model='mrt', precision='double',
+                      periodic_fused=[1, 1, 1], **kw)
+    elif case == 'ghost_pbc_x':
+        r = _run_pair(backend, sym.D3Q19, size, 7, (True, True, True), model='bgk', precision='single',
+                      periodic_fused=[0, 1, 1], **kw)
+    elif case == 'cavity':
+        r = _run_pair(backend, sym.D3Q19, (nx, 5, 4), 7, (False, False, False), node_map_fn=geo.cavity_3d,
+                      init='rest', model='bgk', precision='single', fluid_only=False, type_kind=geo.TYPE_KIND,
+                      nt_bits=geo.NT_BITS, node_params=[0.05, 0.0, 0.0], **kw)
+    else:
+        def holes(desc):
+            m = geo.empty_map(desc)
+            m[1:4, 1:4, 30:nx - 10] = geo.encode(geo.T_FULLBB)
+            m[2, 2, 31:nx - 11] = geo.encode(geo.T_UNUSED)      # enclosed by walls in all 19 directions
+            return m
+        r = _run_pair(backend, sym.D3Q19, (nx, 5, 5), 7, (True, True, True), node_map_fn=holes, init='rest',
+                      model='mrt', precision='single', fluid_only=False, type_kind=geo.TYPE_KIND,
+                      nt_bits=geo.NT_BITS, periodic_fused=[1, 1, 1], accel=[1e-5, 0.0, 0.0], **kw)
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    assert r['dist_exact'], r

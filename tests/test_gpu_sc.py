@@ -218,3 +218,32 @@ def test_sc_edm(dim, size):
     g = OracleSCSubdomain(runners[0])
     g.run(15)
     assert not np.array_equal(g.real(g.current()[0]), o.real(o.current()[0]))
+
+
+@pytest.mark.parametrize('nx', [64, 128, 256, 512, 1024])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('single', [False, True])
+def test_sc_full_wave_rows(nx, pattern, single):
+    """Shan-Chen row sweeps (slf_sc.hip on top of row_push) at rows that fill their wavefronts exactly
+    (nx = 64 k): x == nx is lane 63 of the last wave and the seam exchange has no idle lane to hide behind.
+    Bit-identical to the oracle (linear pseudopotential)."""
+    from tests._oracle_group import OracleSCSingle
+    steps, size = 7, (nx, 4, 3)
+    if single:
+        kw = dict(pattern=pattern, fused=True, potential='linear', G=-1.2)
+        r = run_gpu_single(3, size, steps, **kw)
+        sim_cls, geo = _sc.make_single_sim(3)
+        cfg_, specs, runners = _host.build_runners(sim_cls, 3, geo, _sc.single_config(3, size, **kw))
+        o = OracleSCSingle(runners[0])
+        o.run(steps)
+        assert np.array_equal(r._sim.rho, o.real(o.rho))
+        gd = r._debug_get_dist()[(slice(None),) + tuple(r._spec._nonghost_slice)]
+        assert np.array_equal(gd, o.real(o.current()))
+        return
+    r = run_gpu(3, size, steps, pattern=pattern, fused=True)
+    o = run_oracle(3, size, steps, pattern=pattern, fused=True)
+    assert np.array_equal(r._sim.rho, o.real(o.rho)) and np.array_equal(r._sim.phi, o.real(o.phi))
+    for grid_num, od in enumerate(o.current()):
+        gd = r._debug_get_dist(grid_num=grid_num)
+        gd = gd[(slice(None),) + tuple(r._spec._nonghost_slice)]
+        assert np.array_equal(gd, o.real(od)), 'lattice %d populations differ' % grid_num

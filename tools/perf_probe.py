@@ -19,6 +19,7 @@ from sailfish_amd.box import make_box_desc
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--dims', default='', help='NXxNYxNZ instead of --size (cube)')
     ap.add_argument('--variants', default='0,1,4,5')
     ap.add_argument('--blocks', default='576,256')
     ap.add_argument('--reps', type=int, default=30)
@@ -39,6 +40,9 @@ def main():
     n = args.size
     grid = sym.D3Q19
     size = (n, n, n)
+    if args.dims:
+        size = tuple(int(x) for x in args.dims.split('x'))
+        assert not args.general, '--general needs a cube'
     desc0 = make_box_desc(grid, size, model=args.model, precision='single', access_pattern='AA', visc=1.0 / 6.0,
                           periodic_fused=[1, 1, 1], dist_pad=0)
     nodes = desc0.arr_nx * desc0.arr_ny * desc0.arr_nz
@@ -86,8 +90,8 @@ def main():
         k = b.get_kernel(mod0, 'SetInitialConditions', (64,), [d] + g_v + [g_rho, 0], 'PPPPPP')
         b.run_kernel(k, None, stream)
     stream.synchronize()
-    bytes_step = n ** 3 * 152
-    print('size %d^3, arr_nx %d, %d reps' % (n, desc0.arr_nx, args.reps))
+    bytes_step = size[0] * size[1] * size[2] * 152
+    print('size %s, arr_nx %d, %d reps' % ('x'.join(map(str, size)), desc0.arr_nx, args.reps))
     for variant in [int(x) for x in args.variants.split(',')]:
       for pad in pads:
         for bx in [int(x) for x in args.blocks.split(',')]:
