@@ -51,6 +51,7 @@ def main():
     off = b.dist_align_offset(4) if not args.noalign else 0
     dist_a = b.alloc_buf(size=19 * maxstride * 4, align_offset=off)
     dist_b = b.alloc_buf(size=19 * maxstride * 4, align_offset=off) if 'ab' in args.modes else 0
+    print('dist_a 0x%x dist_b 0x%x stride_bytes %d' % (dist_a, dist_b, maxstride * 4))
     shape = (desc0.arr_nz, desc0.arr_ny, desc0.arr_nx)
     rho = np.ones(shape, dtype=np.float32)
     rho += (1e-3 * np.random.RandomState(1).rand(*shape)).astype(np.float32)
