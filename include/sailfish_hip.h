@@ -163,6 +163,21 @@ int slf_memcpy_d2d_async(slf_ctx* ctx, void* dst, const void* src, size_t bytes,
 int slf_memcpy_peer_async(slf_ctx* ctx, void* dst, int dst_device, const void* src, int src_device,
                           size_t bytes, slf_stream* s);          /* same-process multi-GPU halo */
 
+/* ---- placed allocations (extension; no counterpart in the reference).  One virtual address range, backed by
+ *      separately created physical chunks that can be swapped under a fixed address.  Why: the sweep keeps 2 x Q
+ *      streams open in HBM at once, and on MI355X its rate depends on WHICH physical regions those streams fall
+ *      into (5.3 TB/s when the whole distribution array lies inside one ~16 GiB region, 6.4 TB/s when it straddles
+ *      two: profiles/r02/README.md); a plain hipMalloc lands in either case at random.  The backend therefore
+ *      reserves the range, creates a few candidate chunks, times the real kernels on candidate pairs and keeps
+ *      the best pair (sailfish_amd/placement.py).  All sizes / addresses are multiples of slf_vmm_granularity. ---- */
+int slf_vmm_granularity(slf_ctx* ctx, size_t* bytes);
+int slf_vmm_reserve(slf_ctx* ctx, size_t bytes, void** va);              /* address range only, no memory */
+int slf_vmm_release_range(slf_ctx* ctx, void* va, size_t bytes);
+int slf_vmm_chunk_create(slf_ctx* ctx, size_t bytes, uint64_t* handle); /* physical memory, not yet addressable */
+int slf_vmm_chunk_release(slf_ctx* ctx, uint64_t handle);
+int slf_vmm_map(slf_ctx* ctx, void* va, size_t bytes, uint64_t handle);  /* whole chunk at va, read-write */
+int slf_vmm_unmap(slf_ctx* ctx, void* va, size_t bytes);
+
 /* ---- streams / events: make_stream, make_event, sync_stream
  *      (backend_cuda.py:291-308, 24-52) ---- */
 int slf_stream_create(slf_ctx* ctx, slf_stream** out);

@@ -26,7 +26,7 @@ import weakref
 
 import numpy as np
 
-from sailfish_amd import hipabi
+from sailfish_amd import hipabi, placement
 
 
 class HIPFatalError(RuntimeError):
@@ -175,7 +175,7 @@ class HIPKernel(object):
             pass
 
 
-class HIPBackend(object):
+class HIPBackend(placement.VmmMixin):
     name = 'hip'
     FatalError = HIPFatalError
 
@@ -206,6 +206,7 @@ class HIPBackend(object):
         self.buffers = {}   # device address -> host mirror
         self._sizes = {}
         self._raw = {}
+        self._placed = {}
         # kernels whose trailing iteration argument set_iteration() rewrites; weak: a kernel that its owner
         # dropped (a released simulation) must not be kept alive -- or updated -- by this registry
         self._iteration_kernels = weakref.WeakSet()
@@ -283,7 +284,27 @@ class HIPBackend(object):
                    'slf_memset')
         return addr
 
+    def alloc_placed(self, sizes, align_offset=0):
+        """Distribution arrays whose physical backing is spread over HBM (sailfish_amd/placement.py): one
+        PlacedBuffer per entry of `sizes`, placed together; use their .addr like any device address."""
+        bufs = [placement.PlacedBuffer(self, n, align_offset) for n in sizes]
+        for buf in bufs:
+            self._placed[buf.addr] = buf
+            self._total_memory_bytes += buf.total
+        self.last_placement = placement.place(self, bufs)
+        for buf in bufs:       # padding columns / strides start from zeros, as in alloc_buf()
+            self.memset_buf(buf.va, 0, buf.total)
+        return bufs
+
+    def allocated_bytes(self):
+        return self._total_memory_bytes
+
     def free_buf(self, addr):
+        if addr in self._placed:
+            buf = self._placed.pop(addr)
+            self._total_memory_bytes -= buf.total
+            buf.release()
+            return
         raw = self._raw.pop(addr, addr)
         _check(self._lib, self._lib.slf_free(self._ctx, ctypes.c_void_p(raw)), 'slf_free')
         self.buffers.pop(addr, None)
@@ -311,15 +332,30 @@ class HIPBackend(object):
             return self.buffers[buf]
         return self._host_base(other)
 
+    def _segments(self, addr, nbytes):
+        """[(device address, offset, bytes)] covering [addr, addr + nbytes) without crossing the boundary between two
+        physical chunks of a placed buffer: the runtime's copy / fill calls work per allocation."""
+        for pb in self._placed.values():
+            if pb.va <= addr < pb.va + pb.total:
+                out, a, end = [], int(addr), int(addr) + int(nbytes)
+                while a < end:
+                    stop = min(end, pb.va + ((a - pb.va) // pb.part_bytes + 1) * pb.part_bytes)
+                    out.append((a, a - int(addr), stop - a))
+                    a = stop
+                return out
+        return [(int(addr), 0, int(nbytes))]
+
     def to_buf(self, buf, source=None):
         host = self._resolve(buf, source)
-        _check(self._lib, self._lib.slf_memcpy_h2d(self._ctx, ctypes.c_void_p(buf), host.ctypes.data, host.nbytes),
-               'slf_memcpy_h2d')
+        for a, off, n in self._segments(buf, host.nbytes):
+            _check(self._lib, self._lib.slf_memcpy_h2d(self._ctx, ctypes.c_void_p(a), host.ctypes.data + off, n),
+                   'slf_memcpy_h2d')
 
     def from_buf(self, buf, target=None):
         host = self._resolve(buf, target)
-        _check(self._lib, self._lib.slf_memcpy_d2h(self._ctx, host.ctypes.data, ctypes.c_void_p(buf), host.nbytes),
-               'slf_memcpy_d2h')
+        for a, off, n in self._segments(buf, host.nbytes):
+            _check(self._lib, self._lib.slf_memcpy_d2h(self._ctx, host.ctypes.data + off, ctypes.c_void_p(a), n),
+                   'slf_memcpy_d2h')
 
     def to_buf_async(self, buf, stream=None):
         host = self.buffers[buf]
@@ -345,8 +381,9 @@ class HIPBackend(object):
                'slf_memcpy_peer_async')
 
     def memset_buf(self, buf, value, nbytes, stream=None):
-        _check(self._lib, self._lib.slf_memset(self._ctx, ctypes.c_void_p(buf), int(value), int(nbytes),
-                                              stream.handle if stream else None), 'slf_memset')
+        for a, off, n in self._segments(buf, nbytes):
+            _check(self._lib, self._lib.slf_memset(self._ctx, ctypes.c_void_p(a), int(value), n,
+                                                  stream.handle if stream else None), 'slf_memset')
 
     # -- modules / kernels --------------------------------------------------
     def build(self, source):

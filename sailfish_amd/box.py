@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from sailfish_amd import hipabi, sym
+from sailfish_amd import hipabi, placement, sym
 
 
 def padded_nx(lat_nx, alignment=32):
@@ -78,9 +78,17 @@ class BoxSim(object):
         fbytes = self.stride * self.dtype().itemsize
         self.module = b.build(desc)
         off = b.dist_align_offset(self.dtype().itemsize)
-        self.gpu_dist = [b.alloc_buf(size=self.Q * fbytes, align_offset=off)]
-        if not self.aa:
-            self.gpu_dist.append(b.alloc_buf(size=self.Q * fbytes, align_offset=off))
+        # large distribution arrays are *placed*: spread over physical HBM (placement.py)
+        self.placed = []
+        self.placement_info = None
+        if placement.enabled() and self.Q * fbytes >= placement.MIN_BYTES and not int(desc.node_addressing):
+            self.placed = b.alloc_placed([self.Q * fbytes] * (1 if self.aa else 2), off)
+            self.placement_info = b.last_placement
+            self.gpu_dist = [pb.addr for pb in self.placed]
+        else:
+            self.gpu_dist = [b.alloc_buf(size=self.Q * fbytes, align_offset=off)]
+            if not self.aa:
+                self.gpu_dist.append(b.alloc_buf(size=self.Q * fbytes, align_offset=off))
         # host mirrors of the macroscopic fields (ghost = +inf sentinel, reference
         # subdomain_runner.py:278-297)
         self.rho = np.full(self.shape, np.inf, dtype=self.dtype)

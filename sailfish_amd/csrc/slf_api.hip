@@ -164,6 +164,75 @@ int slf_memset(slf_ctx* ctx, void* dptr, int value, size_t bytes, slf_stream* st
   return SLF_OK;
 }
 
+// ---- placed allocations: one virtual range, backed by separately created physical chunks -----------------
+// (HIP virtual memory management: hipMemAddressReserve / hipMemCreate / hipMemMap)
+int slf_vmm_granularity(slf_ctx* ctx, size_t* bytes) {
+  if (!ctx || !bytes) return fail(SLF_ERR_INVALID, "NULL argument");
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ctx->device;
+  SLF_HIP(hipMemGetAllocationGranularity(bytes, &prop, hipMemAllocationGranularityRecommended));
+  return SLF_OK;
+}
+
+int slf_vmm_reserve(slf_ctx* ctx, size_t bytes, void** va) {
+  if (!ctx || !va) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(ctx->device));
+  SLF_HIP(hipMemAddressReserve(va, bytes, 0, nullptr, 0));
+  return SLF_OK;
+}
+
+int slf_vmm_release_range(slf_ctx* ctx, void* va, size_t bytes) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipMemAddressFree(va, bytes));
+  return SLF_OK;
+}
+
+int slf_vmm_chunk_create(slf_ctx* ctx, size_t bytes, uint64_t* handle) {
+  if (!ctx || !handle) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(ctx->device));
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ctx->device;
+  hipMemGenericAllocationHandle_t h;
+  SLF_HIP(hipMemCreate(&h, bytes, &prop, 0));
+  static_assert(sizeof(h) <= sizeof(uint64_t), "allocation handle does not fit the ABI type");
+  *handle = 0;
+  memcpy(handle, &h, sizeof(h));
+  return SLF_OK;
+}
+
+int slf_vmm_chunk_release(slf_ctx* ctx, uint64_t handle) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  hipMemGenericAllocationHandle_t h;
+  memcpy(&h, &handle, sizeof(h));
+  SLF_HIP(hipMemRelease(h));
+  return SLF_OK;
+}
+
+int slf_vmm_map(slf_ctx* ctx, void* va, size_t bytes, uint64_t handle) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipSetDevice(ctx->device));
+  hipMemGenericAllocationHandle_t h;
+  memcpy(&h, &handle, sizeof(h));
+  SLF_HIP(hipMemMap(va, bytes, 0, h, 0));
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = ctx->device;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  SLF_HIP(hipMemSetAccess(va, bytes, &acc, 1));
+  return SLF_OK;
+}
+
+int slf_vmm_unmap(slf_ctx* ctx, void* va, size_t bytes) {
+  if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipSetDevice(ctx->device));
+  SLF_HIP(hipMemUnmap(va, bytes));
+  return SLF_OK;
+}
+
 int slf_host_alloc_pinned(size_t bytes, void** hptr) {
   if (!hptr) return fail(SLF_ERR_INVALID, "hptr is NULL");
   SLF_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
@@ -409,6 +478,20 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   g.variant = SLF_DEFAULT_VARIANT;
   if (d->sparse_geometry) g.variant |= 64;
   if (const char* ev = getenv("SLF_VARIANT")) g.variant = atoi(ev);
+  g.layout = 0;
+  if (const char* ev = getenv("SLF_LAYOUT")) g.layout = atoi(ev);
+  {
+    const long long Q = (d->lattice == SLF_D2Q9) ? 9 : 19;
+    if (g.layout == 1) {
+      g.dq = (unsigned long long)g.arr_nx;
+      g.dsy = Q * g.arr_nx;
+      g.dsz = Q * (long long)g.arr_nx * g.arr_ny;
+    } else {
+      g.dq = g.dist_size;
+      g.dsy = g.arr_nx;
+      g.dsz = g.arr_nxy;
+    }
+  }
   g.row_order = 0;
   g.lds_pad = 0;
   if (const char* ev = getenv("SLF_ROW_ORDER")) g.row_order = atoi(ev);

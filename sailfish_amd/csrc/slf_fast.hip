@@ -51,10 +51,11 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512, (VEC == 2 && MODEL == 0 
   const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
   const uint32_t gi = row + (uint32_t)gx0;
   const uint32_t vb = vi * (uint32_t)sizeof(V);                // ... and its byte offset from x = 1
-  const size_t ds = g.dist_size;
+  const size_t ds = g.dq;
+  const size_t drow = (size_t)(g.dsy * gy + g.dsz * gz);       // the row in distribution space (layout, slf_kernels.h)
   V fv[L::Q];
   static_for<0, L::Q>([&](auto I) {
-    fv[I] = ldg<NT>(at_byte(uniform_base((const V*)(p.din + ds * (size_t)I + row + 1)), vb));
+    fv[I] = ldg<NT>(at_byte(uniform_base((const V*)(p.din + ds * (size_t)I + drow + 1)), vb));
   });
   V orho, ovx, ovy, ovz;
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512, (VEC == 2 && MODEL == 0 
   // nodes of the last group beyond x = nx are the high ghost / padding: their own slots are never read
   // when x is wrapped in-sweep
   static_for<0, L::Q>([&](auto I) {
-    stg<NT>(at_byte(uniform_base((V*)(p.dout + ds * (size_t)L::opp(I) + row + 1)), vb), fv[I]);
+    stg<NT>(at_byte(uniform_base((V*)(p.dout + ds * (size_t)L::opp(I) + drow + 1)), vb), fv[I]);
   });
 }
 
@@ -166,18 +167,17 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
   const uint32_t xi = (uint32_t)(live ? x : 1);  // idle lanes: an in-row address, never stored
   const uint32_t xb = xi * 4u;                   // the ONE per-lane address register: byte offset of x in its row
   const uint32_t gi = row + xi;
-  const AxisOff ox0 = {0, 0};
-  AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
-  AxisOff oz = axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]);
-  oy.p = sgpr(oy.p); oy.m = sgpr(oy.m); oz.p = sgpr(oz.p); oz.m = sgpr(oz.m);
-  const size_t ds = g.dist_size;
+  const DistOff oy = dist_axis_off(gy, g.lat_ny, g.dsy, g.wrap[1]);
+  const DistOff oz = dist_axis_off(gz, g.lat_nz, g.dsz, g.wrap[2]);
+  const size_t ds = g.dq;
+  const long long drow = g.dsy * gy + g.dsz * gz;              // the row in distribution space (layout, slf_kernels.h)
 
   float f[L::Q];
   if constexpr (PROP == PROP_AA_ODD) {
     // raw_i(x) = slot opp(i) at (x, y - e_y, z - e_z): the value node x + e_x will use as f_i
     static_for<0, L::Q>([&](auto I) {
-      const int off = dir_offset<L, I>(ox0, oy, oz, false);
-      f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)row + off)), xb));
+      const long long off = dist_dir_offset<L, I>(oy, oz, false);
+      f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)L::opp(I) + (size_t)(drow + off)), xb));
     });
     {
       int kp = 0, km = 0;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
       });
     }
   } else {
-    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
+    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + (size_t)drow), xb)); });
   }
 
   float rho, v[3];
@@ -266,8 +266,8 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
         km++;
       }
       if (live) {
-        const int off = dir_offset<L, I>(ox0, oy, oz, true);
-        stg<NT>(at_byte(uniform_base(p.dout + ds * (size_t)I + (uint32_t)((int)row + off)), xb), t);
+        const long long off = dist_dir_offset<L, I>(oy, oz, true);
+        stg<NT>(at_byte(uniform_base(p.dout + ds * (size_t)I + (size_t)(drow + off)), xb), t);
       }
     });
   }

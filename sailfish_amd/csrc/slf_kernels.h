@@ -26,6 +26,12 @@ struct Geometry {
   int use_link_tags;
   int variant;                 // tuned-kernel selection bits (SLF_VARIANT), see slf_fast.hip
   int indirect;                // distributions hold active nodes only, addressed through SweepArgs::nodes
+  // Distribution addressing: element (q, x, y, z) lives at q * dq + x + dsy * y + dsz * z.
+  //   direction-major (reference layout, kernel_common.mako:459-461):  dq = dist_size, dsy = arr_nx, dsz = arr_nxy
+  //   row-interleaved [z][y][q][x]:                                     dq = arr_nx, dsy = Q arr_nx, dsz = Q arr_nx arr_ny
+  unsigned long long dq;
+  long long dsy, dsz;
+  int layout;                  // 0 direction-major, 1 row-interleaved
   int row_order;               // workgroup -> row mapping of the whole-row kernels (SLF_ROW_ORDER), see row_of_block()
   int lds_pad;                 // extra dynamic LDS bytes per workgroup (SLF_LDS_PAD): occupancy throttle, experiments
 };

@@ -110,6 +110,31 @@ __device__ __forceinline__ void stg(SLF_GLOBAL T* p, T v) {
   else *p = v;
 }
 
+// Distribution-space neighbour offsets along y and z (64-bit: in the row-interleaved layout a periodic wrap
+// spans the whole array) -- wave-uniform, they live in SGPRs.
+struct DistOff {
+  long long p, m;
+};
+__device__ __forceinline__ DistOff dist_axis_off(int c, int lat, long long stride, int wrap) {
+  DistOff o;
+  o.p = stride;
+  o.m = -stride;
+  if (wrap) {
+    if (c == lat - 2) o.p = -(long long)(lat - 3) * stride;
+    if (c == 1) o.m = (long long)(lat - 3) * stride;
+  }
+  return o;
+}
+// offset of (y, z) + e_i (forward) or - e_i in distribution space, y and z components only
+template <class L, int I>
+__device__ __forceinline__ long long dist_dir_offset(const DistOff& oy, const DistOff& oz, bool forward) {
+  long long off = 0;
+  constexpr int ey = L::ey(I), ez = L::ez(I);
+  if constexpr (ey != 0) off += ((ey > 0) == forward) ? oy.p : oy.m;
+  if constexpr (ez != 0) off += ((ez > 0) == forward) ? oz.p : oz.m;
+  return off;
+}
+
 // Which (y, z) row does workgroup (by, bz) of an (ny x nz)-row launch work on?  Workgroups are dispatched in
 // linear order and workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), so the mapping decides which rows are
 // in flight together and which XCD / L2 sees which addresses.

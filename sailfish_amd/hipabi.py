@@ -76,6 +76,13 @@ SIGNATURES = {
     'slf_malloc': (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     'slf_free': (c_int, [c_void_p, c_void_p]),
     'slf_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'slf_vmm_granularity': (c_int, [c_void_p, POINTER(c_size_t)]),
+    'slf_vmm_reserve': (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    'slf_vmm_release_range': (c_int, [c_void_p, c_void_p, c_size_t]),
+    'slf_vmm_chunk_create': (c_int, [c_void_p, c_size_t, POINTER(ctypes.c_uint64)]),
+    'slf_vmm_chunk_release': (c_int, [c_void_p, ctypes.c_uint64]),
+    'slf_vmm_map': (c_int, [c_void_p, c_void_p, c_size_t, ctypes.c_uint64]),
+    'slf_vmm_unmap': (c_int, [c_void_p, c_void_p, c_size_t]),
     'slf_host_alloc_pinned': (c_int, [c_size_t, POINTER(c_void_p)]),
     'slf_host_free': (c_int, [c_void_p]),
     'slf_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),

@@ -1,0 +1,125 @@
+"""Placement of the distribution arrays in HBM (MI355X-specific; no counterpart in the reference).
+
+What was measured (profiles/r02/README.md): the sweep keeps 2 x Q = 38 streams open in HBM at once.  On MI355X the
+rate it sustains depends on WHERE in physical memory the array it writes lies: 5.3 TB/s when the whole array sits
+inside one coarse region (tens of GiB) of the physical address space, 6.1-6.4 TB/s when it is spread over several,
+best with the traffic split evenly.  Single-stream kernels (copy, fill, read) do not care, the stride between the
+direction arrays does not matter, clocks / power / TLB counters are identical in both cases -- only the number of
+outstanding memory requests differs.  A plain hipMalloc puts a 10 GB array into one region about 40 % of the time.
+
+What is done about it: a large distribution array is a *placed* buffer -- one reserved virtual range (so the layout
+the kernels and the host see is the reference's `q * dist_stride + node`), backed by PARTS separately created
+physical chunks.  While the chunks are created, spacer allocations are put between them and released afterwards, so
+the chunks end up spread over SPAN bytes of physical memory, whatever the regions are; nothing is wasted once the
+spacers are gone.  Several buffers placed together (the two copies of the AB pattern) share the span.  Skipped for
+arrays below MIN_BYTES (they run from the caches / are launch bound) and with SLF_PLACEMENT=0.
+"""
+import ctypes
+import os
+
+MIN_BYTES = 1 << 30
+PARTS = 16
+SPAN = 72 << 30
+
+
+def enabled():
+    return os.environ.get('SLF_PLACEMENT', '1') not in ('0', 'off', 'no')
+
+
+class PlacedBuffer(object):
+    """A device buffer at a fixed virtual address made of `parts` equally sized physical chunks."""
+
+    def __init__(self, backend, nbytes, align_offset=0, parts=PARTS):
+        self.backend = backend
+        gran = backend.vmm_granularity()
+        need = int(nbytes) + 256
+        self.parts = parts
+        self.part_bytes = (need + parts * gran - 1) // (parts * gran) * gran
+        self.total = self.part_bytes * parts
+        self.va = backend.vmm_reserve(self.total)
+        self.addr = self.va + int(align_offset)
+        self.nbytes = int(nbytes)
+        self.mapped = [None] * parts
+
+    def map_part(self, i, handle):
+        assert self.mapped[i] is None
+        self.backend.vmm_map(self.va + i * self.part_bytes, self.part_bytes, handle)
+        self.mapped[i] = handle
+
+    def release(self):
+        """Unmaps and releases the chunks and the address range."""
+        b = self.backend
+        for i, h in enumerate(self.mapped):
+            if h is not None:
+                b.vmm_unmap(self.va + i * self.part_bytes, self.part_bytes)
+                b.vmm_chunk_release(h)
+                self.mapped[i] = None
+        if self.va:
+            b.vmm_release_range(self.va, self.total)
+            self.va = 0
+
+
+def place(backend, buffers, span=None):
+    """Backs `buffers` (PlacedBuffer with equal part counts) with physical chunks spread over `span` bytes: part i of
+    every buffer, then a spacer, for i = 0 .. parts-1; the spacers are released at the end."""
+    parts = buffers[0].parts
+    assert all(b.parts == parts for b in buffers)
+    gran = backend.vmm_granularity()
+    payload = sum(b.total for b in buffers)
+    if span is None:
+        span = int(os.environ.get('SLF_PLACEMENT_SPAN_GIB', SPAN >> 30)) << 30
+    free = backend.total_memory - backend.allocated_bytes()
+    span = min(span, int(0.8 * free))
+    spacer = max(0, (span - payload) // parts) // gran * gran
+    spacers = []
+    try:
+        for i in range(parts):
+            for b in buffers:
+                b.map_part(i, backend.vmm_chunk_create(b.part_bytes))
+            if spacer and i + 1 < parts:
+                spacers.append(backend.vmm_chunk_create(spacer))
+    finally:
+        for h in spacers:
+            backend.vmm_chunk_release(h)
+    return {'parts': parts, 'part_gib': round(buffers[0].part_bytes / 2.0 ** 30, 3),
+            'spacer_gib': round(spacer / 2.0 ** 30, 3), 'span_gib': round((payload + spacer * (parts - 1)) / 2.0 ** 30, 1)}
+
+
+def _check(lib, status, what):
+    if status != 0:
+        from sailfish_amd.backend_hip import HIPFatalError
+        msg = lib.slf_last_error()
+        raise HIPFatalError('%s failed (status %d): %s' % (what, status, msg.decode() if msg else '?'))
+
+
+class VmmMixin(object):
+    """Thin ctypes wrappers of the slf_vmm_* entry points (mixed into HIPBackend)."""
+
+    def vmm_granularity(self):
+        n = ctypes.c_size_t()
+        _check(self._lib, self._lib.slf_vmm_granularity(self._ctx, ctypes.byref(n)), 'slf_vmm_granularity')
+        return int(n.value)
+
+    def vmm_reserve(self, nbytes):
+        p = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_vmm_reserve(self._ctx, int(nbytes), ctypes.byref(p)), 'slf_vmm_reserve')
+        return p.value
+
+    def vmm_release_range(self, va, nbytes):
+        _check(self._lib, self._lib.slf_vmm_release_range(self._ctx, ctypes.c_void_p(va), int(nbytes)),
+               'slf_vmm_release_range')
+
+    def vmm_chunk_create(self, nbytes):
+        h = ctypes.c_uint64()
+        _check(self._lib, self._lib.slf_vmm_chunk_create(self._ctx, int(nbytes), ctypes.byref(h)), 'slf_vmm_chunk_create')
+        return int(h.value)
+
+    def vmm_chunk_release(self, handle):
+        _check(self._lib, self._lib.slf_vmm_chunk_release(self._ctx, ctypes.c_uint64(handle)), 'slf_vmm_chunk_release')
+
+    def vmm_map(self, va, nbytes, handle):
+        _check(self._lib, self._lib.slf_vmm_map(self._ctx, ctypes.c_void_p(va), int(nbytes), ctypes.c_uint64(handle)),
+               'slf_vmm_map')
+
+    def vmm_unmap(self, va, nbytes):
+        _check(self._lib, self._lib.slf_vmm_unmap(self._ctx, ctypes.c_void_p(va), int(nbytes)), 'slf_vmm_unmap')

@@ -342,3 +342,25 @@ def test_full_wave_rows_row_kernels(backend, nx, pattern, case, monkeypatch):
                       nt_bits=geo.NT_BITS, periodic_fused=[1, 1, 1], accel=[1e-5, 0.0, 0.0], **kw)
     assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
     assert r['dist_exact'], r
+
+
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+def test_placed_distribution_arrays(backend, pattern, monkeypatch):
+    """Distribution arrays as placed buffers (sailfish_amd/placement.py: one virtual range backed by separately
+    created physical chunks with spacers in between while they are created): same results as a plain allocation,
+    bit for bit -- including host copies that cross chunk boundaries -- and everything is given back."""
+    from sailfish_amd import placement
+    monkeypatch.setattr(placement, 'MIN_BYTES', 0)
+    monkeypatch.setenv('SLF_PLACEMENT_SPAN_GIB', '1')
+    size = (128, 24, 20)
+    r = _run_pair(backend, sym.D3Q19, size, 9, (True, True, True), model='bgk', precision='single',
+                  access_pattern=pattern, visc=0.01, periodic_fused=[1, 1, 1])
+    assert r['dist_exact'] and r['rho_err'] == 0.0 and r['v_err'] == 0.0, r
+    desc = make_box_desc(sym.D3Q19, size, access_pattern=pattern, periodic_fused=[1, 1, 1])
+    used = backend.allocated_bytes()
+    s = BoxSim(backend, desc, periodic=(True, True, True))
+    assert len(s.placed) == (1 if pattern == 'AA' else 2) and s.placement_info['parts'] == placement.PARTS
+    assert all(h is not None for pb in s.placed for h in pb.mapped)
+    addrs = [pb.addr for pb in s.placed]
+    s.release()
+    assert not any(a in backend._placed for a in addrs) and backend.allocated_bytes() == used

@@ -52,3 +52,36 @@ int probe_launch(int kind, int nt, void* dst, const void* src, size_t bytes, voi
   return (int)hipGetLastError();
 }
 }
+
+// K streams S bytes apart: block b works on stream b % K, chunk b / K (4 KiB chunks).  kind: 0 write, 1 read,
+// 2 in-place read-modify-write.  Emulates "K arrays written concurrently" with a controlled separation.
+template <int KIND>
+__global__ void __launch_bounds__(256) kstream_k(f4* __restrict__ base, size_t chunks_per_stream, int K, size_t s_bytes,
+                                                 float* sink) {
+  const size_t b = blockIdx.x;
+  const size_t stream = b % (size_t)K, chunk = b / (size_t)K;
+  if (chunk >= chunks_per_stream) return;
+  f4* p = (f4*)((char*)base + stream * s_bytes + chunk * 4096) + threadIdx.x;
+  if (KIND == 0) {
+    f4 v = {1.f, 2.f, 3.f, 4.f};
+    __builtin_nontemporal_store(v, p);
+  } else if (KIND == 1) {
+    f4 v = __builtin_nontemporal_load(p);
+    if (v[0] + v[1] + v[2] + v[3] == 123456.789f) sink[0] = v[0];
+  } else {
+    f4 v = __builtin_nontemporal_load(p);
+    v[0] += 1.f;
+    __builtin_nontemporal_store(v, p);
+  }
+}
+
+extern "C" int probe_kstream(int kind, void* base, size_t bytes_per_stream, int K, size_t s_bytes, void* sink, void* stream) {
+  const size_t chunks = bytes_per_stream / 4096;
+  const size_t blocks = chunks * (size_t)K;
+  if (blocks > 0x7fffffffull) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 0) hipLaunchKernelGGL(kstream_k<0>, dim3((unsigned)blocks), dim3(256), 0, s, (f4*)base, chunks, K, s_bytes, (float*)sink);
+  else if (kind == 1) hipLaunchKernelGGL(kstream_k<1>, dim3((unsigned)blocks), dim3(256), 0, s, (f4*)base, chunks, K, s_bytes, (float*)sink);
+  else hipLaunchKernelGGL(kstream_k<2>, dim3((unsigned)blocks), dim3(256), 0, s, (f4*)base, chunks, K, s_bytes, (float*)sink);
+  return (int)hipGetLastError();
+}

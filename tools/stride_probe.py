@@ -22,8 +22,9 @@ def main():
     ap.add_argument('--dims', default='512x512x512')
     ap.add_argument('--offsets', default='0,8,16,24,28,32')
     ap.add_argument('--pads', default='0,32,1024,32768,65536,131072,262144,524288,1048576,2097152')
-    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--reps', type=int, default=6)
     ap.add_argument('--mode', default='even')
+    ap.add_argument('--ab_interleave', action='store_true', help='mode ab: copy B sits in the gaps of copy A (half a stride later)')
     args = ap.parse_args()
 
     class Opt(object):
@@ -37,7 +38,8 @@ def main():
     nodes = desc0.arr_nx * desc0.arr_ny * desc0.arr_nz
     nbytes_max = 19 * (nodes + max(pads)) * 4
     span = int(max(offsets) * (1 << 30))
-    block = b.alloc_buf(size=nbytes_max + span + (4 << 20))
+    two = 2 if (args.mode == 'ab' and not args.ab_interleave) else 1
+    block = b.alloc_buf(size=two * (nbytes_max + (2 << 20)) + span + (4 << 20))
     base = (block + (2 << 20) - 1) // (2 << 20) * (2 << 20)
     off0 = b.dist_align_offset(4)
     shape = (desc0.arr_nz, desc0.arr_ny, desc0.arr_nx)
@@ -53,18 +55,32 @@ def main():
         desc = make_box_desc(grid, size, precision='single', access_pattern='AA', visc=1.0 / 6.0, periodic_fused=[1, 1, 1],
                              dist_pad=pad) if pad else desc0
         mod = b.build(desc)
+        desc_ab = make_box_desc(grid, size, precision='single', access_pattern='AB', visc=1.0 / 6.0,
+                                periodic_fused=[1, 1, 1], dist_pad=pad)
+        mod_ab = b.build(desc_ab)
         row = []
         for o in offsets:
             d = base + (int(o * 1024) << 20) + off0
             ki = b.get_kernel(mod, 'SetInitialConditions', (64,), [d] + g_v + [g_rho, 0], 'PPPPPP')
             b.run_kernel(ki, None, stream)
-            kern = b.get_kernel(mod, 'CollideAndPropagate', (64,), [0, d, d, g_rho] + g_v + [0], sig, needs_iteration=True)
-            b._lib.slf_kernel_set_iteration(kern.handle, 0 if args.mode == 'even' else 1)
-            for _ in range(2):
-                b.run_kernel(kern, None, stream)
+            if args.mode == 'ab':
+                d2 = d + (nbytes_max + (2 << 20)) // (2 << 20) * (2 << 20)
+                if args.ab_interleave:
+                    d2 = d + ((nodes + pad) // 2 * 4) // (2 << 20) * (2 << 20)
+                    assert (nodes + pad) // 2 * 4 >= nodes * 4 + (4 << 20), 'gaps too small for copy B'
+                ki2 = b.get_kernel(mod, 'SetInitialConditions', (64,), [d2] + g_v + [g_rho, 0], 'PPPPPP')
+                b.run_kernel(ki2, None, stream)
+                ks = [b.get_kernel(mod_ab, 'CollideAndPropagate', (64,), [0, d, d2, g_rho] + g_v + [0], sig),
+                      b.get_kernel(mod_ab, 'CollideAndPropagate', (64,), [0, d2, d, g_rho] + g_v + [0], sig)]
+            else:
+                kern = b.get_kernel(mod, 'CollideAndPropagate', (64,), [0, d, d, g_rho] + g_v + [0], sig, needs_iteration=True)
+                b._lib.slf_kernel_set_iteration(kern.handle, 0 if args.mode == 'even' else 1)
+                ks = [kern, kern]
+            for i in range(2):
+                b.run_kernel(ks[i & 1], None, stream)
             e0 = b.make_event(stream, timing=True)
-            for _ in range(args.reps):
-                b.run_kernel(kern, None, stream)
+            for i in range(args.reps):
+                b.run_kernel(ks[i & 1], None, stream)
             e1 = b.make_event(stream, timing=True)
             e1.synchronize()
             row.append(e1.time_since(e0) / args.reps)
