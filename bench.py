@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: MLUPS of the fused collide-and-stream sweep, D3Q19 BGK,
-single precision, 512^3 fully periodic box per GPU (BASELINE.json metric;
-SURVEY.md §8(d) "M0"), through backend_hip -> libsailfish_hip.so.
+"""Headline benchmark: MLUPS of the fused collide-and-stream sweep, D3Q19 BGK, single precision, periodic box
+(BASELINE.json metric; SURVEY.md §8(d) "M0" / "C4"), through backend_hip -> libsailfish_hip.so.
 
     python bench.py --gpus N --steps K --warmup W
+        weak scaling (default): 512^3 per GPU, the global box is 512 x 512 x (512 N) cut into N z-slabs
+    python bench.py --gpus N --scaling strong --domain 1024x512x512 --axis {x,z}
+        BASELINE config 4: a fixed box cut into N slabs along x (the reference's default axis, geo.py:100-135) or z
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the global domain
-is 512 x 512 x (512 N), cut into N slabs along z (weak scaling), halo planes
-exchanged device-to-device over RCCL every step (sailfish_amd/connector.py).
+N > 1: launched by torch.distributed.run, one rank per GPU; face layers are exchanged device-to-device over RCCL
+every step on a halo stream that overlaps the interior sweep (sailfish_amd/slab.py).  --force_distributed takes the
+same path with a single rank (the slab is its own ring neighbour; RCCL send / recv to self).
 
-Prints ONE JSON line on rank 0 (see the field list in DESIGN.md §6).
+Prints ONE JSON line on rank 0 (field list: DESIGN.md §6).  `value` is the best of --repeats timed runs of exactly
+K steps (each bracketed by barrier + synchronize, max over ranks); the median and every run are in `config`.
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -31,7 +36,12 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--size', type=int, default=512, help='box edge per GPU (512 = the headline config)')
+    ap.add_argument('--size', type=int, default=512, help='weak scaling: box edge per GPU (512 = the headline config)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--domain', default='1024x512x512', help='strong scaling: the global box NXxNYxNZ')
+    ap.add_argument('--axis', default='z', choices=['x', 'y', 'z'], help='axis the box is cut along')
+    ap.add_argument('--force_distributed', action='store_true',
+                    help='one rank, but through the halo path (pack, RCCL send / recv to self, unpack)')
     ap.add_argument('--access_pattern', default='auto', choices=['auto', 'AA', 'AB'],
                     help='AA = in-place single copy, AB = two copies (the reference default); auto times both '
                          'with the same K steps and reports the faster one')
@@ -41,50 +51,42 @@ def parse_args():
                     help='use ghost-layer PBC kernels (reference scheme) instead of in-sweep wrap')
     ap.add_argument('--visc', type=float, default=1.0 / 6.0)
     ap.add_argument('--no_cpu_baseline', action='store_true')
-    ap.add_argument('--cpu_seconds', type=float, default=12.0)
+    ap.add_argument('--cpu_seconds', type=float, default=10.0)
     ap.add_argument('--repeats', type=int, default=2,
-                    help='each candidate access pattern is timed this many times (K steps each); the best is kept')
+                    help='each candidate access pattern is timed this many times (K steps each)')
     ap.add_argument('--prewarm_steps', type=int, default=300,
-                    help='untimed steps before the W warm-up steps (same count on every rank), so that clocks and '
-                         'caches are in steady state: about 1 s at 512^3')
+                    help='untimed steps before the W warm-up steps (same count on every rank): about 1 s at 512^3')
+    ap.add_argument('--no_gpu_state', action='store_true', help='do not sample amd-smi before / after')
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """The oracle (CPU restatement, OpenMP) timed on this box's host cores on a bounded sample of
-    the same workload: D3Q19 BGK AA periodic box, 128^3, as many steps as fit in ~cpu_seconds.
-    The reference has no CPU compute path, hence kind = "port"."""
-    from sailfish_amd import sym
-    from sailfish_amd.box import make_box_desc
-    from tests._oracle_box import OracleBox, synthetic_fields
-    n = 128
-    size = (n, n, n)
-    desc = make_box_desc(sym.D3Q19, size, model=args.model, precision=args.precision, access_pattern='AA',
-                         visc=args.visc, periodic_fused=[1, 1, 1])
-    ob = OracleBox(desc, periodic=(True, True, True))
-    rho, v = synthetic_fields(size, 3, dtype=np.float32)
-    ob.set_fields(rho, v)
-    ob.initial_conditions()
-    ob.run(2, save_last=False)
-    t0 = time.time()
-    steps = 0
-    while time.time() - t0 < args.cpu_seconds:
-        ob.run(2, save_last=False)
-        steps += 2
-    dt = time.time() - t0
-    cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
-    cpu_model = 'unknown CPU'
+def gpu_state():
+    """Clocks, power and temperatures from `amd-smi metric` (evidence that a run was not throttled)."""
     try:
-        with open('/proc/cpuinfo') as fh:
-            for line in fh:
-                if line.startswith('model name'):
-                    cpu_model = line.split(':', 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    return {'value': round(n ** 3 * steps / dt * 1e-6, 2), 'unit': 'MLUPS', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle/lbm_oracle.c (OpenMP, %d threads on %s), D3Q19 %s f%d AA periodic %d^3, %d steps in %.1f s'
-                      % (cores, cpu_model, args.model.upper(), 32 if args.precision == 'single' else 64, n, steps, dt)}
+        out = subprocess.run(['amd-smi', 'metric', '-g', '0'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             timeout=20).stdout.decode(errors='replace')
+    except Exception:  # noqa: BLE001
+        return None
+    st = {}
+    gfx = [int(x) for x in re.findall(r'GFX_\d+:\s*\n\s*CLK:\s*(\d+) MHz', out)]
+    if gfx:
+        st['gfx_clk_mhz_min'], st['gfx_clk_mhz_max'] = min(gfx), max(gfx)
+    for key, pat in (('mem_clk_mhz', r'MEM_0:\s*\n\s*CLK:\s*(\d+) MHz'), ('socket_power_w', r'SOCKET_POWER:\s*(\d+) W'),
+                     ('temp_hotspot_c', r'HOTSPOT:\s*(\d+)'), ('temp_mem_c', r'\n\s*MEM:\s*(\d+)\s*.C'),
+                     ('throttle', r'THROTTLE_STATUS:\s*(\S+)')):
+        m = re.search(pat, out)
+        if m:
+            st[key] = int(m.group(1)) if m.group(1).isdigit() else m.group(1)
+    return st or None
+
+
+def cpu_baseline(args):
+    """The CPU restatement of the sweep timed on this box's host cores: the blocked OpenMP twin
+    (oracle/lbm_fast.c, bit-identical to the table-driven oracle: tests/test_cpu_twin.py) at 256^3 D3Q19 and on
+    BASELINE config 1 (256^2 D2Q9), best of 3, all cores and one thread.  The reference has no CPU compute path
+    (SURVEY.md F1), hence kind = "port"."""
+    from oracle import cpu_twin
+    return cpu_twin.baseline(args.model, args.precision, args.visc, budget_s=args.cpu_seconds)
 
 
 def load_traffic(workload_key):
@@ -94,7 +96,7 @@ def load_traffic(workload_key):
     try:
         with open(p) as fh:
             return json.load(fh).get(workload_key)
-    except Exception:
+    except Exception:  # noqa: BLE001
         return None
 
 
@@ -114,30 +116,60 @@ def main():
 
     from sailfish_amd import sym
     from sailfish_amd.backend_hip import HIPBackend
-    from sailfish_amd.slab import SlabSim
+    from sailfish_amd.slab import AXES, SlabSim
 
     class Opt(object):
         pass
 
     backend = HIPBackend(Opt(), local_rank)
-    n = args.size
+    distributed = world > 1 or args.force_distributed
+    if distributed:
+        from sailfish_amd.connector import init_distributed
+        init_distributed(force=True)
+    axis = AXES[args.axis]
+    if args.scaling == 'weak':
+        local = [args.size] * 3
+        domain = list(local)
+        domain[axis] *= world
+    else:
+        domain = [int(x) for x in args.domain.split('x')]
+        if domain[axis] % world:
+            raise SystemExit('the %s extent of --domain must be a multiple of the rank count' % args.axis)
+        local = list(domain)
+        local[axis] //= world
+    local_nodes = local[0] * local[1] * local[2]
 
     def barrier(sim):
         sim.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
 
     def measure(pattern):
-        sim = SlabSim(backend, sym.D3Q19, (n, n, n), rank=rank, world=world, model=args.model,
+        sim = SlabSim(backend, sym.D3Q19, tuple(local), rank=rank, world=world, model=args.model,
                       precision=args.precision, access_pattern=pattern, visc=args.visc,
-                      fused_periodic=not args.no_fused_periodic)
+                      fused_periodic=not args.no_fused_periodic, axis=args.axis, force_halo=args.force_distributed)
+        res = {'pattern': pattern, 'block': sim.block_size, 'placement': sim.placement_info}
         sim.init_synthetic(seed=1234)
+        if sim.halo:
+            # what the sweep launches cost when nothing is waited for (reference for the overlap figure)
+            for _ in range(10):
+                sim.step_sweep_only()
+            sim.sync()
+            e0 = backend.make_event(sim.calc_stream, timing=True)
+            for _ in range(20):
+                sim.step_sweep_only()
+            e1 = backend.make_event(sim.calc_stream, timing=True)
+            e1.synchronize()
+            res['sweep_only_ms'] = e1.time_since(e0) / 20
+            sim.init_synthetic(seed=1234)
         for _ in range(args.prewarm_steps + (args.prewarm_steps & 1)):   # untimed, even count: GPU clocks ramp up
             sim.step()
         for _ in range(args.warmup):
             sim.step()
         barrier(sim)
+        if sim.halo:
+            sim.start_halo_timing()
         ev0 = backend.make_event(sim.calc_stream, timing=True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -145,50 +177,81 @@ def main():
         ev1 = backend.make_event(sim.calc_stream, timing=True)
         barrier(sim)
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if distributed:
             t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
         ev1.synchronize()
-        kernel_ms = ev1.time_since(ev0) / args.steps   # HIP events on the sweep's own stream
-        res = {'pattern': pattern, 'elapsed': elapsed, 'kernel_ms': kernel_ms, 'block': sim.block_size}
+        res['elapsed'] = elapsed
+        res['kernel_ms'] = ev1.time_since(ev0) / args.steps   # HIP events on the sweep's own stream
+        if sim.halo:
+            res['halo_ms'] = sim.stop_halo_timing()
         sim.release()
         return res
 
+    st_before = None if (args.no_gpu_state or rank) else gpu_state()
     patterns = ['AA', 'AB'] if args.access_pattern == 'auto' else [args.access_pattern]
-    results = {}
+    runs = dict((p, []) for p in patterns)
     for _ in range(max(1, args.repeats)):
         for pat in patterns:
-            r = measure(pat)
-            if pat not in results or r['elapsed'] < results[pat]['elapsed']:
-                results[pat] = r
-    results = [results[p] for p in patterns]
-    best = min(results, key=lambda r: r['elapsed'])
+            runs[pat].append(measure(pat))
+    st_after = None if (args.no_gpu_state or rank) else gpu_state()
+    best_of = dict((p, min(rs, key=lambda r: r['elapsed'])) for p, rs in runs.items())
+    best = min(best_of.values(), key=lambda r: r['elapsed'])
     elapsed, kernel_ms = best['elapsed'], best['kernel_ms']
     args.access_pattern = best['pattern']
+    per_rank = None
+    if distributed:
+        mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms') if k in best)
+        mine['rank'] = rank
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        per_rank = gathered
 
-    fluid_nodes = n ** 3 * world
-    mlups = fluid_nodes * args.steps / elapsed * 1e-6
+    total_nodes = local_nodes * world
+    to_mlups = lambda t: total_nodes * args.steps / t * 1e-6   # noqa: E731
     prec = 4 if args.precision == 'single' else 8
     if rank == 0:
-        bpu = BYTES_PER_UPDATE[prec] if True else None
-        achieved = n ** 3 * bpu / (kernel_ms * 1e-3) / 1e9
-        wkey = 'D3Q19_%s_f%d_%s_%d_%s' % (args.model, prec * 8, args.access_pattern, n,
+        bpu = BYTES_PER_UPDATE[prec]
+        achieved = local_nodes * bpu / (kernel_ms * 1e-3) / 1e9
+        shape = 'x'.join(str(v) for v in local)
+        wkey = 'D3Q19_%s_f%d_%s_%s_%s' % (args.model, prec * 8, args.access_pattern,
+                                          str(local[0]) if len(set(local)) == 1 else shape,
                                           'ghostpbc' if args.no_fused_periodic else 'fused')
+        all_mlups = sorted(to_mlups(r['elapsed']) for r in runs[args.access_pattern])
+        if args.scaling == 'weak':
+            what = 'D3Q19 %s %s^3 per GPU' % (args.model.upper(), args.size)
+        else:
+            what = 'D3Q19 %s %s box over %d GPU(s)' % (args.model.upper(), 'x'.join(map(str, domain)), world)
+        cfg = {'workload': 'D3Q19 %s periodic box, %s nodes per GPU, global %s (fluid nodes only counted)'
+                           % (args.model.upper(), shape, 'x'.join(map(str, domain))),
+               'access_pattern': args.access_pattern,
+               'periodic': 'in-sweep wrap' if not args.no_fused_periodic else 'ghost-layer PBC kernels',
+               'decomposition': ('%s-slabs x%d, RCCL halo' % (args.axis, world)) if distributed else 'single subdomain',
+               'visc': args.visc, 'block_x': best['block'], 'repeats': max(1, args.repeats),
+               'value_is': 'best of repeats', 'median_mlups': round(float(np.median(all_mlups)), 1),
+               'runs_mlups': [round(v, 1) for v in all_mlups],
+               'candidates_mlups': dict((p, round(to_mlups(r['elapsed']), 1)) for p, r in best_of.items()),
+               'placement': best['placement']}
+        if distributed:
+            hm = max(r.get('halo_ms', 0.0) for r in per_rank)
+            so = max(r.get('sweep_only_ms', 0.0) for r in per_rank)
+            step_ms = elapsed / args.steps * 1e3
+            exposed = max(0.0, step_ms - so)
+            cfg.update({'rccl_ranks': torch.distributed.get_world_size(),
+                        'dist_backend': torch.distributed.get_backend(),
+                        'per_rank': per_rank,
+                        'halo_overlap_frac': round(max(0.0, min(1.0, 1.0 - exposed / hm)), 3) if hm > 0 else None,
+                        'halo_exposed_ms': round(exposed, 4)})
+        if st_before or st_after:
+            cfg['gpu_state'] = {'before': st_before, 'after': st_after}
         out = {
-            'metric': 'MLUPS (million lattice updates/s), D3Q19 BGK 512^3',
-            'value': round(mlups, 1), 'unit': 'MLUPS', 'n_gpus': world, 'steps': args.steps,
+            'metric': 'MLUPS (million lattice updates/s), %s' % what,
+            'value': round(to_mlups(elapsed), 1), 'unit': 'MLUPS', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32' if prec == 4 else 'f64', 'data': 'synthetic',
-            'config': {'workload': 'D3Q19 %s periodic box %d^3 per GPU (fluid nodes only counted)'
-                                   % (args.model.upper(), n),
-                       'access_pattern': args.access_pattern,
-                       'periodic': 'in-sweep wrap' if not args.no_fused_periodic else 'ghost-layer PBC kernels',
-                       'decomposition': 'z-slabs x%d, RCCL halo' % world if world > 1 else 'single subdomain',
-                       'visc': args.visc, 'block_x': best['block'], 'repeats': max(1, args.repeats),
-                       'candidates_mlups': dict((r['pattern'], round(fluid_nodes * args.steps / r['elapsed'] * 1e-6, 1))
-                                                for r in results)},
+            'config': cfg,
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': load_traffic(wkey),
                          'bytes_per_update': bpu, 'kernel_ms': round(kernel_ms, 4)},
@@ -196,7 +259,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -214,7 +214,11 @@ int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]);
  * "SetInitialConditions", "ApplyPeriodicBoundaryConditions",
  * "ApplyPeriodicBoundaryConditionsWithSwap" (AA modules only),
  * "ApplyMacroPeriodicBoundaryConditions", "CollectSparseData", "DistributeSparseData"
- * (index lists are uint64: q * dist_stride + node index), plus "ComputeMacroFields"
+ * (index lists are uint64: q * dist_stride + node index),
+ * "CollectContinuousData" / "DistributeContinuousData"(dist, buffer, dirs, base, col_stride, ncols, row_stride, nrows)
+ * (reference kernel_utils.mako:526-543, 629-645, 692-708, 777-793: face planes without index lists -- the
+ * populations in bit mask `dirs` of the node box base + c col_stride + r row_stride <-> dense buffer [k][r][c];
+ * 'i' arguments, base < 2^32), plus "ComputeMacroFields"
  * (rho / v of the current state, arguments as CollideAndPropagate).
  * Binary Shan-Chen modules (simtype = SLF_SIM_SHAN_CHEN_BINARY) provide instead of CollideAndPropagate:
  * "ShanChenPrepareMacroFields"(map, dist1, dist2, rho, phi, vx, vy[, vz], options),

@@ -192,6 +192,9 @@ class HIPBackend(placement.VmmMixin):
                            help='print the workgroup shape chosen for the sweep kernels')
         group.add_argument('--nohip_graphs', dest='hip_graphs', action='store_false', default=True,
                            help='do not replay stretches of steps without host interaction as HIP graphs')
+        group.add_argument('--nohip_placement', dest='hip_placement', action='store_false', default=True,
+                           help='plain allocations for the distribution arrays instead of spreading their physical '
+                                'backing over HBM (sailfish_amd/placement.py)')
         group.add_argument('--nohip_fused_periodic', dest='hip_fused_periodic', action='store_false',
                            default=True,
                            help='apply periodic boundary conditions with separate ghost-layer kernels '
@@ -207,6 +210,7 @@ class HIPBackend(placement.VmmMixin):
         self._sizes = {}
         self._raw = {}
         self._placed = {}
+        self._pinned = []
         # kernels whose trailing iteration argument set_iteration() rewrites; weak: a kernel that its owner
         # dropped (a released simulation) must not be kept alive -- or updated -- by this registry
         self._iteration_kernels = weakref.WeakSet()
@@ -225,9 +229,38 @@ class HIPBackend(placement.VmmMixin):
         self._cu_count = cus.value
         self._wavefront = wave.value
 
+    def close(self, free_pinned=False):
+        """Releases every device buffer this backend handed out (the reference leaves that to the PyCUDA context
+        going away with the subdomain process; here one process may run many simulations).  Called by
+        SubdomainRunner.release() and when the backend is collected.  Pinned host arrays are only freed on
+        request: numpy views of them (sim.rho, sim.v of asynchronous fields) may outlive the backend."""
+        lib = getattr(self, '_lib', None)
+        if lib is None or getattr(self, '_ctx', None) is None:
+            return
+        try:
+            lib.slf_ctx_sync(self._ctx)
+        except Exception:
+            pass
+        for addr in list(self._placed):
+            try:
+                self.free_buf(addr)
+            except Exception:
+                pass
+        for addr in list(self._raw):
+            try:
+                self.free_buf(addr)
+            except Exception:
+                pass
+        if free_pinned:
+            for ptr in self._pinned:
+                lib.slf_host_free(ctypes.c_void_p(ptr))
+            self._pinned = []
+
     def __del__(self):
         try:
+            self.close()
             self._lib.slf_ctx_destroy(self._ctx)
+            self._ctx = None
         except Exception:
             pass
 
@@ -320,6 +353,7 @@ class HIPBackend(placement.VmmMixin):
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = ctypes.c_void_p()
         _check(self._lib, self._lib.slf_host_alloc_pinned(max(1, n), ctypes.byref(ptr)), 'slf_host_alloc_pinned')
+        self._pinned.append(ptr.value)      # freed by close(); the array must not be used after that
         buf = (ctypes.c_char * max(1, n)).from_address(ptr.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
         arr[...] = 0

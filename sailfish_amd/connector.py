@@ -10,15 +10,16 @@ collective is involved: a step needs one send + one receive per neighbour.
 import os
 
 
-def init_distributed(backend=None):
-    """Initialise torch.distributed from the torchrun environment (RANK, WORLD_SIZE, MASTER_*)."""
+def init_distributed(backend=None, force=False):
+    """Initialise torch.distributed from the torchrun environment (RANK, WORLD_SIZE, MASTER_*).  A single rank
+    needs no process group unless `force` (bench.py --force_distributed: the RCCL path with one rank)."""
     import torch
     import torch.distributed as dist
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if world == 1:
+    if world == 1 and not force:
         return 0, 1
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -42,8 +43,9 @@ class RingExchanger(object):
       send_up   -> rank+1, arrives in its recv_low
       send_down -> rank-1, arrives in its recv_high
     All four are torch tensors (CUDA for nccl, CPU for gloo).  Operations are
-    batched (ncclGroupStart/End under the hood); with two ranks both messages go
-    to the same peer and are matched by posting order (up first, then down).
+    batched (ncclGroupStart/End under the hood); with two ranks (or one: send / recv
+    to self) both messages go to the same peer and are matched by posting order (up
+    first, then down).
     """
 
     def __init__(self, rank, world):
@@ -53,8 +55,8 @@ class RingExchanger(object):
 
     def exchange(self, send_up, send_down, recv_low, recv_high):
         import torch.distributed as dist
-        if self.world == 1:
-            recv_low.copy_(send_up)
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            recv_low.copy_(send_up)       # a ring of one without a process group: the slab is its own neighbour
             recv_high.copy_(send_down)
             return []
         ops = [dist.P2POp(dist.isend, send_up, self.up),

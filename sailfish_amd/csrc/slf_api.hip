@@ -42,6 +42,8 @@ enum KernelKind {
   KK_MACRO_PBC,
   KK_COLLECT_SPARSE,
   KK_DISTRIBUTE_SPARSE,
+  KK_COLLECT_BOX,
+  KK_DISTRIBUTE_BOX,
   KK_COMPUTE_MACRO,
   KK_SC_MACRO,
   KK_SC_SWEEP0,
@@ -609,6 +611,8 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   else if (!strcmp(name, "ApplyMacroPeriodicBoundaryConditions")) kk = KK_MACRO_PBC;
   else if (!strcmp(name, "CollectSparseData")) kk = KK_COLLECT_SPARSE;
   else if (!strcmp(name, "DistributeSparseData")) kk = KK_DISTRIBUTE_SPARSE;
+  else if (!strcmp(name, "CollectContinuousData")) kk = KK_COLLECT_BOX;
+  else if (!strcmp(name, "DistributeContinuousData")) kk = KK_DISTRIBUTE_BOX;
   else if (!strcmp(name, "ComputeMacroFields")) kk = KK_COMPUTE_MACRO;
   else return fail(SLF_ERR_NOT_FOUND, std::string("unknown kernel: ") + name);
   if (kk == KK_SCS_MACRO && m->sc.enabled != 2)
@@ -660,6 +664,8 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_MACRO_PBC: want_p = 1; want_i = 1; break;             // dist|field, axis
     case KK_COLLECT_SPARSE:
     case KK_DISTRIBUTE_SPARSE: want_p = 3; want_i = 1; break;     // idx_array, dist, buffer, n
+    case KK_COLLECT_BOX:
+    case KK_DISTRIBUTE_BOX: want_p = 2; want_i = 6; break;        // dist, buffer, dirs, base, col_stride, ncols, row_stride, nrows
     case KK_SC_MACRO:
     case KK_SC_SWEEP0:
     case KK_SC_SWEEP1: want_p = 5 + dim; want_i = 1; break;       // map, dist, dist, rho, phi, v.., options
@@ -830,6 +836,12 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       break;
     case KK_MACRO_PBC:
       e = slf::launch_macro_pbc(m->sel, g, (void*)k->ptrs[0], (int)k->ints[0], s);
+      break;
+    case KK_COLLECT_BOX:
+    case KK_DISTRIBUTE_BOX:
+      e = slf::launch_box(m->sel, g, k->kind == KK_COLLECT_BOX, (void*)k->ptrs[0], (void*)k->ptrs[1],
+                          (unsigned int)k->ints[0], (unsigned long long)(uint32_t)k->ints[1], (long long)k->ints[2],
+                          (int)k->ints[3], (long long)k->ints[4], (int)k->ints[5], s);
       break;
     case KK_COLLECT_SPARSE:
     case KK_DISTRIBUTE_SPARSE:

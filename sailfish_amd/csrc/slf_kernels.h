@@ -87,6 +87,10 @@ hipError_t launch_macro_pbc(const KernelSelector& sel, const Geometry& g, void* 
 hipError_t launch_sparse(const KernelSelector& sel, bool collect, const unsigned long long* idx, void* dist, void* buffer,
                          int n, hipStream_t s);
 
+hipError_t launch_box(const KernelSelector& sel, const Geometry& g, bool collect, void* dist, void* buffer,
+                      unsigned int dirs, unsigned long long base, long long col_stride, int ncols, long long row_stride,
+                      int nrows, hipStream_t s);
+
 hipError_t launch_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
                         const SweepArgs& a, hipStream_t s);
 

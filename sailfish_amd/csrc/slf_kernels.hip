@@ -249,6 +249,48 @@ __global__ void __launch_bounds__(256) sparse_kernel(const unsigned long long* _
   }
 }
 
+// Face pack / unpack without index lists (reference Collect/DistributeContinuousData, kernel_utils.mako:526-543,
+// 629-645, 692-708, 777-793): the populations `dirs` (bit mask over q, ascending) of an ncols x nrows box of nodes
+// base + c * col_stride + r * row_stride  <->  dense buffer [k][r][c].  z and y faces have col_stride = 1: every
+// wave moves whole contiguous row segments; x faces (col_stride = arr_nx) are a strided gather / scatter, still
+// without the 8 bytes of index per 4 bytes of payload of the sparse kernels.
+template <class R, bool COLLECT>
+__global__ void __launch_bounds__(256) box_kernel(R* dist, R* buffer, size_t dq, unsigned int dirs, unsigned long long base,
+                                                  long long col_stride, int ncols, long long row_stride, int nrows) {
+  const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int r = (int)blockIdx.y;
+  if (c >= ncols) return;
+  unsigned int m = dirs;
+  for (int i = 0; i < (int)blockIdx.z; i++) m &= m - 1u;      // the blockIdx.z-th set bit
+  const int q = __ffs(m) - 1;
+  R* node = dist + dq * (size_t)q + base + (size_t)((long long)c * col_stride + (long long)r * row_stride);
+  R* slot = buffer + ((size_t)blockIdx.z * (size_t)nrows + (size_t)r) * (size_t)ncols + (size_t)c;
+  if constexpr (COLLECT) {
+    *slot = *node;
+  } else {
+    const R val = *slot;
+    if (slf_isfinite(val)) *node = val;      // sentinels are not delivered (as sparse_kernel / the PBC kernels)
+  }
+}
+
+hipError_t launch_box(const KernelSelector& sel, const Geometry& g, bool collect, void* dist, void* buffer,
+                      unsigned int dirs, unsigned long long base, long long col_stride, int ncols, long long row_stride,
+                      int nrows, hipStream_t s) {
+  const int nd = __builtin_popcount(dirs);
+  if (nd == 0 || ncols <= 0 || nrows <= 0) return hipSuccess;
+  dim3 block(256, 1, 1);
+  dim3 grid((ncols + 255) / 256, nrows, nd);
+  const size_t dq = g.dist_size;
+  if (sel.precision == 4) {
+    if (collect) hipLaunchKernelGGL((box_kernel<float, true>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
+    else hipLaunchKernelGGL((box_kernel<float, false>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
+  } else {
+    if (collect) hipLaunchKernelGGL((box_kernel<double, true>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
+    else hipLaunchKernelGGL((box_kernel<double, false>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
+  }
+  return hipGetLastError();
+}
+
 // PrepareMacroFields-style pass: density/velocity of every wet node without
 // collision or streaming (lb_single_fluid.mako:129-159, used for output of
 // the current state, e.g. right after initialisation or a restore).

@@ -1,83 +1,117 @@
-"""Periodic box cut into z-slabs, one slab per GPU (the weak-scaling benchmark
-geometry: SURVEY.md §8(d) M0/C4, reference geo.py:100-135 EqualSubdomainsGeometry3D
-with conn_axis=z).
+"""Periodic box cut into slabs along one axis, one slab per GPU (the scaling benchmark geometry: SURVEY.md §8(d)
+M0 / C4, reference geo.py:100-135 EqualSubdomainsGeometry3D with conn_axis = x | y | z).
 
-Per step (reference subdomain_runner.py:1028-1058 boundary/bulk split):
-  calc stream : wait(previous halo) -> sweep plane z=1, sweep plane z=n -> event
-                -> sweep interior planes
-  halo stream : wait(event) -> pack the two face layers (index-list gather)
-                -> RCCL send/recv with the two ring neighbours -> unpack -> event
-x and y are wrapped inside the sweep; z is wrapped inside the sweep when there
-is a single slab, otherwise it goes through the ghost planes + halo.
+Per step (reference subdomain_runner.py:1028-1058 boundary / bulk split):
+  calc stream : wait(previous halo) -> sweep the two face layers -> event -> sweep the interior
+  halo stream : wait(event) -> pack the two faces -> RCCL send / recv with the two ring neighbours -> unpack -> event
+The other two axes are wrapped inside the sweep; the split axis is wrapped inside the sweep when there is a single
+slab, otherwise it goes through the ghost layers + halo.  x faces cannot be split off (a workgroup owns whole rows):
+with axis = 'x' the whole sweep runs before the pack.
 
-Which layer travels (reference subdomain_runner.py:1069-1103, Appendix A.4-5 of
-SURVEY.md):
-  push steps (AB, odd AA): my ghost plane (populations pushed across the face)
-      -> neighbour's first real plane, same slots;
-  even AA step (in-place, opposite slots): my first real plane, opposite slots
-      -> neighbour's ghost plane, so that its next (odd) step can pull them.
+Faces are packed with the box kernels (Collect / DistributeContinuousData: no index lists; reference
+kernel_utils.mako:526-543, 629-645): z and y faces move contiguous row segments, x faces are a strided gather.
+
+Which layer travels (reference subdomain_runner.py:1069-1103, Appendix A.4-5 of SURVEY.md):
+  push steps (AB, odd AA): my ghost layer (populations pushed across the face) -> neighbour's first real layer, same slots;
+  even AA step (in-place, opposite slots): my first real layer, opposite slots -> neighbour's ghost layer, so that
+      its next (odd) step can pull them.
 """
 import numpy as np
 
 from sailfish_amd import hipabi, sym
 from sailfish_amd.box import BoxSim, make_box_desc
 
+AXES = {'x': 0, 'y': 1, 'z': 2}
+
 
 class SlabPlan(object):
-    """Pure host logic: index lists (q * dist_size + gi, uint64) for the halo pack / unpack."""
+    """Pure host logic: the node boxes (base, strides, extents) and direction masks of the halo pack / unpack."""
 
-    def __init__(self, grid, desc):
-        self.grid, self.desc = grid, desc
-        self.nx, self.ny, self.nz = desc.lat_nx - 2, desc.lat_ny - 2, desc.lat_nz - 2
-        self.dist_size = hipabi.dist_stride(desc)
-        self.up_dists = sym.get_prop_dists(grid, 1, 2)      # e_z = +1
-        self.down_dists = sym.get_prop_dists(grid, -1, 2)   # e_z = -1
-        self.count = len(self.up_dists) * self.nx * self.ny
+    def __init__(self, grid, desc, axis=2):
+        self.grid, self.desc, self.axis = grid, desc, axis
+        self.n = [desc.lat_nx - 2, desc.lat_ny - 2, desc.lat_nz - 2]
+        self.up_dists = sym.get_prop_dists(grid, 1, axis)       # e_axis = +1
+        self.down_dists = sym.get_prop_dists(grid, -1, axis)    # e_axis = -1
+        others = [a for a in range(3) if a != axis]
+        self.col_axis, self.row_axis = others                   # columns = the faster-varying of the two
+        self.ncols, self.nrows = self.n[self.col_axis], self.n[self.row_axis]
+        self.count = len(self.up_dists) * self.ncols * self.nrows
+        self.strides = [1, desc.arr_nx, desc.arr_nx * desc.arr_ny]
 
-    def _plane(self, z, dists):
-        d = self.desc
-        y, x = np.meshgrid(np.arange(1, self.ny + 1, dtype=np.uint64), np.arange(1, self.nx + 1, dtype=np.uint64),
-                           indexing='ij')
-        gi = x + np.uint64(d.arr_nx) * (y + np.uint64(d.arr_ny) * np.uint64(z))
-        return np.concatenate([np.uint64(q) * np.uint64(self.dist_size) + gi.ravel() for q in dists])
+    def box(self, layer, dists):
+        """(dirs mask, base node, col stride, ncols, row stride, nrows) of the face layer at coordinate `layer`."""
+        coord = [1, 1, 1]
+        coord[self.axis] = layer
+        base = sum(c * s for c, s in zip(coord, self.strides))
+        mask = 0
+        for q in dists:
+            mask |= 1 << q
+        return (mask, base, self.strides[self.col_axis], self.ncols, self.strides[self.row_axis], self.nrows)
 
-    def lists(self, swap):
-        """Returns (send_up, send_down, recv_low, recv_high) index arrays.
-        swap = True after the even AA step."""
-        n = self.nz
+    def boxes(self, swap):
+        """(send_up, send_down, recv_low, recv_high); swap = True after the even AA step."""
+        n = self.n[self.axis]
         opp = self.grid.idx_opposite
         if not swap:
-            return (self._plane(n + 1, self.up_dists), self._plane(0, self.down_dists),
-                    self._plane(1, self.up_dists), self._plane(n, self.down_dists))
+            return (self.box(n + 1, self.up_dists), self.box(0, self.down_dists),
+                    self.box(1, self.up_dists), self.box(n, self.down_dists))
         up_s = [opp[i] for i in self.up_dists]
         dn_s = [opp[i] for i in self.down_dists]
-        return (self._plane(n, up_s), self._plane(1, dn_s), self._plane(0, up_s), self._plane(n + 1, dn_s))
+        return (self.box(n, up_s), self.box(1, dn_s), self.box(0, up_s), self.box(n + 1, dn_s))
+
+    def index_list(self, box):
+        """The same box as a q * dist_size + node index list, buffer order [k][row][col] (tests, oracle twin)."""
+        mask, base, cs, nc, rs, nr = box
+        ds = hipabi.dist_stride(self.desc)
+        r, c = np.meshgrid(np.arange(nr, dtype=np.uint64), np.arange(nc, dtype=np.uint64), indexing='ij')
+        node = (np.uint64(base) + c * np.uint64(cs) + r * np.uint64(rs)).ravel()
+        qs = [q for q in range(self.grid.Q) if mask >> q & 1]
+        return np.concatenate([np.uint64(q) * np.uint64(ds) + node for q in qs])
+
+    def regions(self):
+        """(boundary regions, bulk region) as (y0, y1, z0, z1) row ranges; no split for x faces / thin slabs."""
+        nx, ny, nz = self.n
+        full = (1, ny + 1, 1, nz + 1)
+        if self.axis == 2 and nz > 2:
+            return [(1, ny + 1, 1, 2), (1, ny + 1, nz, nz + 1)], (1, ny + 1, 2, nz)
+        if self.axis == 1 and ny > 2:
+            return [(1, 2, 1, nz + 1), (ny, ny + 1, 1, nz + 1)], (2, ny, 1, nz + 1)
+        return [], full
 
 
 class SlabSim(BoxSim):
     def __init__(self, backend, grid, size, rank=0, world=1, model='bgk', precision='single',
-                 access_pattern='AA', visc=1.0 / 6.0, fused_periodic=True, exchanger=None):
+                 access_pattern='AA', visc=1.0 / 6.0, fused_periodic=True, exchanger=None, axis='z',
+                 force_halo=False):
+        """size: the LOCAL slab (nx, ny, nz); the global box is `world` slabs stacked along `axis`."""
         self.grid, self.size, self.rank, self.world = grid, size, rank, world
+        self.axis = AXES[axis] if isinstance(axis, str) else int(axis)
         assert grid.dim == 3
-        if world > 1 and not fused_periodic:
-            raise ValueError('multi-slab runs wrap x and y inside the sweep')
-        fused = [int(fused_periodic), int(fused_periodic), int(fused_periodic and world == 1)]
+        self.halo = world > 1 or force_halo
+        if self.halo and not fused_periodic:
+            raise ValueError('multi-slab runs wrap the unsplit axes inside the sweep')
+        fused = [int(fused_periodic)] * 3
+        if self.halo:
+            fused[self.axis] = 0
         desc = make_box_desc(grid, size, model=model, precision=precision, access_pattern=access_pattern, visc=visc,
                              periodic_fused=fused, fluid_only=True)
-        periodic = (True, True, world == 1)
-        BoxSim.__init__(self, backend, desc, periodic=periodic)
+        periodic = [True, True, True]
+        periodic[self.axis] = not self.halo
+        BoxSim.__init__(self, backend, desc, periodic=tuple(periodic))
         self.calc_stream = self.stream
         self.block_size = self.module.block_size
-        if world > 1:
+        self.halo_ms = []
+        if self.halo:
             self._init_halo(exchanger)
 
     # -- halo machinery ------------------------------------------------------
     def _init_halo(self, exchanger):
         import torch
         from sailfish_amd.connector import RingExchanger, init_distributed
-        init_distributed()
+        if exchanger is None:
+            init_distributed()
         b = self.backend
-        self.plan = SlabPlan(self.grid, self.desc)
+        self.plan = SlabPlan(self.grid, self.desc, self.axis)
         self.exchanger = exchanger or RingExchanger(self.rank, self.world)
         self.halo_stream = b.make_stream()
         self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
@@ -85,30 +119,22 @@ class SlabSim(BoxSim):
         n = self.plan.count
         dev = torch.device('cuda', b.gpu_id)
         self.t_bufs = [torch.empty(n, dtype=tdtype, device=dev) for _ in range(4)]  # s_up s_down r_low r_high
-        self._idx_keep = []
         self.k_halo = {}
         for swap in ((False, True) if self.aa else (False,)):
-            lists = self.plan.lists(swap)
-            gpu_idx = []
-            for a in lists:
-                a = np.ascontiguousarray(a, dtype=np.uint64)
-                self._idx_keep.append(a)
-                gpu_idx.append(b.alloc_buf(like=a))
+            boxes = self.plan.boxes(swap)
             for di, dbuf in enumerate(self.gpu_dist):
                 ks = []
                 for j in range(4):
-                    name = 'CollectSparseData' if j < 2 else 'DistributeSparseData'
-                    ks.append(b.get_kernel(self.module, name, (64,),
-                                           [gpu_idx[j], dbuf, self.t_bufs[j].data_ptr(), n], 'PPPi'))
+                    name = 'CollectContinuousData' if j < 2 else 'DistributeContinuousData'
+                    ks.append(b.get_kernel(self.module, name, (64,), [dbuf, self.t_bufs[j].data_ptr()] + list(boxes[j]),
+                                           'PPiiiiii'))
                 self.k_halo[(swap, di)] = ks
         self.ev_halo = None
-        nz = self.desc.lat_nz - 2
-        ny = self.desc.lat_ny - 2
-        self.reg_low, self.reg_high = (1, ny + 1, 1, 2), (1, ny + 1, nz, nz + 1)
-        self.reg_bulk = (1, ny + 1, 2, nz)
+        self.regs_bnd, self.reg_bulk = self.plan.regions()
+        self.time_halo = False
 
     def step_compute(self, save_macro=False):
-        """Boundary planes, event, bulk planes on the calc stream; halo pack on the halo stream."""
+        """Face layers, event, interior on the calc stream; halo pack on the halo stream."""
         b = self.backend
         it = self.iteration
         if self.aa:
@@ -117,11 +143,17 @@ class SlabSim(BoxSim):
             k, out, swap = self.k_sweep[int(save_macro)][it & 1], 1 - (it & 1), False
         if self.ev_halo is not None:
             self.calc_stream.wait_for_event(self.ev_halo)
-        b.run_kernel(k, self.reg_low, self.calc_stream)
-        b.run_kernel(k, self.reg_high, self.calc_stream)
-        ev_bnd = b.make_event(self.calc_stream)
-        b.run_kernel(k, self.reg_bulk, self.calc_stream)
+        for reg in self.regs_bnd:
+            b.run_kernel(k, reg, self.calc_stream)
+        if self.regs_bnd:
+            ev_bnd = b.make_event(self.calc_stream)
+            b.run_kernel(k, self.reg_bulk, self.calc_stream)
+        else:
+            b.run_kernel(k, self.reg_bulk, self.calc_stream)
+            ev_bnd = b.make_event(self.calc_stream)
         self.halo_stream.wait_for_event(ev_bnd)
+        if self.time_halo:
+            self._ev_h0 = b.make_event(self.halo_stream, timing=True)
         self._ks = self.k_halo[(swap, out)]
         b.run_kernel(self._ks[0], None, self.halo_stream)
         b.run_kernel(self._ks[1], None, self.halo_stream)
@@ -137,33 +169,62 @@ class SlabSim(BoxSim):
         b = self.backend
         b.run_kernel(self._ks[2], None, self.halo_stream)
         b.run_kernel(self._ks[3], None, self.halo_stream)
+        if self.time_halo:
+            self._halo_events.append((self._ev_h0, b.make_event(self.halo_stream, timing=True)))
         self.ev_halo = b.make_event(self.halo_stream)
 
     def step(self, save_macro=False, region=None):
-        if self.world == 1:
+        if not self.halo:
             return BoxSim.step(self, save_macro)
         self.step_compute(save_macro)
         self.step_exchange()
         self.step_finish()
 
+    def step_sweep_only(self):
+        """The sweep launches of one step without any halo traffic (timing reference: what the calc stream costs
+        when nothing has to be waited for).  Leaves the slab faces stale -- re-initialise afterwards."""
+        b = self.backend
+        it = self.iteration
+        k = self.k_sweep[0][0] if self.aa else self.k_sweep[0][it & 1]
+        for reg in getattr(self, 'regs_bnd', []):
+            b.run_kernel(k, reg, self.calc_stream)
+        b.run_kernel(k, getattr(self, 'reg_bulk', None), self.calc_stream)
+        self.iteration += 1
+        b.set_iteration(self.iteration)
+
+    def start_halo_timing(self):
+        self.time_halo, self._halo_events = True, []
+
+    def stop_halo_timing(self):
+        """Mean time (ms) the halo stream was busy per step (pack -> exchange -> unpack) since start_halo_timing()."""
+        self.time_halo = False
+        self.sync()
+        ms = [e1.time_since(e0) for e0, e1 in self._halo_events]
+        self._halo_events = []
+        return float(np.mean(ms)) if ms else 0.0
+
     def sync(self):
         self.stream.synchronize()
-        if self.world > 1:
+        if self.halo:
             self.halo_stream.synchronize()
 
     # -- initial state ---------------------------------------------------------
     def init_synthetic(self, seed=1234):
         """rho = 1 + 1e-3 U[0,1), u = 0.05 (sin 2 pi y/Ly, sin 2 pi z/Lz, sin 2 pi x/Lx),
-        z measured in the global (all slabs) box."""
+        coordinates measured in the global (all slabs) box."""
         nx, ny, nz = self.size
+        g = [nx, ny, nz]
+        g[self.axis] *= self.world
+        o = [0, 0, 0]
+        o[self.axis] = self.rank * self.size[self.axis]
         rng = np.random.RandomState(seed + self.rank)
         rho = (1.0 + 1e-3 * rng.rand(nz, ny, nx)).astype(self.dtype)
-        x = np.arange(nx, dtype=np.float64)
-        y = np.arange(ny, dtype=np.float64)
-        z = np.arange(nz, dtype=np.float64) + self.rank * nz
-        vx = np.broadcast_to((0.05 * np.sin(2 * np.pi * y / ny))[None, :, None], (nz, ny, nx))
-        vy = np.broadcast_to((0.05 * np.sin(2 * np.pi * z / (nz * self.world)))[:, None, None], (nz, ny, nx))
-        vz = np.broadcast_to((0.05 * np.sin(2 * np.pi * x / nx))[None, None, :], (nz, ny, nx))
+        x = np.arange(nx, dtype=np.float64) + o[0]
+        y = np.arange(ny, dtype=np.float64) + o[1]
+        z = np.arange(nz, dtype=np.float64) + o[2]
+        vx = np.broadcast_to((0.05 * np.sin(2 * np.pi * y / g[1]))[None, :, None], (nz, ny, nx))
+        vy = np.broadcast_to((0.05 * np.sin(2 * np.pi * z / g[2]))[:, None, None], (nz, ny, nx))
+        vz = np.broadcast_to((0.05 * np.sin(2 * np.pi * x / g[0]))[None, None, :], (nz, ny, nx))
         self.set_fields(rho, [vx.astype(self.dtype), vy.astype(self.dtype), vz.astype(self.dtype)])
         self.initial_conditions()
         self.sync()

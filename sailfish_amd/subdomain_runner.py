@@ -267,10 +267,21 @@ class SubdomainRunner(object):
             self._build_indirect_address_map()
         nbytes = self._sim.grid.Q * self._dist_stride * self.float().itemsize
         off = b.dist_align_offset(self.float().itemsize)
-        for _ in self._sim.grids:
-            self._gpu_grids_primary.append(b.alloc_buf(size=nbytes, align_offset=off))
-            if self.config.access_pattern == 'AB':
-                self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes, align_offset=off))
+        ab = self.config.access_pattern == 'AB'
+        from sailfish_amd import placement
+        if placement.enabled() and nbytes >= placement.MIN_BYTES and not self.indirect and \
+                getattr(self.config, 'hip_placement', True):
+            # large arrays: physical backing spread over HBM (placement.py); all lattices and copies share the span
+            n = len(self._sim.grids)
+            bufs = b.alloc_placed([nbytes] * (n * (2 if ab else 1)), off)
+            self._gpu_grids_primary = [pb.addr for pb in bufs[:n]]
+            self._gpu_grids_secondary = [pb.addr for pb in bufs[n:]]
+            self.config.logger.debug('placed distributions: %s' % b.last_placement)
+        else:
+            for _ in self._sim.grids:
+                self._gpu_grids_primary.append(b.alloc_buf(size=nbytes, align_offset=off))
+                if ab:
+                    self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes, align_offset=off))
         self.config.logger.debug('distributions: %d MiB' % (nbytes * (2 if self._gpu_grids_secondary else 1) >> 20))
 
     def gpu_field(self, field):
@@ -752,6 +763,15 @@ class SubdomainRunner(object):
         self._sim.after_main_loop(self)
         if self._output is not None:
             self._output.wait()
+
+    def release(self):
+        """Gives the device memory of this subdomain back (fields, populations, node map, halo buffers).  The
+        runner must not be stepped or queried for device data afterwards; the host copies of the output fields
+        (sim.rho, sim.v) stay valid."""
+        self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self._kernels_full = self._kernels_none = self._pbc_kernels = None
+        self._links, self._macro_links = {}, {}
+        self.backend.close()
 
     def main(self):
         """Main loop of a runner that owns its process (one subdomain per GPU process)."""

@@ -1,6 +1,6 @@
 """The multi-slab (multi-GPU) driver of bench.py, exercised on ONE GPU: two SlabSim instances of a
 2-rank ring live in this process and exchange their halo tensors through a loop-back exchanger
-(device copies on the halo streams instead of RCCL send/recv).  Everything else -- index lists,
+(device copies on the halo streams instead of RCCL send/recv).  Everything else -- face boxes,
 pack / unpack kernels, boundary / bulk split, events, torch ExternalStream hand-over -- is the code
 that runs under torch.distributed.  The merged result must equal the single-slab run of the whole
 box bit for bit."""
@@ -28,20 +28,21 @@ class Loopback(object):
 
 
 @pytest.mark.parametrize('pattern', ['AA', 'AB'])
-@pytest.mark.parametrize('model', ['bgk', 'mrt'])
-def test_two_slabs_equal_one_box(pattern, model):
+@pytest.mark.parametrize('model,axis', [('bgk', 'z'), ('mrt', 'z'), ('bgk', 'y'), ('bgk', 'x'), ('mrt', 'x')])
+def test_two_slabs_equal_one_box(pattern, model, axis):
     import torch
     from sailfish_amd.backend_hip import HIPBackend
-    from sailfish_amd.slab import SlabSim
+    from sailfish_amd.slab import AXES, SlabSim
 
     class Opt(object):
         pass
     n = (40, 12, 8)
+    a = AXES[axis]
     lb = Loopback()
     # one backend object per rank, as in the real one-process-per-GPU run (the iteration counter of the
     # AA kernels is per backend)
     sims = [SlabSim(HIPBackend(Opt(), 0), sym.D3Q19, n, rank=r, world=2, model=model, access_pattern=pattern,
-                    visc=0.02, exchanger=lb.bind(r)) for r in range(2)]
+                    visc=0.02, exchanger=lb.bind(r), axis=axis) for r in range(2)]
     for s in sims:
         s.init_synthetic(seed=5)
     steps = 9
@@ -61,16 +62,43 @@ def test_two_slabs_equal_one_box(pattern, model):
         torch.cuda.synchronize()
         for s in sims:
             s.step_finish()
-    got = np.concatenate([s.real_view(s.get_dist()) for s in sims], axis=1)     # stack along z
+    np_axis = 3 - a                                   # arrays are [q, z, y, x]
+    got = np.concatenate([s.real_view(s.get_dist()) for s in sims], axis=np_axis)
 
-    one = SlabSim(HIPBackend(Opt(), 0), sym.D3Q19, (n[0], n[1], 2 * n[2]), rank=0, world=1, model=model, access_pattern=pattern,
+    whole = list(n)
+    whole[a] *= 2
+    one = SlabSim(HIPBackend(Opt(), 0), sym.D3Q19, tuple(whole), rank=0, world=1, model=model, access_pattern=pattern,
                   visc=0.02)
     # same initial state as the two slabs
-    rho = np.concatenate([s.real_view(s.rho) for s in sims], axis=0)
-    v = [np.concatenate([s.real_view(s.v[d]) for s in sims], axis=0) for d in range(3)]
+    rho = np.concatenate([s.real_view(s.rho) for s in sims], axis=np_axis - 1)
+    v = [np.concatenate([s.real_view(s.v[d]) for s in sims], axis=np_axis - 1) for d in range(3)]
     one.set_fields(rho, v)
     one.initial_conditions()
     for _ in range(steps):
         one.step()
     ref = one.real_view(one.get_dist())
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+@pytest.mark.parametrize('axis', ['x', 'z'])
+def test_single_slab_ring_of_one(pattern, axis):
+    """world = 1 through the halo path (bench.py --force_distributed): the slab is its own ring neighbour, faces
+    travel through the pack / exchange / unpack machinery instead of the in-sweep wrap.  Same populations."""
+    from sailfish_amd.backend_hip import HIPBackend
+    from sailfish_amd.connector import RingExchanger
+    from sailfish_amd.slab import SlabSim
+
+    class Opt(object):
+        pass
+    n = (64, 10, 9)
+    res = []
+    for force in (True, False):
+        s = SlabSim(HIPBackend(Opt(), 0), sym.D3Q19, n, rank=0, world=1, access_pattern=pattern, visc=0.02, axis=axis,
+                    force_halo=force, exchanger=RingExchanger(0, 1) if force else None)
+        s.init_synthetic(seed=3)
+        for _ in range(8):
+            s.step()
+        s.sync()
+        res.append(s.real_view(s.get_dist()))
+    assert np.array_equal(res[0], res[1])
