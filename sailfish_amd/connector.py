@@ -97,7 +97,9 @@ class TorchDistConnector(object):
         import numpy as np
         import torch
         tdtype = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
-        dev = self.device if self.device is not None else torch.device('cuda', runner.backend.gpu_id)
+        dev = self.device
+        if dev is None:     # where the backend's kernels can reach memory: the GPU of the runner (CPU test backends say so)
+            dev = torch.device(getattr(runner.backend, 'tensor_device', None) or ('cuda:%d' % runner.backend.gpu_id))
         t = torch.empty(max(1, nelems), dtype=tdtype, device=dev)
         self._tensors[t.data_ptr()] = t
         return t.data_ptr()
@@ -128,6 +130,9 @@ class TorchDistConnector(object):
             if n_recv:
                 recvs.append((self.tensor(recv_buf)[:n_recv], peer))
         if not sends and not recvs:
+            return
+        if not (sends + recvs)[0][0].is_cuda:      # CPU tensors (gloo): no stream to order against
+            self.exchange_tensors(sends, recvs)
             return
         if self._stream is None:
             self._stream = torch.cuda.ExternalStream(runner._data_stream.native,

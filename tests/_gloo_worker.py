@@ -106,3 +106,35 @@ def nn_worker(rank, world, port, dim, size, nsub_axis, single, steps, outdir):
              size=np.array(specs[rank].size))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def controller_worker(rank, world, port, case, steps, outdir):
+    """The PRODUCT's process-per-subdomain path on the CPU: LBSimulationController.run() under WORLD_SIZE > 1 ->
+    init_distributed -> SubdomainRunner.run() -> step() -> halo_messages() -> TorchDistConnector.exchange(runner)
+    (reference subdomain_runner.py:1028-1139), with tests/_oracle_backend.OracleBackend standing in for the GPU
+    (kernels executed by the oracle on host memory, halo tensors on the CPU, gloo instead of RCCL)."""
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank)})
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from sailfish_amd import geo as geo_mod, util
+    from sailfish_amd.controller import LBSimulationController
+    from tests import _host
+    from tests._oracle_backend import OracleBackend
+    util.get_backends = lambda backends=('hip',): iter([OracleBackend])
+    module, sim, dim, geo, cfg = case
+    sim_cls = _host.load_sim_class(module, sim)
+    cfg = dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0, backends='oracle_test')
+    ctrl = LBSimulationController(sim_cls, getattr(geo_mod, geo), default_config=cfg)
+    ctrl.run(ignore_cmdline=True)
+    assert dist.is_initialized() and dist.get_world_size() == world and dist.get_backend() == 'gloo'
+    assert len(ctrl.runners) == 1
+    r = ctrl.runners[0]
+    assert r._spec.id == rank and r._links, 'the runner of this rank must have halo links'
+    assert type(r._connector).__name__ == 'TorchDistConnector' and r._sim.iteration == steps
+    f = r._debug_get_dist()
+    sl = (slice(None),) + tuple(r._spec._nonghost_slice)
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), dist=np.ascontiguousarray(f[sl]),
+             rho=np.ascontiguousarray(r._sim.rho), location=np.array(r._spec.location), size=np.array(r._spec.size))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from tests import _host
-from tests._gloo_worker import worker
+from tests._gloo_worker import controller_worker, worker
 from tests._oracle_group import OracleGroup
 
 
@@ -96,3 +96,34 @@ def test_shan_chen_two_ranks(single):
         got_f[(slice(None),) + sl] = p['dist']
         got_rho[sl] = p['rho']
     assert np.array_equal(got_f, ref_f) and np.array_equal(got_rho, ref_rho)
+
+
+def _merge(parts, ref_f, ref_rho):
+    got_f, got_rho = np.zeros_like(ref_f), np.zeros_like(ref_rho)
+    for p in parts:
+        sl = tuple(slice(int(o), int(o + n)) for o, n in zip(reversed(p['location']), reversed(p['size'])))
+        got_f[(slice(None),) + sl] = p['dist']
+        got_rho[sl] = p['rho']
+    return got_f, got_rho
+
+
+@pytest.mark.parametrize('case', CASES + [
+    ('ldc_3d', 'LDCSim', 3, 'EqualSubdomainsGeometry3D',
+     dict(lat_nx=18, lat_ny=10, lat_nz=8, visc=0.03, access_pattern='AB', subdomains=2, conn_axis='x')),
+], ids=['ldc3d_AA_z', 'channel_AB_periodic_y', 'ldc3d_AB_x'])
+def test_controller_branch_for_world_size_2(case):
+    """The real `world > 1` branch of LBSimulationController.run() (controller.py) -- one process per subdomain,
+    SubdomainRunner.run(), runner.step(), halo_messages(), TorchDistConnector.exchange(runner) -- on two gloo ranks
+    with the CPU test backend.  Merged result == one subdomain, bit for bit."""
+    import torch.multiprocessing as mp
+    steps = 7
+    module, sim, dim, geo, cfg = case
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(controller_worker, args=(2, _free_port(), case, steps, d), nprocs=2, join=True)
+        parts = [np.load(os.path.join(d, 'rank%d.npz' % r)) for r in range(2)]
+    one = OracleGroup(_host.load_sim_class(module, sim), dim, geo, dict(cfg, subdomains=1))
+    one.run(steps, save_last=True)
+    ref_f, ref_rho = one.merged('dist'), one.merged('rho')
+    got_f, got_rho = _merge(parts, ref_f, ref_rho)
+    assert np.array_equal(got_f, ref_f, equal_nan=True)
+    assert np.array_equal(got_rho, ref_rho, equal_nan=True)
