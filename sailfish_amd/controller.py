@@ -80,6 +80,9 @@ class LocalGroup(object):
                 else:
                     r.backend.copy_peer_async(recv_buf, r.backend.gpu_id, send_buf, src.backend.gpu_id, nbytes,
                                               r._data_stream)
+                # the owner of send_buf must not pack into it again before this copy has read it (its next pack
+                # is ordered only after its own unpack, i.e. after *its* neighbours' packs, not after our copy)
+                src.send_buffer_readers(kind).append(r.backend.make_event(r._data_stream))
 
     def run(self):
         runners = self.runners
@@ -255,6 +258,10 @@ class LBSimulationController(object):
         self.config = self._config_parser.parse(args)
         cfg = self.config
         self._lb_class.modify_config(cfg)
+        if getattr(cfg, 'minimize_roundoff', False):
+            # the reference then stores delta-populations (templates/models/lb_single_fluid.mako:113, sym.py:656-661);
+            # silently running the standard formulation would give different numbers under the same flag
+            raise NotImplementedError('--minimize_roundoff is not implemented by the HIP backend')
         if cfg.base_name:
             cfg.output = cfg.output or cfg.base_name
             cfg.checkpoint_file = cfg.checkpoint_file or cfg.base_name

@@ -260,18 +260,21 @@ int slf_memcpy_d2h(slf_ctx* ctx, void* hptr, const void* dptr, size_t bytes) {
 
 int slf_memcpy_h2d_async(slf_ctx* ctx, void* dptr, const void* hptr, size_t bytes, slf_stream* s) {
   if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipSetDevice(ctx->device));
   SLF_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, native(s)));
   return SLF_OK;
 }
 
 int slf_memcpy_d2h_async(slf_ctx* ctx, void* hptr, const void* dptr, size_t bytes, slf_stream* s) {
   if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipSetDevice(ctx->device));
   SLF_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, native(s)));
   return SLF_OK;
 }
 
 int slf_memcpy_d2d_async(slf_ctx* ctx, void* dst, const void* src, size_t bytes, slf_stream* s) {
   if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipSetDevice(ctx->device));
   SLF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, native(s)));
   return SLF_OK;
 }
@@ -279,6 +282,7 @@ int slf_memcpy_d2d_async(slf_ctx* ctx, void* dst, const void* src, size_t bytes,
 int slf_memcpy_peer_async(slf_ctx* ctx, void* dst, int dst_device, const void* src, int src_device, size_t bytes,
                           slf_stream* s) {
   if (!ctx) return fail(SLF_ERR_INVALID, "ctx is NULL");
+  SLF_HIP(hipSetDevice(ctx->device));
   SLF_HIP(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, native(s)));
   return SLF_OK;
 }
@@ -344,6 +348,7 @@ int slf_graph_capture_end(slf_stream* s, slf_graph** out) {
 
 int slf_graph_launch(slf_graph* g, slf_stream* s) {
   if (!g) return fail(SLF_ERR_INVALID, "graph is NULL");
+  if (s && s->ctx) SLF_HIP(hipSetDevice(s->ctx->device));
   SLF_HIP(hipGraphLaunch(g->exec, native(s)));
   return SLF_OK;
 }
@@ -358,6 +363,7 @@ int slf_graph_destroy(slf_graph* g) {
 
 int slf_stream_wait_event(slf_stream* s, slf_event* ev) {
   if (!ev) return fail(SLF_ERR_INVALID, "event is NULL");
+  if (s && s->ctx) SLF_HIP(hipSetDevice(s->ctx->device));      // the waiting stream's device; the event may belong to another
   SLF_HIP(hipStreamWaitEvent(native(s), ev->e, 0));
   return SLF_OK;
 }
@@ -386,6 +392,7 @@ int slf_event_destroy(slf_event* ev) {
 
 int slf_event_record(slf_event* ev, slf_stream* s) {
   if (!ev) return fail(SLF_ERR_INVALID, "event is NULL");
+  if (ev->ctx) SLF_HIP(hipSetDevice(ev->ctx->device));
   SLF_HIP(hipEventRecord(ev->e, native(s)));
   return SLF_OK;
 }
@@ -694,6 +701,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
   if (!k->bound) return fail(SLF_ERR_INVALID, "kernel arguments not set");
   slf_module* m = k->mod;
   const slf::Geometry& g = m->geo;
+  SLF_HIP(hipSetDevice(m->ctx->device));   // several contexts may live in one process (one per GPU): launch on ours
   hipStream_t s = native(stream);
   hipError_t e = hipSuccess;
   switch (k->kind) {

@@ -49,9 +49,11 @@ class LBSim(object):
                            help='Lattice access pattern: AB (two copies of the whole domain in memory), '
                                 'AA (single domain copy in memory).')
         group.add_argument('--node_addressing', type=str, default='direct', choices=('direct', 'indirect'),
-                           help='Node addressing mode (only direct is implemented by the HIP backend).')
+                           help='Node addressing mode: direct (dense arrays) or indirect (populations stored for the active '
+                                'nodes only; single-fluid models).')
         group.add_argument('--minimize_roundoff', action='store_true', default=False,
-                           help='(not implemented by the HIP backend)')
+                           help='store rho - 1 / f - w instead of rho / f (reference sym.py:656-661); not implemented '
+                                'by the HIP backend: refused')
         group.add_argument('--propagate_on_read', action='store_true', default=False,
                            help='(accepted for compatibility; the HIP kernels choose the streaming scheme)')
         group.add_argument('--propagate_with_shuffle', action='store_true', dest='propagate_with_shuffle',

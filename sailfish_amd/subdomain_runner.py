@@ -365,6 +365,17 @@ class SubdomainRunner(object):
                     link.kernels[(mode, copy)] = (packs, unpacks, len(s_idx) * n_grids, len(r_idx) * n_grids)
             self._links[nid] = link
 
+    def send_buffer_readers(self, kind='dist'):
+        """Events after which the send buffers of `kind` have been read by the neighbours that copy them
+        (same-process groups, controller.LocalGroup); the next pack waits for them."""
+        return self.__dict__.setdefault('_send_readers', {}).setdefault(kind, [])
+
+    def _wait_send_buffers_free(self, kind='dist'):
+        evs = self.send_buffer_readers(kind)
+        for ev in evs:
+            self._data_stream.wait_for_event(ev)
+        del evs[:]
+
     def halo_messages(self, kind='dist'):
         """[(neighbour id, send buffer, #send, receive buffer, #recv)] of the exchange that is due now,
         ordered by neighbour id: 'dist' = populations of the step just computed, 'macro' = fields read
@@ -405,20 +416,26 @@ class SubdomainRunner(object):
             return [], full
         if spec.has_face_conn(spec.X_LOW) or spec.has_face_conn(spec.X_HIGH):
             return [], full
+        z_conn = self.dim == 3 and (spec.has_face_conn(spec.Z_LOW) or spec.has_face_conn(spec.Z_HIGH))
+        y_conn = spec.has_face_conn(spec.Y_LOW) or spec.has_face_conn(spec.Y_HIGH)
+        if (z_conn and nz <= 2) or (y_conn and ny <= 2):
+            # a connected face whose layer cannot be split off: its ghosts would be written by the bulk launch,
+            # after the event the pack waits for -- sweep everything first
+            return [], full
         bnd = []
         bz0, bz1 = z0, z1
         if self.dim == 3:
-            if spec.has_face_conn(spec.Z_LOW) and nz > 2:
+            if spec.has_face_conn(spec.Z_LOW):
                 bnd.append((y0, y1, 1, 2))
                 bz0 = 2
-            if spec.has_face_conn(spec.Z_HIGH) and nz > 2:
+            if spec.has_face_conn(spec.Z_HIGH):
                 bnd.append((y0, y1, nz, nz + 1))
                 bz1 = nz
         by0, by1 = y0, y1
-        if spec.has_face_conn(spec.Y_LOW) and ny > 2:
+        if spec.has_face_conn(spec.Y_LOW):
             bnd.append((1, 2, bz0, bz1))
             by0 = 2
-        if spec.has_face_conn(spec.Y_HIGH) and ny > 2:
+        if spec.has_face_conn(spec.Y_HIGH):
             bnd.append((ny, ny + 1, bz0, bz1))
             by1 = ny
         if not bnd:
@@ -471,6 +488,7 @@ class SubdomainRunner(object):
             # x-connected or unsplit subdomains: the whole sweep (and the local PBC) must be done first
             ev = ev_bnd if (ev_bnd is not None and not self._pbc_axes) else b.make_event(self._calc_stream)
             self._data_stream.wait_for_event(ev)
+            self._wait_send_buffers_free('dist')
             self._profile.record_gpu_start(TimeProfile.COLLECTION, self._data_stream)
             for nid, link in self._links.items():
                 for pack in link.kernels[(self._halo_mode, self._halo_copy)][0]:
@@ -564,24 +582,37 @@ class SubdomainRunner(object):
             fname = io.checkpoint_filename(self.config.checkpoint_file, io.filename_iter_digits(self.config.max_iters),
                                            self._spec.id, self._sim.iteration)
         data = {'state': np.frombuffer(pickle.dumps(self._sim.get_state()), dtype=np.uint8)}
+        cur = (self._sim.iteration & 1) if self._gpu_grids_secondary else 0
         for n in range(len(self._gpu_grids_primary)):
-            data['dist%da' % n] = self._debug_get_dist(grid_num=n, copy=0)
+            # dist<N>a = gpu_dist(N, iteration & 1): the current state; dist<N>b the other copy (reference :1420-1427)
+            data['dist%da' % n] = self._debug_get_dist(grid_num=n, copy=cur)
             if self._gpu_grids_secondary:
-                data['dist%db' % n] = self._debug_get_dist(grid_num=n, copy=1)
+                data['dist%db' % n] = self._debug_get_dist(grid_num=n, copy=1 - cur)
         np.savez(fname, **data)
 
     def restore_checkpoint(self, fname):
         self.config.logger.info('Restoring checkpoint from {0}'.format(fname))
         cpoint = np.load(fname, allow_pickle=False)
+        state = pickle.loads(cpoint['state'].tobytes())
+        saved_it = int(state.get('iteration', 0)) if isinstance(state, dict) else 0
+        # the simulation state is always restored (subclass state lives there); without --restore_time only the
+        # clock is reset afterwards (reference :1436-1449)
+        self._sim.set_state(state)
+        if not getattr(self.config, 'restore_time', True):
+            self._sim.iteration = 0
+        it = self._sim.iteration
+        if not self._gpu_grids_secondary and (saved_it & 1) != (it & 1):
+            raise ValueError('AA checkpoint written at iteration %d cannot be continued from iteration %d: the in-place '
+                             'pattern stores the populations in a layout that depends on the parity of the step'
+                             % (saved_it, it))
+        cur = (it & 1) if self._gpu_grids_secondary else 0
         for key in cpoint.files:
             if not key.startswith('dist'):
                 continue
-            n, copy = int(key[4:-1]), (0 if key.endswith('a') else 1)
-            if n >= len(self._gpu_grids_primary) or (copy == 1 and not self._gpu_grids_secondary):
+            n, is_a = int(key[4:-1]), key.endswith('a')
+            if n >= len(self._gpu_grids_primary) or (not is_a and not self._gpu_grids_secondary):
                 continue
-            self._debug_set_dist(cpoint[key], grid_num=n, copy=copy)
-        if getattr(self.config, 'restore_time', True):
-            self._sim.set_state(pickle.loads(cpoint['state'].tobytes()))
+            self._debug_set_dist(cpoint[key], grid_num=n, copy=cur if is_a else 1 - cur)
         self.backend.set_iteration(self._sim.iteration)
 
     # ------------------------------------------------------------------ life cycle
@@ -883,6 +914,7 @@ class NNSubdomainRunner(SubdomainRunner):
         self._macro_done = True
         if self._macro_links:
             self._data_stream.wait_for_event(b.make_event(self._calc_stream))
+            self._wait_send_buffers_free('macro')
             self._profile.record_gpu_start(TimeProfile.MACRO_COLLECTION, self._data_stream)
             for nid, link in self._macro_links.items():
                 for k in link.packs:

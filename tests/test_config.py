@@ -38,3 +38,14 @@ def test_rc_file(tmp_path, monkeypatch):
     assert cfg.precision == 'double'
     cfg = _ctrl()._config_parser.parse(['--precision=single'])
     assert cfg.precision == 'single'
+
+
+def test_minimize_roundoff_is_refused_not_ignored():
+    import pytest
+    from sailfish_amd.controller import LBSimulationController
+    from sailfish_amd.geo import LBGeometry2D
+    from tests import _host
+    sim_cls = _host.load_sim_class('ldc_2d', 'LDCSim')
+    ctrl = LBSimulationController(sim_cls, LBGeometry2D, default_config=dict(minimize_roundoff=True, max_iters=1, quiet=True))
+    with pytest.raises(NotImplementedError):
+        ctrl.run(ignore_cmdline=True)
