@@ -284,6 +284,7 @@ def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
         profile = vx[:, vx.shape[1] // 2]
         theory = sim_cls.subdomain.velocity_profile(r.config, np.arange(vx.shape[0]))
         err = np.nanmax(profile) / np.nanmax(theory) - 1.0
+        print('poiseuille %s %s visc %.5f: err %+.6e recorded %+.6e' % (model, precision, visc, err, recorded))
         if precision == 'double':
             assert abs(err) <= abs(recorded) + 5e-5, (visc, err, recorded)
         else:

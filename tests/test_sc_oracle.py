@@ -156,3 +156,78 @@ def test_per_lattice_body_force(dim, size):
         gain = res[key][0] - m_none
         expect = steps * (mass[0] * np.array(f0 if f0 else [0.0] * dim) + mass[1] * np.array(f1))
         assert np.allclose(gain, expect, rtol=1e-6, atol=1e-10), (key, gain, expect)
+
+
+# ---- pinned to the reference: fixtures composed from its own objects (tools/capture_goldens.py: shan_chen_goldens)
+@pytest.mark.parametrize('grid', [sym.D2Q9, sym.D3Q19])
+def test_pseudopotentials_match_reference(grid, golden_dir):
+    """sym.SHAN_CHEN_POTENTIALS (sym.py:896-908) through the oracle's force routine: one neighbour carries psi."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'shan_chen_%s.npz' % grid.__name__))
+    w1 = grid.weights_float[1]
+    for pot_id, pot in ((0, 'linear'), (1, 'classic')):
+        for x, psi in zip(g['psi_in'], g['psi_' + pot]):
+            neigh = np.zeros(grid.Q)
+            neigh[1] = x                      # e_1 = +x; psi(0) = 0 for both potentials
+            # F_x = -G psi(rho_loc) w_1 psi(x); with G = -1 and rho_loc chosen so that psi(rho_loc) = known
+            out = oracle.sc_force_node(grid.slf_id, pot_id, -1.0, x, neigh, precision=8)
+            assert abs(out[0] - psi * psi * w1) < 2e-14
+
+
+@pytest.mark.parametrize('grid', [sym.D2Q9, sym.D3Q19])
+@pytest.mark.parametrize('potential', ['linear', 'classic'])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_node_update_matches_reference_composition(grid, potential, pattern, golden_dir):
+    """One node of the binary Shan-Chen model through the oracle's whole-field kernels -- ShanChenPrepareMacroFields
+    then ShanChenCollideAndPropagate0/1 -- against values composed from the reference's own sympy objects
+    (pseudopotential, second-lattice equilibrium rho = rho0 = phi, common velocity, per-lattice Guo term) in f64.
+    A 3^dim block of fluid nodes: the centre node carries the sample's populations, its neighbours the sample's
+    rho / phi values."""
+    import os
+    from sailfish_amd import hipabi
+    g = np.load(os.path.join(golden_dir, 'shan_chen_%s.npz' % grid.__name__))
+    dim, Q = grid.dim, grid.Q
+    e = grid.basis_array
+    visc, tau_phi = float(g['visc'][0]), float(g['tau_phi'][0])
+    n = len(g['f1'])
+    lat = [5, 5, 5 if dim == 3 else 1]
+    worst = 0.0
+    for k in range(n):
+        desc = hipabi.make_desc(lattice=grid.slf_id, model=hipabi.SLF_BGK, precision=8,
+                                access_pattern=hipabi.SLF_AA if pattern == 'AA' else hipabi.SLF_AB,
+                                lat_nx=5, lat_ny=5, lat_nz=lat[2], arr_nx=32, arr_ny=5, arr_nz=lat[2], fluid_only=1,
+                                tau=sym.relaxation_time(visc), visc=visc, tau_phi=tau_phi,
+                                simtype=hipabi.SLF_SIM_SHAN_CHEN_BINARY, sc_G=list(g['G'][k]),
+                                sc_potential=0 if potential == 'linear' else 1,
+                                accel=list(g['body_accel'][k, 0]) + [0.0] * (3 - dim),
+                                accel1=list(g['body_accel'][k, 1]) + [0.0] * (3 - dim),
+                                has_force=int(np.any(g['body_accel'][k] != 0.0)))
+        o = oracle.OracleSim(desc)
+        c = (2, 2, 2) if dim == 3 else (0, 2, 2)            # (z, y, x) of the centre node
+        d1, d2 = o.new_dist(), o.new_dist()
+        w = np.array(grid.weights_float)
+        for d, f in ((d1, g['f1'][k]), (d2, g['f2'][k])):
+            d[...] = w.reshape((Q,) + (1,) * 3)              # benign values everywhere
+            d[(slice(None),) + c] = f
+        rho, phi = o.new_field(1.0), o.new_field(1.0)
+        v = [o.new_field(0.0) for _ in range(3)]
+        # even AA step / AB: the node's own slots hold f_i
+        o.sc_macro(1 if pattern == 'AA' else 0, None, d1, d2, rho, phi, v[0], v[1], v[2])
+        assert abs(rho[c] - g['sc_rho'][k]) < 1e-14 and abs(phi[c] - g['sc_phi'][k]) < 1e-14
+        for a in range(dim):
+            assert abs(v[a][c] - g['sc_v'][k, a]) < 1e-15
+        for i in range(1, Q):                                 # the neighbours' densities as in the sample
+            p = (c[0] + (e[i][2] if dim == 3 else 0), c[1] + e[i][1], c[2] + e[i][0])
+            rho[p], phi[p] = g['rho_nb'][k, i], g['phi_nb'][k, i]
+        post = g['sc_post_' + potential][k]
+        for l, (din, field) in enumerate(((d1, rho), (d2, phi))):
+            dout = din if pattern == 'AA' else o.new_dist()
+            o.sc_step(l, 1 if pattern == 'AA' else 0, None, din, dout, rho, phi, v[0], v[1], v[2])
+            for i in range(Q):
+                if pattern == 'AA':                           # in place, opposite slot
+                    got = dout[(grid.idx_opposite[i],) + c]
+                else:                                         # pushed to x + e_i
+                    p = (c[0] + (e[i][2] if dim == 3 else 0), c[1] + e[i][1], c[2] + e[i][0])
+                    got = dout[(i,) + p]
+                worst = max(worst, abs(got - post[l, i]))
+    assert worst < 1e-13, worst

@@ -54,6 +54,8 @@ def run(label, sim_cls, geo, settings, bytes_per_update):
         out['GBps_eff'] = round(ctrl.mlups_total * bytes_per_update / 1e3, 1)   # wall clock, everything included
         out['frac_of_8TBps'] = round(ctrl.mlups_comp * bytes_per_update / 8e6, 4)
     print(json.dumps(out), flush=True)
+    for r in ctrl.runners:      # give the device memory back before the next configuration
+        r.release()
     return out
 
 

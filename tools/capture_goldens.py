@@ -333,7 +333,96 @@ def arithmetic_goldens(grid, rng, n=48):
     return out
 
 
+def shan_chen_goldens(grid, rng, n=24):
+    """Binary Shan-Chen node update composed from the reference's own objects: pseudopotentials
+    sym.SHAN_CHEN_POTENTIALS (sym.py:896-908), moments sym.ex_rho / ex_velocity, the second lattice's equilibrium
+    bgk_equilibrium(rho=S.phi, rho0=S.phi) (lb_binary.py:378-380), the per-lattice Guo term
+    sym_force.guo_external_force(grid, grid_num=k) with guo_external_force_pref, in the order of
+    binary_shan_chen.mako:69-83 (common velocity), shan_chen.mako:9-84 (force -> acceleration) and
+    relaxation_common.mako:110-149 (equilibrium at v + a/2, Guo source term)."""
+    from functools import partial
+    dim, Q = grid.dim, grid.Q
+    cfg = _Cfg()
+    out = {}
+    w = np.array([float(x) for x in grid.weights])
+    f = [w[None, :] * rng.uniform(0.8, 1.2, (n, Q)) * rng.uniform(0.7, 1.3, (n, 1)) for _ in range(2)]
+    nb = [rng.uniform(0.4, 1.6, (n, Q)) for _ in range(2)]        # rho / phi at x + e_i (index 0 unused)
+    G = rng.uniform(-1.0, 1.5, (n, 4))
+    G[:, 2] = G[:, 1]                                                # G21 = G12 (lb_binary.py:393)
+    G[n // 2:, 0] = 0.0                                              # couplings that are switched off are skipped
+    G[n // 3:2 * n // 3, 3] = 0.0
+    body = rng.uniform(-2e-5, 2e-5, (n, 2, dim))
+    body[:n // 2] = 0.0
+    visc, tau_phi = 0.07, 0.83
+    tau = [float(sym.relaxation_time(visc)), tau_phi]
+    out.update(f1=f[0], f2=f[1], rho_nb=nb[0], phi_nb=nb[1], G=G, body_accel=body, visc=np.array([visc]),
+               tau_phi=np.array([tau_phi]))
+    eqs = [sym_equilibrium.bgk_equilibrium(grid, cfg),
+           partial(sym_equilibrium.bgk_equilibrium, rho=S.phi, rho0=S.phi)(grid, cfg)]
+    guo = [sym_force.guo_external_force(grid, grid_num=k) for k in range(2)]
+    prefs = [sym_force.guo_external_force_pref(grid, cfg, grid_num=k) for k in range(2)]
+    rho_e = sym.ex_rho(grid, 'fi', False)
+    # macroscopic pass
+    rho = np.zeros((n, 2))
+    mom = np.zeros((n, 2, dim))
+    for k in range(n):
+        for l in range(2):
+            subs = _fi_subs(grid, f[l][k])
+            rho[k, l] = _evalf(rho_e, subs)
+            for d in range(dim):
+                mom[k, l, d] = _evalf(sym.ex_velocity(grid, 'fi', d, cfg, momentum=True), subs)
+    ti = [1.0 / tau[0], 1.0 / tau[1]]
+    vc = (ti[0] * mom[:, 0] + ti[1] * mom[:, 1]) / (ti[0] * rho[:, 0] + ti[1] * rho[:, 1])[:, None]
+    out.update(sc_rho=rho[:, 0], sc_phi=rho[:, 1], sc_v=vc)
+    basis = [np.array([int(c) for c in e]) for e in grid.basis]
+    for pot in ('linear', 'classic'):
+        pe = sym.SHAN_CHEN_POTENTIALS[pot]('lfield')
+        psi = lambda x: _evalf(pe, {'lfield': x})     # noqa: E731
+        acc = np.zeros((n, 2, dim))
+        post = np.zeros((n, 2, Q))
+        for k in range(n):
+            for l in range(2):
+                a = np.zeros(dim)
+                for j in range(2):
+                    cc = G[k, 2 * l + j]
+                    if cc == 0.0:
+                        continue
+                    force = np.zeros(dim)
+                    for i in range(1, Q):
+                        p = psi(nb[j][k, i])
+                        for d in range(dim):
+                            if basis[i][d] != 0:
+                                force[d] += p * float(basis[i][d] * grid.weights[i])
+                    a += force * (-psi(rho[k, l]) * cc)
+                a = a / rho[k, l] + body[k, l]
+                acc[k, l] = a
+                v0 = vc[k] + 0.5 * a
+                subs = {'g0m0': rho[k, 0], 'g1m0': rho[k, 1], 'rho': rho[k, l], 'rho0': rho[k, l],
+                        'tau0': tau[0], 'tau1': tau[1]}
+                for d, c in enumerate('xyz'[:dim]):
+                    subs['g0m1' + c] = v0[d]
+                    subs['g%dea%s' % (l, c)] = a[d]
+                subs['pref'] = _evalf(prefs[l], subs)
+                for i in range(Q):
+                    feq = _evalf(eqs[l].expression[i], subs)
+                    post[k, l, i] = f[l][k, i] + ti[l] * (feq - f[l][k, i]) + _evalf(guo[l][i], subs)
+        out['sc_accel_' + pot] = acc
+        out['sc_post_' + pot] = post
+    xs = rng.uniform(0.1, 2.0, n)
+    out['psi_in'] = xs
+    for pot in ('linear', 'classic'):
+        pe = sym.SHAN_CHEN_POTENTIALS[pot]('lfield')
+        out['psi_' + pot] = np.array([_evalf(pe, {'lfield': x}) for x in xs])
+    return out
+
+
 def main():
+    rng_sc = np.random.RandomState(777)
+    for grid in (sym.D2Q9, sym.D3Q19):
+        np.savez_compressed(os.path.join(OUT, 'shan_chen_%s.npz' % grid.__name__), **shan_chen_goldens(grid, rng_sc))
+        print('wrote Shan-Chen goldens for', grid.__name__)
+    if len(sys.argv) > 1 and sys.argv[1] == 'sc':
+        return
     rng = np.random.RandomState(20260926)
     tables = {}
     for grid in (sym.D2Q9, sym.D3Q19):

@@ -49,8 +49,14 @@ def main():
     pads = [int(x) for x in args.pads.split(',')]
     maxstride = nodes + max(pads)
     off = b.dist_align_offset(4) if not args.noalign else 0
-    dist_a = b.alloc_buf(size=19 * maxstride * 4, align_offset=off)
-    dist_b = b.alloc_buf(size=19 * maxstride * 4, align_offset=off) if 'ab' in args.modes else 0
+    from sailfish_amd import placement
+    if placement.enabled() and 19 * maxstride * 4 >= placement.MIN_BYTES:
+        bufs = b.alloc_placed([19 * maxstride * 4] * (2 if 'ab' in args.modes else 1), off)
+        dist_a = bufs[0].addr
+        dist_b = bufs[1].addr if len(bufs) > 1 else 0
+    else:
+        dist_a = b.alloc_buf(size=19 * maxstride * 4, align_offset=off)
+        dist_b = b.alloc_buf(size=19 * maxstride * 4, align_offset=off) if 'ab' in args.modes else 0
     print('dist_a 0x%x dist_b 0x%x stride_bytes %d' % (dist_a, dist_b, maxstride * 4))
     shape = (desc0.arr_nz, desc0.arr_ny, desc0.arr_nx)
     rho = np.ones(shape, dtype=np.float32)
