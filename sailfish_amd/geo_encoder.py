@@ -18,16 +18,34 @@ from sailfish_amd import node_type as nt
 from sailfish_amd import util
 
 
+class _ParamTable(object):
+    """Flat table of boundary-condition parameter values; equal values (numbers or tuples) share one entry.
+    The table index of an entry is what the node code stores."""
+
+    def __init__(self):
+        self.values = []
+        self._where = {}
+
+    def index_of(self, value):
+        """value: a number or a tuple of numbers.  Returns the index of its first element in the table."""
+        if value not in self._where:
+            self._where[value] = len(self.values)
+            self.values.extend(float(v) for v in (value if isinstance(value, tuple) else (value,)))
+        return self._where[value]
+
+
 class GeoEncoderConst(object):
+    """Node map -> one uint32 per node, parameters -> one flat table (the role of reference geo_encoder.py:76-382;
+    the bit layout, the dense renumbering of the types in use and the order of the parameter table are part of the
+    contract with the reference's node maps, see the module docstring)."""
+
     def __init__(self, subdomain):
         self.subdomain = subdomain
         self.dim = subdomain.dim
         self.config = subdomain.config
         self._type_id_remap = {0: 0}
         self._node_types = set([nt._NTFluid])
-        self._bits_type = 0
-        self._bits_param = 0
-        self._bits_scratch = 0
+        self._bits_type = self._bits_param = self._bits_scratch = 0
         self._type_map = None
         self._geo_params = []
         self.scratch_space_size = 0
@@ -37,81 +55,77 @@ class GeoEncoderConst(object):
     def _type_id(self, node_type):
         return self._type_id_remap.get(node_type, 0xffffffff)
 
-    def prepare_encode(self, type_map, param_map, param_dict, orientation, have_link_tags):
-        """type_map: node type ids; param_map: keys into param_dict (LBNodeType instances)."""
-        uniq_types = [int(x) for x in np.unique(type_map)]
-        for nt_id in uniq_types:
-            self._node_types.add(nt._NODE_TYPES[nt_id])
-        # dense renumbering, starting at 1 (reference geo_encoder.py:83-91)
-        for i, node_type in enumerate(uniq_types):
-            self._type_id_remap[node_type] = i + 1
-        self._bits_type = util.bit_len(len(uniq_types))
-        self._type_map = type_map
-        self._encoded_param_map = np.zeros_like(type_map)
-        self._scratch_map = np.zeros_like(type_map)
-
-        param_to_idx = {}
-        param_items = 0
-        for node_key, node_type in param_dict.items():
-            for param in node_type.params.values():
-                if util.is_number(param):
-                    if param not in param_to_idx:
-                        self._geo_params.append(float(param))
-                        param_to_idx[param] = param_items
-                        param_items += 1
-                    self._encoded_param_map[param_map == node_key] = param_to_idx[param]
-                elif type(param) is tuple:
-                    if param not in param_to_idx:
-                        self._geo_params.extend(float(p) for p in param)
-                        param_to_idx[param] = param_items
-                        param_items += len(param)
-                    self._encoded_param_map[param_map == node_key] = param_to_idx[param]
-                elif isinstance(param, np.ndarray):
-                    nodes_idx = np.argwhere(param_map == node_key)
-                    for value in np.unique(param):
-                        key = tuple(value) if hasattr(value, '__len__') else (float(value),)
-                        if key not in param_to_idx:
-                            self._geo_params.extend(float(p) for p in key)
-                            param_to_idx[key] = param_items
-                            param_items += len(key)
-                        idxs = nodes_idx[param == value]
-                        self._encoded_param_map[tuple(idxs[:, k] for k in range(idxs.shape[1]))] = param_to_idx[key]
-                else:
-                    raise ValueError('unsupported node parameter type for the HIP backend: %r' % type(param))
-        self._bits_param = util.bit_len(param_items)
-        for node_type in self._node_types:
-            if node_type.scratch_space_size(self.dim) > 0:
+    # -- step 1: what occurs in the map decides the field widths
+    def _renumber_types(self, type_map):
+        """Types in use get the dense ids 1, 2, ... in ascending order of their global ids."""
+        present = [int(t) for t in np.unique(type_map)]
+        self._node_types.update(nt._NODE_TYPES[t] for t in present)
+        self._type_id_remap.update((t, k + 1) for k, t in enumerate(present))
+        self._bits_type = util.bit_len(len(present))
+        for cls in self._node_types:
+            if cls.scratch_space_size(self.dim) > 0:
                 raise NotImplementedError('%s needs node scratch space, which the HIP backend does not provide'
-                                          % node_type.__name__)
+                                          % cls.__name__)
         self._bits_scratch = 0
-        self._have_link_tags = have_link_tags
+
+    def _index_params(self, param_map, param_dict):
+        """Parameter-table index of every node (0 where a node has no parameter)."""
+        table = _ParamTable()
+        index_map = np.zeros(param_map.shape, dtype=np.uint32)
+        for key, node_type in param_dict.items():              # in the order the nodes were set
+            nodes = param_map == key
+            for value in node_type.params.values():
+                if util.is_number(value) or type(value) is tuple:
+                    index_map[nodes] = table.index_of(value)
+                elif isinstance(value, np.ndarray):            # one value (row) per selected node, in C order
+                    where = np.argwhere(nodes)
+                    for v in np.unique(value):
+                        entry = tuple(v) if hasattr(v, '__len__') else (float(v),)
+                        sel = where[value == v]
+                        index_map[tuple(sel[:, k] for k in range(sel.shape[1]))] = table.index_of(entry)
+                else:
+                    raise ValueError('unsupported node parameter type for the HIP backend: %r' % type(value))
+        self._geo_params = table.values
+        self._bits_param = util.bit_len(len(table.values))
+        return index_map
+
+    def prepare_encode(self, type_map, param_map, param_dict, orientation, have_link_tags):
+        """type_map: node type ids (overwritten by encode()); param_map: per-node keys into param_dict
+        ({key: LBNodeType instance}); orientation: orientation codes or link tags."""
+        self._renumber_types(type_map)
+        self._type_map = type_map
+        self._encoded_param_map = self._index_params(param_map, param_dict)
+        self._have_link_tags = bool(have_link_tags)
         if have_link_tags:
             tags = orientation[orientation > 0]
-            if tags.size:
-                self._unused_tag_bits = int(np.bitwise_and.reduce(tags))
+            self._unused_tag_bits = int(np.bitwise_and.reduce(tags)) if tags.size else 0
+            if self.config.use_link_tags and 32 - self._bits_type - self._bits_param - self._bits_scratch < \
+                    self.subdomain.grid.Q - 1:
+                raise ValueError('Not enough bits available to tag neighbor nodes.')
 
-    def _encode_node(self, orientation, param, node_type, scratch_id=0):
-        if (32 - self._bits_scratch < self.subdomain.grid.Q - 1 and self.config.use_link_tags and
-                self._have_link_tags):
-            raise ValueError('Not enough bits available to tag neighbor nodes.')
-        misc_data = (orientation << self._bits_scratch) | scratch_id
-        misc_data = (misc_data << self._bits_param) | param
-        return (misc_data << self._bits_type) | node_type
+    # -- step 2: pack  orientation | scratch | param | type
+    def _pack(self, orientation, param, dense_type, scratch=0):
+        code = np.asarray(orientation, dtype=np.uint32)
+        for width, field in ((self._bits_scratch, scratch), (self._bits_param, param), (self._bits_type, dense_type)):
+            code = (code << np.uint32(width)) | np.asarray(field, dtype=np.uint32)
+        return code
+
+    def _dense_lut(self):
+        lut = np.zeros(max(self._type_id_remap) + 1, dtype=np.uint32)
+        for orig, dense in self._type_id_remap.items():
+            lut[orig] = dense
+        return lut
 
     def encode(self, orientation):
-        assert self._type_map is not None
-        max_type_code = max(self._type_id_remap.keys())
-        self._type_choice_map = np.zeros(max_type_code + 1, dtype=np.uint32)
-        for orig_code, new_code in self._type_id_remap.items():
-            self._type_choice_map[orig_code] = new_code
-        self._type_map[:] = self._encode_node(orientation.astype(np.uint32),
-                                              self._encoded_param_map.astype(np.uint32),
-                                              self._type_choice_map[self._type_map.astype(np.int64)],
-                                              self._scratch_map.astype(np.uint32))
+        """Replaces the type ids in the map handed to prepare_encode() by the packed node codes."""
+        assert self._type_map is not None, 'prepare_encode() first'
+        self._type_choice_map = self._dense_lut()
+        self._type_map[:] = self._pack(orientation, self._encoded_param_map,
+                                       self._type_choice_map[self._type_map.astype(np.int64)])
         self._type_map = None
 
     def _subdomain_encode_node(self, orientation, node_type, param):
-        return self._encode_node(np.uint32(orientation), param, self._type_choice_map[np.int64(node_type)])
+        return self._pack(orientation, param, self._type_choice_map[np.int64(node_type)])
 
     def get_param(self, location, values=1):
         idx = self._encoded_param_map[tuple(reversed(location))]

@@ -143,11 +143,10 @@ class LBSim(object):
 
     def need_sync_fields(self):
         """(sync to host requested, macroscopic fields requested) -- reference lb_base.py:233-252."""
-        need_sync = self.need_sync_flag or self.need_output()
-        need_fields = self.need_fields_flag or need_sync
-        self.need_fields_flag = False
-        self.need_sync_flag = False
-        return need_sync, need_fields
+        sync = bool(self.need_sync_flag or self.need_output())
+        fields = bool(sync or self.need_fields_flag)
+        self.need_sync_flag = self.need_fields_flag = False      # one-shot requests
+        return sync, fields
 
     def need_checkpoint(self):
         return (self.config.checkpoint_every > 0 and (self.iteration % self.config.checkpoint_every) == 0 and

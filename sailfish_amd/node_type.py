@@ -201,24 +201,19 @@ class NTSlip(LBNodeType):
     standard_macro = True
 
 
-def __init_node_type_list():
-    """Assigns ids in alphabetical (dir()) order, reference node_type.py:406-421."""
-    import sys
-    mod = sys.modules[__name__]
-    ret = []
-    for symbol in dir(mod):
-        obj = getattr(mod, symbol)
-        try:
-            if obj != LBNodeType and issubclass(obj, LBNodeType):
-                ret.append(obj)
-                if obj.id is None:
-                    obj.id = len(ret)
-        except TypeError:
-            pass
-    return dict((t.id, t) for t in ret)
+def _number_node_types():
+    """Every LBNodeType subclass defined in this module gets the next free id, walking the module in name order
+    (that order is the contract: ids end up in node maps, golden fixtures and checkpoints; classes that fix their
+    own id keep it).  Returns {id: class}."""
+    classes = [obj for _, obj in sorted(globals().items())
+               if isinstance(obj, type) and issubclass(obj, LBNodeType) and obj is not LBNodeType]
+    for position, cls in enumerate(classes, start=1):
+        if cls.id is None:
+            cls.id = position
+    return {cls.id: cls for cls in classes}
 
 
-_NODE_TYPES = __init_node_type_list()
+_NODE_TYPES = _number_node_types()
 
 
 def get_wet_node_type_ids(allow_unused=None):
@@ -239,24 +234,18 @@ def get_link_tag_node_type_ids():
 
 
 def multifield(values, where=None):
-    """Collapses arrays / scalars into one structured array usable as a per-node BC
-    parameter (reference node_type.py:436-468)."""
-    shape = None
-    new_values = []
-    for val in values:
-        if isinstance(val, np.ndarray):
-            assert shape is None or shape == val.shape
-            new_values.append(val.astype(np.float64))
-            shape = val.shape
-        else:
-            new_values.append(None)
-    assert shape is not None
-    for i, (old, new) in enumerate(zip(values, new_values)):
-        if new is None:
-            new_values[i] = np.zeros(shape, dtype=np.float64)
-            new_values[i][:] = old
-    rec = np.rec.fromarrays(new_values)
-    return rec[where] if where is not None else rec.flatten()
+    """One record array holding several per-node parameters (e.g. the components of a velocity): every entry of
+    `values` is an array over the nodes or a scalar that is broadcast to them.  With `where` the records of the
+    selected nodes are returned, otherwise all of them, flattened -- the form set_node() expects."""
+    arrays = [v for v in values if isinstance(v, np.ndarray)]
+    if not arrays:
+        raise AssertionError('multifield() needs at least one array to take the node shape from')
+    shape = arrays[0].shape
+    if any(a.shape != shape for a in arrays):
+        raise AssertionError('multifield(): arrays of different shapes')
+    columns = [np.array(np.broadcast_to(v, shape), dtype=np.float64) for v in values]
+    rec = np.rec.fromarrays(columns)
+    return rec.flatten() if where is None else rec[where]
 
 
 class DynamicValue(object):

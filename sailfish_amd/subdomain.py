@@ -15,9 +15,7 @@ box needs no scipy.  Pinned against node maps produced by the reference itself
 (tests/golden/geometry_*.npz).
 """
 import inspect
-import operator
 from collections import defaultdict
-from functools import reduce
 
 import numpy as np
 
@@ -26,80 +24,64 @@ from sailfish_amd import util
 
 
 class SubdomainSpec(object):
-    """Location of a subdomain and its links to other subdomains (reference subdomain.py:32-304)."""
+    """Where a subdomain sits in the global lattice and which subdomains touch its faces (the role of reference
+    subdomain.py:32-304; attribute names are the ones user code and the runner rely on: location, size, ox.., nx..,
+    ex.., end_location, actual_size, envelope_size, id, runner)."""
     dim = None
-
-    # Face IDs.
-    X_LOW = 0
-    X_HIGH = 1
-    Y_LOW = 2
-    Y_HIGH = 3
-    Z_LOW = 4
-    Z_HIGH = 5
+    # face ids: 2 * axis + (0: low side, 1: high side)
+    X_LOW, X_HIGH, Y_LOW, Y_HIGH, Z_LOW, Z_HIGH = range(6)
 
     def __init__(self, location, size, envelope_size=None, id_=None, *args, **kwargs):
-        self.location = tuple(location)
-        self.size = tuple(size)
+        assert len(location) == len(size) == self.dim
+        self.location, self.size = tuple(location), tuple(size)
+        self.end_location = [o + n for o, n in zip(location, size)]
+        for axis, name in enumerate('xyz'[:self.dim]):          # ox, nx, ex, ... per axis
+            setattr(self, 'o' + name, location[axis])
+            setattr(self, 'n' + name, size[axis])
+            setattr(self, 'e' + name, self.end_location[axis])
+        self.actual_size = self.envelope_size = None
         if envelope_size is not None:
             self.set_actual_size(envelope_size)
-        else:
-            self.actual_size = None
-            self.envelope_size = None
-        self._runner = None
-        self._id = id_
+        self.id = id_
+        self.runner = None
+        self._periodicity = [False] * self.dim
         self._clear_connections()
         self._clear_connectors()
-        self._periodicity = [False] * self.dim
 
     def __repr__(self):
-        return '{0}({1}, {2}, id_={3})'.format(self.__class__.__name__, self.location, self.size, self._id)
+        return '%s(%s, %s, id_=%s)' % (type(self).__name__, self.location, self.size, self.id)
 
-    @property
-    def runner(self):
-        return self._runner
-
-    @runner.setter
-    def runner(self, x):
-        self._runner = x
-
-    @property
-    def id(self):
-        return self._id
-
-    @id.setter
-    def id(self, x):
-        self._id = x
+    # -- sizes
+    def set_actual_size(self, envelope_size):
+        """Size including the ghost envelope on both sides of every axis."""
+        self.envelope_size = envelope_size
+        self.actual_size = [n + 2 * envelope_size for n in self.size]
 
     @property
     def num_nodes(self):
-        return reduce(operator.mul, self.size)
+        return int(np.prod(self.size, dtype=np.int64))
 
     @property
     def num_actual_nodes(self):
-        return reduce(operator.mul, self.actual_size)
+        return int(np.prod(self.actual_size, dtype=np.int64))
 
     @property
-    def periodic_x(self):
-        return self._periodicity[0]
+    def _nonghost_slice(self):
+        """Index (numpy axis order, x last) of the real nodes inside a ghost-including array."""
+        es = self.envelope_size
+        return tuple(slice(es, es + n) for n in reversed(self.size))
 
-    @property
-    def periodic_y(self):
-        return self._periodicity[1]
-
-    @property
-    def periodic_z(self):
-        return self.dim == 3 and self._periodicity[2]
-
-    @property
-    def periodic(self):
-        return any(self._periodicity)
-
+    # -- periodicity handled inside this subdomain (it spans the whole periodic axis)
     def enable_local_periodicity(self, axis):
-        """The subdomain spans the whole (periodic) axis: PBC is applied inside it."""
-        assert axis <= self.dim - 1
+        assert 0 <= axis < self.dim
         self._periodicity[axis] = True
 
-    # -- connections: face -> set of neighbour subdomain ids -------------------------
+    periodic_x = property(lambda self: self._periodicity[0])
+    periodic_y = property(lambda self: self._periodicity[1])
+    periodic_z = property(lambda self: self.dim == 3 and self._periodicity[2])
+    periodic = property(lambda self: any(self._periodicity))
+
+    # -- connections: face -> ids of the subdomains behind it
     def _clear_connections(self):
         self._connections = defaultdict(list)
 
@@ -107,85 +89,57 @@ class SubdomainSpec(object):
         self._connectors = {}
 
     def _add_connection(self, face, neighbour_id):
-        if neighbour_id not in self._connections[face]:
-            self._connections[face].append(neighbour_id)
+        ids = self._connections[face]
+        if neighbour_id not in ids:
+            ids.append(neighbour_id)
 
     def add_connector(self, subdomain_id, connector):
         assert subdomain_id not in self._connectors
         self._connectors[subdomain_id] = connector
 
     def connecting_subdomains(self):
-        """List of (face, subdomain id) pairs."""
+        """[(face, subdomain id)]"""
         return [(face, nid) for face, ids in self._connections.items() for nid in ids]
 
     def neighbour_ids(self):
-        return sorted(set(nid for ids in self._connections.values() for nid in ids))
+        return sorted({nid for ids in self._connections.values() for nid in ids})
 
     def has_face_conn(self, face):
-        return len(self._connections.get(face, ())) > 0
+        return bool(self._connections.get(face))
 
-    def set_actual_size(self, envelope_size):
-        self.actual_size = [x + 2 * envelope_size for x in self.size]
-        self.envelope_size = envelope_size
+    # -- face algebra
+    @staticmethod
+    def face_to_axis(face):
+        return face >> 1
 
-    @classmethod
-    def face_to_dir(cls, face):
-        return -1 if face in (cls.X_LOW, cls.Y_LOW, cls.Z_LOW) else 1
+    @staticmethod
+    def face_to_dir(face):
+        return 1 if face & 1 else -1
 
-    @classmethod
-    def face_to_axis(cls, face):
-        return face // 2
+    @staticmethod
+    def axis_dir_to_face(axis, dir_):
+        return 2 * axis + int(dir_ > 0)
 
-    def face_to_normal(self, face):
-        direction = [0] * self.dim
-        direction[self.face_to_axis(face)] = self.face_to_dir(face)
-        return direction
-
-    def opposite_face(self, face):
+    @staticmethod
+    def opposite_face(face):
         return face ^ 1
 
-    @classmethod
-    def axis_dir_to_face(cls, axis, dir_):
-        return 2 * axis + (1 if dir_ > 0 else 0)
+    def face_to_normal(self, face):
+        normal = [0] * self.dim
+        normal[face >> 1] = 1 if face & 1 else -1
+        return normal
 
     def contains_global(self, pos):
-        """Is the global node position inside this subdomain's real region?"""
-        return all(o <= p < o + n for p, o, n in zip(pos, self.location, self.size))
+        """Is the global node position a real node of this subdomain?"""
+        return all(o <= p < e for p, o, e in zip(pos, self.location, self.end_location))
 
 
 class SubdomainSpec2D(SubdomainSpec):
     dim = 2
 
-    def __init__(self, location, size, envelope_size=None, *args, **kwargs):
-        self.ox, self.oy = location
-        self.nx, self.ny = size
-        self.ex = self.ox + self.nx
-        self.ey = self.oy + self.ny
-        self.end_location = [self.ex, self.ey]
-        SubdomainSpec.__init__(self, location, size, envelope_size, *args, **kwargs)
-
-    @property
-    def _nonghost_slice(self):
-        es = self.envelope_size
-        return (slice(es, es + self.ny), slice(es, es + self.nx))
-
 
 class SubdomainSpec3D(SubdomainSpec):
     dim = 3
-
-    def __init__(self, location, size, envelope_size=None, *args, **kwargs):
-        self.ox, self.oy, self.oz = location
-        self.nx, self.ny, self.nz = size
-        self.ex = self.ox + self.nx
-        self.ey = self.oy + self.ny
-        self.ez = self.oz + self.nz
-        self.end_location = [self.ex, self.ey, self.ez]
-        SubdomainSpec.__init__(self, location, size, envelope_size, *args, **kwargs)
-
-    @property
-    def _nonghost_slice(self):
-        es = self.envelope_size
-        return (slice(es, es + self.nz), slice(es, es + self.ny), slice(es, es + self.nx))
 
 
 def _neighbour_sum(arr, kernel_offsets, cval):
@@ -227,14 +181,15 @@ class Subdomain(object):
                                     (self.active_nodes / float(self.spec.num_actual_nodes) * 100))
 
     def allocate(self):
+        """Host arrays of the node map pipeline, in the runner's padded layout: node types (with a ghost-including
+        view), parameter keys and orientation codes; `<name>_base` is the whole padded array behind a view."""
         runner = self.spec.runner
-        self._type_map_ghost, _ = runner.make_scalar_field(np.uint32, register=False, nonghost_view=False)
+        for name, dtype, ghosts in (('_type_map_ghost', np.uint32, True), ('_param_map', np.int64, False),
+                                    ('_orientation', np.uint32, False)):
+            view, _ = runner.make_scalar_field(dtype, register=False, nonghost_view=not ghosts)
+            setattr(self, name, view)
+            setattr(self, (name[:-len('_ghost')] if ghosts else name) + '_base', runner.field_base(view))
         self._type_map = self._type_map_ghost[self.spec._nonghost_slice]
-        self._type_map_base = runner.field_base(self._type_map_ghost)
-        self._param_map, _ = runner.make_scalar_field(dtype=np.int64, register=False)
-        self._param_map_base = runner.field_base(self._param_map)
-        self._orientation, _ = runner.make_scalar_field(np.uint32, register=False)
-        self._orientation_base = runner.field_base(self._orientation)
 
     @property
     def config(self):
@@ -283,103 +238,109 @@ class Subdomain(object):
     def active_nodes(self):
         if self.active_node_mask is not None:
             return int(np.sum(self.active_node_mask))
-        return reduce(operator.mul, self.lat_shape)
+        return int(np.prod(self.lat_shape, dtype=np.int64))
 
     @util.lazy_property
     def num_fluid_nodes(self):
         return int(np.sum(self.fluid_map()))
 
     # -- node assignment ---------------------------------------------------------------
-    def _verify_params(self, where, node_type):
-        for name, param in node_type.params.items():
-            if util.is_number(param):
-                continue
-            elif type(param) is tuple:
-                for el in param:
-                    if not util.is_number(el):
-                        raise ValueError('Tuple elements have to be numbers.')
-            elif isinstance(param, np.ndarray):
-                assert param.size == np.sum(where), (
-                    "Your array needs to have exactly as many nodes as there are True values in the "
-                    "'where' array.  Use node_type.multifield() to generate the array in an easy way.")
-            else:
-                raise ValueError('Unrecognized node param: {0} (type {1})'.format(name, type(param)))
+    @staticmethod
+    def _check_param(name, value, n_selected):
+        """A node parameter is a number, a tuple of numbers, or one value per selected node (ndarray)."""
+        if util.is_number(value):
+            return
+        if isinstance(value, np.ndarray):
+            if value.size != n_selected:
+                raise AssertionError("A per-node parameter array needs exactly as many entries as there are True "
+                                     "values in the 'where' array; node_type.multifield() builds such arrays.")
+            return
+        if type(value) is tuple:
+            if all(util.is_number(el) for el in value):
+                return
+            raise ValueError('Tuple elements have to be numbers.')
+        raise ValueError('Unrecognized node param: {0} (type {1})'.format(name, type(value)))
 
     @staticmethod
-    def _hashable_params(param_dict):
-        params = []
-        for k, v in param_dict.items():
-            params.append((k, v.tobytes()) if hasattr(v, 'tobytes') else (k, v))
-        return frozenset(params)
+    def _param_key(node_type):
+        """One integer per distinct (node type, parameter values) combination: what the parameter map stores for
+        the selected nodes until the encoder turns it into indices of the parameter table."""
+        items = frozenset((name, value.tobytes() if isinstance(value, np.ndarray) else value)
+                          for name, value in node_type.params.items())
+        return hash((node_type.id, items))
 
     def set_node(self, where, node_type):
-        """Set a boundary condition at the selected nodes (reference subdomain.py:532-559)."""
-        where_array = where
-        where = np.where(where)
-        assert not self._type_map_encoded
+        """Makes the nodes selected by the Boolean array `where` (ghost-including index grid) nodes of `node_type`
+        (a node_type.LBNodeType class or instance).  A node can be set once."""
+        if self._type_map_encoded:
+            raise AssertionError('the node map has been encoded already')
         if inspect.isclass(node_type):
-            assert issubclass(node_type, nt.LBNodeType)
             node_type = node_type()
-        else:
-            assert isinstance(node_type, nt.LBNodeType)
-        self._verify_params(where_array, node_type)
-        self._type_map_base[where] = node_type.id
-        key = hash((node_type.id, self._hashable_params(node_type.params)))
-        assert np.all(self._param_map_base[where] == 0), 'Overriding previously set nodes is not allowed.'
-        self._param_map_base[where] = key
+        if not isinstance(node_type, nt.LBNodeType):
+            raise AssertionError('node_type must be an LBNodeType class or instance')
+        mask = np.asarray(where)
+        selected = np.nonzero(mask)
+        n_selected = int(np.count_nonzero(mask))
+        for name, value in node_type.params.items():
+            self._check_param(name, value, n_selected)
+        if np.any(self._param_map_base[selected]):
+            raise AssertionError('Overriding previously set nodes is not allowed.')
+        key = self._param_key(node_type)
         self._params[key] = node_type
         self._seen_types.add(node_type.id)
-        if getattr(node_type, 'orientation', None) is not None:
-            self._orientation_base[where] = node_type.orientation
+        self._type_map_base[selected] = node_type.id
+        self._param_map_base[selected] = key
+        fixed = getattr(node_type, 'orientation', None)
+        if fixed is not None:
+            self._orientation_base[selected] = fixed
         elif node_type.needs_orientation:
             self._needs_orientation = True
 
     # -- orientation -----------------------------------------------------------------------
+    def _present(self, type_ids):
+        """Those of `type_ids` that occur in the node map."""
+        return sorted(set(type_ids) & set(int(t) for t in np.unique(self._type_map_base)))
+
+    def _at_neighbour(self, arr, vec):
+        """arr[x + vec] for every node x (vec in lattice order x, y[, z]); wraps around the array, like the
+        reference's np.roll-based detection."""
+        shift = tuple(-int(c) for c in reversed(vec))
+        return np.roll(arr, shift, axis=tuple(range(arr.ndim)))
+
     def tag_directions(self):
-        """Link tags: bit i-1 set <=> direction i points to a wet node (reference subdomain.py:593-642)."""
-        ngs = list(self.spec._nonghost_slice)
-        for i, periodic in enumerate(reversed(self.spec._periodicity)):
-            if not periodic:
-                ngs[i] = slice(None)
-        ngs = tuple(ngs)
-        uniq_types = set(int(x) for x in np.unique(self._type_map_base))
-        wet_types = list(set(nt.get_wet_node_type_ids()) & uniq_types)
-        orient_types = list(set(nt.get_link_tag_node_type_ids()) & uniq_types)
-        if not orient_types:
+        """Link tags for the node types that use them: bit i - 1 of the orientation field is set when lattice
+        direction i points from the node to a wet node.  Axes that are not locally periodic include their ghost
+        layers (a wall node next to a connected face sees the neighbour's nodes).  Returns False when no such
+        node type is present."""
+        tagged_types = self._present(nt.get_link_tag_node_type_ids())
+        if not tagged_types:
             return False
-        orient_map = (util.in_anyd_fast(self._type_map_base[ngs], orient_types) &
-                      (self._orientation_base[ngs] == 0))
-        l = self.grid.dim - 1
-        for i, vec in enumerate(self.grid.basis[1:]):
-            shifted_map = self._type_map_base[ngs]
-            for j, shift in enumerate(vec):
-                if shift == 0:
-                    continue
-                shifted_map = np.roll(shifted_map, int(-shift), axis=l - j)
-            idx = orient_map & util.in_anyd_fast(shifted_map, wet_types)
-            self._orientation_base[ngs][idx] |= np.uint32(1 << i)
+        window = tuple(ng if periodic else slice(None)
+                       for ng, periodic in zip(self.spec._nonghost_slice, reversed(self.spec._periodicity)))
+        types = self._type_map_base[window]
+        tags = self._orientation_base[window]            # a view: updated in place
+        todo = util.in_anyd_fast(types, tagged_types) & (tags == 0)
+        wet = util.in_anyd_fast(types, self._present(nt.get_wet_node_type_ids()))
+        for bit, vec in enumerate(self.grid.basis[1:]):
+            tags[todo & self._at_neighbour(wet, vec)] |= np.uint32(1 << bit)
         return True
 
     def detect_orientation(self, use_tags):
-        """Primary-direction orientation = the axis-aligned vector pointing to a fluid node
-        (reference subdomain.py:644-673)."""
-        uniq_types = set(int(x) for x in np.unique(self._type_map_base))
-        orient_types = list((set(nt.get_orientation_node_type_ids()) -
-                             set(nt.get_link_tag_node_type_ids() if use_tags else [])) & uniq_types)
-        if not orient_types:
+        """Orientation code of the remaining orientation-aware node types: the axis-aligned lattice direction
+        that points to a plain fluid node (first match in basis order)."""
+        wanted = set(nt.get_orientation_node_type_ids())
+        if use_tags:
+            wanted -= set(nt.get_link_tag_node_type_ids())
+        wanted = self._present(wanted)
+        if not wanted:
             return
-        orient_map = util.in_anyd_fast(self._type_map_base, orient_types)
-        l = self.grid.dim - 1
+        candidates = util.in_anyd_fast(self._type_map_base, wanted)
+        fluid = self._type_map_base == 0
         for vec in self.grid.basis:
-            if sum(c * c for c in vec) != 1:
+            if sum(abs(int(c)) for c in vec) != 1:
                 continue
-            shifted_map = self._type_map_base
-            for j, shift in enumerate(vec):
-                if shift == 0:
-                    continue
-                shifted_map = np.roll(shifted_map, int(-shift), axis=l - j)
-            idx = orient_map & (shifted_map == 0) & (self._orientation_base == 0)
-            self._orientation_base[idx] = self.grid.vec_to_dir(list(vec))
+            hit = candidates & self._at_neighbour(fluid, vec) & (self._orientation_base == 0)
+            self._orientation_base[hit] = self.grid.vec_to_dir(list(vec))
 
     # -- pipeline ----------------------------------------------------------------------------
     def reset(self, encode=True):
@@ -460,6 +421,27 @@ class Subdomain(object):
         where = _neighbour_sum(used_map, offs, 0) > 0
         self._type_map_base[where & (self._type_map_base == nt._NTUnused.id)] = nt._NTPropagationOnly.id
 
+    # -- index grids -----------------------------------------------------------------------------
+    def _index_grids(self, envelope):
+        """Global coordinates (hx, hy[, hz]) of the nodes of this subdomain, `envelope` ghost layers included."""
+        shape = [n + 2 * envelope for n in reversed(self.spec.size)]
+        grids = np.indices(shape)
+        return [grids[self.dim - 1 - axis] + (self.spec.location[axis] - envelope) for axis in range(self.dim)]
+
+    def _get_mgrid(self):
+        """Index arrays of the real nodes (what initial_conditions() receives)."""
+        return self._index_grids(0)
+
+    def _get_mgrid_base(self, config):
+        """Index arrays including the ghost layers (what boundary_conditions() receives); along a globally
+        periodic axis the ghost layers carry the coordinates of the nodes they mirror."""
+        grids = self._index_grids(self.spec.envelope_size)
+        periodic = [config.periodic_x, config.periodic_y] + ([config.periodic_z] if self.dim == 3 else [])
+        for axis, g in enumerate(reversed(self.grid_shape)):
+            if periodic[axis]:
+                grids[axis] %= g
+        return grids
+
     # -- ghosts --------------------------------------------------------------------------------
     def _embed(self, lat_mask):
         """Lattice-shaped (ghost-including) boolean array -> padded array shape."""
@@ -525,24 +507,6 @@ class Subdomain2D(Subdomain):
         self.gy, self.gx = grid_shape
         Subdomain.__init__(self, grid_shape, spec, *args, **kwargs)
 
-    def _get_mgrid(self):
-        """Index arrays (x, y) of the non-ghost nodes in global coordinates."""
-        return reversed(np.mgrid[self.spec.oy:self.spec.oy + self.spec.ny,
-                                 self.spec.ox:self.spec.ox + self.spec.nx])
-
-    def _get_mgrid_base(self, config):
-        """Index arrays including ghosts; wrapped for globally periodic axes (reference subdomain.py:885-899)."""
-        es = self.spec.envelope_size
-        ox, oy = self.spec.ox - es, self.spec.oy - es
-        hx, hy = reversed(np.mgrid[oy:oy + self.spec.ny + 2 * es, ox:ox + self.spec.nx + 2 * es])
-        if config.periodic_x:
-            hx[hx < 0] += self.gx
-            hx[hx >= self.gx] -= self.gx
-        if config.periodic_y:
-            hy[hy < 0] += self.gy
-            hy[hy >= self.gy] -= self.gy
-        return hx, hy
-
 
 class Subdomain3D(Subdomain):
     dim = 3
@@ -550,25 +514,3 @@ class Subdomain3D(Subdomain):
     def __init__(self, grid_shape, spec, *args, **kwargs):
         self.gz, self.gy, self.gx = grid_shape
         Subdomain.__init__(self, grid_shape, spec, *args, **kwargs)
-
-    def _get_mgrid(self):
-        return reversed(np.mgrid[self.spec.oz:self.spec.oz + self.spec.nz,
-                                 self.spec.oy:self.spec.oy + self.spec.ny,
-                                 self.spec.ox:self.spec.ox + self.spec.nx])
-
-    def _get_mgrid_base(self, config):
-        es = self.spec.envelope_size
-        ox, oy, oz = self.spec.ox - es, self.spec.oy - es, self.spec.oz - es
-        hx, hy, hz = reversed(np.mgrid[oz:oz + self.spec.nz + 2 * es,
-                                       oy:oy + self.spec.ny + 2 * es,
-                                       ox:ox + self.spec.nx + 2 * es])
-        if config.periodic_x:
-            hx[hx < 0] += self.gx
-            hx[hx >= self.gx] -= self.gx
-        if config.periodic_y:
-            hy[hy < 0] += self.gy
-            hy[hy >= self.gy] -= self.gy
-        if config.periodic_z:
-            hz[hz < 0] += self.gz
-            hz[hz >= self.gz] -= self.gz
-        return hx, hy, hz
