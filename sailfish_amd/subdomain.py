@@ -163,22 +163,21 @@ class Subdomain(object):
 
     def __init__(self, grid_shape, spec, grid, *args, **kwargs):
         """grid_shape: global lattice size, x last; spec: SubdomainSpec; grid: lattice class."""
-        self.spec = spec
-        self.grid_shape = grid_shape
-        self.grid = grid
-        self._type_vis_map = np.zeros(self.lat_shape, dtype=np.uint8)
-        self._type_map_encoded = False
-        self._params = {}
-        self._encoder = None
-        self._seen_types = set([0])
+        self.spec, self.grid, self.grid_shape = spec, grid, grid_shape
+        # state of the node-map pipeline (set_node -> reset -> encoder)
+        self._params = {}                 # parameter key -> LBNodeType instance, in the order of the set_node calls
+        self._seen_types = {0}
         self._needs_orientation = False
-        # indirect addressing only: dense boolean array over all nodes incl. ghosts, True = the node takes
-        # part in the simulation and owns a slot in the distribution arrays (reference subdomain.py:385-394)
+        self._type_map_encoded = False
+        self._encoder = None
+        self._type_vis_map = np.zeros(self.lat_shape, dtype=np.uint8)     # node types of the real nodes, for output
+        # indirect addressing only: dense Boolean array over all nodes incl. ghosts, True = the node takes part in
+        # the simulation and owns a slot in the distribution arrays
         self.active_node_mask = None
         if self.config.node_addressing == 'indirect':
             self.load_active_node_map(*self._get_mgrid_base(self.config))
-            self.config.logger.info('Fill ratio is: %0.2f%%' %
-                                    (self.active_nodes / float(self.spec.num_actual_nodes) * 100))
+            fill = 100.0 * self.active_nodes / self.spec.num_actual_nodes
+            self.config.logger.info('Fill ratio is: %0.2f%%' % fill)
 
     def allocate(self):
         """Host arrays of the node map pipeline, in the runner's padded layout: node types (with a ghost-including
@@ -344,25 +343,26 @@ class Subdomain(object):
 
     # -- pipeline ----------------------------------------------------------------------------
     def reset(self, encode=True):
+        """Builds the node map: user boundary conditions on the ghost-including index grid, provisional ghosts,
+        unused / propagation-only nodes, orientation (link tags first where allowed), final ghosts, encoder."""
+        cfg = self.config
         self._type_map_encoded = False
-        self.boundary_conditions(*self._get_mgrid_base(self.config))
-        have_link_tags = False
+        self.boundary_conditions(*self._get_mgrid_base(cfg))
         self._define_ghosts(unset_only=True)
         self._postprocess_nodes()
+        tagged = False
         if self._needs_orientation:
-            if self.config.use_link_tags:
-                have_link_tags = self.tag_directions()
-            self.detect_orientation(self.config.use_link_tags)
+            tagged = bool(cfg.use_link_tags) and self.tag_directions()
+            self.detect_orientation(cfg.use_link_tags)
         self._define_ghosts()
-        self._type_vis_map[:] = self._type_map[:]
+        np.copyto(self._type_vis_map, self._type_map)
         from sailfish_amd import geo_encoder
         self._encoder = geo_encoder.GeoEncoderConst(self)
         self._encoder.prepare_encode(self._type_map_base, self._param_map_base, self._params,
-                                     self._orientation_base, have_link_tags)
+                                     self._orientation_base, tagged)
         if encode:
             self.encoded_map()
-        self.config.logger.info('Fluid node fraction: %.1f%%' %
-                                (self.num_fluid_nodes * 100.0 / self.spec.num_nodes))
+        cfg.logger.info('Fluid node fraction: %.1f%%' % (100.0 * self.num_fluid_nodes / self.spec.num_nodes))
 
     @property
     def scratch_space_size(self):
