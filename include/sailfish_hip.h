@@ -178,6 +178,25 @@ int slf_vmm_chunk_release(slf_ctx* ctx, uint64_t handle);
 int slf_vmm_map(slf_ctx* ctx, void* va, size_t bytes, uint64_t handle);  /* whole chunk at va, read-write */
 int slf_vmm_unmap(slf_ctx* ctx, void* va, size_t bytes);
 
+/* ---- halo exchange between subdomain processes: replaces SubdomainRunner._send_dists / _recv_dists + the zmq
+ *      connectors (reference subdomain_runner.py:1064-1139, connector.py:73-174: device -> pinned host -> socket
+ *      -> pinned host -> device) by RCCL point-to-point operations between device buffers (xGMI inside a node).
+ *      One communicator per context; rank = subdomain process.  The 128-byte id of slf_comm_unique_id() is created
+ *      by one rank and handed to the others by the host code (any side channel).  slf_comm_sendrecv() posts one
+ *      send and / or one receive with `peer` on `stream` (counts in elements of elem_bytes = 1 | 4 | 8); exchanges
+ *      with several peers in one step go between slf_comm_group_begin() and slf_comm_group_end().  RCCL is bound at
+ *      run time (dlopen), so a process that never creates a communicator does not need it.  sailfish_amd's own
+ *      runner reaches the same RCCL through torch.distributed (backend "nccl"); these entry points are the
+ *      boundary for a host that does not carry torch. ---- */
+typedef struct slf_comm slf_comm;
+int slf_comm_unique_id(void* id128);
+int slf_comm_init(slf_ctx* ctx, int nranks, int rank, const void* unique_id, slf_comm** out);
+int slf_comm_destroy(slf_comm* comm);
+int slf_comm_group_begin(void);
+int slf_comm_group_end(void);
+int slf_comm_sendrecv(slf_comm* comm, int peer, const void* send_dptr, size_t n_send, void* recv_dptr, size_t n_recv,
+                      int elem_bytes, slf_stream* stream);
+
 /* ---- streams / events: make_stream, make_event, sync_stream
  *      (backend_cuda.py:291-308, 24-52) ---- */
 int slf_stream_create(slf_ctx* ctx, slf_stream** out);

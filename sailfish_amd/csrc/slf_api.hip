@@ -1,6 +1,7 @@
 // C ABI of libsailfish_hip.so (see include/sailfish_hip.h for the contract and
 // the reference interfaces each entry point replaces).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -233,6 +234,117 @@ int slf_vmm_unmap(slf_ctx* ctx, void* va, size_t bytes) {
   SLF_HIP(hipSetDevice(ctx->device));
   SLF_HIP(hipMemUnmap(va, bytes));
   return SLF_OK;
+}
+
+// ---- device-to-device halo exchange over RCCL (xGMI) --------------------------------------------------------
+// RCCL is bound at run time (dlopen): the library has no link-time dependency on it, and a process that already
+// carries an RCCL (PyTorch bundles one) keeps exactly that one.
+namespace {
+struct RcclUniqueId {      // ncclUniqueId: 128 opaque bytes, passed by value
+  char b[128];
+};
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+  if (g_rccl.handle) return SLF_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {           // one that is loaded already wins
+    h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    if (h) break;
+  }
+  for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(SLF_ERR_NOT_FOUND, std::string("librccl not found: ") + dlerror());
+#define SLF_SYM(field, name)                                                        \
+  *(void**)(&g_rccl.field) = dlsym(h, name);                                        \
+  if (!g_rccl.field) return fail(SLF_ERR_NOT_FOUND, std::string("librccl lacks ") + name);
+  SLF_SYM(GetUniqueId, "ncclGetUniqueId")
+  SLF_SYM(CommInitRank, "ncclCommInitRank")
+  SLF_SYM(CommDestroy, "ncclCommDestroy")
+  SLF_SYM(Send, "ncclSend")
+  SLF_SYM(Recv, "ncclRecv")
+  SLF_SYM(GroupStart, "ncclGroupStart")
+  SLF_SYM(GroupEnd, "ncclGroupEnd")
+  SLF_SYM(GetErrorString, "ncclGetErrorString")
+#undef SLF_SYM
+  g_rccl.handle = h;
+  return SLF_OK;
+}
+
+int rccl_fail(int rc, const char* what) {
+  return fail(SLF_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+}
+}  // namespace
+
+struct slf_comm {
+  slf_ctx* ctx;
+  void* comm;
+  int nranks, rank;
+};
+
+int slf_comm_unique_id(void* id128) {
+  if (!id128) return fail(SLF_ERR_INVALID, "id buffer is NULL");
+  if (int e = rccl_load()) return e;
+  int rc = g_rccl.GetUniqueId(id128);
+  return rc ? rccl_fail(rc, "ncclGetUniqueId") : SLF_OK;
+}
+
+int slf_comm_init(slf_ctx* ctx, int nranks, int rank, const void* unique_id, slf_comm** out) {
+  if (!ctx || !unique_id || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (int e = rccl_load()) return e;
+  SLF_HIP(hipSetDevice(ctx->device));
+  RcclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  void* comm = nullptr;
+  int rc = g_rccl.CommInitRank(&comm, nranks, id, rank);
+  if (rc) return rccl_fail(rc, "ncclCommInitRank");
+  *out = new slf_comm{ctx, comm, nranks, rank};
+  return SLF_OK;
+}
+
+int slf_comm_destroy(slf_comm* c) {
+  if (!c) return SLF_OK;
+  int rc = g_rccl.CommDestroy(c->comm);
+  delete c;
+  return rc ? rccl_fail(rc, "ncclCommDestroy") : SLF_OK;
+}
+
+int slf_comm_group_begin(void) {
+  if (int e = rccl_load()) return e;
+  int rc = g_rccl.GroupStart();
+  return rc ? rccl_fail(rc, "ncclGroupStart") : SLF_OK;
+}
+
+int slf_comm_group_end(void) {
+  if (int e = rccl_load()) return e;
+  int rc = g_rccl.GroupEnd();
+  return rc ? rccl_fail(rc, "ncclGroupEnd") : SLF_OK;
+}
+
+int slf_comm_sendrecv(slf_comm* c, int peer, const void* send_dptr, size_t n_send, void* recv_dptr, size_t n_recv,
+                      int elem_bytes, slf_stream* stream) {
+  if (!c) return fail(SLF_ERR_INVALID, "comm is NULL");
+  if (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 1) return fail(SLF_ERR_INVALID, "elem_bytes must be 1, 4 or 8");
+  const int dtype = elem_bytes == 4 ? 7 /* ncclFloat32 */ : (elem_bytes == 8 ? 8 /* ncclFloat64 */ : 0 /* ncclInt8 */);
+  SLF_HIP(hipSetDevice(c->ctx->device));
+  int rc = g_rccl.GroupStart();
+  if (rc) return rccl_fail(rc, "ncclGroupStart");
+  if (n_send) rc = g_rccl.Send(send_dptr, n_send, dtype, peer, c->comm, native(stream));
+  if (!rc && n_recv) rc = g_rccl.Recv(recv_dptr, n_recv, dtype, peer, c->comm, native(stream));
+  int rc2 = g_rccl.GroupEnd();
+  if (rc) return rccl_fail(rc, "ncclSend/ncclRecv");
+  return rc2 ? rccl_fail(rc2, "ncclGroupEnd") : SLF_OK;
 }
 
 int slf_host_alloc_pinned(size_t bytes, void** hptr) {

@@ -83,6 +83,12 @@ SIGNATURES = {
     'slf_vmm_chunk_release': (c_int, [c_void_p, ctypes.c_uint64]),
     'slf_vmm_map': (c_int, [c_void_p, c_void_p, c_size_t, ctypes.c_uint64]),
     'slf_vmm_unmap': (c_int, [c_void_p, c_void_p, c_size_t]),
+    'slf_comm_unique_id': (c_int, [c_void_p]),
+    'slf_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    'slf_comm_destroy': (c_int, [c_void_p]),
+    'slf_comm_group_begin': (c_int, []),
+    'slf_comm_group_end': (c_int, []),
+    'slf_comm_sendrecv': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]),
     'slf_host_alloc_pinned': (c_int, [c_size_t, POINTER(c_void_p)]),
     'slf_host_free': (c_int, [c_void_p]),
     'slf_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
