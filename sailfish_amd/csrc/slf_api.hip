@@ -258,13 +258,24 @@ RcclApi g_rccl;
 
 int rccl_load() {
   if (g_rccl.handle) return SLF_OK;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  // exactly one RCCL per process, and the one that belongs to the HIP runtime in use: the copy next to the
+  // libamdhip64 this library is bound to (a PyTorch wheel bundles both; torch.distributed will load that same
+  // file), then whatever the loader finds
+  std::vector<std::string> names;
+  Dl_info info;
+  if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) names.push_back(dir.substr(0, slash) + "/librccl.so");
+  }
+  names.push_back("librccl.so");
+  names.push_back("librccl.so.1");
   void* h = nullptr;
-  for (const char* n : names) {           // one that is loaded already wins
-    h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  for (const std::string& n : names) {           // one that is loaded already wins
+    h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD);
     if (h) break;
   }
-  for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  for (size_t i = 0; !h && i < names.size(); i++) h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_GLOBAL);
   if (!h) return fail(SLF_ERR_NOT_FOUND, std::string("librccl not found: ") + dlerror());
 #define SLF_SYM(field, name)                                                        \
   *(void**)(&g_rccl.field) = dlsym(h, name);                                        \

@@ -148,8 +148,13 @@ __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q
 // (x = 1 <-> x = nx).  This is the MI355X counterpart of the reference's shuffle / shared-memory
 // propagation (propagation.mako:180-382).  Requires blockDim.x >= nx (the row fits one workgroup) and
 // x wrapped in-sweep.
-template <int MODEL, int PROP, int NT, bool FORCE>
-__global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19, float> p) {
+// NSEG = 2 (rows longer than 512 nodes): every thread owns TWO nodes, x = t + 1 and x = t + 1 + blockDim.x, i.e. the
+// workgroup walks the row as two segments at once.  A 1024-node row is then 8 waves with 38 loads in flight each
+// instead of 16 waves that meet at every barrier (4.7 -> 6 TB/s on the odd step, profiles/r02/README.md); the
+// exchange is the same code with "virtual waves" vw = segment * waves + wave.
+template <int MODEL, int PROP, int NT, bool FORCE, int NSEG>
+__global__ void __launch_bounds__(NSEG == 1 ? 1024 : 512, (NSEG == 2 && MODEL == 0 && !FORCE) ? 6 : (NSEG == 1 ? 4 : 2))
+fast_row_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   constexpr int NW = 16;
   __shared__ float s_in_p[NW][5], s_in_m[NW][5], s_out_p[NW][5], s_out_m[NW][5];
@@ -160,115 +165,128 @@ __global__ void __launch_bounds__(1024) fast_row_kernel(const SweepParams<D3Q19,
   const int gy = sgpr(p.y0 + by);
   const int gz = sgpr(p.z0 + bz);
   const int nx = g.lat_nx - 2;
-  const int x = (int)threadIdx.x + 1;
-  const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
-  const bool live = x <= nx;
+  const int lane = (int)threadIdx.x & 63;
+  const int nwave = (int)blockDim.x >> 6;                       // waves per segment
+  int x[NSEG], vw[NSEG];
+  bool live[NSEG];
+  uint32_t xb[NSEG];                                            // per-lane address registers: byte offset of x in its row
+  static_for<0, NSEG>([&](auto S) {
+    x[S] = (int)threadIdx.x + 1 + S * (int)blockDim.x;
+    vw[S] = ((int)threadIdx.x >> 6) + S * nwave;
+    live[S] = x[S] <= nx;
+    xb[S] = (uint32_t)(live[S] ? x[S] : 1) * 4u;                // idle lanes: an in-row address, never stored
+  });
   const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
-  const uint32_t xi = (uint32_t)(live ? x : 1);  // idle lanes: an in-row address, never stored
-  const uint32_t xb = xi * 4u;                   // the ONE per-lane address register: byte offset of x in its row
-  const uint32_t gi = row + xi;
   const DistOff oy = dist_axis_off(gy, g.lat_ny, g.dsy, g.wrap[1]);
   const DistOff oz = dist_axis_off(gz, g.lat_nz, g.dsz, g.wrap[2]);
   const size_t ds = g.dq;
   const long long drow = g.dsy * gy + g.dsz * gz;              // the row in distribution space (layout, slf_kernels.h)
 
-  float f[L::Q];
+  float f[NSEG][L::Q];
   if constexpr (PROP == PROP_AA_ODD) {
     // raw_i(x) = slot opp(i) at (x, y - e_y, z - e_z): the value node x + e_x will use as f_i
     static_for<0, L::Q>([&](auto I) {
       const long long off = dist_dir_offset<L, I>(oy, oz, false);
-      f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)L::opp(I) + (size_t)(drow + off)), xb));
+      const auto base = uniform_base(p.din + ds * (size_t)L::opp(I) + (size_t)(drow + off));
+      static_for<0, NSEG>([&](auto S) { f[S][I] = ldg<NT>(at_byte(base, xb[S])); });
     });
-    {
+    static_for<0, NSEG>([&](auto S) {
       int kp = 0, km = 0;
       static_for<1, L::Q>([&](auto I) {
         if constexpr (L::ex(I) > 0) {
-          if (lane == 63) s_in_p[w][kp] = f[I];
-          if (x == nx) s_inw_p[kp] = f[I];
+          if (lane == 63) s_in_p[vw[S]][kp] = f[S][I];
+          if (x[S] == nx) s_inw_p[kp] = f[S][I];
           kp++;
         }
         if constexpr (L::ex(I) < 0) {
-          if (lane == 0) s_in_m[w][km] = f[I];
-          if (x == 1) s_inw_m[km] = f[I];
+          if (lane == 0) s_in_m[vw[S]][km] = f[S][I];
+          if (x[S] == 1) s_inw_m[km] = f[S][I];
           km++;
         }
       });
-    }
+    });
     __syncthreads();
-    {
+    static_for<0, NSEG>([&](auto S) {
       int kp = 0, km = 0;
       static_for<1, L::Q>([&](auto I) {
         if constexpr (L::ex(I) > 0) {
-          float t = __shfl_up(f[I], 1);
-          if (lane == 0 && w > 0) t = s_in_p[w - 1][kp];
-          if (x == 1) t = s_inw_p[kp];
-          f[I] = t;
+          float t = __shfl_up(f[S][I], 1);
+          if (lane == 0 && vw[S] > 0) t = s_in_p[vw[S] - 1][kp];
+          if (x[S] == 1) t = s_inw_p[kp];
+          f[S][I] = t;
           kp++;
         }
         if constexpr (L::ex(I) < 0) {
-          float t = __shfl_down(f[I], 1);
-          if (lane == 63) t = s_in_m[(w + 1) & (NW - 1)][km];
-          if (x == nx) t = s_inw_m[km];
-          f[I] = t;
+          float t = __shfl_down(f[S][I], 1);
+          if (lane == 63) t = s_in_m[(vw[S] + 1) & (NW - 1)][km];
+          if (x[S] == nx) t = s_inw_m[km];
+          f[S][I] = t;
           km++;
         }
       });
-    }
+    });
   } else {
-    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + (size_t)drow), xb)); });
+    static_for<0, L::Q>([&](auto I) {
+      const auto base = uniform_base(p.din + ds * (size_t)I + (size_t)drow);
+      static_for<0, NSEG>([&](auto S) { f[S][I] = ldg<NT>(at_byte(base, xb[S])); });
+    });
   }
 
-  float rho, v[3];
-  macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
-  if (live) check_invalid<float>(p.status, p.options, rho, x, gy, gz);
-  if (p.relaxation_enabled) {
-    if constexpr (MODEL == 0) bgk_relax<L, float, FORCE>(f, rho, v, p.cp);
-    else mrt_relax<L, float, FORCE>(f, v, p.cp, false);
-  }
-  if ((p.options & 1u) && live) {
-    p.rho[gi] = rho;
-    p.vx[gi] = v[0];
-    p.vy[gi] = v[1];
-    p.vz[gi] = v[2];
-  }
+  static_for<0, NSEG>([&](auto S) {
+    float rho, v[3];
+    macro_standard<L, float>(f[S], p.cp.incompressible != 0, rho, v);
+    if (live[S]) check_invalid<float>(p.status, p.options, rho, x[S], gy, gz);
+    if (p.relaxation_enabled) {
+      if constexpr (MODEL == 0) bgk_relax<L, float, FORCE>(f[S], rho, v, p.cp);
+      else mrt_relax<L, float, FORCE>(f[S], v, p.cp, false);
+    }
+    if ((p.options & 1u) && live[S]) {
+      const uint32_t gi = row + (uint32_t)x[S];
+      p.rho[gi] = rho;
+      p.vx[gi] = v[0];
+      p.vy[gi] = v[1];
+      p.vz[gi] = v[2];
+    }
+  });
 
   // push: the value of node x travels to x + e_x; it is stored by the thread that owns the target x
-  {
+  static_for<0, NSEG>([&](auto S) {
     int kp = 0, km = 0;
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) > 0) {
-        if (lane == 63) s_out_p[w][kp] = f[I];
-        if (x == nx) s_wrap_p[kp] = f[I];
+        if (lane == 63) s_out_p[vw[S]][kp] = f[S][I];
+        if (x[S] == nx) s_wrap_p[kp] = f[S][I];
         kp++;
       }
       if constexpr (L::ex(I) < 0) {
-        if (lane == 0) s_out_m[w][km] = f[I];
-        if (x == 1) s_wrap_m[km] = f[I];
+        if (lane == 0) s_out_m[vw[S]][km] = f[S][I];
+        if (x[S] == 1) s_wrap_m[km] = f[S][I];
         km++;
       }
     });
-  }
+  });
   __syncthreads();
   {
     int kp = 0, km = 0;
     static_for<0, L::Q>([&](auto I) {
-      float t = f[I];
-      if constexpr (L::ex(I) > 0) {
-        t = __shfl_up(f[I], 1);
-        if (lane == 0 && w > 0) t = s_out_p[w - 1][kp];
-        if (x == 1) t = s_wrap_p[kp];
-        kp++;
-      }
-      if constexpr (L::ex(I) < 0) {
-        t = __shfl_down(f[I], 1);
-        if (lane == 63) t = s_out_m[(w + 1) & (NW - 1)][km];
-        if (x == nx) t = s_wrap_m[km];
-        km++;
-      }
-      if (live) {
-        const long long off = dist_dir_offset<L, I>(oy, oz, true);
-        stg<NT>(at_byte(uniform_base(p.dout + ds * (size_t)I + (size_t)(drow + off)), xb), t);
-      }
+      const long long off = dist_dir_offset<L, I>(oy, oz, true);
+      const auto base = uniform_base(p.dout + ds * (size_t)I + (size_t)(drow + off));
+      static_for<0, NSEG>([&](auto S) {
+        float t = f[S][I];
+        if constexpr (L::ex(I) > 0) {
+          t = __shfl_up(f[S][I], 1);
+          if (lane == 0 && vw[S] > 0) t = s_out_p[vw[S] - 1][kp];
+          if (x[S] == 1) t = s_wrap_p[kp];
+        }
+        if constexpr (L::ex(I) < 0) {
+          t = __shfl_down(f[S][I], 1);
+          if (lane == 63) t = s_out_m[(vw[S] + 1) & (NW - 1)][km];
+          if (x[S] == nx) t = s_wrap_m[km];
+        }
+        if (live[S]) stg<NT>(at_byte(base, xb[S]), t);
+      });
+      if constexpr (L::ex(I) > 0) kp++;
+      if constexpr (L::ex(I) < 0) km++;
     });
   }
 }
@@ -298,10 +316,16 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
     const int bx = ((nx + 63) / 64) * 64;
     if ((variant & 512) && bx != 64 && bx != 128 && bx != 256 && bx != 512) return false;  // segmented rows (slf_row.hip)
     if (bx <= 1024) {
-      dim3 block(bx, 1, 1);
       dim3 grid(1, ny, nz);
-      if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT, FORCE>), grid, block, g.lds_pad, s, p);
-      else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT, FORCE>), grid, block, g.lds_pad, s, p);
+      if (bx > 512 && !(variant & 1024)) {       // two nodes per thread (variant bit 1024: one node per thread, 16 waves)
+        dim3 block((((nx + 1) / 2 + 63) / 64) * 64, 1, 1);
+        if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT, FORCE, 2>), grid, block, g.lds_pad, s, p);
+        else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT, FORCE, 2>), grid, block, g.lds_pad, s, p);
+        return true;
+      }
+      dim3 block(bx, 1, 1);
+      if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT, FORCE, 1>), grid, block, g.lds_pad, s, p);
+      else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT, FORCE, 1>), grid, block, g.lds_pad, s, p);
       return true;
     }
   }

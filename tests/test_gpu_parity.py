@@ -291,9 +291,10 @@ def test_odd_row_lengths_and_segmented_rows(backend, nx, pattern, case, segmente
 
 
 FULL_WAVE_NX = [64, 128, 256, 512, 1024]
+LONG_ROW_NX = [576, 700, 1000]      # two nodes per thread (slf_fast.hip NSEG = 2), second segment full / partial
 
 
-@pytest.mark.parametrize('nx', FULL_WAVE_NX)
+@pytest.mark.parametrize('nx', FULL_WAVE_NX + LONG_ROW_NX)
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
 @pytest.mark.parametrize('model', ['bgk', 'mrt'])
 def test_full_wave_rows_headline_kernels(backend, nx, pattern, model):
