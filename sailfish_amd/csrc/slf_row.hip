@@ -95,7 +95,9 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
 }
 
 // Even AA step: every access is to the node's own slots (aligned); per-node kernel with cache hints.
-template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE>
+// SPEC (node-map instantiations, dense geometries): issue the 19 loads before the node map has arrived, as in
+// row_kernel -- the map -> loads dependency is the longest chain of this kernel; excluded nodes then load in vain.
+template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE, bool SPEC = false>
 __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = sgpr(p.y0 + (int)blockIdx.y);
@@ -109,6 +111,9 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   R f[L::Q];
   int kind = NK_FLUID;
   uint32_t code = 0;
+  if constexpr (GENERAL && SPEC) {
+    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
+  }
   if constexpr (GENERAL) {
     code = p.map[gi];
     kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
@@ -117,7 +122,9 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
   const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
-  static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
+  if constexpr (!(GENERAL && SPEC)) {
+    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
+  }
   R rho, v[3];
   bool wet = true;
   node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL, false, FORCE>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
@@ -158,7 +165,10 @@ static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, i
       if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, GENERAL>), grid, block, 0, s, p);
       else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE>), grid, block, 0, s, p);
       break;
-    default: hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT, FORCE>), grid, block, 0, s, p); break;
+    default:
+      if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT, FORCE, GENERAL>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT, FORCE>), grid, block, 0, s, p);
+      break;
   }
 }
 
