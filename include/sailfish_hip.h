@@ -259,6 +259,18 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
 int slf_kernel_set_iteration(slf_kernel* k, uint32_t iteration);
 int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* stream); /* run_kernel */
 
+/* x faces connected to another subdomain (1-D decompositions along x, the reference's default axis, geo.py:100-135):
+ * instead of pushing into the ghost columns x = 0 / nx + 1 and packing them with a strided gather afterwards
+ * (reference Collect/DistributeContinuousData on an x face, kernel_utils.mako:526-543), the two edge lanes of every
+ * row write what leaves the subdomain straight into send_* and read what enters it from recv_* -- dense buffers
+ * [k][z][y] of 5 * arr_ny * arr_nz reals per face (k = rank of the direction among those with e_x > 0 for the high
+ * face / the values entering through the low face, e_x < 0 otherwise; rows cover the padded plane).  Each step the
+ * host only moves send_high -> the high neighbour's recv_low and send_low -> the low neighbour's recv_high.
+ * Entries that are not finite are ignored by the reader (fill the receive buffers with NaN before the first step:
+ * the arrays then count).  All CollideAndPropagate kernels of the module use the buffers once set; NULL pointers
+ * switch a face back to ghost columns.  D3Q19 single-fluid modules, direct addressing, x not wrapped in-sweep. */
+int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high);
+
 /* number of x-threads per workgroup the sweep uses for this module (diagnostics) */
 int slf_module_block_size(slf_module* m, int* threads);
 

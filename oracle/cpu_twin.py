@@ -14,6 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _libs = {}
+_QUOTA = 'unset'
 
 
 def cpu_model():
@@ -27,9 +28,37 @@ def cpu_model():
     return 'unknown CPU'
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup CPU bandwidth limit (v2 cpu.max or v1 cfs quota) and the
+    affinity mask, whichever is smaller; None when unlimited / unknown.  A container that sees 256 logical CPUs but
+    is allowed 8 CPUs' worth of time makes 128 pinned threads slower than 8."""
+    limits = []
+    try:
+        limits.append(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != 'max':
+            limits.append(max(1, int(round(float(quota) / float(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                limits.append(max(1, int(round(q / float(per)))))
+        except (OSError, ValueError):
+            pass
+    return min(limits) if limits else None
+
+
 def lib(precision=4):
     if precision in _libs:
         return _libs[precision]
+    global _QUOTA
+    if _QUOTA == 'unset':
+        _QUOTA = cpu_quota()        # before libgomp pins this thread to one core
     # thread placement must be in the environment before libgomp initialises
     os.environ.setdefault('OMP_PLACES', 'cores')
     os.environ.setdefault('OMP_PROC_BIND', 'close')
@@ -112,6 +141,10 @@ def baseline(model='bgk', precision='single', visc=1.0 / 6.0, budget_s=10.0):
     (256^2 D2Q9), best of 3 each, threads pinned to cores."""
     L = lib(4 if precision == 'single' else 8)
     cores = L.fast_max_threads()
+    quota = _QUOTA
+    if quota is not None and quota < cores:
+        cores = quota
+        L.fast_set_threads(cores)
     note = ''
     if model != 'bgk':
         note = ' (the CPU twin implements BGK only; timed as BGK)'
@@ -131,6 +164,7 @@ def baseline(model='bgk', precision='single', visc=1.0 / 6.0, budget_s=10.0):
     c1.run(20)
     c1_mlups = c1.mlups(400)
     return {'value': round(all_cores, 1), 'unit': 'MLUPS', 'cores': cores, 'kind': 'port',
+            'logical_cpus': os.cpu_count(), 'cpu_quota': quota,
             'single_thread_mlups': round(one, 2), 'config1_d2q9_256x256_mlups': round(c1_mlups, 1),
             'mlups_per_thread': round(all_cores / cores, 2),
             'sample': 'oracle/lbm_fast.c (OpenMP, %d threads pinned to cores, %s): D3Q19 BGK f%d AA periodic 256^3, best of 3 x '

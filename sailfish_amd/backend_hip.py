@@ -177,6 +177,7 @@ class HIPKernel(object):
 
 class HIPBackend(placement.VmmMixin):
     name = 'hip'
+    supports_xface = True      # slf_module_set_xface_buffers (sailfish_amd/xface.py)
     FatalError = HIPFatalError
 
     @classmethod
@@ -192,6 +193,10 @@ class HIPBackend(placement.VmmMixin):
                            help='print the workgroup shape chosen for the sweep kernels')
         group.add_argument('--nohip_graphs', dest='hip_graphs', action='store_false', default=True,
                            help='do not replay stretches of steps without host interaction as HIP graphs')
+        group.add_argument('--nohip_xface', dest='hip_xface', action='store_false', default=True,
+                           help='1-D decompositions along x: exchange the x faces through ghost columns and pack / '
+                                'unpack kernels (the reference\'s scheme) instead of the face buffers the sweep writes '
+                                'and reads itself (sailfish_amd/xface.py)')
         group.add_argument('--nohip_placement', dest='hip_placement', action='store_false', default=True,
                            help='plain allocations for the distribution arrays instead of spreading their physical '
                                 'backing over HBM (sailfish_amd/placement.py)')

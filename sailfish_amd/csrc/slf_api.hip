@@ -81,6 +81,8 @@ struct slf_module {
   int block_x;
   void* node_params;  // device copy, in the module's precision
   uint32_t* status;   // device {flag, x, y, z} of the on-GPU invalid value check
+  void* xsend[2];     // x-face buffers (slf_module_set_xface_buffers), NULL = unused
+  void* xrecv[2];
 };
 struct slf_kernel {
   slf_module* mod;
@@ -668,6 +670,7 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   m->block_x = bx;
   m->node_params = nullptr;
   m->status = nullptr;
+  m->xsend[0] = m->xsend[1] = m->xrecv[0] = m->xrecv[1] = nullptr;
   const int np = d->n_node_params > 0 ? d->n_node_params : 1;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc(&m->node_params, (size_t)np * d->precision);
@@ -718,6 +721,25 @@ int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]) {
   SLF_HIP(hipStreamSynchronize(native(stream)));
   for (int i = 0; i < 4; i++) out[i] = (int32_t)h[i];
   if (h[0]) SLF_HIP(hipMemsetAsync(m->status, 0, sizeof(h), native(stream)));
+  return SLF_OK;
+}
+
+int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high) {
+  if (!m) return fail(SLF_ERR_INVALID, "module is NULL");
+  const bool any = send_low || send_high || recv_low || recv_high;
+  if (any) {
+    const slf::Geometry& g = m->geo;
+    if (m->sel.lattice != 1 || g.indirect || m->sc.enabled || !(g.variant & 8) || (g.variant & 512))
+      return fail(SLF_ERR_UNSUPPORTED, "x-face buffers: D3Q19 single-fluid modules with direct addressing (whole-row kernels) only");
+    if (g.wrap[0]) return fail(SLF_ERR_INVALID, "x-face buffers make no sense with x wrapped inside the sweep");
+    if (g.lat_nx - 2 > 1024) return fail(SLF_ERR_UNSUPPORTED, "x-face buffers: rows of at most 1024 nodes");
+    if ((send_low == nullptr) != (recv_low == nullptr) || (send_high == nullptr) != (recv_high == nullptr))
+      return fail(SLF_ERR_INVALID, "a connected face needs both its send and its receive buffer");
+  }
+  m->xsend[0] = send_low;
+  m->xsend[1] = send_high;
+  m->xrecv[0] = recv_low;
+  m->xrecv[1] = recv_high;
   return SLF_OK;
 }
 
@@ -830,7 +852,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
   switch (k->kind) {
     case KK_COLLIDE_AND_PROPAGATE:
     case KK_COMPUTE_MACRO: {
-      slf::SweepArgs a;
+      slf::SweepArgs a = {};
       const int b0 = g.indirect ? 1 : 0;
       a.nodes = g.indirect ? (const void*)k->ptrs[0] : nullptr;
       a.map = (const void*)k->ptrs[b0 + 0];
@@ -844,6 +866,10 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.node_params = m->node_params;
       a.status = m->status;
       a.options = (uint32_t)k->ints[0];
+      for (int f = 0; f < 2; f++) {
+        a.xsend[f] = m->xsend[f];
+        a.xrecv[f] = m->xrecv[f];
+      }
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       if (g.indirect && !a.nodes) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
       slf::Prop prop = slf::PROP_AB;
@@ -869,7 +895,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     case KK_SC_MACRO:
     case KK_SC_SWEEP0:
     case KK_SC_SWEEP1: {
-      slf::SweepArgs a;
+      slf::SweepArgs a = {};
       a.nodes = nullptr;
       a.map = (const void*)k->ptrs[0];
       a.dist_in = (void*)k->ptrs[1];
@@ -903,7 +929,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     }
     case KK_SCS_MACRO:
     case KK_SCS_SWEEP: {
-      slf::SweepArgs a;
+      slf::SweepArgs a = {};
       a.nodes = nullptr;
       a.map = (const void*)k->ptrs[0];
       a.dist_in = (void*)k->ptrs[1];

@@ -65,6 +65,9 @@ struct SweepArgs {
   const void* node_params;
   void* status;        // device uint32[4]: invalid-value flag + position
   uint32_t options;
+  // x-face buffers (slf_module_set_xface_buffers): [0] low face (x = 1 side), [1] high face; NULL = not used
+  void* xsend[2];
+  const void* xrecv[2];
 };
 
 // One module = one (lattice, model, precision, access pattern) specialisation.

@@ -78,6 +78,8 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
     static_for<0, L::Q>([&](auto I) { f[I] = active ? ldg<NT>(src_of(I)) : (R)0; });
   }
 
+  const FaceRows fr = face_rows(g, gy, gz);
+  if (active) x_face_receive<L, R, PROP == PROP_AA_ODD>(p, f, x, nx, fr);
   R rho, v[3];
   bool wet = true;
   if (active) {
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
     }
   }
 
-  row_push<L, R, GENERAL, NT>(g, f, p.dout, ds, row, xi, x, nx, live, active, oy, oz);
+  row_push<L, R, GENERAL, NT>(g, f, p.dout, ds, row, xi, x, nx, live, active, oy, oz, p.xsend, &fr);
 }
 
 // Even AA step: every access is to the node's own slots (aligned); per-node kernel with cache hints.
@@ -125,6 +127,8 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
   if constexpr (!(GENERAL && SPEC)) {
     static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
   }
+  const FaceRows fr = face_rows(g, gy, gz);
+  x_face_receive<L, R, false>(p, f, gx, g.lat_nx - 2, fr);
   R rho, v[3];
   bool wet = true;
   node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL, false, FORCE>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
@@ -136,6 +140,7 @@ __global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
     if constexpr (L::dim == 3) p.vz[gi] = v[2];
   }
   static_for<0, L::Q>([&](auto I) { stg<NT>(at_byte(uniform_base(p.dout + ds * (size_t)L::opp(I) + row), xb), f[I]); });
+  x_face_send_own_row<L, R>(p, f, gx, g.lat_nx - 2, fr);
 }
 
 // Workgroup width for a row of nx nodes: the whole row.  Rows of 9-12 waves run 15-25 % below the 8-wave rows

@@ -29,7 +29,7 @@ __device__ __forceinline__ R shfl_down1(R v) { return __shfl_down(v, 1); }
 template <class L, class R, bool GENERAL, int NT>
 __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], R* dout, size_t ds, uint32_t row,
                                          uint32_t xi, int x, int nx, bool live, bool active, const AxisOff& oy,
-                                         const AxisOff& oz) {
+                                         const AxisOff& oz, R* const* xsend = nullptr, const FaceRows* fr = nullptr) {
   constexpr int NW = 16;
   constexpr int NXD = count_x_dirs<L>();
   __shared__ R s_out_p[NW][NXD], s_out_m[NW][NXD], s_wrap_p[NXD], s_wrap_m[NXD];
@@ -94,7 +94,13 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
       if constexpr (L::ex(I) > 0) {
         // edge lane: the value leaves the segment -- into the next segment, the ghost column x = nx + 1, or
         // around the periodic seam to x = 1
-        if (edge_stores && x == xe && active) stg<0>(dst + ((wrapx && x == nx) ? -(nx - 1) : 1), f[I]);
+        if (edge_stores && x == xe && active) {
+          if (xsend && xsend[1] && x == nx) {      // leaves through a connected high face: straight into the send buffer
+            xsend[1][(size_t)g.arr_ny * (size_t)g.arr_nz * x_dir_rank<L, I>() + (size_t)face_row_of<L, I>(*fr, true)] = f[I];
+          } else {
+            stg<0>(dst + ((wrapx && x == nx) ? -(nx - 1) : 1), f[I]);
+          }
+        }
         t = shfl_up1<R>(f[I]);
         if (lane == 0 && w > 0) t = s_out_p[w - 1][kp];
         if (x == xs) t = s_wrap_p[kp];
@@ -102,7 +108,13 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
         kp++;
       }
       if constexpr (L::ex(I) < 0) {
-        if (edge_stores && x == xs && active) stg<0>(dst + ((wrapx && x == 1) ? (nx - 1) : -1), f[I]);
+        if (edge_stores && x == xs && active) {
+          if (xsend && xsend[0] && x == 1) {
+            xsend[0][(size_t)g.arr_ny * (size_t)g.arr_nz * x_dir_rank<L, I>() + (size_t)face_row_of<L, I>(*fr, true)] = f[I];
+          } else {
+            stg<0>(dst + ((wrapx && x == 1) ? (nx - 1) : -1), f[I]);
+          }
+        }
         t = shfl_down1<R>(f[I]);
         if (lane == 63) t = s_out_m[(w + 1) & (NW - 1)][km];
         if (x == xe) t = s_wrap_m[km];

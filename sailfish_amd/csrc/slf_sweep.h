@@ -22,6 +22,12 @@ struct SweepParams {
   uint32_t options;
   int y0, z0;
   int relaxation_enabled;
+  // x faces connected to another subdomain (1-D decompositions along x): what crosses the face is exchanged through
+  // dense buffers [k][z][y] (k = position of the direction among those with e_x > 0 resp. < 0, rows over the whole
+  // padded (arr_ny x arr_nz) plane) which the two edge lanes of a row write / read directly -- no ghost-column
+  // stores in the sweep, no strided pack / unpack kernels (see x_face_* below).  NULL = face not connected.
+  R* xsend[2];
+  const R* xrecv[2];
   Geometry g;
   CollideParams<L, R> cp;
 };
@@ -160,6 +166,72 @@ __device__ __forceinline__ void row_of_block(int order, int ny, int nz, int& y, 
   }
   y = (int)(l % (uint32_t)ny);
   z = (int)(l / (uint32_t)ny);
+}
+
+// ---- x-face buffers ------------------------------------------------------------------------------------------
+// Row index of (y, z) in a face buffer and its +-1 neighbours along y / z with the same in-sweep wrap as the
+// distribution arrays (values that leave through a face land in the row the neighbour's edge node sits in).
+struct FaceRows {
+  int row;          // gy + arr_ny * gz
+  AxisOff oy, oz;   // strides 1 and arr_ny
+};
+__device__ __forceinline__ FaceRows face_rows(const Geometry& g, int gy, int gz) {
+  FaceRows fr;
+  fr.row = gy + g.arr_ny * gz;
+  fr.oy = axis_off(gy, g.lat_ny, 1, g.wrap[1]);
+  fr.oz = (g.dim == 3) ? axis_off(gz, g.lat_nz, g.arr_ny, g.wrap[2]) : AxisOff{0, 0};
+  return fr;
+}
+template <class L, int I>
+__device__ __forceinline__ int face_row_of(const FaceRows& fr, bool forward) {
+  const AxisOff ox0 = {0, 0};
+  return fr.row + dir_offset<L, I>(ox0, fr.oy, fr.oz, forward);
+}
+// position of direction I among the directions with the same sign of e_x (ascending I)
+template <class L, int I>
+constexpr int x_dir_rank() {
+  int n = 0;
+  for (int i = 1; i < I; i++) n += ((L::ex(i) > 0) == (L::ex(I) > 0) && L::ex(i) != 0) ? 1 : 0;
+  return n;
+}
+// Incoming populations of an edge node: f_I with e_x > 0 at x = 1 come from the low neighbour, e_x < 0 at x = nx from
+// the high one.  PULL = the odd AA step (the value sits in the row the pull reads from), otherwise the node's own row.
+// Non-finite entries (never written: the sender's edge node is excluded) leave f as loaded from the arrays.
+template <class L, class R, bool PULL>
+__device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
+  const size_t nrows = (size_t)p.g.arr_ny * (size_t)p.g.arr_nz;
+  if (p.xrecv[0] && x == 1) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) > 0) {
+        const R val = p.xrecv[0][nrows * x_dir_rank<L, I>() + (size_t)(PULL ? face_row_of<L, I>(fr, false) : fr.row)];
+        if (__builtin_isfinite(val)) f[I] = val;
+      }
+    });
+  }
+  if (p.xrecv[1] && x == nx) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) < 0) {
+        const R val = p.xrecv[1][nrows * x_dir_rank<L, I>() + (size_t)(PULL ? face_row_of<L, I>(fr, false) : fr.row)];
+        if (__builtin_isfinite(val)) f[I] = val;
+      }
+    });
+  }
+}
+// Outgoing populations of the even AA step: the post-collision f_I the neighbour's next (odd) step will pull.
+template <class L, class R>
+__device__ __forceinline__ void x_face_send_own_row(const SweepParams<L, R>& p, const R (&f)[L::Q], int x, int nx,
+                                                    const FaceRows& fr) {
+  const size_t nrows = (size_t)p.g.arr_ny * (size_t)p.g.arr_nz;
+  if (p.xsend[1] && x == nx) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) > 0) p.xsend[1][nrows * x_dir_rank<L, I>() + (size_t)fr.row] = f[I];
+    });
+  }
+  if (p.xsend[0] && x == 1) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) < 0) p.xsend[0][nrows * x_dir_rank<L, I>() + (size_t)fr.row] = f[I];
+    });
+  }
 }
 
 // Everything between loading the populations of a node and streaming them: macroscopic quantities,
@@ -318,6 +390,10 @@ inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const
   p.node_params = (const R*)a.node_params;
   p.status = (uint32_t*)a.status;
   p.options = a.options;
+  for (int k = 0; k < 2; k++) {
+    p.xsend[k] = (R*)a.xsend[k];
+    p.xrecv[k] = (const R*)a.xrecv[k];
+  }
   p.y0 = y0;
   p.z0 = z0;
   p.relaxation_enabled = ph.relaxation_enabled;

@@ -109,6 +109,7 @@ SIGNATURES = {
     'slf_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     'slf_module_create': (c_int, [c_void_p, POINTER(SlfModuleDesc), POINTER(c_void_p)]),
     'slf_module_destroy': (c_int, [c_void_p]),
+    'slf_module_set_xface_buffers': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'slf_module_block_size': (c_int, [c_void_p, POINTER(c_int)]),
     'slf_kernel_get': (c_int, [c_void_p, c_char_p, POINTER(c_void_p)]),
     'slf_kernel_destroy': (c_int, [c_void_p]),

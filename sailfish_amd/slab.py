@@ -16,9 +16,11 @@ Which layer travels (reference subdomain_runner.py:1069-1103, Appendix A.4-5 of 
   even AA step (in-place, opposite slots): my first real layer, opposite slots -> neighbour's ghost layer, so that
       its next (odd) step can pull them.
 """
+import os
+
 import numpy as np
 
-from sailfish_amd import hipabi, sym
+from sailfish_amd import hipabi, sym, xface
 from sailfish_amd.box import BoxSim, make_box_desc
 
 AXES = {'x': 0, 'y': 1, 'z': 2}
@@ -116,8 +118,24 @@ class SlabSim(BoxSim):
         self.halo_stream = b.make_stream()
         self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
         tdtype = torch.float32 if self.desc.precision == 4 else torch.float64
-        n = self.plan.count
         dev = torch.device('cuda', b.gpu_id)
+        self.xface = None
+        if self.axis == 0 and xface.supported(self.grid, self.desc) and os.environ.get('SLF_XFACE', '1') != '0':
+            # x faces: the sweep's edge lanes write / read dense face buffers themselves (xface.py) -- no pack / unpack
+            tensors = []
+
+            def alloc(n):
+                tensors.append(torch.empty(n, dtype=tdtype, device=dev))
+                return tensors[-1].data_ptr()
+            self.xface = xface.XFaceHalo.allocate(b, self.module, self.grid, self.desc, (True, True), alloc)
+            s_low, s_high, r_low, r_high = tensors
+            self.t_bufs = [s_high, s_low, r_low, r_high]            # s_up s_down r_low r_high
+            self.xface.reset()
+            self.ev_halo = None
+            self.regs_bnd, self.reg_bulk = self.plan.regions()
+            self.time_halo = False
+            return
+        n = self.plan.count
         self.t_bufs = [torch.empty(n, dtype=tdtype, device=dev) for _ in range(4)]  # s_up s_down r_low r_high
         self.k_halo = {}
         for swap in ((False, True) if self.aa else (False,)):
@@ -154,9 +172,10 @@ class SlabSim(BoxSim):
         self.halo_stream.wait_for_event(ev_bnd)
         if self.time_halo:
             self._ev_h0 = b.make_event(self.halo_stream, timing=True)
-        self._ks = self.k_halo[(swap, out)]
-        b.run_kernel(self._ks[0], None, self.halo_stream)
-        b.run_kernel(self._ks[1], None, self.halo_stream)
+        if self.xface is None:
+            self._ks = self.k_halo[(swap, out)]
+            b.run_kernel(self._ks[0], None, self.halo_stream)
+            b.run_kernel(self._ks[1], None, self.halo_stream)
         self.iteration += 1
         b.set_iteration(self.iteration)
 
@@ -167,8 +186,9 @@ class SlabSim(BoxSim):
 
     def step_finish(self):
         b = self.backend
-        b.run_kernel(self._ks[2], None, self.halo_stream)
-        b.run_kernel(self._ks[3], None, self.halo_stream)
+        if self.xface is None:
+            b.run_kernel(self._ks[2], None, self.halo_stream)
+            b.run_kernel(self._ks[3], None, self.halo_stream)
         if self.time_halo:
             self._halo_events.append((self._ev_h0, b.make_event(self.halo_stream, timing=True)))
         self.ev_halo = b.make_event(self.halo_stream)
@@ -207,6 +227,20 @@ class SlabSim(BoxSim):
         self.stream.synchronize()
         if self.halo:
             self.halo_stream.synchronize()
+
+    def initial_conditions(self):
+        BoxSim.initial_conditions(self)
+        if self.halo and self.xface is not None:
+            self.xface.reset(self.stream)
+            self.ev_halo = None
+
+    def get_dist(self, which=None):
+        """With x-face buffers the arrays are stale at the faces: write the received values into them first."""
+        if self.halo and self.xface is not None and self.iteration > 0:
+            self.sync()
+            pushed = (not self.aa) or ((self.iteration - 1) & 1) == 1
+            self.xface.materialise(self.gpu_dist[self.current_dist_index()], pushed, self.stream)
+        return BoxSim.get_dist(self, which)
 
     # -- initial state ---------------------------------------------------------
     def init_synthetic(self, seed=1234):

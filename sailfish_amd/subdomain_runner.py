@@ -23,7 +23,7 @@ import time
 
 import numpy as np
 
-from sailfish_amd import hipabi, io, subdomain_connection, util
+from sailfish_amd import hipabi, io, subdomain_connection, util, xface
 from sailfish_amd import node_type as nt
 from sailfish_amd.lb_base import LBSim  # noqa: F401  (type reference)
 from sailfish_amd.profile import TimeProfile
@@ -323,6 +323,11 @@ class SubdomainRunner(object):
         self._ev_halo = None
         if self._all_specs is None or len(self._all_specs) < 2:
             return
+        if self._connector is None:
+            from sailfish_amd.connector import LocalConnector
+            self._connector = LocalConnector()
+        if self._x_faces_only():
+            return self._init_xface_halo()
         arr = list(reversed(self._physical_size))
         dense_nodes = self._get_nodes()
         links = subdomain_connection.build_halo_links(self._spec, self._all_specs, self._global_size,
@@ -375,6 +380,61 @@ class SubdomainRunner(object):
         for ev in evs:
             self._data_stream.wait_for_event(ev)
         del evs[:]
+
+    # -- 1-D decompositions along x: dense face buffers written / read by the sweep itself (xface.py)
+    _xface = None
+
+    def _x_faces_only(self):
+        """Every subdomain of the simulation is connected through its x faces only, and the model can use the
+        x-face buffers (same answer in every runner of the simulation)."""
+        if not getattr(self.config, 'hip_xface', True) or self.has_macro_exchange or self.dim != 3 or \
+                not getattr(self.backend, 'supports_xface', False):
+            return False
+        if not xface.supported(self._sim.grid, self._desc, self.indirect) or len(self._sim.grids) != 1:
+            return False
+        for spec in self._all_specs:
+            faces = set(face for face, _ in spec.connecting_subdomains())
+            if not faces or not faces <= set((spec.X_LOW, spec.X_HIGH)):
+                return False
+            if not xface.supported(self._sim.grid, self._desc) or spec.size[0] > 1024:
+                return False
+        return True
+
+    def _init_xface_halo(self):
+        """One message per neighbour and step: [what leaves through my low face | through my high face] (the faces
+        that lead to this neighbour); it arrives as [its high-face input | its low-face input] on the other side."""
+        spec = self._spec
+        n = xface.face_count(self._desc)
+        isz = np.dtype(self.float).itemsize
+        by_neighbour = {}
+        for face, nid in sorted(spec.connecting_subdomains()):
+            by_neighbour.setdefault(nid, []).append(xface.LOW if face == spec.X_LOW else xface.HIGH)
+        send, recv = [0, 0], [0, 0]
+        for nid in sorted(by_neighbour):
+            faces = sorted(by_neighbour[nid])
+            link = subdomain_connection.HaloLink(nid)
+            link.send_buf = self._connector.alloc_buffer(self, n * len(faces), self.float)
+            link.recv_buf = self._connector.alloc_buffer(self, n * len(faces), self.float)
+            for k, face in enumerate(faces):                       # my send order: low, high
+                send[face] = link.send_buf + k * n * isz
+            for k, face in enumerate(reversed(faces)):             # the neighbour's send order seen from here
+                recv[face] = link.recv_buf + k * n * isz
+            link.kernels = {}
+            for mode in ('push', 'pull'):
+                for copy in (0, 1):
+                    link.kernels[(mode, copy)] = ([], [], n * len(faces), n * len(faces))
+            self._links[nid] = link
+        self._xface = xface.XFaceHalo(self.backend, self.module, self._sim.grid, self._desc, send, recv)
+        self._xface.reset()
+
+    def _materialise_halo(self):
+        """x-face buffers: the arrays are stale at the connected faces until the received values are written into
+        them (before anything reads the arrays on the host)."""
+        if self._xface is None or not hasattr(self, '_halo_mode'):
+            return
+        self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self._xface.materialise(self.gpu_dist(0, self._halo_copy), self._halo_mode == 'push', self._calc_stream)
+        self.backend.sync_stream(self._calc_stream)
 
     def halo_messages(self, kind='dist'):
         """[(neighbour id, send buffer, #send, receive buffer, #recv)] of the exchange that is due now,
@@ -543,6 +603,7 @@ class SubdomainRunner(object):
         """Distributions as [Q, (nz,) ny, arr_nx] (reference subdomain_runner.py:1363-1381); with indirect
         addressing the slots are scattered back to their nodes (inactive nodes: 0)."""
         self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self._materialise_halo()
         if copy is None:
             copy = 0 if not self._gpu_grids_secondary else (self._sim.iteration & 1)
         raw = np.zeros((self._sim.grid.Q, self._dist_stride), dtype=self.float)
@@ -653,6 +714,9 @@ class SubdomainRunner(object):
             self.restore_checkpoint(fname)
         if getattr(cfg, 'debug_dump_node_type_map', False) and self._output is not None:
             self._output.dump_node_type(self._subdomain._type_vis_map)
+        if self._xface is not None:          # whatever state was set up (initial conditions, a checkpoint): the arrays count
+            self._xface.reset(self._calc_stream)
+            self.__dict__.pop('_halo_mode', None)
         self._sim.before_main_loop(self)
         self.backend.sync_stream(self._calc_stream)
         self.num_fluid_nodes = self._subdomain.num_fluid_nodes

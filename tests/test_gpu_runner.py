@@ -410,3 +410,33 @@ def test_block_decomposition_on_gpu(pattern, dim, cuts, size):
     fg, fo = merged_gpu(ctrl, 'dist'), og.merged('dist')
     assert np.array_equal(fg, fo, equal_nan=True)
     assert np.array_equal(merged_gpu(ctrl, 'rho'), og.merged('rho'))
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('steps', [7, 8])
+@pytest.mark.parametrize('case', ['cavity_3x', 'pipe_2x', 'cavity_mrt_2x'])
+def test_x_slabs_through_face_buffers(pattern, steps, case):
+    """1-D decompositions along x (the reference's default axis): the sweep's edge lanes write / read dense x-face
+    buffers (sailfish_amd/xface.py, slf_module_set_xface_buffers) instead of ghost columns + pack / unpack kernels.
+    Odd and even step counts (the two halo flavours of the in-place pattern), walls cut by the faces, and the same
+    run with --nohip_xface: all equal to the oracle group bit for bit."""
+    if case == 'cavity_3x':
+        args = ('ldc_3d', 'LDCSim', 3, dict(lat_nx=30, lat_ny=12, lat_nz=10, visc=0.03, model='bgk', access_pattern=pattern,
+                                            subdomains=3, conn_axis='x'))
+        u = 0.05
+    elif case == 'cavity_mrt_2x':
+        args = ('ldc_3d', 'LDCSim', 3, dict(lat_nx=140, lat_ny=8, lat_nz=7, visc=0.03, model='mrt', access_pattern=pattern,
+                                            subdomains=2, conn_axis='x'))
+        u = 0.05
+    else:
+        args = ('poiseuille_3d', 'PoiseuilleSim', 3,
+                dict(lat_nx=18, lat_ny=18, lat_nz=16, visc=0.1, flow_direction='z', stationary=False, drive='force',
+                     force_implementation='guo', access_pattern=pattern, subdomains=2, conn_axis='x'))
+        u = 0.02
+    ctrl, exact = check_against_oracle(*args, steps, u)
+    assert exact
+    assert all(r._xface is not None for r in ctrl.runners)
+    module, sim, dim, cfg = args
+    plain = run_gpu(module, sim, dim, dict(cfg, hip_xface=False), steps)
+    assert all(r._xface is None for r in plain.runners)
+    assert np.array_equal(merged_gpu(ctrl, 'dist'), merged_gpu(plain, 'dist'), equal_nan=True)
