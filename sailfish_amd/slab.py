@@ -161,6 +161,8 @@ class SlabSim(BoxSim):
             k, out, swap = self.k_sweep[int(save_macro)][it & 1], 1 - (it & 1), False
         if self.ev_halo is not None:
             self.calc_stream.wait_for_event(self.ev_halo)
+        if self.xface is not None and self.xface.needs_clear:
+            self.xface.clear_send(self.calc_stream)
         for reg in self.regs_bnd:
             b.run_kernel(k, reg, self.calc_stream)
         if self.regs_bnd:

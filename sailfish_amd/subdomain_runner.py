@@ -392,7 +392,14 @@ class SubdomainRunner(object):
             return False
         if not xface.supported(self._sim.grid, self._desc, self.indirect) or len(self._sim.grids) != 1:
             return False
+        local = self._local_periodic()
+        if any(local[a] and not self._fused[a] for a in range(self.dim)):
+            # periodic images made by the ghost-layer kernels live in the arrays, not in the face buffers
+            return False
+        ref = self._all_specs[0]
         for spec in self._all_specs:
+            if tuple(spec.location[1:]) != tuple(ref.location[1:]) or tuple(spec.size[1:]) != tuple(ref.size[1:]):
+                return False        # faces that only partly overlap: rows of the two sides do not line up
             faces = set(face for face, _ in spec.connecting_subdomains())
             if not faces or not faces <= set((spec.X_LOW, spec.X_HIGH)):
                 return False
@@ -528,6 +535,10 @@ class SubdomainRunner(object):
         it = self._sim.iteration
         kernels = self._kernels_full if sync_req else self._kernels_none
         kernels = kernels.primary if (it & 1) == 0 else kernels.secondary
+        if self._xface is not None and self._xface.needs_clear:
+            if self._ev_halo is not None:
+                self._calc_stream.wait_for_event(self._ev_halo)      # the previous exchange has read the send buffers
+            self._xface.clear_send(self._calc_stream)
         ev_bnd = self._run_sweep(kernels, self._regions)
         base = 1 - (it & 1)
         for axis in self._pbc_axes:

@@ -64,6 +64,18 @@ class XFaceHalo(object):
             if a:
                 self.backend.memset_buf(a, 0xFF, self.nbytes, stream)
 
+    @property
+    def needs_clear(self):
+        """Without in-sweep wrap along y and z some rows of the send buffers are not written in every step (nothing
+        is pushed from a ghost row); they must read as 'nothing crossed here' (NaN), not as last step's value."""
+        d = self.desc
+        return not (d.periodic_fused[1] and d.periodic_fused[2])
+
+    def clear_send(self, stream):
+        for a in self.send:
+            if a:
+                self.backend.memset_buf(a, 0xFF, self.nbytes, stream)
+
     def materialise(self, dist, pushed, stream):
         """Writes the receive buffers into the distribution array `dist`: pushed = True after a push step (AB, odd AA:
         the values belong into the first real column, same slots), False after the even AA step (they belong into the
