@@ -9,21 +9,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'bench_r01_last.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'bench_final.json')))
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
     assert d['unit'] == 'MLUPS' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic'
     assert d['vs_baseline'] is None and d['dtype'] == 'f32' and 'workload' in d['config'] and 'model' not in d['config']
+    assert 'D3Q19 BGK 512^3' in d['metric']
+    c = d['config']
+    assert c['value_is'] == 'best of repeats' and len(c['runs_mlups']) == c['repeats']
+    assert min(c['runs_mlups']) <= c['median_mlups'] <= max(c['runs_mlups']) and abs(max(c['runs_mlups']) - d['value']) < 1.0
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     # achieved = algorithmic bytes per launch / kernel time; value = updates / wall time
     assert abs(r['achieved'] - 512 ** 3 * r['bytes_per_update'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1.0
     assert abs(d['value'] - 512 ** 3 / (d['ms_per_step'] * 1e-3) * 1e-6) / d['value'] < 1e-3
+    assert r['kernel_ms'] <= d['ms_per_step'] * 1.001
     assert r['traffic'] is None or 0.9 < r['traffic'] / (512 ** 3 * 152) < 1.2
-    c = d['cpu_baseline']
-    assert c['kind'] == 'port' and c['unit'] == 'MLUPS' and c['cores'] >= 1 and 'oracle' in c['sample']
+    b = d['cpu_baseline']
+    assert b['kind'] == 'port' and b['unit'] == 'MLUPS' and b['cores'] >= 1 and 'oracle/lbm_fast.c' in b['sample']
+    assert b['single_thread_mlups'] > 0 and b['config1_d2q9_256x256_mlups'] > 0
+
+
+def test_strong_scaling_arguments_are_checked_before_any_gpu_work():
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for flag in ('--scaling', '--domain', '--axis', '--force_distributed'):
+        assert flag in src
+    from sailfish_amd.slab import SlabPlan  # noqa: F401  (the slab driver imports without a GPU)
 
 
 def test_bench_refuses_to_run_without_a_gpu_or_with_inconsistent_ranks():
