@@ -324,12 +324,29 @@ class HIPBackend(placement.VmmMixin):
 
     def alloc_placed(self, sizes, align_offset=0):
         """Distribution arrays whose physical backing is spread over HBM (sailfish_amd/placement.py): one
-        PlacedBuffer per entry of `sizes`, placed together; use their .addr like any device address."""
-        bufs = [placement.PlacedBuffer(self, n, align_offset) for n in sizes]
+        PlacedBuffer per entry of `sizes`, placed together; use their .addr like any device address.  Where the
+        virtual-memory calls are not available or the spacers do not fit, the arrays are plain allocations (same
+        interface: objects with .addr)."""
+        bufs = []
+        try:
+            bufs = [placement.PlacedBuffer(self, n, align_offset) for n in sizes]
+            info = placement.place(self, bufs)
+        except HIPFatalError as e:
+            for buf in bufs:
+                try:
+                    buf.release()
+                except HIPFatalError:
+                    pass
+            self.last_placement = {'fallback': 'plain allocations (%s)' % str(e)[:120]}
+
+            class _Plain(object):
+                def __init__(self, addr):
+                    self.addr = addr
+            return [_Plain(self.alloc_buf(size=n, align_offset=align_offset)) for n in sizes]
         for buf in bufs:
             self._placed[buf.addr] = buf
             self._total_memory_bytes += buf.total
-        self.last_placement = placement.place(self, bufs)
+        self.last_placement = info
         for buf in bufs:       # padding columns / strides start from zeros, as in alloc_buf()
             self.memset_buf(buf.va, 0, buf.total)
         return bufs

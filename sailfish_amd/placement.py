@@ -68,8 +68,8 @@ def place(backend, buffers, span=None):
     payload = sum(b.total for b in buffers)
     if span is None:
         span = int(os.environ.get('SLF_PLACEMENT_SPAN_GIB', SPAN >> 30)) << 30
-    free = backend.total_memory - backend.allocated_bytes()
-    span = min(span, int(0.8 * free))
+    free = backend.total_memory - backend.allocated_bytes() - payload
+    span = max(payload, min(span, payload + int(0.8 * max(0, free))))
     spacer = max(0, (span - payload) // parts) // gran * gran
     spacers = []
     try:
