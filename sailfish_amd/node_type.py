@@ -20,185 +20,81 @@ ScratchSize = namedtuple('ScratchSize', ('dim2', 'dim3'))
 
 
 class LBNodeType(object):
-    """Base class for node types (reference node_type.py:18-80)."""
+    """A node type = a set of flags the host pipeline and the kernels look at, plus the values an instance carries
+    (`params`: name -> number, tuple or per-node array) and optionally a fixed orientation."""
     id = None
     wet_node = False            # undergoes the normal relaxation
     excluded = False            # does not take part in the simulation
     propagation_only = False
     standard_macro = False      # macroscopic fields computed the standard way
     needs_orientation = False
-    link_tags = False           # orientation field holds per-direction link tags
-    scratch_space = 0
-    location = 0.0              # wall position offset along the normal
+    link_tags = False           # the orientation field holds per-direction link tags
+    scratch_space = 0           # reals of per-node scratch memory (ScratchSize where it depends on the dimension)
+    location = 0.0              # wall position relative to the node, along the normal
     allow_unused = False
+    value_name = None           # name of the single positional value of the type ('density', 'velocity'), if any
 
-    def __init__(self, **params):
-        if 'orientation' in params:
-            self.orientation = params['orientation']
-            del params['orientation']
+    def __init__(self, *value, **params):
+        self.orientation = params.pop('orientation', None)
+        if self.value_name is not None:
+            if len(value) > 2 or (not value and self.value_name not in params):
+                raise TypeError('%s(%s[, orientation])' % (type(self).__name__, self.value_name))
+            if value:
+                params[self.value_name] = value[0]
+            if len(value) == 2:
+                self.orientation = value[1]
+        elif value:
+            raise TypeError('%s takes keyword parameters only' % type(self).__name__)
+        if self.orientation is None and not (self.value_name and self.needs_orientation):
+            del self.orientation            # "not given": set_node() then asks the geometry for it
         self.params = params
 
     @classmethod
     def scratch_space_size(cls, dim):
-        if type(cls.scratch_space) is int:
-            return cls.scratch_space
-        return cls.scratch_space.dim2 if dim == 2 else cls.scratch_space.dim3
+        sp = cls.scratch_space
+        return sp if isinstance(sp, int) else (sp.dim2 if dim == 2 else sp.dim3)
 
 
-# -- special types ---------------------------------------------------------------
-class _NTFluid(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    id = 0
+# The node types: name, value parameter, flags, kernel kind of the gfx950 kernels (None = not implemented there).
+# Names and flags are the reference's (sailfish/node_type.py:86-400: user code says `NTFullBBWall`,
+# `NTRegularizedVelocity((0.1, 0.0))`, ...); ids follow from the names (see _number_node_types).
+_W, _S, _O = dict(wet_node=True), dict(standard_macro=True), dict(needs_orientation=True)
+_OUTFLOW = dict(wet_node=True, standard_macro=True, needs_orientation=True)
+_TABLE = (
+    ('_NTFluid', None, dict(_W, id=0, **_S), hipabi.SLF_NK_FLUID),
+    ('_NTGhost', None, dict(excluded=True), hipabi.SLF_NK_GHOST),
+    ('_NTUnused', None, dict(excluded=True), hipabi.SLF_NK_UNUSED),
+    ('_NTPropagationOnly', None, dict(propagation_only=True), hipabi.SLF_NK_PROPAGATION_ONLY),
+    # walls: half-way bounce-back reflects at the link mid-point (link tags), full-way at the node
+    ('NTHalfBBWall', None, dict(_W, link_tags=True, location=-0.5, allow_unused=True, **dict(_S, **_O)), hipabi.SLF_NK_HALF_BB),
+    ('NTFullBBWall', None, dict(_S, location=0.5, **_O), hipabi.SLF_NK_FULL_BB),
+    ('NTWallTMS', None, dict(_W, link_tags=True, location=0.5, allow_unused=True, **dict(_S, **_O)), None),
+    ('NTSlip', None, dict(_S), None),
+    # imposed density (pressure)
+    ('NTEquilibriumDensity', 'density', dict(_W, **_O), hipabi.SLF_NK_EQUILIBRIUM_DENSITY),
+    ('NTRegularizedDensity', 'density', dict(_W, **_O), hipabi.SLF_NK_REGULARIZED_DENSITY),
+    ('NTZouHeDensity', 'density', dict(_W, **_O), hipabi.SLF_NK_ZOUHE_DENSITY),
+    ('NTGuoDensity', 'density', dict(), None),
+    # imposed velocity
+    ('NTEquilibriumVelocity', 'velocity', dict(_W, **_O), hipabi.SLF_NK_EQUILIBRIUM_VELOCITY),
+    ('NTZouHeVelocity', 'velocity', dict(_W, **_O), hipabi.SLF_NK_ZOUHE_VELOCITY),
+    ('NTRegularizedVelocity', 'velocity', dict(_W, **_O), hipabi.SLF_NK_REGULARIZED_VELOCITY),   # Latt et al., PRE 77 056703
+    # outflow and friends
+    ('NTCopy', None, _OUTFLOW, hipabi.SLF_NK_COPY),                 # two-copy (AB) access pattern only, like the reference
+    ('NTYuOutflow', None, _OUTFLOW, hipabi.SLF_NK_YU_OUTFLOW),      # AB only
+    ('NTDoNothing', None, _OUTFLOW, hipabi.SLF_NK_FLUID),           # AB: a plain fluid node; AA: unsupported
+    ('NTExtendedCopy', None, _OUTFLOW, None),
+    ('NTNeumann', None, _OUTFLOW, None),
+    ('NTLaminarize', None, _OUTFLOW, None),
+    ('NTGradFreeflow', None, dict(_W, scratch_space=ScratchSize(dim2=3, dim3=6), **_S), None),
+)
 
-
-class _NTGhost(LBNodeType):
-    excluded = True
-
-
-class _NTUnused(LBNodeType):
-    excluded = True
-
-
-class _NTPropagationOnly(LBNodeType):
-    propagation_only = True
-
-
-# -- walls -----------------------------------------------------------------------
-class NTHalfBBWall(LBNodeType):
-    """Half-way bounce-back: f_i(x, t+1) = f_opp(i)^post(x, t) (reference node_type.py:115-141)."""
-    wet_node = True
-    standard_macro = True
-    needs_orientation = True
-    link_tags = True
-    location = -0.5
-    allow_unused = True
-
-
-class NTFullBBWall(LBNodeType):
-    """Full-way bounce-back (reference node_type.py:144-168)."""
-    standard_macro = True
-    location = 0.5
-    needs_orientation = True
-
-
-class NTWallTMS(LBNodeType):
-    wet_node = True
-    needs_orientation = True
-    link_tags = True
-    location = 0.5
-    allow_unused = True
-    standard_macro = True
-
-
-# -- density (pressure) nodes ------------------------------------------------------
-class NTEquilibriumDensity(LBNodeType):
-    """Density BC using the equilibrium distribution (reference node_type.py:198-205)."""
-    needs_orientation = True
-    wet_node = True
-
-    def __init__(self, density, orientation=None):
-        self.params = {'density': density}
-        self.orientation = orientation
-
-
-class NTRegularizedDensity(LBNodeType):
-    needs_orientation = True
-    wet_node = True
-
-    def __init__(self, density, orientation=None):
-        self.params = {'density': density}
-        self.orientation = orientation
-
-
-class NTGuoDensity(LBNodeType):
-    def __init__(self, density):
-        self.params = {'density': density}
-
-
-class NTZouHeDensity(LBNodeType):
-    needs_orientation = True
-    wet_node = True
-
-    def __init__(self, density, orientation=None):
-        self.params = {'density': density}
-        self.orientation = orientation
-
-
-# -- velocity nodes ------------------------------------------------------------------
-class NTEquilibriumVelocity(LBNodeType):
-    needs_orientation = True
-    wet_node = True
-
-    def __init__(self, velocity, orientation=None):
-        self.params = {'velocity': velocity}
-        self.orientation = orientation
-
-
-class NTZouHeVelocity(LBNodeType):
-    needs_orientation = True
-    wet_node = True
-
-    def __init__(self, velocity, orientation=None):
-        self.params = {'velocity': velocity}
-        self.orientation = orientation
-
-
-class NTRegularizedVelocity(LBNodeType):
-    """Regularized velocity BC, Latt et al. PRE 77 056703 (reference node_type.py:269-283)."""
-    needs_orientation = True
-    wet_node = True
-
-    def __init__(self, velocity, orientation=None):
-        self.params = {'velocity': velocity}
-        self.orientation = orientation
-
-
-# -- outflow / misc (declared for API compatibility; not implemented by the HIP kernels) ---
-class NTGradFreeflow(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    scratch_space = ScratchSize(dim2=3, dim3=6)
-
-
-class NTDoNothing(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    needs_orientation = True
-
-
-class NTCopy(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    needs_orientation = True
-
-
-class NTExtendedCopy(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    needs_orientation = True
-
-
-class NTYuOutflow(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    needs_orientation = True
-
-
-class NTNeumann(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    needs_orientation = True
-
-
-class NTLaminarize(LBNodeType):
-    wet_node = True
-    standard_macro = True
-    needs_orientation = True
-
-
-class NTSlip(LBNodeType):
-    standard_macro = True
+HIP_KIND = {}      # node type class -> canonical kernel kind (SLF_NK_*)
+for _name, _value, _flags, _kind in _TABLE:
+    _cls = type(_name, (LBNodeType,), dict(_flags, value_name=_value, __module__=__name__))
+    globals()[_name] = _cls
+    if _kind is not None:
+        HIP_KIND[_cls] = _kind
 
 
 def _number_node_types():
@@ -254,23 +150,3 @@ class DynamicValue(object):
 
     def __init__(self, *args, **kwargs):
         raise NotImplementedError('DynamicValue boundary parameters are not supported by the HIP backend')
-
-
-# node type -> canonical kernel kind
-HIP_KIND = {
-    _NTFluid: hipabi.SLF_NK_FLUID,
-    _NTGhost: hipabi.SLF_NK_GHOST,
-    _NTUnused: hipabi.SLF_NK_UNUSED,
-    _NTPropagationOnly: hipabi.SLF_NK_PROPAGATION_ONLY,
-    NTFullBBWall: hipabi.SLF_NK_FULL_BB,
-    NTHalfBBWall: hipabi.SLF_NK_HALF_BB,
-    NTRegularizedVelocity: hipabi.SLF_NK_REGULARIZED_VELOCITY,
-    NTEquilibriumDensity: hipabi.SLF_NK_EQUILIBRIUM_DENSITY,
-    NTEquilibriumVelocity: hipabi.SLF_NK_EQUILIBRIUM_VELOCITY,
-    NTZouHeVelocity: hipabi.SLF_NK_ZOUHE_VELOCITY,
-    NTZouHeDensity: hipabi.SLF_NK_ZOUHE_DENSITY,
-    NTRegularizedDensity: hipabi.SLF_NK_REGULARIZED_DENSITY,
-    NTCopy: hipabi.SLF_NK_COPY,                 # two-copy (AB) access pattern only, like the reference
-    NTYuOutflow: hipabi.SLF_NK_YU_OUTFLOW,      # AB only
-    NTDoNothing: hipabi.SLF_NK_FLUID,           # AB: a plain fluid node (reference node_type.py:296-307); AA: unsupported
-}
