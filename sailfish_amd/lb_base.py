@@ -85,33 +85,32 @@ class LBSim(object):
     def dim(self):
         return self.grid.dim
 
+    def _declared_fields(self):
+        """The fields of this simulation class followed by those of the mix-ins in its MRO."""
+        owners = [self] + [c for c in type(self).mro()[1:]
+                           if issubclass(c, LBMixIn) and not issubclass(c, LBSim) and hasattr(c, 'fields')]
+        return [field for owner in owners for field in owner.fields()]
+
     def init_fields(self, runner):
-        """Creates the host mirrors of the macroscopic fields and exposes them as attributes
-        (sim.rho, sim.v, sim.vx, ... -- reference lb_base.py:139-170)."""
-        suffixes = ['x', 'y', 'z']
-        self._scalar_fields = []
-        self._vector_fields = []
-        self._fields = {}
-        sources = [self]
-        for c in self.__class__.mro()[1:]:
-            if issubclass(c, LBMixIn) and hasattr(c, 'fields') and not issubclass(c, LBSim):
-                sources.append(c)
-        for src in sources:
-            for field in src.fields():
-                if type(field) is ScalarField:
-                    f, _ = runner.make_scalar_field(name=field.name, async_=True)
-                    f[:] = field.init
-                    self._scalar_fields.append(FieldPair(field, f))
-                elif type(field) is VectorField:
-                    f = runner.make_vector_field(name=field.name, async_=True)
-                    self._vector_fields.append(FieldPair(field, f))
-                    for i in range(0, self.grid.dim):
-                        setattr(self, field.name + suffixes[i], f[i])
-                else:
-                    assert False, 'Invalid field type %s' % type(field)
-                setattr(self, field.name, f)
-                assert field.name not in self._fields, 'Field %s defined more than once.' % field.name
-                self._fields[field.name] = FieldPair(field, f)
+        """Creates the host mirrors of the macroscopic fields (pinned memory, registered for output) and exposes them
+        as attributes: sim.rho, sim.v (list of components), sim.vx, sim.vy[, sim.vz]."""
+        self._scalar_fields, self._vector_fields, self._fields = [], [], {}
+        for field in self._declared_fields():
+            if field.name in self._fields:
+                raise AssertionError('Field %s defined more than once.' % field.name)
+            if isinstance(field, VectorField):
+                host = runner.make_vector_field(name=field.name, async_=True)
+                for axis, component in zip('xyz', host):
+                    setattr(self, field.name + axis, component)
+                self._vector_fields.append(FieldPair(field, host))
+            elif isinstance(field, ScalarField):
+                host, _ = runner.make_scalar_field(name=field.name, async_=True)
+                host[:] = field.init
+                self._scalar_fields.append(FieldPair(field, host))
+            else:
+                raise AssertionError('Invalid field type %s' % type(field))
+            setattr(self, field.name, host)
+            self._fields[field.name] = FieldPair(field, host)
 
     def verify_fields(self):
         for name, field_pair in self._fields.items():
