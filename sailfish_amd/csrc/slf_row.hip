@@ -29,7 +29,9 @@ namespace slf {
 // row_probe8.log); loading for excluded nodes as well wastes their bytes, so the host asks for SPEC only when
 // few nodes are excluded.
 template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool FORCE, bool SPEC = false>
-__global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
+// (second launch bound = minimum resident waves per SIMD: the f32 node-map instantiations fit 6 without spilling --
+// 77-80 VGPRs instead of 81-91 -- which is worth a wave of occupancy; checked with -Rpass-analysis=kernel-resource-usage)
+__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
   const Geometry& g = p.g;
   const int gy = sgpr(p.y0 + (int)blockIdx.y);
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(1024) row_kernel(const SweepParams<L, R> p) {
 // SPEC (node-map instantiations, dense geometries): issue the 19 loads before the node map has arrived, as in
 // row_kernel -- the map -> loads dependency is the longest chain of this kernel; excluded nodes then load in vain.
 template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE, bool SPEC = false>
-__global__ void __launch_bounds__(1024) even_kernel(const SweepParams<L, R> p) {
+__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && MODEL == 1) ? 6 : 4) even_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = sgpr(p.y0 + (int)blockIdx.y);
   const int gz = (L::dim == 3) ? sgpr(p.z0 + (int)blockIdx.z) : 0;

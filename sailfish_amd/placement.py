@@ -29,8 +29,9 @@ def enabled():
 class PlacedBuffer(object):
     """A device buffer at a fixed virtual address made of `parts` equally sized physical chunks."""
 
-    def __init__(self, backend, nbytes, align_offset=0, parts=PARTS):
+    def __init__(self, backend, nbytes, align_offset=0, parts=None):
         self.backend = backend
+        parts = parts or int(os.environ.get('SLF_PLACEMENT_PARTS', PARTS))
         gran = backend.vmm_granularity()
         need = int(nbytes) + 256
         self.parts = parts
