@@ -440,3 +440,29 @@ def test_x_slabs_through_face_buffers(pattern, steps, case):
     plain = run_gpu(module, sim, dim, dict(cfg, hip_xface=False), steps)
     assert all(r._xface is None for r in plain.runners)
     assert np.array_equal(merged_gpu(ctrl, 'dist'), merged_gpu(plain, 'dist'), equal_nan=True)
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_runner_with_placed_distribution_arrays(pattern, monkeypatch, tmp_path):
+    """The runner's distribution arrays as placed buffers (physical chunks spread over HBM under one virtual range,
+    sailfish_amd/placement.py; normally only for arrays >= 1 GiB): two subdomains, both access patterns, checkpoint
+    round trip through host copies that cross chunk boundaries -- same numbers as the oracle."""
+    from sailfish_amd import placement
+    monkeypatch.setattr(placement, 'MIN_BYTES', 0)
+    monkeypatch.setenv('SLF_PLACEMENT_SPAN_GIB', '1')
+    cfg = dict(lat_nx=40, lat_ny=18, lat_nz=16, visc=0.03, model='bgk', access_pattern=pattern, subdomains=2, conn_axis='z')
+    ctrl, exact = check_against_oracle('ldc_3d', 'LDCSim', 3, cfg, 21, 0.05)
+    assert exact
+    assert all(r.backend._placed for r in ctrl.runners)
+    ck = str(tmp_path / 'ck')
+    first = run_gpu('ldc_3d', 'LDCSim', 3, dict(cfg, subdomains=1), 11, extra=dict(checkpoint_file=ck, final_checkpoint=True))
+    assert first.runners[0].backend._placed
+    cp = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.cpoint.npz'))
+    restored = run_gpu('ldc_3d', 'LDCSim', 3, dict(cfg, subdomains=1), 21,
+                       extra=dict(restore_from=os.path.join(str(tmp_path), cp[0][:-len('.0.cpoint.npz')])))
+    straight = run_gpu('ldc_3d', 'LDCSim', 3, dict(cfg, subdomains=1), 21)
+    assert np.array_equal(restored.runners[0]._debug_get_dist(), straight.runners[0]._debug_get_dist(), equal_nan=True)
+    for c in (ctrl, first, restored, straight):
+        for r in c.runners:
+            r.release()
+            assert not r.backend._placed

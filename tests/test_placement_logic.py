@@ -1,0 +1,99 @@
+"""Host logic of sailfish_amd/placement.py without a GPU: a fake backend records the virtual-memory calls.  Chunks and
+spacers alternate, the spacers (and only they) are released, the span respects the free memory, host copies are cut
+at chunk boundaries, and a failure in the middle gives everything back."""
+import pytest
+
+from sailfish_amd import placement
+
+
+class FakeVmm(object):
+    GRAN = 2 << 20
+
+    def __init__(self, total=288 << 30, fail_after=None):
+        self.total_memory, self.used, self.log = total, 0, []
+        self.live, self.mapped, self.next = {}, {}, 1
+        self.fail_after = fail_after
+
+    def allocated_bytes(self):
+        return self.used
+
+    def vmm_granularity(self):
+        return self.GRAN
+
+    def vmm_reserve(self, n):
+        assert n % self.GRAN == 0
+        self.log.append(('reserve', n))
+        return 0x7000000000 + 0x100000000 * len([e for e in self.log if e[0] == 'reserve'])
+
+    def vmm_release_range(self, va, n):
+        self.log.append(('free_range', n))
+
+    def vmm_chunk_create(self, n):
+        if self.fail_after is not None and len(self.live) >= self.fail_after:
+            from sailfish_amd.backend_hip import HIPFatalError
+            raise HIPFatalError('out of memory (fake)')
+        h, self.next = self.next, self.next + 1
+        self.live[h] = n
+        self.log.append(('create', h, n))
+        return h
+
+    def vmm_chunk_release(self, h):
+        self.log.append(('release', h))
+        del self.live[h]
+
+    def vmm_map(self, va, n, h):
+        assert self.live[h] == n and va % self.GRAN == 0
+        self.mapped[va] = h
+
+    def vmm_unmap(self, va, n):
+        del self.mapped[va]
+
+
+def test_chunks_and_spacers_alternate_and_only_spacers_are_released():
+    b = FakeVmm()
+    nbytes = 19 * 544 * 514 * 514 * 4
+    bufs = [placement.PlacedBuffer(b, nbytes, align_offset=124) for _ in range(2)]
+    assert all(pb.addr == pb.va + 124 and pb.total >= nbytes + 256 and pb.part_bytes % b.GRAN == 0 for pb in bufs)
+    info = placement.place(b, bufs)
+    creates = [e for e in b.log if e[0] == 'create']
+    sizes = [e[2] for e in creates]
+    part, spacer = bufs[0].part_bytes, int(info['spacer_gib'] * 2 ** 30 + 0.5)
+    # per round: part of A, part of B, spacer (none after the last round)
+    assert sizes[:3] == [part, part, sizes[2]] and sizes[2] != part and len(creates) == 16 * 2 + 15
+    assert abs(sizes[2] - spacer) < (1 << 20)
+    released = [e[1] for e in b.log if e[0] == 'release']
+    assert sorted(b.live[h] for h in b.live) == [part] * 32 and len(released) == 15
+    assert all(h is not None for pb in bufs for h in pb.mapped) and len(b.mapped) == 32
+    assert 60 < info['span_gib'] <= 73
+    for pb in bufs:
+        pb.release()
+    assert not b.live and not b.mapped
+
+
+def test_span_shrinks_with_the_free_memory_and_failures_give_everything_back():
+    b = FakeVmm(total=40 << 30)
+    b.used = 10 << 30
+    pb = placement.PlacedBuffer(b, 11 << 30)
+    info = placement.place(b, [pb])
+    assert info['span_gib'] <= 11 + 0.8 * 19 + 0.1
+    pb.release()
+    b2 = FakeVmm(fail_after=5)
+    pb2 = placement.PlacedBuffer(b2, 4 << 30)
+    with pytest.raises(Exception):
+        placement.place(b2, [pb2])
+    pb2.release()
+    assert not b2.live and not b2.mapped       # spacers released by place(), chunks by release()
+
+
+def test_host_copies_are_cut_at_chunk_boundaries():
+    from sailfish_amd.backend_hip import HIPBackend
+    hb = HIPBackend.__new__(HIPBackend)          # no device: only the segment arithmetic
+    fake = FakeVmm()
+    pb = placement.PlacedBuffer(fake, 100 << 20, align_offset=124, parts=4)
+    hb._placed = {pb.addr: pb}
+    segs = hb._segments(pb.addr, 100 << 20)
+    assert segs[0][0] == pb.addr and sum(n for _, _, n in segs) == 100 << 20
+    assert [off for _, off, _ in segs] == [0] + [k * pb.part_bytes - 124 for k in range(1, len(segs))]
+    for a, _, n in segs:
+        assert (a - pb.va) // pb.part_bytes == (a + n - 1 - pb.va) // pb.part_bytes      # inside one chunk
+    assert hb._segments(12345, 10) == [(12345, 0, 10)]
