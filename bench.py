@@ -105,7 +105,8 @@ def main():
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # SLF_FORCE_DEVICE: every rank on that GPU (functional runs of the N > 1 path on a 1-GPU box, with SLF_DIST_BACKEND=gloo)
+    local_rank = int(os.environ.get('SLF_FORCE_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:

@@ -22,14 +22,16 @@ def init_distributed(backend=None, force=False):
     if world == 1 and not force:
         return 0, 1
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # SLF_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses two ranks per device); device tensors are
+        # then staged through the host by the exchangers -- a functional stand-in for tests, not a fast path
+        backend = os.environ.get('SLF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     kw = {}
     if backend == 'nccl':
         # one process per GPU: make that GPU torch's current device too (streams handed to torch and RCCL's
         # own stream must live on it)
-        local = int(os.environ.get('LOCAL_RANK', '0'))
+        local = int(os.environ.get('SLF_FORCE_DEVICE', os.environ.get('LOCAL_RANK', '0')))
         torch.cuda.set_device(local)
         kw['device_id'] = torch.device('cuda', local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
@@ -54,11 +56,17 @@ class RingExchanger(object):
         self.down = (rank - 1) % world
 
     def exchange(self, send_up, send_down, recv_low, recv_high):
+        import torch
         import torch.distributed as dist
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             recv_low.copy_(send_up)       # a ring of one without a process group: the slab is its own neighbour
             recv_high.copy_(send_down)
             return []
+        staged = send_up.is_cuda and dist.get_backend() == 'gloo'
+        if staged:      # gloo moves host memory only (see init_distributed)
+            dev = (recv_low, recv_high)
+            send_up, send_down = send_up.cpu(), send_down.cpu()
+            recv_low, recv_high = torch.empty_like(send_up), torch.empty_like(send_down)
         ops = [dist.P2POp(dist.isend, send_up, self.up),
                dist.P2POp(dist.isend, send_down, self.down),
                dist.P2POp(dist.irecv, recv_low, self.down),
@@ -66,6 +74,9 @@ class RingExchanger(object):
         reqs = dist.batch_isend_irecv(ops)
         for r in reqs:
             r.wait()
+        if staged:
+            dev[0].copy_(recv_low)
+            dev[1].copy_(recv_high)
         return reqs
 
 
