@@ -200,6 +200,8 @@ int slf_comm_sendrecv(slf_comm* comm, int peer, const void* send_dptr, size_t n_
 /* ---- streams / events: make_stream, make_event, sync_stream
  *      (backend_cuda.py:291-308, 24-52) ---- */
 int slf_stream_create(slf_ctx* ctx, slf_stream** out);
+int slf_stream_create_high_priority(slf_ctx* ctx, slf_stream** out);  /* the halo stream (subdomain_runner.py:825-827 has two
+                                                                       equal streams; CUDA / HIP offer a priority) */
 int slf_stream_destroy(slf_stream* s);
 int slf_stream_sync(slf_stream* s);
 int slf_stream_native(slf_stream* s, void** hip_stream);         /* raw hipStream_t, for torch.cuda.ExternalStream */

@@ -40,11 +40,12 @@ def _check(lib, status, what=''):
 
 
 class HIPStream(object):
-    def __init__(self, backend):
+    def __init__(self, backend, high_priority=False):
         self._backend = backend
         self._lib = backend._lib
         h = ctypes.c_void_p()
-        _check(self._lib, self._lib.slf_stream_create(backend._ctx, ctypes.byref(h)), 'slf_stream_create')
+        create = self._lib.slf_stream_create_high_priority if high_priority else self._lib.slf_stream_create
+        _check(self._lib, create(backend._ctx, ctypes.byref(h)), 'slf_stream_create')
         self.handle = h
 
     def synchronize(self):
@@ -178,6 +179,7 @@ class HIPKernel(object):
 class HIPBackend(placement.VmmMixin):
     name = 'hip'
     supports_xface = True      # slf_module_set_xface_buffers (sailfish_amd/xface.py)
+    supports_stream_priority = True
     FatalError = HIPFatalError
 
     @classmethod
@@ -499,8 +501,9 @@ class HIPBackend(placement.VmmMixin):
         _check(self._lib, rc, 'slf_graph_capture_end')
         return HIPGraph(self, h)
 
-    def make_stream(self):
-        return HIPStream(self)
+    def make_stream(self, high_priority=False):
+        """high_priority (no counterpart in backend_cuda.py:291-296): for the halo stream, see slf_api.hip."""
+        return HIPStream(self, high_priority)
 
     def make_event(self, stream, timing=False):
         """Creates an event *and records it* on `stream` (reference backend_cuda.py:298-305)."""

@@ -412,19 +412,28 @@ int slf_memcpy_peer_async(slf_ctx* ctx, void* dst, int dst_device, const void* s
   return SLF_OK;
 }
 
-int slf_stream_create(slf_ctx* ctx, slf_stream** out) {
+static int stream_create(slf_ctx* ctx, bool high_priority, slf_stream** out) {
   if (!ctx || !out) return fail(SLF_ERR_INVALID, "NULL argument");
   SLF_HIP(hipSetDevice(ctx->device));
+  int least = 0, greatest = 0;
+  if (high_priority) SLF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
   slf_stream* s = new slf_stream;
   s->ctx = ctx;
-  hipError_t e = hipStreamCreateWithFlags(&s->s, hipStreamNonBlocking);
+  hipError_t e = high_priority ? hipStreamCreateWithPriority(&s->s, hipStreamNonBlocking, greatest)
+                               : hipStreamCreateWithFlags(&s->s, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete s;
-    return hip_fail(e, "hipStreamCreateWithFlags");
+    return hip_fail(e, "hipStreamCreate");
   }
   *out = s;
   return SLF_OK;
 }
+
+int slf_stream_create(slf_ctx* ctx, slf_stream** out) { return stream_create(ctx, false, out); }
+
+// The halo stream: its small pack / unpack kernels (and whatever waits behind them) are dispatched ahead of the bulk
+// sweep's remaining workgroups instead of queueing behind a full chip.
+int slf_stream_create_high_priority(slf_ctx* ctx, slf_stream** out) { return stream_create(ctx, true, out); }
 
 int slf_stream_destroy(slf_stream* s) {
   if (s) {

@@ -98,6 +98,7 @@ SIGNATURES = {
     'slf_memcpy_d2d_async': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'slf_memcpy_peer_async': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_size_t, c_void_p]),
     'slf_stream_create': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'slf_stream_create_high_priority': (c_int, [c_void_p, POINTER(c_void_p)]),
     'slf_stream_destroy': (c_int, [c_void_p]),
     'slf_stream_sync': (c_int, [c_void_p]),
     'slf_stream_native': (c_int, [c_void_p, POINTER(c_void_p)]),

@@ -115,7 +115,7 @@ class SlabSim(BoxSim):
         b = self.backend
         self.plan = SlabPlan(self.grid, self.desc, self.axis)
         self.exchanger = exchanger or RingExchanger(self.rank, self.world)
-        self.halo_stream = b.make_stream()
+        self.halo_stream = b.make_stream(high_priority=os.environ.get('SLF_HALO_PRIORITY', '1') != '0')
         self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
         tdtype = torch.float32 if self.desc.precision == 4 else torch.float64
         dev = torch.device('cuda', b.gpu_id)

@@ -252,7 +252,9 @@ class SubdomainRunner(object):
         self._desc = self._module_desc()
         self.module = self.backend.build(self._desc)
         self._calc_stream = self.backend.make_stream()
-        self._data_stream = self.backend.make_stream()
+        # the halo stream: ahead of the bulk sweep's queued workgroups where the backend can say so
+        prio = getattr(self.backend, 'supports_stream_priority', False)
+        self._data_stream = self.backend.make_stream(high_priority=True) if prio else self.backend.make_stream()
         self._dist_stride = hipabi.dist_stride(self._desc)
 
     def _init_gpu_data(self):
