@@ -39,7 +39,7 @@ class BoxSim(LBFluidSim):
     subdomain = PeriodicBox
 
 
-def run(label, sim_cls, geo, settings, bytes_per_update):
+def _run(label, sim_cls, geo, settings, bytes_per_update):
     cfg = dict(mode='benchmark', quiet=True, perf_stats_every=0)
     cfg.update(settings)
     ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
@@ -63,12 +63,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,3,4)')
     args = ap.parse_args()
     from examples.ldc_2d import CavitySim as Cavity2D
     from examples.ldc_3d import CavitySim as Cavity3D
     from examples.binary_fluid.sc_separation_3d import SeparationSim
     it = 0.3 if args.quick else 1.0
+    only = set(x for x in args.only.split(',') if x)
+
     res = []
+
+    def run(label, *a, **kw):       # noqa: F811 -- filters by id, then the module-level run()
+        if only and label.split(':')[0] not in only:
+            return None
+        return _run(label, *a, **kw)
     # config 0: the reference's own small case, on the GPU here (its CPU figure is bench.py's cpu_baseline)
     res.append(run('0: ldc_2d D2Q9 BGK 256x256', Cavity2D, LBGeometry2D,
                    dict(lat_nx=256, lat_ny=256, visc=0.0254, access_pattern='AA', max_iters=int(40000 * it),
@@ -98,7 +106,7 @@ def main():
                         benchmark_sample_from=int(500 * it)), 516))
     if args.out:
         with open(args.out, 'w') as fh:
-            for r in res:
+            for r in filter(None, res):
                 fh.write(json.dumps(r) + '\n')
 
 

@@ -11,6 +11,7 @@
 #   pmc             separate rocprofv3 --pmc passes of bench.py (HBM traffic; $BENCH_ARGS)
 #   torchrun        the N>1 code paths on one GPU: torch.distributed.run --nproc-per-node 1, weak + strong
 #   configs         tools/bench_configs.py (all single-GPU BASELINE configs through the host stack)
+#   tracecfg        rocprofv3 --kernel-trace --stats of bench_configs.py --quick --only <id>, for id in $TRACE_CONFIGS
 #   py <file> ...   python <file> ... (rest of the line)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; TAG=${GPU_TAG:-visit}; O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -52,6 +53,12 @@ while [ $# -gt 0 ]; do
       done ;;
     configs)
       timeout 1500 python tools/bench_configs.py $CONFIG_ARGS 2>&1 | tee $O/configs.jsonl | tail -12 ;;
+    tracecfg)
+      for c in ${TRACE_CONFIGS:-4}; do
+        ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg$c -o trace -- \
+            python $R/tools/bench_configs.py --quick --only $c > $O/trace_cfg$c.log 2>&1 )
+        summarise_trace $O/trace_cfg$c $O/kernel_stats_cfg$c.csv; tail -1 $O/trace_cfg$c.log | cut -c1-300
+      done ;;
     py)
       timeout ${PY_TIMEOUT:-900} python "$@" 2>&1 | tee -a $O/py.log | tail -${PY_TAIL:-40}; break ;;
     *) echo "unknown task $task" ;;
