@@ -42,39 +42,116 @@ __device__ __forceinline__ R sc_psi(R rho, int potential) {
   return (R)1 - (R)exp((double)((R)0 - rho));
 }
 
+// Cache hints for the populations: streamed once per kernel in 3-D (non-temporal); 2-D lattices live in the caches.
+template <class L>
+constexpr int sc_nt() { return L::dim == 3 ? 3 : 0; }
+
+// A node's row and lane position, the way slf_row.hip addresses memory: everything that is the same for the whole
+// workgroup (y, z, the row's first element, the y / z neighbour offsets) is pinned to SGPRs, so that every access is
+// (uniform base) + (one shared 32-bit lane offset) -- see uniform_base(), slf_sweep.h.
+struct ScNode {
+  int gx, gy, gz;
+  uint32_t row, xi, gi;
+  AxisOff ox, oy, oz;
+};
+template <class L>
+__device__ __forceinline__ ScNode sc_node(const Geometry& g, int y0, int z0, int nx, bool& live) {
+  ScNode n;
+  n.gy = sgpr(y0 + (int)blockIdx.y);
+  n.gz = (L::dim == 3) ? sgpr(z0 + (int)blockIdx.z) : 0;
+  n.gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  live = n.gx <= nx;
+  n.row = sgpr((uint32_t)g.arr_nx * (uint32_t)n.gy + (uint32_t)g.arr_nxy * (uint32_t)n.gz);
+  n.xi = (uint32_t)(live ? n.gx : nx);      // idle lanes: an in-row address, never stored
+  n.gi = n.row + n.xi;
+  n.ox = axis_off(n.gx, g.lat_nx, 1, g.wrap[0]);
+  n.oy = axis_off(n.gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  n.oz = (L::dim == 3) ? axis_off(n.gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  n.oy.p = sgpr(n.oy.p); n.oy.m = sgpr(n.oy.m); n.oz.p = sgpr(n.oz.p); n.oz.m = sgpr(n.oz.m);
+  return n;
+}
+
+// element (row + yz-offset of direction I, forward or backward) + (xi shifted along x) of a node-indexed array
+template <class L, int I, class T>
+__device__ __forceinline__ const SLF_GLOBAL T* sc_neighbour(const T* base, const ScNode& n, bool forward) {
+  const AxisOff ox0 = {0, 0};
+  const int off = dir_offset<L, I>(ox0, n.oy, n.oz, forward);          // y, z part: uniform
+  constexpr int ex = L::ex(I);
+  const int xs = (ex == 0) ? 0 : (((ex > 0) == forward) ? n.ox.p : n.ox.m);   // x part: per lane
+  return at_byte(uniform_base(base + (uint32_t)((int)n.row + off)), (uint32_t)((int)n.xi + xs) * (uint32_t)sizeof(T));
+}
+
 template <class L, class R, int PROP>
-__device__ __forceinline__ void sc_load(R (&f)[L::Q], const R* din, size_t ds, uint32_t gi, const AxisOff& ox,
-                                        const AxisOff& oy, const AxisOff& oz) {
+__device__ __forceinline__ void sc_load(R (&f)[L::Q], const R* din, size_t ds, const ScNode& n) {
   static_for<0, L::Q>([&](auto I) {
     if constexpr (PROP == PROP_AA_ODD) {
-      const int off = dir_offset<L, I>(ox, oy, oz, false);
-      f[I] = (din + ds * (size_t)L::opp(I))[(uint32_t)((int)gi + off)];
+      f[I] = ldg<sc_nt<L>()>(sc_neighbour<L, I>(din + ds * (size_t)L::opp(I), n, false));
     } else {
-      f[I] = (din + ds * (size_t)I)[gi];
+      f[I] = ldg<sc_nt<L>()>(at_byte(uniform_base(din + ds * (size_t)I + n.row), n.xi * (uint32_t)sizeof(R)));
     }
   });
+}
+
+// Shan-Chen acceleration of one lattice (sc_calculate_force, shan_chen.mako:9-27): the 18 neighbour values of each
+// coupled field come through the caches (every value is used by 18 nodes).
+template <class L, class R, int NFIELDS>
+__device__ __forceinline__ void sc_accel(const R* const (&fields)[2], const R (&G)[2], R rho, int potential, const ScNode& n,
+                                         R (&a)[3]) {
+  static_for<0, NFIELDS>([&](auto J) {
+    const R cc = G[J];
+    if (cc != (R)0) {
+      R force[3] = {(R)0, (R)0, (R)0};
+      static_for<1, L::Q>([&](auto I) {
+        const R psi = sc_psi<R>(*sc_neighbour<L, I>(fields[J], n, true), potential);
+        static_for<0, L::dim>([&](auto D) {
+          constexpr int e = e_comp<L>(I, D);
+          if constexpr (e > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
+          if constexpr (e < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
+        });
+      });
+      const R psi_loc = sc_psi<R>(rho, potential);
+      static_for<0, L::dim>([&](auto D) {
+        force[D] = force[D] * (((R)0 - psi_loc) * cc);
+        a[D] = a[D] + force[D];
+      });
+    }
+  });
+}
+
+// the streaming part of a sweep: whole-row push (3-D x-streaming steps), own slots (even AA step), or per-node push
+template <class L, class R, int PROP, bool GENERAL, bool ROW>
+__device__ __forceinline__ void sc_store(const Geometry& g, R (&f)[L::Q], R* dout, size_t ds, const ScNode& n, int nx,
+                                         bool live, bool active) {
+  if constexpr (ROW && PROP != PROP_AA_EVEN) {
+    row_push<L, R, GENERAL, sc_nt<L>()>(g, f, dout, ds, n.row, n.xi, n.gx, nx, live, active, n.oy, n.oz);
+  } else {
+    static_for<0, L::Q>([&](auto I) {
+      if constexpr (PROP == PROP_AA_EVEN) {
+        stg<sc_nt<L>()>(at_byte(uniform_base(dout + ds * (size_t)L::opp(I) + n.row), n.xi * (uint32_t)sizeof(R)), f[I]);
+      } else {
+        const int off = dir_offset<L, I>(n.ox, n.oy, n.oz, true);
+        (dout + ds * (size_t)I)[(uint32_t)((int)n.gi + off)] = f[I];
+      }
+    });
+  }
 }
 
 template <class L, class R, int PROP, bool GENERAL>
 __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
-  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (gx > g.lat_nx - 2) return;
-  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  bool live;
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live);
+  if (!live) return;
+  const uint32_t gi = n.gi;
   if constexpr (GENERAL) {
     const uint32_t code = p.map[gi];
     const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
     if (!kind_is_wet(kind)) return;
   }
-  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
-  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
-  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
   const size_t ds = g.dist_size;
   R f[L::Q];
   // lattice 0
-  sc_load<L, R, PROP>(f, p.d_in, ds, gi, ox, oy, oz);
+  sc_load<L, R, PROP>(f, p.d_in, ds, n);
   const R rho0 = density<L, R>(f);
   R v[3];
   v[0] = p.omega[0] * momentum<L, R, 0>(f);
@@ -82,7 +159,7 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   v[2] = (R)0;
   if constexpr (L::dim == 3) v[2] = p.omega[0] * momentum<L, R, 2>(f);
   // lattice 1
-  sc_load<L, R, PROP>(f, (const R*)p.d_out, ds, gi, ox, oy, oz);
+  sc_load<L, R, PROP>(f, (const R*)p.d_out, ds, n);
   const R rho1 = density<L, R>(f);
   v[0] = v[0] + p.omega[1] * momentum<L, R, 0>(f);
   v[1] = v[1] + p.omega[1] * momentum<L, R, 1>(f);
@@ -101,15 +178,13 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
 template <class L, class R, int K, int PROP, bool GENERAL, bool ROW = false>
 __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
-  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int nx = g.lat_nx - 2;
-  const bool live = gx <= nx;
+  bool live;
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
   if constexpr (!ROW) {
     if (!live) return;
   }
-  const uint32_t gi = (uint32_t)(live ? gx : nx) + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const uint32_t gi = n.gi;
   int kind = NK_FLUID;
   bool active = live;
   if constexpr (GENERAL) {
@@ -122,45 +197,21 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
     }
   }
   const bool wet = kind_is_wet(kind) && active;
-  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
-  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
-  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
   const size_t ds = g.dist_size;
 
+  R f[L::Q];
+  sc_load<L, R, PROP>(f, p.d_in, ds, n);
   const R* own = (K == 0) ? p.rho0 : p.rho1;
   const R rho = own[gi];
-  // ---- Shan-Chen acceleration (sc_calculate_force, shan_chen.mako:9-27)
   R a[3] = {(R)0, (R)0, (R)0};
   if (wet) {
-    static_for<0, 2>([&](auto J) {
-      const R cc = p.G[J];
-      if (cc != (R)0) {
-        const R* field = (J == 0) ? p.rho0 : p.rho1;
-        R force[3] = {(R)0, (R)0, (R)0};
-        static_for<1, L::Q>([&](auto I) {
-          const int off = dir_offset<L, I>(ox, oy, oz, true);
-          const R psi = sc_psi<R>(field[(uint32_t)((int)gi + off)], p.potential);
-          static_for<0, L::dim>([&](auto D) {
-            constexpr int e = e_comp<L>(I, D);
-            if constexpr (e > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
-            if constexpr (e < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
-          });
-        });
-        const R psi_loc = sc_psi<R>(rho, p.potential);
-        static_for<0, L::dim>([&](auto D) {
-          force[D] = force[D] * (((R)0 - psi_loc) * cc);
-          a[D] = a[D] + force[D];
-        });
-      }
-    });
+    const R* const fields[2] = {p.rho0, p.rho1};
+    sc_accel<L, R, 2>(fields, p.G, rho, p.potential, n, a);
     static_for<0, L::dim>([&](auto D) { a[D] = a[D] / rho; });
     if (p.has_body_force) {
       static_for<0, L::dim>([&](auto D) { a[D] = a[D] + p.accel[D]; });
     }
   }
-
-  R f[L::Q];
-  sc_load<L, R, PROP>(f, p.d_in, ds, gi, ox, oy, oz);
   R v[3];
   v[0] = p.vx[gi];
   v[1] = p.vy[gi];
@@ -170,20 +221,7 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
     if (kind == NK_FULL_BB) bounce_back<L, R>(f);
   }
   if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
-
-  if constexpr (ROW && PROP != PROP_AA_EVEN) {
-    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz,
-                               (uint32_t)(live ? gx : nx), gx, nx, live, active, oy, oz);
-  } else {
-    static_for<0, L::Q>([&](auto I) {
-      if constexpr (PROP == PROP_AA_EVEN) {
-        (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
-      } else {
-        const int off = dir_offset<L, I>(ox, oy, oz, true);
-        (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
-      }
-    });
-  }
+  sc_store<L, R, PROP, GENERAL, ROW>(g, f, p.d_out, ds, n, nx, live, active);
 }
 
 // ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
@@ -191,37 +229,30 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 template <class L, class R, int PROP, bool GENERAL>
 __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
-  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (gx > g.lat_nx - 2) return;
-  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  bool live;
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live);
+  if (!live) return;
   if constexpr (GENERAL) {
-    const uint32_t code = p.map[gi];
+    const uint32_t code = p.map[n.gi];
     const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
     if (kind_is_excluded(kind)) return;
   }
-  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
-  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
-  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
   R f[L::Q];
-  sc_load<L, R, PROP>(f, p.d_in, g.dist_size, gi, ox, oy, oz);
-  p.rho0[gi] = density<L, R>(f);
+  sc_load<L, R, PROP>(f, p.d_in, g.dist_size, n);
+  p.rho0[n.gi] = density<L, R>(f);
 }
 
 // CollideAndPropagate with the self-interaction force F = -G psi(rho(x)) sum_i w_i e_i psi(rho(x + e_i))
 template <class L, class R, int PROP, bool GENERAL, bool ROW = false>
 __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
-  const int gy = p.y0 + (int)blockIdx.y;
-  const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
-  const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int nx = g.lat_nx - 2;
-  const bool live = gx <= nx;
+  bool live;
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
   if constexpr (!ROW) {
     if (!live) return;
   }
-  const uint32_t gi = (uint32_t)(live ? gx : nx) + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const uint32_t gi = n.gi;
   int kind = NK_FLUID;
   bool active = live;
   if constexpr (GENERAL) {
@@ -234,34 +265,15 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
     }
   }
   const bool wet = kind_is_wet(kind) && active;
-  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
-  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
-  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
   const size_t ds = g.dist_size;
   R f[L::Q];
-  sc_load<L, R, PROP>(f, p.d_in, ds, gi, ox, oy, oz);
+  sc_load<L, R, PROP>(f, p.d_in, ds, n);
   R rho, v[3];
   macro_standard<L, R>(f, false, rho, v);
   R a[3] = {(R)0, (R)0, (R)0};
   if (wet) {
-    const R cc = p.G[0];
-    if (cc != (R)0) {
-      R force[3] = {(R)0, (R)0, (R)0};
-      static_for<1, L::Q>([&](auto I) {
-        const int off = dir_offset<L, I>(ox, oy, oz, true);
-        const R psi = sc_psi<R>(p.rho0[(uint32_t)((int)gi + off)], p.potential);
-        static_for<0, L::dim>([&](auto D) {
-          constexpr int e = e_comp<L>(I, D);
-          if constexpr (e > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
-          if constexpr (e < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
-        });
-      });
-      const R psi_loc = sc_psi<R>(rho, p.potential);
-      static_for<0, L::dim>([&](auto D) {
-        force[D] = force[D] * (((R)0 - psi_loc) * cc);
-        a[D] = a[D] + force[D];
-      });
-    }
+    const R* const fields[2] = {p.rho0, p.rho0};
+    sc_accel<L, R, 1>(fields, p.G, rho, p.potential, n, a);
     static_for<0, L::dim>([&](auto D) { a[D] = a[D] / rho; });
     if (p.has_body_force) {
       static_for<0, L::dim>([&](auto D) { a[D] = a[D] + p.accel[D]; });
@@ -277,19 +289,7 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
     p.vy[gi] = v[1];
     if constexpr (L::dim == 3) p.vz[gi] = v[2];
   }
-  if constexpr (ROW && PROP != PROP_AA_EVEN) {
-    row_push<L, R, GENERAL, 2>(g, f, p.d_out, ds, (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz,
-                               (uint32_t)(live ? gx : nx), gx, nx, live, active, oy, oz);
-  } else {
-    static_for<0, L::Q>([&](auto I) {
-      if constexpr (PROP == PROP_AA_EVEN) {
-        (p.d_out + ds * (size_t)L::opp(I))[gi] = f[I];
-      } else {
-        const int off = dir_offset<L, I>(ox, oy, oz, true);
-        (p.d_out + ds * (size_t)I)[(uint32_t)((int)gi + off)] = f[I];
-      }
-    });
-  }
+  sc_store<L, R, PROP, GENERAL, ROW>(g, f, p.d_out, ds, n, nx, live, active);
 }
 
 // f1 = feq(rho, v), f2 = feq(phi, v) on every node (no type test)

@@ -19,7 +19,9 @@ SLF_SIM_LBM, SLF_SIM_SHAN_CHEN_BINARY, SLF_SIM_SHAN_CHEN_SINGLE = 0, 1, 2
  SLF_NK_REGULARIZED_VELOCITY, SLF_NK_EQUILIBRIUM_DENSITY, SLF_NK_EQUILIBRIUM_VELOCITY, SLF_NK_ZOUHE_VELOCITY,
  SLF_NK_ZOUHE_DENSITY, SLF_NK_REGULARIZED_DENSITY, SLF_NK_COPY, SLF_NK_YU_OUTFLOW) = range(14)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libsailfish_hip.so')
+# SLF_LIBRARY: another build of the library (A/B runs of kernel changes on the same GPU box)
+LIB_PATH = os.environ.get('SLF_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',
+                                                         'libsailfish_hip.so')
 
 
 class SlfModuleDesc(Structure):
