@@ -11,13 +11,15 @@ What is done about it: a large distribution array is a *placed* buffer -- one re
 the kernels and the host see is the reference's `q * dist_stride + node`), backed by PARTS separately created
 physical chunks.  While the chunks are created, spacer allocations are put between them and released afterwards, so
 the chunks end up spread over SPAN bytes of physical memory, whatever the regions are; nothing is wasted once the
-spacers are gone.  Several buffers placed together (the two copies of the AB pattern) share the span.  Skipped for
-arrays below MIN_BYTES (they run from the caches / are launch bound) and with SLF_PLACEMENT=0.
+spacers are gone.  Several buffers placed together (the two copies of the AB pattern) share the span.  Skipped with
+SLF_PLACEMENT=0 and for arrays below MIN_BYTES: measured on D2Q9 / D3Q19 boxes of 150 MB .. 2.4 GB per array
+(profiles/r02/placement_threshold.log), placement gains 20 % at 600 MB (D2Q9 4096^2), is neutral at 570 MB (D3Q19 192^3)
+and costs 8-20 % for arrays of 340 MB and less, which live partly in the 256 MB memory-side cache.
 """
 import ctypes
 import os
 
-MIN_BYTES = 1 << 30
+MIN_BYTES = int(os.environ.get('SLF_PLACEMENT_MIN_MIB', 512)) << 20
 PARTS = 16
 SPAN = 72 << 30
 

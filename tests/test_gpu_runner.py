@@ -445,7 +445,7 @@ def test_x_slabs_through_face_buffers(pattern, steps, case):
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
 def test_runner_with_placed_distribution_arrays(pattern, monkeypatch, tmp_path):
     """The runner's distribution arrays as placed buffers (physical chunks spread over HBM under one virtual range,
-    sailfish_amd/placement.py; normally only for arrays >= 1 GiB): two subdomains, both access patterns, checkpoint
+    sailfish_amd/placement.py; normally only for arrays >= 512 MiB): two subdomains, both access patterns, checkpoint
     round trip through host copies that cross chunk boundaries -- same numbers as the oracle."""
     from sailfish_amd import placement
     monkeypatch.setattr(placement, 'MIN_BYTES', 0)
