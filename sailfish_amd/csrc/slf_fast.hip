@@ -329,6 +329,7 @@ static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19
       return true;
     }
   }
+  if (prop != PROP_AA_EVEN && (variant & 8) && nx > 1024) return false;  // long rows: segmented row kernel (slf_row.hip)
   if (NT == 0) return false;  // plain scalar: the general kernel already does that
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, ny, nz);

@@ -145,19 +145,6 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && MODEL == 1
   x_face_send_own_row<L, R>(p, f, gx, g.lat_nx - 2, fr);
 }
 
-// Workgroup width for a row of nx nodes: the whole row.  Rows of 9-12 waves run 15-25 % below the 8-wave rows
-// of nx = 512, but cutting them into x-segments of 8 waves (row_push supports it: gridDim.x > 1, variant bit
-// 512) is slower still -- the partial-line stores of the segment edges cost more than the better fit buys
-// (profiles/r01/segmented_rows.log vs pad_rowshape.log).
-static inline int row_block_x(int nx, int variant) {
-  if (!(variant & 512)) return ((nx + 63) / 64) * 64;
-  const int waves = (nx + 63) / 64;
-  if (waves == 1 || waves == 2 || waves == 4 || waves == 8) return waves * 64;
-  int seg = 512;
-  while (seg >= nx) seg >>= 1;
-  return seg < 64 ? 64 : seg;
-}
-
 template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE>
 static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
   const int bx = row_block_x(nx, p.g.variant);
@@ -209,7 +196,6 @@ bool launch_sweep_row(const KernelSelector& sel, Prop prop, const Geometry& g, c
   // 3-D only: in 2-D (D2Q9, a few thousand rows, ~20 us per sweep) the per-node kernel with its smaller
   // workgroups is 7-15 % faster (profiles/r01/row_general2.log)
   if (!(g.variant & 8) || sel.lattice != 1 || nx < 1) return false;
-  if (nx > 1024 && !(g.variant & 512)) return false;   // longer rows: per-node kernel (or segments, experimental)
   const int ny = y1 - y0, nz = (g.dim == 3) ? z1 - z0 : 1;
   if (ny <= 0 || nz <= 0) return false;
   const int nt = (g.variant & 1) ? 3 : 0;

@@ -126,4 +126,23 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
   }
 }
 
+// Workgroup width for a row of nx nodes.  Up to 1024 nodes: the whole row.  Rows of 9-12 waves run 15-25 % below
+// the 8-wave rows of nx = 512, but cutting them into x-segments of 8 waves (row_push supports it: gridDim.x > 1,
+// variant bit 512) is slower still -- the partial-line stores of the segment edges cost more than the better fit buys
+// (profiles/r01/segmented_rows.log vs pad_rowshape.log).  Longer rows have no whole-row form: equal segments of at
+// most 8 waves, each a multiple of 64 nodes so that segment starts stay line aligned -- 5.9-6.1 TB/s on the
+// x-streaming steps where the per-node kernel with its misaligned stores reaches 5.2-5.5 (profiles/r02/long_rows.log).
+static inline int row_block_x(int nx, int variant) {
+  const int waves = (nx + 63) / 64;
+  if (nx > 1024) {
+    const int nseg = (waves + 7) / 8;
+    return ((waves + nseg - 1) / nseg) * 64;
+  }
+  if (!(variant & 512)) return waves * 64;
+  if (waves == 1 || waves == 2 || waves == 4 || waves == 8) return waves * 64;
+  int seg = 512;
+  while (seg >= nx) seg >>= 1;
+  return seg < 64 ? 64 : seg;
+}
+
 }  // namespace slf

@@ -402,8 +402,8 @@ static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometr
   const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, grid_idx, y0, z0);
   const int nx = g.lat_nx - 2;
   // whole-row workgroups + aligned stores for the x-streaming steps in 3-D (as slf_row.hip)
-  const bool row = L::dim == 3 && (g.variant & 8) && nx <= 1024 && prop != PROP_AA_EVEN;
-  if (row) block_x = ((nx + 63) / 64) * 64;
+  const bool row = L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
+  if (row) block_x = row_block_x(nx, g.variant);
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
@@ -443,8 +443,8 @@ static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometr
   p.G[0] = (R)sc.G[0];
   p.G[1] = (R)0;
   const int nx = g.lat_nx - 2;
-  const bool row = !macro && L::dim == 3 && (g.variant & 8) && nx <= 1024 && prop != PROP_AA_EVEN;
-  if (row) block_x = ((nx + 63) / 64) * 64;
+  const bool row = !macro && L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
+  if (row) block_x = row_block_x(nx, g.variant);
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;

@@ -345,6 +345,39 @@ def test_full_wave_rows_row_kernels(backend, nx, pattern, case, monkeypatch):
     assert r['dist_exact'], r
 
 
+@pytest.mark.parametrize('nx', [1088, 1536, 2100])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('case', ['periodic_f32', 'periodic_f32_mrt', 'periodic_f64', 'ghost_pbc_x', 'cavity', 'holes'])
+def test_rows_longer_than_a_workgroup(backend, nx, pattern, case):
+    """nx > 1024: no whole-row workgroup; the x-streaming steps cut the row into equal segments of at most 8 waves
+    (slf_row.hip: row_block_x -- 3 x 384, 3 x 512, 5 x 448 nodes, the last one partly idle), the even AA step runs per
+    node (fast_even_kernel / even_kernel with gridDim.x > 1).  Bit-identical to the oracle across the segment
+    boundaries, around the periodic seam and into the ghost columns."""
+    size = (nx, 4, 3)
+    kw = dict(u_scale=0.05, access_pattern=pattern, visc=0.03)
+    if case in ('periodic_f32', 'periodic_f32_mrt', 'periodic_f64'):
+        r = _run_pair(backend, sym.D3Q19, size, 7, (True, True, True), model='mrt' if case.endswith('mrt') else 'bgk',
+                      precision='double' if case.endswith('f64') else 'single', periodic_fused=[1, 1, 1], **kw)
+    elif case == 'ghost_pbc_x':
+        r = _run_pair(backend, sym.D3Q19, size, 7, (True, True, True), model='bgk', precision='single',
+                      periodic_fused=[0, 1, 1], **kw)
+    elif case == 'cavity':
+        r = _run_pair(backend, sym.D3Q19, (nx, 5, 4), 7, (False, False, False), node_map_fn=geo.cavity_3d,
+                      init='rest', model='bgk', precision='single', fluid_only=False, type_kind=geo.TYPE_KIND,
+                      nt_bits=geo.NT_BITS, node_params=[0.05, 0.0, 0.0], **kw)
+    else:
+        def holes(desc):
+            m = geo.empty_map(desc)
+            m[1:4, 1:4, 300:nx - 200] = geo.encode(geo.T_FULLBB)
+            m[2, 2, 301:nx - 201] = geo.encode(geo.T_UNUSED)
+            return m
+        r = _run_pair(backend, sym.D3Q19, (nx, 5, 5), 7, (True, True, True), node_map_fn=holes, init='rest',
+                      model='mrt', precision='single', fluid_only=False, type_kind=geo.TYPE_KIND,
+                      nt_bits=geo.NT_BITS, periodic_fused=[1, 1, 1], accel=[1e-5, 0.0, 0.0], **kw)
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    assert r['dist_exact'], r
+
+
 @pytest.mark.parametrize('pattern', ['AA', 'AB'])
 def test_placed_distribution_arrays(backend, pattern, monkeypatch):
     """Distribution arrays as placed buffers (sailfish_amd/placement.py: one virtual range backed by separately
