@@ -377,10 +377,12 @@ class SubdomainRunner(object):
         (same-process groups, controller.LocalGroup); the next pack waits for them."""
         return self.__dict__.setdefault('_send_readers', {}).setdefault(kind, [])
 
-    def _wait_send_buffers_free(self, kind='dist'):
+    def _wait_send_buffers_free(self, kind='dist', stream=None):
+        """`stream` (default: the data stream, where the pack kernels run) waits until the neighbours have read the
+        send buffers of the previous step."""
         evs = self.send_buffer_readers(kind)
         for ev in evs:
-            self._data_stream.wait_for_event(ev)
+            (stream or self._data_stream).wait_for_event(ev)
         del evs[:]
 
     # -- 1-D decompositions along x: dense face buffers written / read by the sweep itself (xface.py)
@@ -537,10 +539,14 @@ class SubdomainRunner(object):
         it = self._sim.iteration
         kernels = self._kernels_full if sync_req else self._kernels_none
         kernels = kernels.primary if (it & 1) == 0 else kernels.secondary
-        if self._xface is not None and self._xface.needs_clear:
+        if self._xface is not None:
+            # the sweep itself writes the send buffers: whoever copies them (the neighbours of a same-process group on
+            # THEIR data streams, our own exchange on ours) must have read the previous step's values
+            self._wait_send_buffers_free('dist', self._calc_stream)
             if self._ev_halo is not None:
-                self._calc_stream.wait_for_event(self._ev_halo)      # the previous exchange has read the send buffers
-            self._xface.clear_send(self._calc_stream)
+                self._calc_stream.wait_for_event(self._ev_halo)
+            if self._xface.needs_clear:
+                self._xface.clear_send(self._calc_stream)
         ev_bnd = self._run_sweep(kernels, self._regions)
         base = 1 - (it & 1)
         for axis in self._pbc_axes:
