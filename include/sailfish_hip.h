@@ -150,6 +150,8 @@ int slf_ctx_destroy(slf_ctx* ctx);
 int slf_ctx_sync(slf_ctx* ctx);                                  /* backend.sync() */
 int slf_ctx_info(slf_ctx* ctx, char* name, size_t name_len, size_t* total_mem, int* cu_count,
                  int* wavefront);                                /* backend.info / total_memory / get_defines */
+int slf_ctx_free_memory(slf_ctx* ctx, size_t* free_bytes);       /* device memory not in use by ANY process / context
+                                                                    (sizes the span of placed arrays) */
 int slf_malloc(slf_ctx* ctx, size_t bytes, void** dptr);         /* alloc_buf */
 int slf_free(slf_ctx* ctx, void* dptr);
 int slf_memset(slf_ctx* ctx, void* dptr, int value, size_t bytes, slf_stream* stream);

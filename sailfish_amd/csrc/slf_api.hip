@@ -149,6 +149,14 @@ int slf_ctx_info(slf_ctx* ctx, char* name, size_t name_len, size_t* total_mem, i
   return SLF_OK;
 }
 
+int slf_ctx_free_memory(slf_ctx* ctx, size_t* free_bytes) {
+  if (!ctx || !free_bytes) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(ctx->device));
+  size_t total = 0;
+  SLF_HIP(hipMemGetInfo(free_bytes, &total));
+  return SLF_OK;
+}
+
 int slf_malloc(slf_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return fail(SLF_ERR_INVALID, "NULL argument");
   SLF_HIP(hipSetDevice(ctx->device));

@@ -75,6 +75,7 @@ SIGNATURES = {
     'slf_ctx_destroy': (c_int, [c_void_p]),
     'slf_ctx_sync': (c_int, [c_void_p]),
     'slf_ctx_info': (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_size_t), POINTER(c_int), POINTER(c_int)]),
+    'slf_ctx_free_memory': (c_int, [c_void_p, POINTER(c_size_t)]),
     'slf_malloc': (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     'slf_free': (c_int, [c_void_p, c_void_p]),
     'slf_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),

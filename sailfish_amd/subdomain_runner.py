@@ -18,6 +18,7 @@ Launch geometry is a region of rows / planes (`backend.run_kernel(kernel, region
 instead of the reference's bulk / boundary block arithmetic (:396-475).
 """
 import math
+import os
 import pickle
 import time
 
@@ -253,11 +254,12 @@ class SubdomainRunner(object):
         self.module = self.backend.build(self._desc)
         self._calc_stream = self.backend.make_stream()
         # the halo stream: ahead of the bulk sweep's queued workgroups where the backend can say so
-        prio = getattr(self.backend, 'supports_stream_priority', False)
+        prio = getattr(self.backend, 'supports_stream_priority', False) and os.environ.get('SLF_HALO_PRIORITY', '1') != '0'
         self._data_stream = self.backend.make_stream(high_priority=True) if prio else self.backend.make_stream()
         self._dist_stride = hipabi.dist_stride(self._desc)
 
     def _init_gpu_data(self):
+        self._alloc_distributions()     # first: placed arrays want an allocator that has handed out nothing yet
         b = self.backend
         for field in self._scalar_fields:
             self._gpu_field_map[id(field)] = b.alloc_buf(like=self._host_base[id(field)])
@@ -267,6 +269,9 @@ class SubdomainRunner(object):
         self._gpu_geo_map = b.alloc_buf(like=self._host_base[id(self._subdomain._type_map_ghost)])
         if self.indirect:
             self._build_indirect_address_map()
+
+    def _alloc_distributions(self):
+        b = self.backend
         nbytes = self._sim.grid.Q * self._dist_stride * self.float().itemsize
         off = b.dist_align_offset(self.float().itemsize)
         ab = self.config.access_pattern == 'AB'
@@ -542,7 +547,8 @@ class SubdomainRunner(object):
         if self._xface is not None:
             # the sweep itself writes the send buffers: whoever copies them (the neighbours of a same-process group on
             # THEIR data streams, our own exchange on ours) must have read the previous step's values
-            self._wait_send_buffers_free('dist', self._calc_stream)
+            if not os.environ.get('SLF_DEBUG_NO_WAR'):
+                self._wait_send_buffers_free('dist', self._calc_stream)
             if self._ev_halo is not None:
                 self._calc_stream.wait_for_event(self._ev_halo)
             if self._xface.needs_clear:

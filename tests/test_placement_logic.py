@@ -14,8 +14,8 @@ class FakeVmm(object):
         self.live, self.mapped, self.next = {}, {}, 1
         self.fail_after = fail_after
 
-    def allocated_bytes(self):
-        return self.used
+    def free_memory(self):
+        return self.total_memory - self.used - sum(self.live.values())
 
     def vmm_granularity(self):
         return self.GRAN
@@ -97,3 +97,21 @@ def test_host_copies_are_cut_at_chunk_boundaries():
     for a, _, n in segs:
         assert (a - pb.va) // pb.part_bytes == (a + n - 1 - pb.va) // pb.part_bytes      # inside one chunk
     assert hb._segments(12345, 10) == [(12345, 0, 10)]
+
+
+def test_spacers_of_a_group_are_held_until_every_member_is_placed():
+    """Two simulations set up one after the other in one process (subdomain runners of a same-process group): inside
+    placement.holding() the first one's spacers are still allocated while the second one is placed (its chunks cannot
+    fall into the holes), and all of them are released when the block ends."""
+    b1, b2 = FakeVmm(), FakeVmm()
+    with placement.holding():
+        p1 = placement.PlacedBuffer(b1, 3 << 30)
+        placement.place(b1, [p1])
+        assert len(b1.live) == 16 + 15 and not [e for e in b1.log if e[0] == 'release']
+        p2 = placement.PlacedBuffer(b2, 3 << 30)
+        placement.place(b2, [p2])
+        assert len(b2.live) == 16 + 15
+    assert len(b1.live) == 16 and len(b2.live) == 16          # chunks stay, spacers are gone
+    p3 = placement.PlacedBuffer(b1, 3 << 30)
+    placement.place(b1, [p3])                                   # outside: released on the spot
+    assert len(b1.live) == 32
