@@ -547,8 +547,7 @@ class SubdomainRunner(object):
         if self._xface is not None:
             # the sweep itself writes the send buffers: whoever copies them (the neighbours of a same-process group on
             # THEIR data streams, our own exchange on ours) must have read the previous step's values
-            if not os.environ.get('SLF_DEBUG_NO_WAR'):
-                self._wait_send_buffers_free('dist', self._calc_stream)
+            self._wait_send_buffers_free('dist', self._calc_stream)
             if self._ev_halo is not None:
                 self._calc_stream.wait_for_event(self._ev_halo)
             if self._xface.needs_clear:

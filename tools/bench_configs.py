@@ -48,6 +48,10 @@ def _run(label, sim_cls, geo, settings, bytes_per_update):
     nodes = sum(r.num_fluid_nodes for r in ctrl.runners)
     out = {'config': label, 'MLUPS_eff': round(ctrl.mlups_total, 1), 'MLUPS_comp': round(ctrl.mlups_comp, 1),
            'fluid_nodes': int(nodes), 'settings': dict((k, v) for k, v in settings.items())}
+    if os.environ.get('SLF_BENCH_DETAIL'):       # per-subdomain mean / fastest / slowest minibatch (ms per step)
+        out['step_ms'] = [dict(id=r._spec.id, mean=round(r.summary[0].total * 1e3, 4), min=round(r.summary[1].total * 1e3, 4),
+                               max=round(r.summary[2].total * 1e3, 4), comp=round(r.summary[0].comp * 1e3, 4),
+                               coll=round(r.summary[0].coll * 1e3, 4)) for r in ctrl.runners if r.summary]
     if bytes_per_update:
         out['bytes_per_update'] = bytes_per_update
         out['GBps_comp'] = round(ctrl.mlups_comp * bytes_per_update / 1e3, 1)   # sweep kernels only
@@ -65,6 +69,22 @@ def main():
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,3,4)')
     args = ap.parse_args()
+    if not args.only:
+        # one fresh process per configuration: what a configuration measures must not depend on what ran before it in
+        # the same process (stream -> hardware-queue mapping, allocator state; profiles/r02/README.md "config 3")
+        import subprocess
+        lines = []
+        for cid in ('0', '1', '2', '2b', '3', '4'):
+            cmd = [sys.executable, os.path.abspath(__file__), '--only', cid] + (['--quick'] if args.quick else [])
+            out = subprocess.run(cmd, stdout=subprocess.PIPE).stdout.decode(errors='replace')
+            for ln in out.splitlines():
+                if ln.startswith('{'):
+                    print(ln, flush=True)
+                    lines.append(ln)
+        if args.out:
+            with open(args.out, 'w') as fh:
+                fh.write('\n'.join(lines) + '\n')
+        return
     from examples.ldc_2d import CavitySim as Cavity2D
     from examples.ldc_3d import CavitySim as Cavity3D
     from examples.binary_fluid.sc_separation_3d import SeparationSim
