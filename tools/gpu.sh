@@ -11,6 +11,7 @@
 #   pmc             separate rocprofv3 --pmc passes of bench.py (HBM traffic; $BENCH_ARGS)
 #   torchrun        the N>1 code paths on one GPU: torch.distributed.run --nproc-per-node 1, weak + strong
 #   configs         tools/bench_configs.py (all single-GPU BASELINE configs through the host stack)
+#   pmccfg          FETCH_SIZE / WRITE_SIZE passes of bench_configs.py --quick --only <id>, for id in $TRACE_CONFIGS
 #   tracecfg        rocprofv3 --kernel-trace --stats of bench_configs.py --quick --only <id>, for id in $TRACE_CONFIGS
 #   py <file> ...   python <file> ... (rest of the line)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -58,6 +59,16 @@ while [ $# -gt 0 ]; do
         ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg$c -o trace -- \
             python $R/tools/bench_configs.py --quick --only $c > $O/trace_cfg$c.log 2>&1 )
         summarise_trace $O/trace_cfg$c $O/kernel_stats_cfg$c.csv; tail -1 $O/trace_cfg$c.log | cut -c1-300
+      done ;;
+    pmccfg)
+      for c in ${TRACE_CONFIGS:-4}; do
+        i=0
+        for C in "FETCH_SIZE" "WRITE_SIZE"; do
+          i=$((i+1))
+          ( cd /tmp && timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/pmc_cfg$c/p$i -o pmc -- \
+              python $R/tools/bench_configs.py --quick --only $c > $O/pmc_cfg${c}_p$i.log 2>&1 )
+        done
+        python tools/pmc_summary.py $O/pmc_cfg$c | tee $O/pmc_summary_cfg$c.txt
       done ;;
     py)
       timeout ${PY_TIMEOUT:-900} python "$@" 2>&1 | tee -a $O/py.log | tail -${PY_TAIL:-40}; break ;;
