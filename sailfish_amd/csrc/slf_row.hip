@@ -65,8 +65,13 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row
       return at_byte(uniform_base(p.din + ds * (size_t)I + row), xi * (uint32_t)sizeof(R));
     }
   };
+  // (the x-shifted pulls of the odd step share every line with the neighbouring wave: no non-temporal hint on those)
+  auto load = [&](auto I) -> R {
+    constexpr int nt = (PROP == PROP_AA_ODD && L::ex(I) != 0) ? (NT & ~1) : NT;
+    return ldg<nt>(src_of(I));
+  };
   if constexpr (SPEC || !GENERAL) {
-    static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(src_of(I)); });
+    static_for<0, L::Q>([&](auto I) { f[I] = load(I); });
   }
   int kind = NK_FLUID;
   uint32_t code = 0;
@@ -77,7 +82,7 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row
     active = live && !kind_is_excluded(kind);
   }
   if constexpr (GENERAL && !SPEC) {
-    static_for<0, L::Q>([&](auto I) { f[I] = active ? ldg<NT>(src_of(I)) : (R)0; });
+    static_for<0, L::Q>([&](auto I) { f[I] = active ? load(I) : (R)0; });
   }
 
   const FaceRows fr = face_rows(g, gy, gz);

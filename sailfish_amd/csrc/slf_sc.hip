@@ -85,7 +85,8 @@ template <class L, class R, int PROP>
 __device__ __forceinline__ void sc_load(R (&f)[L::Q], const R* din, size_t ds, const ScNode& n) {
   static_for<0, L::Q>([&](auto I) {
     if constexpr (PROP == PROP_AA_ODD) {
-      f[I] = ldg<sc_nt<L>()>(sc_neighbour<L, I>(din + ds * (size_t)L::opp(I), n, false));
+      constexpr int nt = (L::ex(I) != 0) ? (sc_nt<L>() & ~1) : sc_nt<L>();     // shifted pulls share their lines
+      f[I] = ldg<nt>(sc_neighbour<L, I>(din + ds * (size_t)L::opp(I), n, false));
     } else {
       f[I] = ldg<sc_nt<L>()>(at_byte(uniform_base(din + ds * (size_t)I + n.row), n.xi * (uint32_t)sizeof(R)));
     }
