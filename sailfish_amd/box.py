@@ -27,7 +27,7 @@ def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='A
     dim = grid.dim
     assert len(size) == dim
     lat = [s + 2 for s in size]
-    alignment = int(os.environ.get('SLF_MEM_ALIGNMENT', alignment))     # experiments (tools/gpu_pad.sh)
+    alignment = int(os.environ.get('SLF_MEM_ALIGNMENT', alignment))     # experiments
     kw = dict(lattice=grid.slf_id,
               model=hipabi.SLF_MRT if model == 'mrt' else hipabi.SLF_BGK,
               precision=4 if precision == 'single' else 8,
