@@ -8,8 +8,10 @@ The other two axes are wrapped inside the sweep; the split axis is wrapped insid
 slab, otherwise it goes through the ghost layers + halo.  x faces cannot be split off (a workgroup owns whole rows):
 with axis = 'x' the whole sweep runs before the pack.
 
-Faces are packed with the box kernels (Collect / DistributeContinuousData: no index lists; reference
-kernel_utils.mako:526-543, 629-645): z and y faces move contiguous row segments, x faces are a strided gather.
+z and y faces are packed with the box kernels (Collect / DistributeContinuousData: no index lists; reference
+kernel_utils.mako:526-543, 629-645) and move contiguous row segments.  x faces are not packed at all: the edge lanes
+of the sweep write / read dense face buffers (xface.py), the halo stream only exchanges them; the box kernels remain
+the fallback (SLF_XFACE=0, rows longer than 1024 nodes) and then gather with stride arr_nx.
 
 Which layer travels (reference subdomain_runner.py:1069-1103, Appendix A.4-5 of SURVEY.md):
   push steps (AB, odd AA): my ghost layer (populations pushed across the face) -> neighbour's first real layer, same slots;
