@@ -34,14 +34,11 @@ def init_distributed(backend=None, force=False):
         local = int(os.environ.get('SLF_FORCE_DEVICE', os.environ.get('LOCAL_RANK', '0')))
         torch.cuda.set_device(local)
         kw['device_id'] = torch.device('cuda', local)
-        try:    # RCCL's own stream ahead of the bulk sweep as well (SLF_HALO_PRIORITY=0: A/B switch of tools/gpu.sh)
-            if os.environ.get('SLF_HALO_PRIORITY', '1') == '0':
-                raise AttributeError
+        # RCCL's own stream ahead of the bulk sweep as well (SLF_HALO_PRIORITY=0: the A/B switch)
+        if os.environ.get('SLF_HALO_PRIORITY', '1') != '0' and hasattr(dist, 'ProcessGroupNCCL'):
             opts = dist.ProcessGroupNCCL.Options()
             opts.is_high_priority_stream = True
             kw['pg_options'] = opts
-        except AttributeError:
-            pass
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world
 
