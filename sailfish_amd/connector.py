@@ -128,13 +128,22 @@ class TorchDistConnector(object):
         """sends / recvs: lists of (tensor, peer rank), each ordered by neighbour subdomain id.  One
         batched group of point-to-point operations (no collective); returns after the operations have
         been *enqueued* for CUDA tensors (stream-ordered) and completed for CPU tensors."""
+        import torch
         import torch.distributed as dist
+        staged = []
+        if dist.get_backend() == 'gloo' and any(t.is_cuda for t, _ in sends + recvs):
+            # several ranks on one GPU (init_distributed: SLF_DIST_BACKEND=gloo): gloo moves host memory only
+            sends = [(t.cpu(), peer) for t, peer in sends]
+            staged = [(t, torch.empty(t.shape, dtype=t.dtype)) for t, _ in recvs]
+            recvs = [(h, peer) for (_, h), (_, peer) in zip(staged, recvs)]
         ops = [dist.P2POp(dist.isend, t, peer) for t, peer in sends]
         ops += [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
         if not ops:
             return
         for r in dist.batch_isend_irecv(ops):
             r.wait()
+        for dev, host in staged:
+            dev.copy_(host)
 
     def exchange(self, runner, kind='dist'):
         import torch

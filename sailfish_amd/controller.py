@@ -310,7 +310,8 @@ class LBSimulationController(object):
             if len(subdomains) != world:
                 raise GeometryError('torch.distributed run: need exactly one subdomain per rank '
                                     '(%d subdomains, %d ranks)' % (len(subdomains), world))
-            local_rank = int(os.environ.get('LOCAL_RANK', rank))
+            # (SLF_FORCE_DEVICE: every rank on that GPU, with SLF_DIST_BACKEND=gloo -- tests/test_gpu_two_ranks.py)
+            local_rank = int(os.environ.get('SLF_FORCE_DEVICE', os.environ.get('LOCAL_RANK', rank)))
             connector = TorchDistConnector(dict((s.id, s.id) for s in subdomains))
             runner = make_runner(subdomains[rank], local_rank, connector)
             self.runners = [runner]

@@ -121,10 +121,12 @@ def controller_worker(rank, world, port, case, steps, outdir):
     from sailfish_amd.controller import LBSimulationController
     from tests import _host
     from tests._oracle_backend import OracleBackend
-    util.get_backends = lambda backends=('hip',): iter([OracleBackend])
+    on_gpu = os.environ.get('SLF_TEST_CONTROLLER_ON_GPU') == '1'     # test_gpu_two_ranks.py: the real HIP backend
+    if not on_gpu:
+        util.get_backends = lambda backends=('hip',): iter([OracleBackend])
     module, sim, dim, geo, cfg = case
     sim_cls = _host.load_sim_class(module, sim)
-    cfg = dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0, backends='oracle_test')
+    cfg = dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0, backends='hip' if on_gpu else 'oracle_test')
     ctrl = LBSimulationController(sim_cls, getattr(geo_mod, geo), default_config=cfg)
     ctrl.run(ignore_cmdline=True)
     assert dist.is_initialized() and dist.get_world_size() == world and dist.get_backend() == 'gloo'

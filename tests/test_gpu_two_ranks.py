@@ -56,3 +56,37 @@ def test_two_processes_equal_one_box(axis, pattern, model):
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
     out = res.stdout.decode(errors='replace')
     assert res.returncode == 0 and 'TWO_RANK_PARITY OK backend=gloo world=2' in out, out[-3000:]
+
+
+def _controller_cases():
+    from tests.test_distributed_gloo import CASES
+    return CASES + [('ldc_3d', 'LDCSim', 3, 'EqualSubdomainsGeometry3D',
+                     dict(lat_nx=18, lat_ny=10, lat_nz=8, visc=0.03, access_pattern='AB', subdomains=2, conn_axis='x'))]
+
+
+@pytest.mark.parametrize('case', _controller_cases(), ids=['ldc3d_AA_z', 'channel_AB_periodic_y', 'ldc3d_AB_x'])
+def test_controller_branch_two_processes_on_the_gpu(case, monkeypatch):
+    """The product's process-per-subdomain branch (LBSimulationController.run() under WORLD_SIZE > 1 ->
+    SubdomainRunner.run() -> step() -> halo_messages() -> TorchDistConnector.exchange(runner)) with the HIP backend in
+    two OS processes on the one GPU of the box (gloo group, halo tensors staged through the host).  The merged
+    populations and densities equal the single-subdomain oracle run bit for bit."""
+    import tempfile
+    import numpy as np
+    import torch.multiprocessing as mp
+    from tests import _host
+    from tests._gloo_worker import controller_worker
+    from tests._oracle_group import OracleGroup
+    from tests.test_distributed_gloo import _merge
+    for k, v in (('SLF_DIST_BACKEND', 'gloo'), ('SLF_FORCE_DEVICE', '0'), ('SLF_TEST_CONTROLLER_ON_GPU', '1')):
+        monkeypatch.setenv(k, v)
+    steps = 7
+    module, sim, dim, geo, cfg = case
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(controller_worker, args=(2, _free_port(), case, steps, d), nprocs=2, join=True)
+        parts = [np.load(os.path.join(d, 'rank%d.npz' % r)) for r in range(2)]
+    one = OracleGroup(_host.load_sim_class(module, sim), dim, geo, dict(cfg, subdomains=1))
+    one.run(steps, save_last=True)
+    ref_f, ref_rho = one.merged('dist'), one.merged('rho')
+    got_f, got_rho = _merge(parts, ref_f, ref_rho)
+    assert np.array_equal(got_f, ref_f, equal_nan=True)
+    assert np.array_equal(got_rho, ref_rho, equal_nan=True)
