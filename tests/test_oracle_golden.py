@@ -112,6 +112,20 @@ def test_mrt_collision(gold, precision):
             _close(f, G['mrt_post'][a, k], TOL[precision] * (4 if precision == 4 else 50))
 
 
+@pytest.mark.parametrize('precision', [8, 4])
+def test_mrt_collision_with_body_force(gold, precision):
+    """Moment-space forcing (reference relaxation_mrt.mako:10-27, 45-46, 91: half of sym_force.accel_vector in the
+    momentum moments before the equilibrium, half after the relaxation; output velocity u + a / 2)."""
+    grid, G = gold
+    nu = float(G['mrt_force_visc'][0])
+    for k in range(len(G['rho'])):
+        d = _desc(grid, precision, visc=nu, model='mrt', accel=G['accel'][k])
+        f, rho, v = oracle.node_update(d, hipabi.SLF_NK_FLUID, 0, None, G['f'][k], precision)
+        _close(f, G['mrt_force_post'][k], TOL[precision] * (4 if precision == 4 else 50))
+        _close(v[:grid.dim], G['guo_out_v'][k], TOL[precision])
+        assert np.max(np.abs(G['mrt_force_post'][k] - G['mrt_post'][len(G['bgk_visc']) // 2, k])) > 0
+
+
 def _no_relax(grid, precision):
     d = _desc(grid, precision)
     d.relaxation_enabled = 0

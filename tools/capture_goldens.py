@@ -225,6 +225,33 @@ def arithmetic_goldens(grid, rng, n=48):
                         m[i] -= cval * (m[i] - meq)
                 postm[a, k] = Minv.dot(m)
         out['mrt_post'] = postm
+        # with a body force (relaxation_mrt.mako:10-27 fluid_momentum(), :45-46, :91): half of the acceleration
+        # sym_force.accel_vector(grid, 0) goes into the momentum moments before the equilibrium is evaluated, the
+        # other half after the relaxation; the output velocity is shifted by a / 2 as for BGK
+        ea = sym_force.accel_vector(grid, 0)
+        mom = [grid.mrt_names.index('m' + c) for c in 'xyz'[:dim]]
+        nu = visc[len(visc) // 2]
+        postf = np.zeros((n, Q))
+        for k in range(n):
+            asub = {'g0ea' + c: accel[k, j] for j, c in enumerate('xyz'[:dim])}
+            half = [0.5 * _evalf(ea[j], asub) for j in range(dim)]
+            m = M.dot(f[k])
+            for j in range(dim):
+                m[mom[j]] += half[j]
+            subs = {'rho': m[0], 'g0m0': m[0], 'rho0': m[0], 'visc': nu}
+            subs.update({'m' + c: m[mom[j]] for j, c in enumerate('xyz'[:dim])})
+            for lv in grid.mrt_eq_symbols:
+                subs[lv.lhs.name] = _evalf(lv.rhs, subs)
+            for i in range(Q):
+                c = grid.mrt_collision[i]
+                cval = _evalf(c, subs) if isinstance(c, sympy.Basic) else float(c)
+                if cval != 0:
+                    m[i] -= cval * (m[i] - _evalf(grid.mrt_equilibrium[i], subs))
+            for j in range(dim):
+                m[mom[j]] += half[j]
+            postf[k] = Minv.dot(m)
+        out['mrt_force_post'] = postf
+        out['mrt_force_visc'] = np.array([nu])
 
     # --- velocity-BC density: boundary.mako:443-459, sym.py:621-627
     # --- non-equilibrium bounce-back: sym.py:750-766; regularisation: sym.py:882-891,
