@@ -94,6 +94,11 @@ def test_body_force_and_incompressible(backend, grid, size):
     r = _run_pair(backend, grid, size, 10, (True, True, True), model='mrt', precision='single',
                   access_pattern='AB', visc=0.02, periodic_fused=[0] * 3, accel=[1e-5, -2e-5, 3e-5][:grid.dim])
     assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    # moment-space forcing through the tuned fluid-only kernels (in-sweep wrap), both access patterns
+    for pattern in ('AA', 'AB'):
+        r = _run_pair(backend, grid, size, 10, (True, True, True), model='mrt', precision='single',
+                      access_pattern=pattern, visc=0.02, periodic_fused=[1] * 3, accel=[1e-5, -2e-5, 3e-5][:grid.dim])
+        assert r['rho_err'] < RTOL and r['v_err'] < RTOL and r['dist_exact'], r
 
 
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
