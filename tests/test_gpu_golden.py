@@ -28,13 +28,13 @@ def backend():
     return HIPBackend(Opt(), 0)
 
 
-def _one_step(backend, grid, size, f, precision, fused, **kw):
+def _one_step(backend, grid, size, f, precision, fused, box_cls=None, **kw):
     """Every node = f, one AB step; returns the populations of the real nodes [Q, nodes]."""
     edm = kw.pop('edm', False)
     desc = make_box_desc(grid, size, precision=precision, access_pattern='AB', periodic_fused=[fused] * 3, **kw)
     if edm:
         desc.force_implementation = hipabi.SLF_FORCE_EDM
-    s = BoxSim(backend, desc, periodic=(True, True, True))
+    s = (box_cls or BoxSim)(backend, desc, periodic=(True, True, True))
     full = np.empty((s.Q,) + s.shape, dtype=s.dtype)
     full[...] = np.asarray(f, dtype=s.dtype).reshape((s.Q,) + (1,) * len(s.shape))
     s.set_dist(full, 0)
@@ -61,6 +61,10 @@ def _check(res, gold, tol, rho=None, v=None):
 @pytest.mark.parametrize('precision', ['double', 'single'])
 @pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
 def test_collision_kernels_against_reference_fixtures(backend, golden_dir, name, precision, fused):
+    collision_probe(backend, golden_dir, name, precision, fused)
+
+
+def collision_probe(backend, golden_dir, name, precision, fused, box_cls=None):
     grid, size = GRIDS[name]
     G = np.load(os.path.join(golden_dir, 'arith_%s.npz' % name))
     tol = TOL[precision]
@@ -69,15 +73,74 @@ def test_collision_kernels_against_reference_fixtures(backend, golden_dir, name,
         f = G['f'][k]
         accel = list(G['accel'][k])
         for a, nu in enumerate(G['bgk_visc']):
-            _check(_one_step(backend, grid, size, f, precision, fused, model='bgk', visc=float(nu)), G['bgk_post'][a, k], tol,
+            _check(_one_step(backend, grid, size, f, precision, fused, box_cls, model='bgk', visc=float(nu)), G['bgk_post'][a, k], tol,
                    rho=float(G['mom_rho'][k]), v=list(G['mom_v'][k]))
-            _check(_one_step(backend, grid, size, f, precision, fused, model='mrt', visc=float(nu)), G['mrt_post'][a, k],
+            _check(_one_step(backend, grid, size, f, precision, fused, box_cls, model='mrt', visc=float(nu)), G['mrt_post'][a, k],
                    mrt_tol)
         nu = float(G['guo_visc'][0])
-        _check(_one_step(backend, grid, size, f, precision, fused, model='bgk', visc=nu, accel=accel), G['guo_post'][k], tol,
+        _check(_one_step(backend, grid, size, f, precision, fused, box_cls, model='bgk', visc=nu, accel=accel), G['guo_post'][k], tol,
                rho=float(G['mom_rho'][k]), v=list(G['guo_out_v'][k]))
-        _check(_one_step(backend, grid, size, f, precision, fused, model='bgk', visc=nu, accel=accel, edm=True),
+        _check(_one_step(backend, grid, size, f, precision, fused, box_cls, model='bgk', visc=nu, accel=accel, edm=True),
                G['edm_post'][k], tol)
         nu = float(G['mrt_force_visc'][0])
-        _check(_one_step(backend, grid, size, f, precision, fused, model='mrt', visc=nu, accel=accel),
+        _check(_one_step(backend, grid, size, f, precision, fused, box_cls, model='mrt', visc=nu, accel=accel),
                G['mrt_force_post'][k], mrt_tol)
+
+
+BC_CASES = {    # kind: (type id in tests/_geometry.TYPE_KIND, parameter fixture, expected populations, expected rho, expected v)
+    'regularized_velocity': ('T_REGVEL', 'bc_v', 'regvel_post', 'regvel_rho', 'bc_v'),
+    'zouhe_velocity': ('T_ZHVEL', 'bc_v', 'zouhe_vel_post', 'regvel_rho', 'bc_v'),
+    'equilibrium_density': ('T_EQDENS', 'bc_rho', 'eqdens_post', 'bc_rho', 'eqdens_v'),
+    'zouhe_density': ('T_ZHDENS', 'bc_rho', 'zouhe_dens_post', 'bc_rho', 'zouhe_dens_v'),
+    'regularized_density': ('T_REGDENS', 'bc_rho', 'regdens_post', 'bc_rho', 'eqdens_v'),
+}
+
+
+@pytest.mark.parametrize('kind', sorted(BC_CASES))
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_boundary_nodes_against_reference_fixtures(backend, golden_dir, name, precision, kind):
+    boundary_probe(backend, golden_dir, name, precision, kind)
+
+
+def boundary_probe(backend, golden_dir, name, precision, kind, box_cls=None):
+    """Single-node probes of the pre-collision boundary conditions (reference boundary.mako:343-382, 425-459, 784-878;
+    fixtures from sym.noneq_bb / zouhe_fixup / reglb_flux_tensor / ex_rho): one boundary node per orientation in a
+    box whose nodes all carry the fixture state f, relaxation switched off, one two-copy step through the node-map
+    kernels; what the node pushed is collected from its neighbours (population i of x sits in slot i of x + e_i)."""
+    from tests import _geometry as geo
+    grid, _ = GRIDS[name]
+    dim = grid.dim
+    G = np.load(os.path.join(golden_dir, 'arith_%s.npz' % name))
+    tname, pkey, fkey, rkey, vkey = BC_CASES[kind]
+    tol = TOL[precision] * 2
+    norient = 2 * dim
+    size = (2 * norient + 3, 5) + ((5,) if dim == 3 else ())
+    for k in SAMPLES[:3]:
+        params = [float(x) for x in np.atleast_1d(G[pkey][k])]
+        desc = make_box_desc(grid, size, precision=precision, access_pattern='AB', fluid_only=False,
+                             type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS, node_params=params, relaxation_enabled=False)
+        m = geo.empty_map(desc)
+        probes = []
+        for o in range(1, norient + 1):
+            pos = (3 if dim == 3 else 0, 3, 2 * o)                       # (z, y, x) array indices, ghost layer included
+            m[pos] = geo.encode(getattr(geo, tname), orientation=o, param=0)
+            probes.append(pos)
+        s = (box_cls or BoxSim)(backend, desc, periodic=(False, False, False), node_map=m)
+        full = np.empty((s.Q,) + s.shape, dtype=s.dtype)
+        full[...] = np.asarray(G['f'][k], dtype=s.dtype).reshape((s.Q,) + (1,) * len(s.shape))
+        s.set_dist(full, 0)
+        s.set_dist(full, 1)
+        s.step(save_macro=True)
+        out = s.get_dist().astype(np.float64)
+        rho, v = s.fetch_fields()
+        for o, (z, y, x) in enumerate(probes):
+            got = np.array([out[i, z + (grid.basis[i][2] if dim == 3 else 0), y + grid.basis[i][1], x + grid.basis[i][0]]
+                            for i in range(grid.Q)])
+            err = float(np.max(np.abs(got - G[fkey][o, k])))
+            assert err < tol, (kind, o + 1, k, err)
+            want_rho = G[rkey][o, k] if G[rkey].ndim == 2 else G[rkey][k]
+            want_v = G[vkey][o, k] if G[vkey].ndim == 3 else G[vkey][k]
+            assert abs(float(rho[z, y, x]) - float(want_rho)) < max(tol, 1e-7)
+            assert max(abs(float(v[d][z, y, x]) - float(want_v[d])) for d in range(dim)) < max(tol, 1e-7)
+        s.release()
