@@ -4,6 +4,7 @@ pseudopotential."""
 import numpy as np
 import pytest
 
+from sailfish_amd import sym
 from tests import _host, _sc
 from tests._oracle_group import OracleSCSubdomain
 
@@ -247,3 +248,95 @@ def test_sc_full_wave_rows(nx, pattern, single):
         gd = r._debug_get_dist(grid_num=grid_num)
         gd = gd[(slice(None),) + tuple(r._spec._nonghost_slice)]
         assert np.array_equal(gd, o.real(od)), 'lattice %d populations differ' % grid_num
+
+
+@pytest.mark.parametrize('grid', [sym.D2Q9, sym.D3Q19])
+@pytest.mark.parametrize('potential', ['linear', 'classic'])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_sc_kernels_against_reference_composition(grid, potential, pattern, golden_dir):
+    """The HIP Shan-Chen kernels against the fixtures composed from the reference's own objects, without the oracle
+    in between (the GPU twin of tests/test_sc_oracle.py::test_node_update_matches_reference_composition):
+    ShanChenPrepareMacroFields, then ShanChenCollideAndPropagate0 / 1 on a 3^dim block of fluid nodes whose centre
+    carries the sample's populations and whose neighbours carry the sample's rho / phi.  f64, <= 1e-13."""
+    import os
+    from sailfish_amd import hipabi
+    from sailfish_amd.backend_hip import HIPBackend
+
+    class Opt(object):
+        pass
+    b = HIPBackend(Opt(), 0)
+    g = np.load(os.path.join(golden_dir, 'shan_chen_%s.npz' % grid.__name__))
+    dim, Q = grid.dim, grid.Q
+    e = grid.basis_array
+    visc, tau_phi = float(g['visc'][0]), float(g['tau_phi'][0])
+    nz = 5 if dim == 3 else 1
+    aa = pattern == 'AA'
+    worst = 0.0
+    w = np.array(grid.weights_float)
+    stream = b.make_stream()
+    for k in range(len(g['f1'])):
+        desc = hipabi.make_desc(lattice=grid.slf_id, model=hipabi.SLF_BGK, precision=8,
+                                access_pattern=hipabi.SLF_AA if aa else hipabi.SLF_AB,
+                                lat_nx=5, lat_ny=5, lat_nz=nz, arr_nx=32, arr_ny=5, arr_nz=nz, fluid_only=1,
+                                tau=sym.relaxation_time(visc), visc=visc, tau_phi=tau_phi,
+                                simtype=hipabi.SLF_SIM_SHAN_CHEN_BINARY, sc_G=list(g['G'][k]),
+                                sc_potential=0 if potential == 'linear' else 1,
+                                accel=list(g['body_accel'][k, 0]) + [0.0] * (3 - dim),
+                                accel1=list(g['body_accel'][k, 1]) + [0.0] * (3 - dim),
+                                has_force=int(np.any(g['body_accel'][k] != 0.0)))
+        module = b.build(desc)
+        shape = (nz, 5, 32)
+        nodes, stride = nz * 5 * 32, hipabi.dist_stride(desc)
+        c = (2, 2, 2) if dim == 3 else (0, 2, 2)
+        host = []
+        for f in (g['f1'][k], g['f2'][k]):
+            raw = np.zeros((Q, stride))
+            d = raw[:, :nodes].reshape((Q,) + shape)
+            d[...] = w.reshape((Q, 1, 1, 1))
+            d[(slice(None),) + c] = f
+            host.append(raw)
+        off = b.dist_align_offset(8)
+        dev_in = [b.alloc_buf(size=Q * stride * 8, align_offset=off) for _ in range(2)]
+        dev_out = dev_in if aa else [b.alloc_buf(size=Q * stride * 8, align_offset=off) for _ in range(2)]
+        for addr, raw in zip(dev_in, host):
+            b.to_buf(addr, raw)
+        if not aa:
+            for addr in dev_out:
+                b.to_buf(addr, np.zeros((Q, stride)))
+        fields = [np.full(shape, 1.0), np.full(shape, 1.0)] + [np.zeros(shape) for _ in range(dim)]
+        dev_f = [b.alloc_buf(like=a) for a in fields]
+        sig = 'P' * (5 + dim) + 'i'
+
+        def kern(name, a, o):
+            return b.get_kernel(module, name, (64,), [0, a, o] + dev_f + [0], sig, needs_iteration=aa)
+        b.set_iteration(0)                                   # even AA step / AB: the node's own slots hold f_i
+        b.run_kernel(kern('ShanChenPrepareMacroFields', dev_in[0], dev_in[1]), None, stream)
+        stream.synchronize()
+        for addr in dev_f:
+            b.from_buf(addr)
+        rho, phi, v = fields[0], fields[1], fields[2:]
+        assert abs(rho[c] - g['sc_rho'][k]) < 1e-14 and abs(phi[c] - g['sc_phi'][k]) < 1e-14
+        for a in range(dim):
+            assert abs(v[a][c] - g['sc_v'][k, a]) < 1e-15
+        for i in range(1, Q):                                 # the neighbours' densities as in the sample
+            p = (c[0] + (e[i][2] if dim == 3 else 0), c[1] + e[i][1], c[2] + e[i][0])
+            rho[p], phi[p] = g['rho_nb'][k, i], g['phi_nb'][k, i]
+        b.to_buf(dev_f[0])
+        b.to_buf(dev_f[1])
+        post = g['sc_post_' + potential][k]
+        for l in range(2):
+            b.run_kernel(kern('ShanChenCollideAndPropagate%d' % l, dev_in[l], dev_out[l]), None, stream)
+            stream.synchronize()
+            raw = np.zeros((Q, stride))
+            b.from_buf(dev_out[l], raw)
+            dout = raw[:, :nodes].reshape((Q,) + shape)
+            for i in range(Q):
+                if aa:                                        # in place, opposite slot
+                    got = dout[(grid.idx_opposite[i],) + c]
+                else:                                         # pushed to x + e_i
+                    p = (c[0] + (e[i][2] if dim == 3 else 0), c[1] + e[i][1], c[2] + e[i][0])
+                    got = dout[(i,) + p]
+                worst = max(worst, abs(got - post[l, i]))
+        for addr in set(dev_in + dev_out + dev_f):
+            b.free_buf(addr)
+    assert worst < 1e-13, worst
