@@ -144,3 +144,29 @@ def boundary_probe(backend, golden_dir, name, precision, kind, box_cls=None):
             assert abs(float(rho[z, y, x]) - float(want_rho)) < max(tol, 1e-7)
             assert max(abs(float(v[d][z, y, x]) - float(want_v[d])) for d in range(dim)) < max(tol, 1e-7)
         s.release()
+
+
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_initial_conditions_against_reference_fixtures(backend, golden_dir, name, precision):
+    init_probe(backend, golden_dir, name, precision)
+
+
+def init_probe(backend, golden_dir, name, precision, box_cls=None):
+    """SetInitialConditions (reference lb_single_fluid.mako:101-127): f = feq(rho, v) from sym_equilibrium.bgk_equilibrium,
+    compressible and incompressible."""
+    grid, size = GRIDS[name]
+    G = np.load(os.path.join(golden_dir, 'arith_%s.npz' % name))
+    for inc in (0, 1):
+        for k in SAMPLES:
+            desc = make_box_desc(grid, size, precision=precision, access_pattern='AB', periodic_fused=[1] * 3,
+                                 incompressible=bool(inc))
+            s = (box_cls or BoxSim)(backend, desc, periodic=(True, True, True))
+            shape = tuple(reversed(size))
+            s.set_fields(np.full(shape, G['rho'][k]), [np.full(shape, G['v'][k][d]) for d in range(grid.dim)])
+            s.initial_conditions()
+            s.sync()
+            out = s.real_view(s.get_dist()).reshape(s.Q, -1).astype(np.float64)
+            err = float(np.max(np.abs(out - G['feq_inc%d' % inc][k][:, None])))
+            assert err < TOL[precision], (inc, k, err)
+            s.release()

@@ -43,3 +43,9 @@ def test_oracle_sweep_collisions(golden_dir, name, precision, fused):
 @pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
 def test_oracle_sweep_boundary_nodes(golden_dir, name, precision, kind):
     probes.boundary_probe(None, golden_dir, name, precision, kind, box_cls=OracleProbeBox)
+
+
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_oracle_initial_conditions(golden_dir, name, precision):
+    probes.init_probe(None, golden_dir, name, precision, box_cls=OracleProbeBox)
