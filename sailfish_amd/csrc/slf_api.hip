@@ -624,6 +624,17 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
                                        "two-copy (AB) access pattern only, as in the reference (boundary.mako:626-628)");
     }
   }
+  g.bc_level = 0;
+  for (int i = 0; i < d->n_types; i++) {
+    const int k = d->type_kind[i];
+    const bool plain = k == SLF_NK_FLUID || k == SLF_NK_GHOST || k == SLF_NK_UNUSED || k == SLF_NK_PROPAGATION_ONLY ||
+                       k == SLF_NK_FULL_BB;
+    const int level = (k == SLF_NK_COPY || k == SLF_NK_YU_OUTFLOW) ? 2 : (plain ? 0 : 1);
+    if (level > g.bc_level) g.bc_level = level;
+  }
+  if (const char* ev = getenv("SLF_BC_LEVEL")) {      // tests: force the full instantiation
+    if (atoi(ev) > g.bc_level) g.bc_level = atoi(ev);
+  }
   g.use_link_tags = d->use_link_tags;
   g.indirect = d->node_addressing == SLF_ADDR_INDIRECT;
   g.variant = SLF_DEFAULT_VARIANT;

@@ -34,6 +34,12 @@ struct Geometry {
   int layout;                  // 0 direction-major, 1 row-interleaved
   int row_order;               // workgroup -> row mapping of the whole-row kernels (SLF_ROW_ORDER), see row_of_block()
   int lds_pad;                 // extra dynamic LDS bytes per workgroup (SLF_LDS_PAD): occupancy throttle, experiments
+  // What the module's node-type table contains (decided once, at module creation): 0 = nothing beyond fluid, ghost,
+  // unused, propagation-only and full-way bounce-back nodes; 1 = boundary-condition nodes; 2 = also the outflow
+  // nodes that read neighbouring nodes (two-copy pattern).  The f32 whole-row kernels are instantiated per level: the
+  // code of conditions a simulation does not use costs registers (52 instead of 78-80 VGPRs at level 0) and, for
+  // the outflow nodes, spills in the hot path of the two-copy kernel.
+  int bc_level;
 };
 
 struct Physics {

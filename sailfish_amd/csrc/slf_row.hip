@@ -28,10 +28,11 @@ namespace slf {
 // dependent round trip map -> loads costs 4-6 % of the odd step at 512^3 (profiles/r01/row_probe7.log,
 // row_probe8.log); loading for excluded nodes as well wastes their bytes, so the host asks for SPEC only when
 // few nodes are excluded.
-template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool FORCE, bool SPEC = false>
+template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool FORCE, bool SPEC = false, int BCL = 2>
 // (second launch bound = minimum resident waves per SIMD: the f32 node-map instantiations fit 6 without spilling --
-// 77-80 VGPRs instead of 81-91 -- which is worth a wave of occupancy; checked with -Rpass-analysis=kernel-resource-usage)
-__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row_kernel(const SweepParams<L, R> p) {
+// 77-80 VGPRs instead of 81-91 -- which is worth a wave of occupancy; checked with -Rpass-analysis=kernel-resource-usage.
+// Not the BGK instantiations with a body force: their Guo / exact-difference branches need ~94 and would spill 60-100 B)
+__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && !(FORCE && MODEL == 0)) ? 6 : 4) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
   const Geometry& g = p.g;
   const int gy = sgpr(p.y0 + (int)blockIdx.y);
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row
   R rho, v[3];
   bool wet = true;
   if (active) {
-    node_update<L, R, MODEL, PROP, GENERAL, false, FORCE>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+    node_update<L, R, MODEL, PROP, GENERAL, false, FORCE, BCL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
     if (wet) check_invalid<R>(p.status, p.options, rho, x, gy, gz);
     if ((p.options & 1u) && wet) {
       p.rho[gi] = rho;
@@ -155,12 +156,26 @@ static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, i
   const int bx = row_block_x(nx, p.g.variant);
   dim3 block(bx, 1, 1);
   dim3 grid((nx + bx - 1) / bx, ny, nz);
+  // node-map kernels in single precision: one instantiation per Geometry::bc_level (slf_kernels.h)
+  constexpr bool LEVELS = GENERAL && sizeof(R) == 4;
+  const int bcl = LEVELS ? p.g.bc_level : 2;
   switch (prop) {
     case PROP_AB:   // (no gain from SPEC here: row_probe8.log)
+      if constexpr (LEVELS) {
+        if (bcl == 0) { hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT, FORCE, false, 0>), grid, block, 0, s, p); break; }
+        if (bcl == 1) { hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT, FORCE, false, 1>), grid, block, 0, s, p); break; }
+      }
       hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT, FORCE>), grid, block, 0, s, p);
       break;
     case PROP_AA_ODD:
       // variant bit 64 = the module descriptor says "sparse geometry" (many excluded nodes): predicate
+      if constexpr (LEVELS) {
+        if (bcl == 0) {
+          if (!(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, true, 0>), grid, block, 0, s, p);
+          else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, false, 0>), grid, block, 0, s, p);
+          break;
+        }
+      }
       if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, GENERAL>), grid, block, 0, s, p);
       else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE>), grid, block, 0, s, p);
       break;

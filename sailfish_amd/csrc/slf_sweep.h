@@ -256,7 +256,8 @@ __device__ __forceinline__ void check_invalid(uint32_t* status, uint32_t options
 }
 
 // gi: dense node index; si: the node's slot in the distribution arrays (= gi unless INDIRECT).
-template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool FORCE = true>
+// BCL: the module's Geometry::bc_level the instantiation is for (2 = everything).
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool FORCE = true, int BCL = 2>
 __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L::Q], uint32_t code, int kind,
                                             uint32_t gi, const AxisOff& ox, const AxisOff& oy, const AxisOff& oz,
                                             R& rho, R (&v)[3], bool& wet, uint32_t si = INVALID_NODE) {
@@ -264,14 +265,22 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
   const Geometry& g = p.g;
   const size_t ds = g.dist_size;
   (void)ds;
-  if constexpr (GENERAL) {
+  if constexpr (GENERAL && BCL == 0) {
+    wet = kind_is_wet(kind);
+    macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
+    if (kind == NK_FULL_BB) bounce_back<L, R>(f);
+    if (wet && p.relaxation_enabled) {
+      if constexpr (MODEL == 0) bgk_relax<L, R, FORCE>(f, rho, v, p.cp);
+      else mrt_relax<L, R, FORCE>(f, v, p.cp, false);
+    }
+  } else if constexpr (GENERAL) {
     wet = kind_is_wet(kind);
     const int orientation = (int)(code >> g.orient_shift);
     const int pidx = (int)((code >> g.param_shift) & g.param_mask);
     const bool inc = p.cp.incompressible != 0;
     // ---- fixMissingDistributions (boundary.mako:509-603): outflow nodes fill their unknown populations from
     // the incoming state of the nodes one / two steps along the inward normal (two-copy pattern only)
-    if constexpr (PROP == PROP_AB) {
+    if constexpr (PROP == PROP_AB && BCL == 2) {
       if ((kind == NK_COPY || kind == NK_YU_OUTFLOW) && orientation != 0) {
         with_orientation<L>(orientation, [&](auto O) {
           constexpr int n = L::dir2vecidx(O);

@@ -350,6 +350,35 @@ def test_full_wave_rows_row_kernels(backend, nx, pattern, case, monkeypatch):
     assert r['dist_exact'], r
 
 
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+@pytest.mark.parametrize('force', [False, True])
+@pytest.mark.parametrize('nx', [70, 512])
+def test_node_map_kernels_per_boundary_condition_level(backend, nx, force, model, pattern, monkeypatch):
+    """The f32 whole-row node-map kernels exist once per Geometry::bc_level (slf_kernels.h): 0 = the type table holds
+    nothing beyond fluid / ghost / unused / full-way bounce-back (52 VGPRs), 1 = boundary-condition nodes, 2 = also
+    the outflow nodes of the two-copy pattern.  Same geometry (walls, holes, a body force or not) through level 0
+    (plain table), level 1 (full table) and the level 2 instantiation (forced): every one bit-identical to the oracle."""
+    from sailfish_amd import hipabi as h
+    plain = (h.SLF_NK_FLUID, h.SLF_NK_GHOST, h.SLF_NK_FULL_BB, h.SLF_NK_UNUSED)
+
+    def holes(desc):
+        m = geo.empty_map(desc)
+        m[1:4, 1:4, 30:nx - 10] = geo.encode(geo.T_FULLBB)
+        m[2, 2, 31:nx - 11] = geo.encode(geo.T_UNUSED)
+        m[1:6, 4, 5:9] = geo.encode(geo.T_FULLBB)
+        return m
+    for table, forced in (([k if k in plain else h.SLF_NK_UNUSED for k in geo.TYPE_KIND], None), (geo.TYPE_KIND, None),
+                          (geo.TYPE_KIND, '2')):
+        if forced:
+            monkeypatch.setenv('SLF_BC_LEVEL', forced)
+        r = _run_pair(backend, sym.D3Q19, (nx, 5, 5), 7, (True, True, True), node_map_fn=holes, init='rest', model=model,
+                      precision='single', fluid_only=False, type_kind=table, nt_bits=geo.NT_BITS,
+                      periodic_fused=[1, 1, 1], accel=[1e-5, -2e-5, 0.0] if force else None, u_scale=0.05,
+                      access_pattern=pattern, visc=0.03)
+        assert r['rho_err'] < RTOL and r['v_err'] < RTOL and r['dist_exact'], (table is geo.TYPE_KIND, forced, r)
+
+
 @pytest.mark.parametrize('nx', [1088, 1536, 2100])
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
 @pytest.mark.parametrize('case', ['periodic_f32', 'periodic_f32_mrt', 'periodic_f64', 'ghost_pbc_x', 'cavity', 'holes'])

@@ -31,6 +31,9 @@ def main():
     ap.add_argument('--general', default='', choices=['', 'fluid', 'walls', 'pipe'],
                     help='run the node-map (general) kernels: all-fluid periodic box / closed box of full-BB walls / '
                          'circular pipe along z (unused nodes outside)')
+    ap.add_argument('--accel', type=float, default=0.0, help='body-force acceleration along x (FORCE instantiations)')
+    ap.add_argument('--plain_types', action='store_true',
+                    help='--general: a type table without boundary-condition kinds (Geometry::bc_level 0)')
     ap.add_argument('--trace', type=int, default=0, help='also print the time of every batch of N launches')
     args = ap.parse_args()
 
@@ -90,7 +93,12 @@ def main():
             m[1:n + 1, (~inside & ~ring) & real] = geo.encode(geo.T_UNUSED)
             m[1:n + 1, ring & real] = geo.encode(geo.T_FULLBB)
         g_map = b.alloc_buf(like=np.ascontiguousarray(m))
-        gkw = dict(fluid_only=False, type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS)
+        kinds = list(geo.TYPE_KIND)
+        if args.plain_types:
+            from sailfish_amd import hipabi as h
+            plain = (h.SLF_NK_FLUID, h.SLF_NK_GHOST, h.SLF_NK_FULL_BB, h.SLF_NK_UNUSED)
+            kinds = [k if k in plain else h.SLF_NK_UNUSED for k in kinds]
+        gkw = dict(fluid_only=False, type_kind=kinds, nt_bits=geo.NT_BITS)
         print('general map %s: %.1f%% of the real nodes excluded' % (
             args.general, 100.0 * np.mean((m[1:n + 1, 1:n + 1, 1:n + 1] & 7) == geo.T_UNUSED)))
     for d in ([dist_a, dist_b] if dist_b else [dist_a]):
@@ -109,7 +117,8 @@ def main():
                 ap_ = 'AB' if mode == 'ab' else 'AA'
                 desc = make_box_desc(grid, size, model=args.model, precision='single', access_pattern=ap_,
                                      visc=1.0 / 6.0, periodic_fused=fused,
-                                     relaxation_enabled=not args.norelax, dist_pad=pad, **gkw)
+                                     relaxation_enabled=not args.norelax, dist_pad=pad,
+                                     accel=[args.accel, 0.0, 0.0] if args.accel else None, **gkw)
                 mod = b.build(desc)
                 sig = 'PPPPPPPi'
                 for dd in ([dist_a, dist_b] if dist_b else [dist_a]):
