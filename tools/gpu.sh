@@ -25,7 +25,7 @@ while [ $# -gt 0 ]; do
   echo "=== $task"
   case $task in
     host)
-      { nproc; grep -m1 "model name" /proc/cpuinfo; echo "cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; echo "affinity: $(python -c 'import os;print(len(os.sched_getaffinity(0)))')"; lscpu | grep -i "numa\|socket\|thread" | head -8; rocm-smi --showproductname 2>/dev/null | head -12; } | tee $O/host.txt ;;
+      { nproc; grep -m1 "model name" /proc/cpuinfo; echo "cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; echo "affinity: $(python -c 'import os;print(len(os.sched_getaffinity(0)))')"; lscpu | grep -i "numa\|socket\|thread" | head -8; rocm-smi --showproductname 2>/dev/null | head -12; rocm-smi --showmemorypartition --showcomputepartition 2>/dev/null | grep -i partition; amd-smi metric -g 0 2>/dev/null | grep -A2 -i "GFX_0\|MEM_0\|SOCKET_POWER\|THROTTLE" | head -16; } | tee $O/host.txt ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tee $O/smoke.log | tail -3 ;;
     tests)
