@@ -67,14 +67,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--quick', action='store_true')
-    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,3,4)')
+    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,4)')
     args = ap.parse_args()
     if not args.only:
         # one fresh process per configuration: what a configuration measures must not depend on what ran before it in
         # the same process (stream -> hardware-queue mapping, allocator state; profiles/r02/README.md "config 3")
         import subprocess
         lines = []
-        for cid in ('0', '1', '2', '2b', '2c', '3', '4'):
+        for cid in ('0', '1', '2', '2b', '2c', '5a', '5b', '3', '4'):
             cmd = [sys.executable, os.path.abspath(__file__), '--only', cid] + (['--quick'] if args.quick else [])
             out = subprocess.run(cmd, stdout=subprocess.PIPE).stdout.decode(errors='replace')
             for ln in out.splitlines():
@@ -117,6 +117,13 @@ def main():
                    LBGeometry3D,
                    dict(lat_nx=512, lat_ny=512, lat_nz=512, model='bgk', visc=0.0256, access_pattern='AB',
                         max_iters=int(700 * it), benchmark_sample_from=int(200 * it)), 152))
+    # a force-driven pipe (examples/poiseuille_3d.py: circular cross-section of full-way bounce-back walls, unused nodes
+    # outside, periodic along x, body force): the node-map kernels with the Guo term, in-place and two-copy
+    from examples.poiseuille_3d import PoiseuilleSim as Pipe3D
+    for cid, pattern in (('5a', 'AA'), ('5b', 'AB')):
+        res.append(run('%s: D3Q19 BGK force-driven pipe 512x256x256 (%s)' % (cid, pattern), Pipe3D, LBGeometry3D,
+                       dict(lat_nx=512, lat_ny=256, lat_nz=256, visc=0.05, access_pattern=pattern,
+                            max_iters=int(1500 * it), benchmark_sample_from=int(500 * it)), 152))
     # config 3 (8 GPUs) is bench.py --gpus 8; here its per-GPU shape for both decompositions, 2 subdomains
     # of the reference's x-split layout on this one GPU (halo path exercised, no xGMI)
     res.append(run('3: D3Q19 BGK 1024x512x512 / 8: one 128x512x512 x-slab pair on one GPU', BoxSim,
