@@ -119,7 +119,7 @@ def main():
                         max_iters=int(700 * it), benchmark_sample_from=int(200 * it)), 152))
     # a force-driven pipe (examples/poiseuille_3d.py: circular cross-section of full-way bounce-back walls, unused nodes
     # outside, periodic along x, body force): the node-map kernels with the Guo term, in-place and two-copy
-    from examples.poiseuille_3d import PoiseuilleSim as Pipe3D
+    from examples.poiseuille_3d import PipeSim as Pipe3D
     for cid, pattern in (('5a', 'AA'), ('5b', 'AB')):
         res.append(run('%s: D3Q19 BGK force-driven pipe 512x256x256 (%s)' % (cid, pattern), Pipe3D, LBGeometry3D,
                        dict(lat_nx=512, lat_ny=256, lat_nz=256, visc=0.05, access_pattern=pattern,
