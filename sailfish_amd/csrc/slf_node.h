@@ -170,16 +170,21 @@ SLF_D void bgk_relax_accel(R (&f)[L::Q], R rho, R (&v)[3], R omega, R guo_pref, 
   }
 }
 
-// FORCE = false: the module has no body force -- a compile-time fact for the kernel, so that the Guo / exact
-// difference branches (and the registers their merge points cost: 98 -> 48 VGPRs in the whole-row kernel, i.e.
-// 4 -> 8 resident waves per SIMD) do not exist in the instantiation the force-free configurations run.
-template <class L, class R, bool FORCE = true>
+// FORCE: what the instantiation knows about the body force at compile time.
+//   0  the module has none: the Guo / exact-difference code (and the registers its merge points cost: 98 -> 48 VGPRs in
+//      the whole-row kernel, 4 -> 8 resident waves per SIMD) does not exist in the instantiation;
+//   1  the module has one (the launchers pick this instantiation iff Physics::has_force): no run-time "is there a
+//      force" test either -- 95-100 -> 74-82 VGPRs in the node-map row kernels;
+//   2  decided at run time (the per-node kernels, which exist once per module kind).
+constexpr int FORCE_RUNTIME = 2;
+template <class L, class R, int FORCE = FORCE_RUNTIME>
 SLF_D void bgk_relax(R (&f)[L::Q], R rho, R (&v)[3], const CollideParams<L, R>& cp) {
-  if constexpr (FORCE) {
-    bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, cp.has_force != 0, cp.accel,
-                          cp.force_edm != 0);
-  } else {
+  if constexpr (FORCE == 0) {
     bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, false, cp.accel, false);
+  } else {
+    const bool has_force = (FORCE == 1) ? true : (cp.has_force != 0);
+    bgk_relax_accel<L, R>(f, rho, v, cp.omega, cp.guo_pref, cp.incompressible != 0, has_force, cp.accel,
+                          cp.force_edm != 0);
   }
 }
 
@@ -242,11 +247,11 @@ SLF_D void mrt_equilibrium(const R (&m)[L::Q], R inv_rho, R (&meq)[L::Q]) {
 
 // C7: relaxation in moment space.  force_eq: equilibrium-type node (moments
 // forced to equilibrium, relaxation_mrt.mako:58-77).
-template <class L, class R, bool FORCE = true>
+template <class L, class R, int FORCE = FORCE_RUNTIME>
 SLF_D void mrt_relax(R (&f)[L::Q], R (&v)[3], const CollideParams<L, R>& cp, bool force_eq) {
   R m[L::Q];
   static_for<0, L::Q>([&](auto K) { m[K] = mrt_row<L, R, K>(f); });
-  const bool has_force = FORCE && cp.has_force;
+  const bool has_force = (FORCE == 1) ? true : ((FORCE == 0) ? false : (cp.has_force != 0));
   if (has_force) {
     m[L::M_MX] = m[L::M_MX] + (R)0.5 * cp.accel[0];
     m[L::M_MY] = m[L::M_MY] + (R)0.5 * cp.accel[1];

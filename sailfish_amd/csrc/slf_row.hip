@@ -32,7 +32,7 @@ template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool FORC
 // (second launch bound = minimum resident waves per SIMD: the f32 node-map instantiations fit 6 without spilling --
 // 77-80 VGPRs instead of 81-91 -- which is worth a wave of occupancy; checked with -Rpass-analysis=kernel-resource-usage.
 // Not the BGK instantiations with a body force: their Guo / exact-difference branches need ~94 and would spill 60-100 B)
-__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && !(FORCE && MODEL == 0)) ? 6 : 4) row_kernel(const SweepParams<L, R> p) {
+__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
   const Geometry& g = p.g;
   const int gy = sgpr(p.y0 + (int)blockIdx.y);

@@ -257,7 +257,7 @@ __device__ __forceinline__ void check_invalid(uint32_t* status, uint32_t options
 
 // gi: dense node index; si: the node's slot in the distribution arrays (= gi unless INDIRECT).
 // BCL: the module's Geometry::bc_level the instantiation is for (2 = everything).
-template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool FORCE = true, int BCL = 2>
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, int FORCE = FORCE_RUNTIME, int BCL = 2>
 __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L::Q], uint32_t code, int kind,
                                             uint32_t gi, const AxisOff& ox, const AxisOff& oy, const AxisOff& oz,
                                             R& rho, R (&v)[3], bool& wet, uint32_t si = INVALID_NODE) {
