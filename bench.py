@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument('--prewarm_steps', type=int, default=300,
                     help='untimed steps before the W warm-up steps (same count on every rank): about 1 s at 512^3')
     ap.add_argument('--no_gpu_state', action='store_true', help='do not sample amd-smi before / after')
+    ap.add_argument('--no_validate', action='store_true',
+                    help='skip the check of the final state against the CPU oracle after the timed region')
     return ap.parse_args()
 
 
@@ -100,6 +102,71 @@ def load_traffic(workload_key):
         return None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, the way the reference's
+    controller spawns one process per subdomain (master.py:242-312) -- here through torch.distributed.run, the same
+    command line the driver uses; rank 0 prints the JSON line.  Returns the exit status."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def validate(sim, backend, mass0, distributed, axis):
+    """AFTER the timed region, on the state the timed steps left behind: (a) sampled z-planes of the next two steps
+    against the CPU oracle (7-plane windows seeded from the device, oracle/window.py: bit-identical populations
+    expected), (b) total mass and momentum against the initial state (periodic BGK box without forcing: conserved
+    up to f32 round-off).  The oracle is the checker here, never part of what is timed."""
+    from oracle import window
+    import torch
+    out = {}
+    nz = sim.desc.lat_nz - 2
+    if not sim.halo:
+        zs = [1, nz // 3, nz]
+        zs += [z for z in window.chunk_boundary_planes(sim.placed, sim.desc, sim.stride, limit=2) if z not in zs]
+    elif axis == 'z' and nz >= 16:
+        zs = [8, nz // 2, nz - 7]         # interior planes: the windows do not model the neighbours' halo
+    else:
+        zs = []
+    chk = None
+    sim.sync()
+    if zs:
+        chk = window.PlaneCheck(backend, sim.desc, None, zs, sim.gpu_dist, sim.stride,
+                                [sim.gpu_rho] + list(sim.gpu_v))
+        chk.seed(sim.iteration)
+    sim.step()
+    sim.step(save_macro=True)
+    sim.sync()
+    if chk is not None:
+        chk.advance(2, save_last=True)
+        r = chk.compare()
+        out.update(planes=r['planes'], populations_compared=r['compared_values'], populations_bit_identical=r['dist_exact'],
+                   max_abs_err=r['dist_err'], rho_rel_err=r['rho_err'], u_abs_err=r['v_abs_err'])
+    rho, v = sim.fetch_fields()
+    r64 = sim.real_view(rho).astype(np.float64)
+    tot = [float(r64.sum())] + [float((r64 * sim.real_view(c)).sum()) for c in v]
+    if distributed:
+        t = torch.tensor(tot + list(mass0), dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t)
+        tot, mass0 = t[:4].tolist(), t[4:].tolist()
+    out['mass_rel_drift'] = abs(tot[0] - mass0[0]) / mass0[0]
+    out['momentum_drift_over_mass_u'] = max(abs(a - b) for a, b in zip(tot[1:], mass0[1:])) / (mass0[0] * 0.05)
+    out['steps_before_check'] = sim.iteration - 2
+    out['ok'] = bool(out['mass_rel_drift'] < 1e-5 and out['momentum_drift_over_mass_u'] < 1e-4 and
+                     out.get('populations_bit_identical', True) and out.get('rho_rel_err', 0.0) < 1e-6)
+    if distributed:                      # every rank checked its own planes: all of them must agree
+        t = torch.tensor([1.0 if out['ok'] else 0.0], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        out['ok'] = bool(t.item() > 0.5)
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -110,7 +177,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit('N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        raise SystemExit(self_launch(args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP backend has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -146,12 +213,15 @@ def main():
         if distributed:
             torch.distributed.barrier()
 
-    def measure(pattern):
+    def measure(pattern, check=False):
         sim = SlabSim(backend, sym.D3Q19, tuple(local), rank=rank, world=world, model=args.model,
                       precision=args.precision, access_pattern=pattern, visc=args.visc,
                       fused_periodic=not args.no_fused_periodic, axis=args.axis, force_halo=args.force_distributed)
         res = {'pattern': pattern, 'block': sim.block_size, 'placement': sim.placement_info}
         sim.init_synthetic(seed=1234)
+        if check:
+            r64 = sim.real_view(sim.rho).astype(np.float64)
+            mass0[0] = [float(r64.sum())] + [float((r64 * sim.real_view(c)).sum()) for c in sim.v]
         if sim.halo:
             # what the sweep launches cost when nothing is waited for (reference for the overlap figure)
             for _ in range(10):
@@ -187,15 +257,19 @@ def main():
         res['kernel_ms'] = ev1.time_since(ev0) / args.steps   # HIP events on the sweep's own stream
         if sim.halo:
             res['halo_ms'] = sim.stop_halo_timing()
+        if check:
+            res['validation'] = validate(sim, backend, mass0[0], distributed, args.axis)
         sim.release()
         return res
 
     st_before = None if (args.no_gpu_state or rank) else gpu_state()
     patterns = ['AA', 'AB'] if args.access_pattern == 'auto' else [args.access_pattern]
     runs = dict((p, []) for p in patterns)
-    for _ in range(max(1, args.repeats)):
+    mass0 = [None]
+    reps = max(1, args.repeats)
+    for i in range(reps):
         for pat in patterns:
-            runs[pat].append(measure(pat))
+            runs[pat].append(measure(pat, check=(i == reps - 1 and not args.no_validate)))
     st_after = None if (args.no_gpu_state or rank) else gpu_state()
     best_of = dict((p, min(rs, key=lambda r: r['elapsed'])) for p, rs in runs.items())
     best = min(best_of.values(), key=lambda r: r['elapsed'])
@@ -234,6 +308,10 @@ def main():
                'runs_mlups': [round(v, 1) for v in all_mlups],
                'candidates_mlups': dict((p, round(to_mlups(r['elapsed']), 1)) for p, r in best_of.items()),
                'placement': best['placement']}
+        checks = dict((p, rs[-1]['validation']) for p, rs in runs.items() if 'validation' in rs[-1])
+        if checks:
+            cfg['validated'] = all(c['ok'] for c in checks.values())
+            cfg['validation'] = checks
         if distributed:
             hm = max(r.get('halo_ms', 0.0) for r in per_rank)
             so = max(r.get('sweep_only_ms', 0.0) for r in per_rank)
@@ -248,7 +326,8 @@ def main():
             cfg['gpu_state'] = {'before': st_before, 'after': st_after}
         out = {
             'metric': 'MLUPS (million lattice updates/s), %s' % what,
-            'value': round(to_mlups(elapsed), 1), 'unit': 'MLUPS', 'n_gpus': world, 'steps': args.steps,
+            'value': round(to_mlups(elapsed), 1), 'median_value': round(float(np.median(all_mlups)), 1),
+            'unit': 'MLUPS', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32' if prec == 4 else 'f64', 'data': 'synthetic',

@@ -1,0 +1,178 @@
+"""Full-size parity without a full-size oracle run: z-plane windows.
+
+TEST INFRASTRUCTURE ONLY (see lbm_oracle.c): used by tests/ and by bench.py's validation leg after the timed
+region, never by sailfish_amd/.
+
+The table-driven oracle does ~0.5 MLUPS per core; a 512^3 box is out of its reach in a test, but the state of one
+z-plane after two steps depends only on the five planes around it (one push / pull = one plane per step; the
+in-place AA pair "even (local) + odd (pull and push)" = two planes).  So: copy the seven planes z-3 .. z+3 of the
+GPU's arrays into a 7-plane oracle subdomain that keeps the full x / y extent (node map, in-sweep wrap or
+ghost-layer PBC along x and y, walls, lid -- everything as in the full run), advance both by two steps, and compare
+plane z bit for bit.  Planes whose window would stick out of a non-periodic box are served by a window pushed
+against the box's own ghost plane; a z axis wrapped in-sweep wraps the window.
+"""
+import ctypes
+
+import numpy as np
+
+from oracle.oracle import OracleSim
+from sailfish_amd import hipabi
+
+RADIUS = 2            # planes a plane's state depends on, per side, after two steps
+W = 2 * (RADIUS + 1) + 1
+
+
+def _clone_desc(desc, **changes):
+    d = hipabi.SlfModuleDesc.from_buffer_copy(desc)
+    for k, v in changes.items():
+        setattr(d, k, v)
+    return d
+
+
+class PlaneWindow(object):
+    """One sampled plane `z` (1-based real plane index) of a D3Q19 subdomain."""
+
+    def __init__(self, desc, node_map, z):
+        nz = desc.lat_nz - 2
+        if desc.lat_nz < W:
+            raise ValueError('subdomain too thin for a %d-plane window' % W)
+        self.z = z
+        if desc.periodic_fused[2]:
+            self.planes = [((z - (RADIUS + 1) + k - 1) % nz) + 1 for k in range(W)]
+            self.t = RADIUS + 1
+        else:
+            if desc.periodic_local[2] and (z - RADIUS < 1 or z + RADIUS > nz):
+                raise ValueError('ghost-layer PBC along z: sample planes at least %d from the faces' % RADIUS)
+            lo = min(max(z - (RADIUS + 1), 0), nz + 2 - W)
+            self.planes = list(range(lo, lo + W))
+            self.t = z - lo
+        wd = _clone_desc(desc, lat_nz=W, arr_nz=W, dist_stride=0)
+        wd.periodic_fused[2] = 0
+        wd.periodic_local[2] = 0
+        self.desc, self.full = wd, desc
+        self.o = OracleSim(wd)
+        self.map = None if node_map is None else np.ascontiguousarray(node_map[self.planes])
+        self.aa = desc.access_pattern == hipabi.SLF_AA
+        self.pbc_axes = [a for a in (0, 1) if desc.periodic_local[a] and not desc.periodic_fused[a]]
+        self.dist = None
+
+    def runs(self):
+        """[(first global plane, count, first local plane)]: stretches of consecutive planes (one copy each)."""
+        out, k = [], 0
+        while k < W:
+            j = k
+            while j + 1 < W and self.planes[j + 1] == self.planes[j] + 1:
+                j += 1
+            out.append((self.planes[k], j - k + 1, k))
+            k = j + 1
+        return out
+
+
+class PlaneCheck(object):
+    """Seeds plane windows from a device-resident state, advances them with the oracle and compares the sampled
+    planes with the device again.  `fetch(addr, byte_offset, nbytes) -> bytes-like` reads device memory."""
+
+    def __init__(self, backend, desc, node_map, zs, dist_addrs, stride, field_addrs=None):
+        self.backend, self.desc, self.stride = backend, desc, int(stride)
+        self.dtype = np.float32 if desc.precision == 4 else np.float64
+        self.isz = self.dtype().itemsize
+        self.nxy = desc.arr_nx * desc.arr_ny
+        self.dist_addrs = list(dist_addrs)
+        self.field_addrs = field_addrs            # [rho, vx, vy, vz] or None
+        self.windows = [PlaneWindow(desc, node_map, z) for z in zs]
+        self.iteration = None
+
+    # -- device access ------------------------------------------------------
+    def _fetch_planes(self, base, first_plane, count):
+        out = np.empty(count * self.nxy, dtype=self.dtype)
+        self.backend.from_buf(base + first_plane * self.nxy * self.isz, out)
+        return out.reshape(count, self.desc.arr_ny, self.desc.arr_nx)
+
+    def _fetch_window(self, w, addr):
+        d = np.empty((19, W, self.desc.arr_ny, self.desc.arr_nx), dtype=self.dtype)
+        for q in range(19):
+            base = addr + q * self.stride * self.isz
+            for g0, n, k0 in w.runs():
+                d[q, k0:k0 + n] = self._fetch_planes(base, g0, n)
+        return d
+
+    # -- protocol -------------------------------------------------------------
+    def seed(self, iteration):
+        """Call with the device idle; `iteration` = number of steps done so far (decides the AA parity / which
+        copy is the current one)."""
+        self.iteration = int(iteration)
+        for w in self.windows:
+            w.dist = [self._fetch_window(w, a) for a in self.dist_addrs]
+            w.rho = np.full(w.o.shape, np.inf, dtype=self.dtype)
+            w.v = [np.full(w.o.shape, np.inf, dtype=self.dtype) for _ in range(3)]
+
+    def advance(self, steps=2, save_last=True):
+        if steps > RADIUS:
+            raise ValueError('a window is exact for at most %d steps' % RADIUS)
+        ny = self.desc.lat_ny - 2
+        region = (1, ny + 1, 1, W - 1)
+        for w in self.windows:
+            it = self.iteration
+            for s in range(steps):
+                opts = 1 if (save_last and s == steps - 1) else 0
+                if w.aa:
+                    prop = 2 if (it & 1) else 1
+                    w.o.step(prop, w.map, w.dist[0], w.dist[0], w.rho, w.v[0], w.v[1], w.v[2], opts, region)
+                    out, swap = 0, (it & 1) == 0
+                else:
+                    i = it & 1
+                    w.o.step(0, w.map, w.dist[i], w.dist[1 - i], w.rho, w.v[0], w.v[1], w.v[2], opts, region)
+                    out, swap = 1 - i, False
+                for axis in w.pbc_axes:
+                    w.o.pbc(w.dist[out], axis, swap)
+                it += 1
+        self.iteration += steps
+
+    def compare(self, fields=True):
+        """Device planes against the windows.  Returns {'planes', 'nodes', 'dist_exact', 'dist_err', 'rho_err',
+        'v_abs_err'}; the sampled planes are compared over their real nodes (1..ny, 1..nx), every population."""
+        d = self.desc
+        ys, xs = slice(1, d.lat_ny - 1), slice(1, d.lat_nx - 1)
+        cur = 0 if len(self.dist_addrs) == 1 else (self.iteration & 1)
+        res = {'planes': [w.z for w in self.windows], 'nodes': 0, 'dist_exact': True, 'dist_err': 0.0,
+               'rho_err': 0.0, 'v_abs_err': 0.0, 'compared_values': 0}
+        for w in self.windows:
+            for q in range(19):
+                dev = self._fetch_planes(self.dist_addrs[cur] + q * self.stride * self.isz, w.z, 1)[0][ys, xs]
+                ref = w.dist[cur][q, w.t][ys, xs]
+                ok = np.isfinite(ref)
+                res['compared_values'] += int(ok.sum())
+                if not np.array_equal(dev[ok], ref[ok]):
+                    res['dist_exact'] = False
+                    with np.errstate(invalid='ignore'):
+                        res['dist_err'] = max(res['dist_err'], float(np.nanmax(np.abs(dev[ok] - ref[ok]))))
+            res['nodes'] += (d.lat_ny - 2) * (d.lat_nx - 2)
+            if fields and self.field_addrs is not None:
+                ref_rho = w.rho[w.t][ys, xs]
+                wet = np.isfinite(ref_rho)
+                dev_rho = self._fetch_planes(self.field_addrs[0], w.z, 1)[0][ys, xs]
+                if wet.any():
+                    res['rho_err'] = max(res['rho_err'], float(np.max(np.abs(dev_rho[wet] - ref_rho[wet]) / np.abs(ref_rho[wet]))))
+                    for c in range(3):
+                        dev_v = self._fetch_planes(self.field_addrs[1 + c], w.z, 1)[0][ys, xs]
+                        res['v_abs_err'] = max(res['v_abs_err'], float(np.max(np.abs(dev_v[wet] - w.v[c][w.t][ys, xs][wet]))))
+        return res
+
+
+def chunk_boundary_planes(placed, desc, stride, limit=4):
+    """z-planes that contain a boundary between two physical chunks of a placed distribution array
+    (sailfish_amd/placement.py): the rows there are where a wrong chunk mapping would show."""
+    isz = 4 if desc.precision == 4 else 8
+    nxy = desc.arr_nx * desc.arr_ny
+    nz = desc.lat_nz - 2
+    out = []
+    for pb in placed:
+        k = 1
+        while k * pb.part_bytes < pb.total and len(out) < limit:
+            off = k * pb.part_bytes - (pb.addr - pb.va)      # byte offset from the array's first element
+            elem = off // isz
+            z = int((elem % stride) // nxy)
+            if RADIUS + 1 <= z <= nz - RADIUS - 1 and z not in out:
+                out.append(z)
+            k += max(1, (pb.total // pb.part_bytes) // limit)
+    return out

@@ -238,12 +238,17 @@ class SlabSim(BoxSim):
             self.xface.reset(self.stream)
             self.ev_halo = None
 
-    def get_dist(self, which=None):
-        """With x-face buffers the arrays are stale at the faces: write the received values into them first."""
+    def materialise_faces(self):
+        """With x-face buffers the arrays are stale at the faces: write the received values into them (before anything
+        reads the arrays on the host)."""
         if self.halo and self.xface is not None and self.iteration > 0:
             self.sync()
             pushed = (not self.aa) or ((self.iteration - 1) & 1) == 1
             self.xface.materialise(self.gpu_dist[self.current_dist_index()], pushed, self.stream)
+            self.sync()
+
+    def get_dist(self, which=None):
+        self.materialise_faces()
         return BoxSim.get_dist(self, which)
 
     # -- initial state ---------------------------------------------------------

@@ -41,9 +41,12 @@ def test_strong_scaling_arguments_are_checked_before_any_gpu_work():
     from sailfish_amd.slab import SlabPlan  # noqa: F401  (the slab driver imports without a GPU)
 
 
-def test_bench_refuses_to_run_without_a_gpu_or_with_inconsistent_ranks():
+def test_bench_launches_its_own_ranks_and_refuses_to_run_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (torch.distributed.run); here,
+    without a GPU, every rank refuses -- there is no CPU fallback -- and the status is passed on."""
     env = dict(os.environ)
-    env.pop('WORLD_SIZE', None)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
-    assert res.returncode != 0 and b'torch.distributed.run' in res.stdout
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=900)
+    assert res.returncode != 0 and b'bench.py needs a GPU' in res.stdout and b'torch.distributed' in res.stdout, res.stdout[-2000:]

@@ -27,6 +27,26 @@ class Loopback(object):
         return _E()
 
 
+def step_pair(sims, lb):
+    """One step of a 2-rank ring living in this process: rank r's send_up -> rank r+1's recv_low, send_down -> rank
+    r-1's recv_high (2 ranks: the other one)."""
+    import torch
+    for s in sims:
+        s.step_compute()
+    for s in sims:
+        s.step_exchange()
+    for r, s in enumerate(sims):
+        o = 1 - r
+        s_up, s_down, _, _ = lb.bufs[r]
+        _, _, r_low, r_high = lb.bufs[o]
+        torch.cuda.synchronize()
+        r_low.copy_(s_up)
+        r_high.copy_(s_down)
+    torch.cuda.synchronize()
+    for s in sims:
+        s.step_finish()
+
+
 @pytest.mark.parametrize('pattern', ['AA', 'AB'])
 @pytest.mark.parametrize('model,axis', [('bgk', 'z'), ('mrt', 'z'), ('bgk', 'y'), ('bgk', 'x'), ('mrt', 'x')])
 def test_two_slabs_equal_one_box(pattern, model, axis):
@@ -47,21 +67,7 @@ def test_two_slabs_equal_one_box(pattern, model, axis):
         s.init_synthetic(seed=5)
     steps = 9
     for _ in range(steps):
-        for s in sims:
-            s.step_compute()
-        for s in sims:
-            s.step_exchange()
-        # rank r: send_up -> rank r+1 recv_low, send_down -> rank r-1 recv_high (2-rank ring: the other one)
-        for r, s in enumerate(sims):
-            o = 1 - r
-            s_up, s_down, _, _ = lb.bufs[r]
-            _, _, r_low, r_high = lb.bufs[o]
-            torch.cuda.synchronize()
-            r_low.copy_(s_up)
-            r_high.copy_(s_down)
-        torch.cuda.synchronize()
-        for s in sims:
-            s.step_finish()
+        step_pair(sims, lb)
     np_axis = 3 - a                                   # arrays are [q, z, y, x]
     got = np.concatenate([s.real_view(s.get_dist()) for s in sims], axis=np_axis)
 

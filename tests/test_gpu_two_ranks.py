@@ -46,6 +46,26 @@ def test_bench_with_two_ranks_on_one_gpu(mode):
     assert set(c['candidates_mlups']) == {'AA', 'AB'}
 
 
+def test_bench_launches_two_ranks_itself():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the shape of the driver's N = 1 command with another
+    N): bench.py starts its ranks itself, rank 0 prints the one JSON line, the final state is validated."""
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--size', '96',
+           '--prewarm_steps', '2', '--repeats', '1', '--no_cpu_baseline', '--no_gpu_state']
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode == 0, out[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 2 and c['rccl_ranks'] == 2 and sorted(r['rank'] for r in c['per_rank']) == [0, 1]
+    assert c['validated'] is True, c['validation']
+    assert all(v['populations_bit_identical'] for v in c['validation'].values())
+
+
 @pytest.mark.parametrize('axis,pattern,model', [('z', 'AA', 'bgk'), ('z', 'AB', 'mrt'), ('x', 'AA', 'bgk'), ('x', 'AB', 'bgk'),
                                                 ('y', 'AB', 'bgk')])
 def test_two_processes_equal_one_box(axis, pattern, model):
