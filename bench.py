@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument('--prewarm_steps', type=int, default=300,
                     help='untimed steps before the W warm-up steps (same count on every rank): about 1 s at 512^3')
     ap.add_argument('--no_gpu_state', action='store_true', help='do not sample amd-smi before / after')
+    ap.add_argument('--no_runner_path', action='store_true',
+                    help='skip the leg through LBSimulationController / SubdomainRunner.step() (N = 1 only)')
     ap.add_argument('--no_validate', action='store_true',
                     help='skip the check of the final state against the CPU oracle after the timed region')
     return ap.parse_args()
@@ -116,6 +118,48 @@ def self_launch(n):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def runner_path(args, gpu_id):
+    """The same 512^3 periodic BGK box through the product's host stack -- LBSimulationController -> SubdomainRunner.step()
+    with --mode=benchmark accounting, which is where the reference measures its MLUPS (subdomain_runner.py:1693-1703,
+    controller.py:740-765) and what `examples run unchanged` exercises.  bench.py's `value` times the slab driver
+    (sailfish_amd/slab.py); the two must agree."""
+    import io as _io
+    from contextlib import redirect_stdout
+    from sailfish.controller import LBSimulationController
+    from sailfish.geo import LBGeometry3D
+    from sailfish.lb_single import LBFluidSim
+    from sailfish.subdomain import Subdomain3D
+
+    class PeriodicBox(Subdomain3D):
+        def boundary_conditions(self, hx, hy, hz):
+            pass
+
+        def initial_conditions(self, sim, hx, hy, hz):
+            sim.rho[:] = 1.0
+            sim.vx[:] = 0.05 * np.sin(2 * np.pi * hy / self.gy)
+            sim.vy[:] = 0.05 * np.sin(2 * np.pi * hz / self.gz)
+            sim.vz[:] = 0.05 * np.sin(2 * np.pi * hx / self.gx)
+
+    class BoxSim(LBFluidSim):
+        subdomain = PeriodicBox
+
+    n = args.size
+    steps = max(200, args.steps + 100)
+    cfg = dict(mode='benchmark', quiet=True, perf_stats_every=0, lat_nx=n, lat_ny=n, lat_nz=n, periodic_x=True,
+               periodic_y=True, periodic_z=True, visc=args.visc, access_pattern=args.access_pattern, grid='D3Q19',
+               model=args.model, precision=args.precision, max_iters=steps, benchmark_sample_from=100, gpus=[gpu_id])
+    ctrl = LBSimulationController(BoxSim, LBGeometry3D, default_config=cfg)
+    with redirect_stdout(_io.StringIO()):
+        ctrl.run(ignore_cmdline=True)
+    r = ctrl.runners[0]
+    out = {'mlups': round(ctrl.mlups_total, 1), 'mlups_sweep_only': round(ctrl.mlups_comp, 1),
+           'kernel_ms': round(r.num_fluid_nodes / ctrl.mlups_comp * 1e-3, 4), 'steps': steps,
+           'access_pattern': args.access_pattern, 'placement_tuning': getattr(r, 'placement_tuning', None),
+           'through': 'LBSimulationController -> SubdomainRunner.step(), --mode=benchmark'}
+    r.release()
+    return out
 
 
 def validate(sim, backend, mass0, distributed, axis):
@@ -246,6 +290,7 @@ def main():
         for _ in range(args.steps):
             sim.step()
         ev1 = backend.make_event(sim.calc_stream, timing=True)
+        res['host_ms'] = (time.perf_counter() - t0) / args.steps * 1e3    # enqueueing only: near ms_per_step = host-bound
         barrier(sim)
         elapsed = time.perf_counter() - t0
         if distributed:
@@ -277,7 +322,7 @@ def main():
     args.access_pattern = best['pattern']
     per_rank = None
     if distributed:
-        mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms') if k in best)
+        mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms', 'host_ms') if k in best)
         mine['rank'] = rank
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, mine)
@@ -336,6 +381,9 @@ def main():
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': load_traffic(wkey),
                          'bytes_per_update': bpu, 'kernel_ms': round(kernel_ms, 4)},
         }
+        if world == 1 and not args.no_runner_path and not distributed and args.scaling == 'weak':
+            cfg['runner_path'] = runner_path(args, local_rank)
+            cfg['runner_path']['vs_value'] = round(cfg['runner_path']['mlups'] / out['value'], 4)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))

@@ -39,6 +39,10 @@ enum { SLF_OK = 0, SLF_ERR_INVALID = 1, SLF_ERR_HIP = 2, SLF_ERR_UNSUPPORTED = 3
 enum { SLF_D2Q9 = 0, SLF_D3Q19 = 1 };
 enum { SLF_BGK = 0, SLF_MRT = 1 };
 enum { SLF_AB = 0, SLF_AA = 1 };
+/* density model = the value of slf_module_desc::incompressible (reference sym.py:573-661, sym_equilibrium.py:100-118):
+ * compressible (rho0 = rho), --incompressible (rho0 = 1), --minimize_roundoff (the arrays hold f_i - w_i, the density
+ * variable is rho - 1, rho0 = rho; BGK with fluid and bounce-back nodes only, as in the reference "BGK-like models") */
+enum { SLF_DENSITY_COMPRESSIBLE = 0, SLF_DENSITY_INCOMPRESSIBLE = 1, SLF_DENSITY_ROUNDOFF = 2 };
 enum { SLF_SIM_LBM = 0, SLF_SIM_SHAN_CHEN_BINARY = 1, SLF_SIM_SHAN_CHEN_SINGLE = 2 };
 
 /* Node addressing (reference subdomain_runner.py:829-878, kernel_common.mako:140-167).  INDIRECT: the
@@ -94,7 +98,7 @@ typedef struct slf_module_desc {
   int32_t arr_nx, arr_ny, arr_nz; /* padded in-memory size (subdomain_runner.py:359-373) */
   int32_t envelope;            /* ghost layer width, always 1 (controller.py:482-494) */
   int32_t periodic_fused[3];   /* 1: the sweep wraps this axis itself (no ghost traffic, no PBC kernel) */
-  int32_t incompressible;      /* --incompressible */
+  int32_t incompressible;      /* density model SLF_DENSITY_*: 0, 1 = --incompressible, 2 = --minimize_roundoff */
   int32_t relaxation_enabled;  /* 0 = streaming only (regtest propagation KATs) */
   int32_t has_force;           /* body force present (lb_base.py:331-359) */
   int32_t fluid_only;          /* 1: no node map is read; every real node is a fluid node */
@@ -170,8 +174,10 @@ int slf_memcpy_peer_async(slf_ctx* ctx, void* dst, int dst_device, const void* s
  *      streams open in HBM at once, and on MI355X its rate depends on WHICH physical regions those streams fall
  *      into (5.3 TB/s when the whole distribution array lies inside one ~16 GiB region, 6.4 TB/s when it straddles
  *      two: profiles/r02/README.md); a plain hipMalloc lands in either case at random.  The backend therefore
- *      reserves the range, creates a few candidate chunks, times the real kernels on candidate pairs and keeps
- *      the best pair (sailfish_amd/placement.py).  All sizes / addresses are multiples of slf_vmm_granularity. ---- */
+ *      reserves the range and backs it with 16 chunks created alternately with spacer allocations, which spreads
+ *      them over ~70 GiB of physical HBM; the runner then times a few steps of the real kernels, places once more
+ *      while the first chunks stay allocated and keeps the better placement (sailfish_amd/placement.py: place(),
+ *      tune()).  All sizes / addresses are multiples of slf_vmm_granularity. ---- */
 int slf_vmm_granularity(slf_ctx* ctx, size_t* bytes);
 int slf_vmm_reserve(slf_ctx* ctx, size_t bytes, void** va);              /* address range only, no memory */
 int slf_vmm_release_range(slf_ctx* ctx, void* va, size_t bytes);
@@ -198,6 +204,18 @@ int slf_comm_group_begin(void);
 int slf_comm_group_end(void);
 int slf_comm_sendrecv(slf_comm* comm, int peer, const void* send_dptr, size_t n_send, void* recv_dptr, size_t n_recv,
                       int elem_bytes, slf_stream* stream);
+/* The whole batch of a halo exchange in one call: n sends / receives posted in the given order (the order in which a
+ * pair of ranks matches them) inside one RCCL group on `stream`. */
+enum { SLF_COMM_SEND = 0, SLF_COMM_RECV = 1 };
+typedef struct slf_comm_op {
+  int32_t kind;        /* SLF_COMM_SEND | SLF_COMM_RECV */
+  int32_t peer;
+  void* dptr;
+  uint64_t count;      /* elements */
+  int32_t elem_bytes;  /* 1 | 4 | 8 */
+  int32_t reserved;
+} slf_comm_op;
+int slf_comm_exchange(slf_comm* comm, const slf_comm_op* ops, int n, slf_stream* stream);
 
 /* ---- streams / events: make_stream, make_event, sync_stream
  *      (backend_cuda.py:291-308, 24-52) ---- */
@@ -233,19 +251,32 @@ int slf_module_destroy(slf_module* m);
  * launched with bit 2 (value 4) of their `options` argument set flag wet nodes whose density is not finite.
  * Waits for `stream`, returns out = {flag, x, y, z} of the first such node and clears the flag. */
 int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]);
+/* Row classes of the node map at `map_dptr` (no counterpart in the reference, whose kernels decode the map in every
+ * thread: geo_helpers.mako:146-161, kernel_common.mako:191-201).  Builds, on the device, one class per 64-node
+ * x-segment of every row -- 0 = all plain fluid: the wavefront that owns the segment neither reads the map (4 of the
+ * 156 bytes a D3Q19 f32 update moves) nor runs node-type code -- and the list of rows that hold boundary-condition
+ * nodes; CollideAndPropagate launches whose map argument is `map_dptr` then sweep the listed rows with the
+ * instantiation for the module's node-type table and all other rows with the small fluid / bounce-back one.
+ * out_counts (may be NULL) = {rows, rows with boundary-condition nodes, segments, plain-fluid segments}.
+ * Optional; call again when the map's contents change, with map_dptr = NULL to drop the tables.  D3Q19 modules with
+ * a node map and direct addressing.  Waits for `stream`. */
+int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* stream, int32_t out_counts[4]);
 /* Kernel names are the reference's: "CollideAndPropagate",
  * "SetInitialConditions", "ApplyPeriodicBoundaryConditions",
  * "ApplyPeriodicBoundaryConditionsWithSwap" (AA modules only),
  * "ApplyMacroPeriodicBoundaryConditions", "CollectSparseData", "DistributeSparseData"
  * (index lists are uint64: q * dist_stride + node index),
- * "CollectContinuousData" / "DistributeContinuousData"(dist, buffer, dirs, base, col_stride, ncols, row_stride, nrows)
+ * "CollectContinuousData" / "DistributeContinuousData"(dist, buffer, dirs, base, col_stride, ncols, row_stride, nrows
+ * [, buffer stride between directions, buffer stride between rows])
  * (reference kernel_utils.mako:526-543, 629-645, 692-708, 777-793: face planes without index lists -- the
  * populations in bit mask `dirs` of the node box base + c col_stride + r row_stride <-> dense buffer [k][r][c];
  * 'i' arguments, base < 2^32), plus "ComputeMacroFields"
  * (rho / v of the current state, arguments as CollideAndPropagate).
  * Binary Shan-Chen modules (simtype = SLF_SIM_SHAN_CHEN_BINARY) provide instead of CollideAndPropagate:
  * "ShanChenPrepareMacroFields"(map, dist1, dist2, rho, phi, vx, vy[, vz], options),
- * "ShanChenCollideAndPropagate0|1"(map, dist_in, dist_out, rho, phi, vx, vy[, vz], options) and the
+ * "ShanChenCollideAndPropagate0|1"(map, dist_in, dist_out, rho, phi, vx, vy[, vz], options),
+ * "ShanChenCollideAndPropagateFused"(map, dist0_in, dist0_out, dist1_in, dist1_out, rho, phi, vx, vy[, vz], options)
+ * = both of them in one pass (the fields and the pseudopotential stencil are read once; same results) and the
  * two-lattice "SetInitialConditions"(map, dist1, dist2, vx, vy[, vz], rho, phi)
  * (reference templates/models/binary_shan_chen.mako:19-141, lb_binary_fluid.mako:87-127).
  * Single-component Shan-Chen modules (SLF_SIM_SHAN_CHEN_SINGLE) keep the single-fluid kernel names; their
@@ -267,13 +298,22 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
  * instead of pushing into the ghost columns x = 0 / nx + 1 and packing them with a strided gather afterwards
  * (reference Collect/DistributeContinuousData on an x face, kernel_utils.mako:526-543), the two edge lanes of every
  * row write what leaves the subdomain straight into send_* and read what enters it from recv_* -- dense buffers
- * [k][z][y] of 5 * arr_ny * arr_nz reals per face (k = rank of the direction among those with e_x > 0 for the high
- * face / the values entering through the low face, e_x < 0 otherwise; rows cover the padded plane).  Each step the
- * host only moves send_high -> the high neighbour's recv_low and send_low -> the low neighbour's recv_high.
- * Entries that are not finite are ignored by the reader (fill the receive buffers with NaN before the first step:
- * the arrays then count).  All CollideAndPropagate kernels of the module use the buffers once set; NULL pointers
+ * [z][k][y] of arr_nz * 5 * arr_ny reals per face (k = rank of the direction among those with e_x > 0 for the high
+ * face / the values entering through the low face, e_x < 0 otherwise; rows cover the padded plane; a range of
+ * z-planes is one contiguous piece, so the planes a z-chunk of the sweep has completed can travel while the next
+ * chunk computes).  Each step the host only moves send_high -> the high neighbour's recv_low and send_low -> the low
+ * neighbour's recv_high.  Entries whose bits are all ones (memset 0xFF) mean "nothing crossed the face here" and are
+ * ignored by the reader -- fill the receive buffers that way before the first step: the arrays then count; every
+ * other value, NaN and infinities included, is delivered.  The pointers may be changed between launches (the
+ * runner alternates two sets by step parity).  All CollideAndPropagate kernels of the module use the buffers once set; NULL pointers
  * switch a face back to ghost columns.  D3Q19 single-fluid modules, direct addressing, x not wrapped in-sweep. */
 int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high);
+
+/* The ghost columns x = 0 (low) / x = nx + 1 (high) of this subdomain are never read -- the face is a wall or open,
+ * neither periodic through the ghost-layer kernels nor connected to another subdomain through ghost columns: the
+ * whole-row sweeps stop pushing into them (five partial-line writes per row and face).  The reference pushes into
+ * ghost nodes regardless (propagation.mako:384-421); only raw dumps of the arrays can tell the difference. */
+int slf_module_set_x_ghost_unused(slf_module* m, int low, int high);
 
 /* number of x-threads per workgroup the sweep uses for this module (diagnostics) */
 int slf_module_block_size(slf_module* m, int* threads);

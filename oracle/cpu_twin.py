@@ -159,6 +159,10 @@ def baseline(model='bgk', precision='single', visc=1.0 / 6.0, budget_s=10.0):
     L.fast_set_threads(1)
     one = box.mlups(2, repeats=1)
     L.fast_set_threads(cores)
+    # the pure-NumPy twin "for context" (SURVEY.md section 8(d)): the kind of CPU path a Python reference would have had
+    from oracle import numpy_twin
+    from sailfish_amd import sym
+    np_mlups = numpy_twin.mlups(sym.D3Q19, (64, 64, 64), visc, steps=2)
     c1 = FastBox('D2Q9', (256, 256), 0.0254, precision)
     c1.init_uniform()
     c1.run(20)
@@ -166,7 +170,9 @@ def baseline(model='bgk', precision='single', visc=1.0 / 6.0, budget_s=10.0):
     return {'value': round(all_cores, 1), 'unit': 'MLUPS', 'cores': cores, 'kind': 'port',
             'logical_cpus': os.cpu_count(), 'cpu_quota': quota,
             'single_thread_mlups': round(one, 2), 'config1_d2q9_256x256_mlups': round(c1_mlups, 1),
+            'numpy_twin_mlups': round(np_mlups, 2),
             'mlups_per_thread': round(all_cores / cores, 2),
             'sample': 'oracle/lbm_fast.c (OpenMP, %d threads pinned to cores, %s): D3Q19 BGK f%d AA periodic 256^3, best of 3 x '
-                      '%d steps; one thread: 2 steps; config 1 = D2Q9 256^2, best of 3 x 400 steps%s'
+                      '%d steps; one thread: 2 steps; config 1 = D2Q9 256^2, best of 3 x 400 steps; numpy_twin = oracle/numpy_twin.py '
+                      '(np.roll, f64, one thread) D3Q19 64^3 x 2 steps%s'
                       % (cores, cpu_model(), 32 if precision == 'single' else 64, steps, note)}

@@ -180,6 +180,7 @@ class HIPBackend(placement.VmmMixin):
     name = 'hip'
     supports_xface = True      # slf_module_set_xface_buffers (sailfish_amd/xface.py)
     supports_stream_priority = True
+    supports_fused_shan_chen = True   # kernel "ShanChenCollideAndPropagateFused"
     FatalError = HIPFatalError
 
     @classmethod
@@ -199,9 +200,18 @@ class HIPBackend(placement.VmmMixin):
                            help='1-D decompositions along x: exchange the x faces through ghost columns and pack / '
                                 'unpack kernels (the reference\'s scheme) instead of the face buffers the sweep writes '
                                 'and reads itself (sailfish_amd/xface.py)')
+        group.add_argument('--nohip_sc_fused', dest='hip_sc_fused', action='store_false', default=True,
+                           help='binary Shan-Chen: one kernel per lattice (the reference\'s ShanChenCollideAndPropagate0 / 1) '
+                                'instead of the fused sweep of both')
+        group.add_argument('--nohip_row_classes', dest='hip_row_classes', action='store_false', default=True,
+                           help='do not classify the rows of the node map: every wavefront reads the map and the whole '
+                                'subdomain runs the kernel instantiation for the module\'s node-type table')
         group.add_argument('--nohip_placement', dest='hip_placement', action='store_false', default=True,
                            help='plain allocations for the distribution arrays instead of spreading their physical '
                                 'backing over HBM (sailfish_amd/placement.py)')
+        group.add_argument('--nohip_placement_tune', dest='hip_placement_tune', action='store_false', default=True,
+                           help='keep the first placement of the distribution arrays instead of timing a few steps on '
+                                'it, placing again and keeping the better one (runs of 200 steps and more)')
         group.add_argument('--nohip_fused_periodic', dest='hip_fused_periodic', action='store_false',
                            default=True,
                            help='apply periodic boundary conditions with separate ghost-layer kernels '
@@ -331,7 +341,8 @@ class HIPBackend(placement.VmmMixin):
         interface: objects with .addr)."""
         bufs = []
         try:
-            bufs = [placement.PlacedBuffer(self, n, align_offset) for n in sizes]
+            for n in sizes:        # one by one: a failure half-way leaves the earlier ones in `bufs` for the clean-up below
+                bufs.append(placement.PlacedBuffer(self, n, align_offset))
             info = placement.place(self, bufs)
         except HIPFatalError as e:
             for buf in bufs:
@@ -472,6 +483,27 @@ class HIPBackend(placement.VmmMixin):
             region = ctypes.byref(hipabi.SlfRegion(int(y0), int(y1), int(z0), int(z1)))
         _check(self._lib, self._lib.slf_kernel_launch(kernel.handle, region, stream.handle if stream else None),
                'slf_kernel_launch(%s)' % kernel.name)
+
+    def classify_rows(self, module, gpu_map, stream=None):
+        """Row classes of the node map at device address `gpu_map` (C ABI slf_module_classify_rows): waves whose 64 nodes
+        are plain fluid skip the map, rows without boundary-condition nodes run the small instantiation.  Returns
+        {'rows', 'bc_rows', 'segments', 'fluid_segments'}; gpu_map = 0 drops the tables."""
+        out = (ctypes.c_int32 * 4)()
+        _check(self._lib, self._lib.slf_module_classify_rows(module.handle, ctypes.c_void_p(gpu_map or None),
+                                                             stream.handle if stream else None, ctypes.byref(out)),
+               'slf_module_classify_rows')
+        return {'rows': out[0], 'bc_rows': out[1], 'segments': out[2], 'fluid_segments': out[3]}
+
+    def set_x_ghost_unused(self, module, low, high):
+        """Nothing reads the ghost column x = 0 (low) / x = nx + 1 (high): the sweeps stop storing into it."""
+        _check(self._lib, self._lib.slf_module_set_x_ghost_unused(module.handle, int(bool(low)), int(bool(high))),
+               'slf_module_set_x_ghost_unused')
+
+    @staticmethod
+    def supports_row_classes(desc):
+        """Modules the row classes exist for: D3Q19 single-fluid with a node map, direct addressing."""
+        return (desc.lattice == hipabi.SLF_D3Q19 and not desc.fluid_only and not int(desc.node_addressing) and
+                not int(desc.simtype))
 
     # -- streams / events -----------------------------------------------------
     def poll_invalid(self, module, stream):

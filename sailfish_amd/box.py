@@ -101,6 +101,9 @@ class BoxSim(object):
             self.node_map = np.ascontiguousarray(node_map, dtype=np.uint32).reshape(self.shape)
             self.gpu_map = b.alloc_buf(like=self.node_map)
         self.stream = b.make_stream()
+        self.row_classes = None
+        if self.gpu_map and b.supports_row_classes(desc) and os.environ.get('SLF_ROW_CLASSES', '1') != '0':
+            self.row_classes = b.classify_rows(self.module, self.gpu_map, self.stream)
         self._make_kernels()
 
     def real_view(self, arr):

@@ -60,6 +60,11 @@ class RingExchanger(object):
         self.up = (rank + 1) % world
         self.down = (rank - 1) % world
 
+    def exchange_range(self, bufs, start, count):
+        """The same exchange for the elements [start, start + count) of the four buffers (x-face buffers: a range of
+        z-planes that the sweep has completed, sailfish_amd/xface.py)."""
+        return self.exchange(*[t[start:start + count] for t in bufs])
+
     def exchange(self, send_up, send_down, recv_low, recv_high):
         import torch
         import torch.distributed as dist
@@ -83,6 +88,91 @@ class RingExchanger(object):
             dev[0].copy_(recv_low)
             dev[1].copy_(recv_high)
         return reqs
+
+
+class DirectRccl(object):
+    """One RCCL communicator per process through the C ABI (slf_comm_*, include/sailfish_hip.h): send / receive are two
+    ctypes calls each, where torch.distributed builds P2POp lists, a coalescing manager and work objects per group --
+    hundreds of microseconds of host time per exchange, which is most of a 0.9 ms step once the halo goes out in
+    several batches.  The 128-byte communicator id is created by rank 0 and handed round through the torch.distributed
+    process group that the launcher set up anyway (the side channel the C ABI asks for)."""
+
+    def __init__(self, backend, rank, world):
+        import ctypes
+        import torch.distributed as dist
+        from sailfish_amd.backend_hip import _check
+        self._ctypes, self._check, self.lib = ctypes, _check, backend._lib
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _check(self.lib, self.lib.slf_comm_unique_id(uid), 'slf_comm_unique_id')
+        if world > 1:
+            box = [uid.raw]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        self.comm = ctypes.c_void_p()
+        _check(self.lib, self.lib.slf_comm_init(backend._ctx, int(world), int(rank), uid, ctypes.byref(self.comm)),
+               'slf_comm_init')
+
+    def prepare(self, ops):
+        """ops: [('send' | 'recv', peer, device address, elements, element bytes)] -> a batch that run() posts in this
+        order inside ONE RCCL group (C ABI slf_comm_exchange: one call per batch; the halo batches of a simulation are
+        the same every step, so they are built once)."""
+        from sailfish_amd import hipabi
+        arr = (hipabi.SlfCommOp * max(1, len(ops)))()
+        for i, (what, peer, addr, n, isz) in enumerate(ops):
+            arr[i].kind = 0 if what == 'send' else 1
+            arr[i].peer, arr[i].dptr, arr[i].count, arr[i].elem_bytes = int(peer), int(addr), int(n), int(isz)
+        return (arr, len(ops))
+
+    def run(self, batch, stream):
+        arr, n = batch
+        self._check(self.lib, self.lib.slf_comm_exchange(self.comm, arr, n, stream.handle), 'slf_comm_exchange')
+
+    def group(self, ops, stream):
+        self.run(self.prepare(ops), stream)
+
+    def close(self):
+        if self.comm:
+            self.lib.slf_comm_destroy(self.comm)
+            self.comm = None
+
+
+class RcclRingExchanger(RingExchanger):
+    """RingExchanger whose transfers go straight to RCCL (DirectRccl) on a stream of the backend."""
+    direct = True
+
+    def __init__(self, rank, world, backend):
+        RingExchanger.__init__(self, rank, world)
+        self.rccl = DirectRccl(backend, rank, world)
+        self._batches = {}
+
+    def exchange_ranges(self, bufs, ranges, stream):
+        """bufs = (send_up, send_down, recv_low, recv_high) tensors; ranges = [(first element, count)]: one group.
+        Posting order = the matching order between a pair of ranks: up first, then down (a ring of two has both
+        messages going to the same peer).  The batch is built once per (buffers, ranges)."""
+        key = (tuple(t.data_ptr() for t in bufs), tuple(ranges))
+        batch = self._batches.get(key)
+        if batch is None:
+            s_up, s_down, r_low, r_high = bufs
+            isz = s_up.element_size()
+            ops = []
+            for start, count in ranges:
+                off = start * isz
+                ops += [('send', self.up, s_up.data_ptr() + off, count, isz), ('send', self.down, s_down.data_ptr() + off, count, isz),
+                        ('recv', self.down, r_low.data_ptr() + off, count, isz), ('recv', self.up, r_high.data_ptr() + off, count, isz)]
+            batch = self._batches[key] = self.rccl.prepare(ops)
+        self.rccl.run(batch, stream)
+
+
+def make_ring_exchanger(rank, world, backend):
+    """The transport of the slab ring: RCCL through the C ABI where the process group is RCCL ("nccl"), otherwise
+    torch.distributed (gloo stages through the host: several ranks on one GPU in the tests), a plain copy for a ring
+    of one without a process group.  SLF_HALO_TRANSPORT=torch forces torch.distributed."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and \
+            os.environ.get('SLF_HALO_TRANSPORT', 'rccl') != 'torch':
+        return RcclRingExchanger(rank, world, backend)
+    return RingExchanger(rank, world)
 
 
 class LocalConnector(object):
@@ -145,10 +235,78 @@ class TorchDistConnector(object):
         for dev, host in staged:
             dev.copy_(host)
 
+    mid_step = True      # exchange_pieces() may be called while the step is still being enqueued
+
+    def view(self, addr, n):
+        """The n elements at device address `addr`, somewhere inside a buffer handed out by alloc_buffer()."""
+        t = self._tensors.get(addr)
+        if t is not None:
+            return t[:n]
+        for base, t in self._tensors.items():
+            off = addr - base
+            if 0 <= off < t.numel() * t.element_size():
+                i = off // t.element_size()
+                return t[i:i + n]
+        raise KeyError('address %#x is not inside a halo buffer of this connector' % addr)
+
+    _rccl = None
+
+    @property
+    def _batches(self):
+        return self.__dict__.setdefault('_batch_cache', {})
+
+    def direct(self, runner):
+        """DirectRccl for this process (None where the process group is not RCCL, or SLF_HALO_TRANSPORT=torch)."""
+        import torch.distributed as dist
+        if self._rccl is None:
+            self._rccl = False
+            if dist.get_backend() == 'nccl' and os.environ.get('SLF_HALO_TRANSPORT', 'rccl') != 'torch' and \
+                    hasattr(runner.backend, '_ctx'):
+                self._rccl = DirectRccl(runner.backend, dist.get_rank(), dist.get_world_size())
+        return self._rccl or None
+
+    def exchange_pieces(self, runner, pieces):
+        """pieces: [(neighbour id, send address, receive address, elements)] -- ranges of the x-face buffers that a
+        z-chunk of the sweep has completed (subdomain_runner._run_sweep_xface); one batched group, on the data stream."""
+        import torch
+        if not pieces:
+            return
+        rccl = self.direct(runner)
+        if rccl is not None:
+            key = tuple(pieces)
+            batch = self._batches.get(key)
+            if batch is None:          # the same few batches every step: built once
+                isz = runner.float().itemsize
+                ops = [('send', self.id_to_rank[nid], s, n, isz) for nid, s, _, n in pieces]
+                ops += [('recv', self.id_to_rank[nid], r, n, isz) for nid, _, r, n in pieces]
+                batch = self._batches[key] = rccl.prepare(ops)
+            rccl.run(batch, runner._data_stream)
+            return
+        sends = [(self.view(s, n), self.id_to_rank[nid]) for nid, s, _, n in pieces]
+        recvs = [(self.view(r, n), self.id_to_rank[nid]) for nid, _, r, n in pieces]
+        if not pieces:
+            return
+        if not sends[0][0].is_cuda:
+            self.exchange_tensors(sends, recvs)
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.ExternalStream(runner._data_stream.native,
+                                                     device=torch.device('cuda', runner.backend.gpu_id))
+        with torch.cuda.stream(self._stream):
+            self.exchange_tensors(sends, recvs)
+
     def exchange(self, runner, kind='dist'):
         import torch
+        msgs = runner.halo_messages(kind)
+        rccl = self.direct(runner) if msgs else None
+        if rccl is not None:
+            isz = runner.float().itemsize
+            ops = [('send', self.id_to_rank[nid], sb, ns, isz) for nid, sb, ns, _, _ in msgs if ns]
+            ops += [('recv', self.id_to_rank[nid], rb, nr, isz) for nid, _, _, rb, nr in msgs if nr]
+            rccl.group(ops, runner._data_stream)
+            return
         sends, recvs = [], []
-        for nid, send_buf, n_send, recv_buf, n_recv in runner.halo_messages(kind):
+        for nid, send_buf, n_send, recv_buf, n_recv in msgs:
             peer = self.id_to_rank[nid]
             if n_send:
                 sends.append((self.tensor(send_buf)[:n_send], peer))

@@ -51,6 +51,11 @@ class LBGeometryProcessor(object):
         return self.subdomains
 
 
+def lb_single_fluid():
+    from sailfish_amd.lb_single import LBFluidSim
+    return LBFluidSim
+
+
 class LocalGroup(object):
     """Lock-step driver for runners that live in this process."""
 
@@ -61,6 +66,8 @@ class LocalGroup(object):
     def exchange(self, kind='dist'):
         """Copies every packed send buffer into the matching receive buffer of the neighbour
         (kind: 'dist' populations, 'macro' fields of non-local models)."""
+        if kind == 'dist' and getattr(self.runners[0], '_xface', None) is not None:
+            return self._exchange_xface()
         events, msgs = {}, {}
         for r in self.runners:
             msgs[r._spec.id] = dict((m[0], m) for m in r.halo_messages(kind))
@@ -83,6 +90,35 @@ class LocalGroup(object):
                 # the owner of send_buf must not pack into it again before this copy has read it (its next pack
                 # is ordered only after its own unpack, i.e. after *its* neighbours' packs, not after our copy)
                 src.send_buffer_readers(kind).append(r.backend.make_event(r._data_stream))
+
+    def _exchange_xface(self):
+        """1-D x decompositions (sailfish_amd/xface.py): every runner has enqueued its sweep in z-chunks; batch i of a
+        runner's face-buffer planes is ready with its i-th chunk event.  The receiver copies it on its data stream and
+        records the event its next step's chunks wait for; the owner of the send set must not write it again (two
+        steps later) before the copy has read it."""
+        for r in self.runners:
+            events = []
+            for pos in range(len(r._xchunks.order)):
+                mine = r.xface_pieces(pos)
+                for nid in sorted(set(p[0] for p in mine)):
+                    src = self.by_id[nid]
+                    # pieces are listed in the order both sides post them: my k-th receive from this neighbour takes
+                    # its k-th send to me
+                    theirs = [p for p in src.xface_pieces(pos) if p[0] == r._spec.id]
+                    r._data_stream.wait_for_event(src._xface_ready[pos])
+                    for (_, _, recv_addr, n), (_, send_addr, _, n_s) in zip([p for p in mine if p[0] == nid], theirs):
+                        assert n == n_s, 'x-face piece mismatch between subdomains %d and %d' % (nid, r._spec.id)
+                        nbytes = n * r.float().itemsize
+                        if src.backend.gpu_id == r.backend.gpu_id:
+                            r.backend.copy_buf_async(recv_addr, send_addr, nbytes, r._data_stream)
+                        else:
+                            r.backend.copy_peer_async(recv_addr, r.backend.gpu_id, send_addr, src.backend.gpu_id,
+                                                      nbytes, r._data_stream)
+                ev = r.backend.make_event(r._data_stream)
+                events.append(ev)
+                for nid in set(p[0] for p in mine):
+                    self.by_id[nid].send_buffer_readers('dist%d' % r._xface_parity).append(ev)
+            r._xface_events = events
 
     def run(self):
         runners = self.runners
@@ -260,10 +296,10 @@ class LBSimulationController(object):
         self.config = self._config_parser.parse(args)
         cfg = self.config
         self._lb_class.modify_config(cfg)
-        if getattr(cfg, 'minimize_roundoff', False):
+        if getattr(cfg, 'minimize_roundoff', False) and not issubclass(self._lb_class, lb_single_fluid()):
             # the reference then stores delta-populations (templates/models/lb_single_fluid.mako:113, sym.py:656-661);
             # silently running the standard formulation would give different numbers under the same flag
-            raise NotImplementedError('--minimize_roundoff is not implemented by the HIP backend')
+            raise NotImplementedError('--minimize_roundoff: single-fluid BGK simulations only')
         if cfg.base_name:
             cfg.output = cfg.output or cfg.base_name
             cfg.checkpoint_file = cfg.checkpoint_file or cfg.base_name

@@ -49,6 +49,7 @@ enum KernelKind {
   KK_SC_MACRO,
   KK_SC_SWEEP0,
   KK_SC_SWEEP1,
+  KK_SC_FUSED,
   KK_SC_INIT,
   KK_SCS_MACRO,
   KK_SCS_SWEEP,
@@ -83,6 +84,8 @@ struct slf_module {
   uint32_t* status;   // device {flag, x, y, z} of the on-GPU invalid value check
   void* xsend[2];     // x-face buffers (slf_module_set_xface_buffers), NULL = unused
   void* xrecv[2];
+  slf::RowClasses rows;   // slf_module_classify_rows; rows.map == NULL: nothing classified
+  void* rows_mem;         // one device allocation behind the tables of `rows`
 };
 struct slf_kernel {
   slf_module* mod;
@@ -368,6 +371,30 @@ int slf_comm_sendrecv(slf_comm* c, int peer, const void* send_dptr, size_t n_sen
   return rc2 ? rccl_fail(rc2, "ncclGroupEnd") : SLF_OK;
 }
 
+// One RCCL group of n point-to-point operations, posted in the given order (= the matching order between a pair of
+// ranks) on `stream`: the whole batch of a halo exchange in one call.
+int slf_comm_exchange(slf_comm* c, const slf_comm_op* ops, int n, slf_stream* stream) {
+  if (!c || (!ops && n > 0)) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (n <= 0) return SLF_OK;
+  SLF_HIP(hipSetDevice(c->ctx->device));
+  int rc = g_rccl.GroupStart();
+  if (rc) return rccl_fail(rc, "ncclGroupStart");
+  for (int i = 0; i < n && !rc; i++) {
+    const slf_comm_op& o = ops[i];
+    if (o.elem_bytes != 4 && o.elem_bytes != 8 && o.elem_bytes != 1) {
+      g_rccl.GroupEnd();
+      return fail(SLF_ERR_INVALID, "elem_bytes must be 1, 4 or 8");
+    }
+    const int dtype = o.elem_bytes == 4 ? 7 /* ncclFloat32 */ : (o.elem_bytes == 8 ? 8 /* ncclFloat64 */ : 0 /* ncclInt8 */);
+    if (o.count == 0) continue;
+    if (o.kind == SLF_COMM_SEND) rc = g_rccl.Send(o.dptr, o.count, dtype, o.peer, c->comm, native(stream));
+    else rc = g_rccl.Recv(o.dptr, o.count, dtype, o.peer, c->comm, native(stream));
+  }
+  const int rc2 = g_rccl.GroupEnd();
+  if (rc) return rccl_fail(rc, "ncclSend/ncclRecv");
+  return rc2 ? rccl_fail(rc2, "ncclGroupEnd") : SLF_OK;
+}
+
 int slf_host_alloc_pinned(size_t bytes, void** hptr) {
   if (!hptr) return fail(SLF_ERR_INVALID, "hptr is NULL");
   SLF_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
@@ -635,29 +662,12 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   if (const char* ev = getenv("SLF_BC_LEVEL")) {      // tests: force the full instantiation
     if (atoi(ev) > g.bc_level) g.bc_level = atoi(ev);
   }
+  g.x_ghost_unused = 0;
   g.use_link_tags = d->use_link_tags;
   g.indirect = d->node_addressing == SLF_ADDR_INDIRECT;
   g.variant = SLF_DEFAULT_VARIANT;
   if (d->sparse_geometry) g.variant |= 64;
   if (const char* ev = getenv("SLF_VARIANT")) g.variant = atoi(ev);
-  g.layout = 0;
-  if (const char* ev = getenv("SLF_LAYOUT")) g.layout = atoi(ev);
-  {
-    const long long Q = (d->lattice == SLF_D2Q9) ? 9 : 19;
-    if (g.layout == 1) {
-      g.dq = (unsigned long long)g.arr_nx;
-      g.dsy = Q * g.arr_nx;
-      g.dsz = Q * (long long)g.arr_nx * g.arr_ny;
-    } else {
-      g.dq = g.dist_size;
-      g.dsy = g.arr_nx;
-      g.dsz = g.arr_nxy;
-    }
-  }
-  g.row_order = 0;
-  g.lds_pad = 0;
-  if (const char* ev = getenv("SLF_ROW_ORDER")) g.row_order = atoi(ev);
-  if (const char* ev = getenv("SLF_LDS_PAD")) g.lds_pad = atoi(ev);
   slf::Physics& ph = m->phys;
   ph.tau = d->tau;
   ph.visc = d->visc;
@@ -670,6 +680,24 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   if (ph.force_edm && d->model != SLF_BGK) {
     delete m;
     return fail(SLF_ERR_UNSUPPORTED, "the exact difference method (force_implementation = EDM) needs the BGK collision");
+  }
+  if (d->incompressible == SLF_DENSITY_ROUNDOFF) {
+    // --minimize_roundoff: "BGK-like models" in the reference (lb_base.py:72-76); here BGK, single fluid, fluid and
+    // bounce-back nodes, through the per-node kernels (slf_node.h: macro_roundoff, bgk_relax_roundoff)
+    bool ok = d->model == SLF_BGK && d->simtype == SLF_SIM_LBM;
+    for (int i = 0; ok && i < d->n_types; i++) {
+      const int k = d->type_kind[i];
+      ok = k == SLF_NK_FLUID || k == SLF_NK_GHOST || k == SLF_NK_UNUSED || k == SLF_NK_PROPAGATION_ONLY ||
+           k == SLF_NK_FULL_BB || k == SLF_NK_HALF_BB;
+    }
+    if (!ok) {
+      delete m;
+      return fail(SLF_ERR_UNSUPPORTED, "minimize_roundoff: BGK single-fluid modules with fluid and bounce-back nodes only");
+    }
+    g.variant = 0;       // no tuned / whole-row kernels: they implement the standard formulation
+  } else if (d->incompressible != SLF_DENSITY_COMPRESSIBLE && d->incompressible != SLF_DENSITY_INCOMPRESSIBLE) {
+    delete m;
+    return fail(SLF_ERR_INVALID, "incompressible must be one of SLF_DENSITY_*");
   }
   m->sc.enabled = (d->simtype == SLF_SIM_SHAN_CHEN_BINARY) ? 1 : ((d->simtype == SLF_SIM_SHAN_CHEN_SINGLE) ? 2 : 0);
   m->sc.tau_phi = d->tau_phi;
@@ -699,6 +727,8 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   m->node_params = nullptr;
   m->status = nullptr;
   m->xsend[0] = m->xsend[1] = m->xrecv[0] = m->xrecv[1] = nullptr;
+  m->rows = slf::RowClasses{};
+  m->rows_mem = nullptr;
   const int np = d->n_node_params > 0 ? d->n_node_params : 1;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc(&m->node_params, (size_t)np * d->precision);
@@ -736,7 +766,66 @@ int slf_module_destroy(slf_module* m) {
   if (m) {
     if (m->node_params) hipFree(m->node_params);
     if (m->status) hipFree(m->status);
+    if (m->rows_mem) hipFree(m->rows_mem);
     delete m;
+  }
+  return SLF_OK;
+}
+
+// Row classes of a node map (RowClasses, slf_kernels.h): which 64-node segments are plain fluid (their waves skip the
+// map), which rows hold boundary-condition nodes (swept by a second launch of the full instantiation, so that all
+// other rows run the small one).  Optional: without it every wave reads the map and the whole subdomain runs the
+// instantiation for the module's node-type table.  Call again after the map's contents changed.
+int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* stream, int32_t out_counts[4]) {
+  if (!m) return fail(SLF_ERR_INVALID, "module is NULL");
+  const slf::Geometry& g = m->geo;
+  if (m->rows_mem) {
+    SLF_HIP(hipFree(m->rows_mem));
+    m->rows_mem = nullptr;
+  }
+  m->rows = slf::RowClasses{};
+  if (out_counts) out_counts[0] = out_counts[1] = out_counts[2] = out_counts[3] = 0;
+  if (!map_dptr) return SLF_OK;                                   // forget the tables
+  if (!m->sel.general || m->sel.lattice != 1 || g.indirect || !(g.variant & 8))
+    return fail(SLF_ERR_UNSUPPORTED, "row classes: D3Q19 modules with a node map and direct addressing (whole-row kernels) only");
+  SLF_HIP(hipSetDevice(m->ctx->device));
+  const int nx = g.lat_nx - 2;
+  const int nseg = (nx + 63) / 64;
+  const size_t nrows_arr = (size_t)g.arr_ny * (size_t)g.arr_nz;
+  const size_t seg_bytes = (nrows_arr * (size_t)nseg + 255) / 256 * 256 + 256;     // + slack: idle waves behind the last segment
+  const size_t row_bytes = (nrows_arr + 255) / 256 * 256;
+  const size_t list_bytes = ((size_t)(g.lat_ny - 2) * (size_t)(g.lat_nz - 2) * 4 + 255) / 256 * 256;
+  char* mem = nullptr;
+  SLF_HIP(hipMalloc((void**)&mem, seg_bytes + row_bytes + list_bytes + 256));
+  hipStream_t s = native(stream);
+  hipError_t e = hipMemsetAsync(mem, 1, seg_bytes + row_bytes, s);          // ghost rows: "mixed", never used
+  if (e == hipSuccess) e = hipMemsetAsync(mem + seg_bytes + row_bytes, 0, list_bytes + 256, s);
+  uint32_t* counters = (uint32_t*)(mem + seg_bytes + row_bytes + list_bytes);
+  if (e == hipSuccess)
+    e = slf::launch_classify_rows(g, map_dptr, (uint32_t*)mem, (uint8_t*)(mem + seg_bytes),
+                                  (uint32_t*)(mem + seg_bytes + row_bytes), counters, nseg, s);
+  uint32_t h[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    hipFree(mem);
+    return hip_fail(e, "slf_module_classify_rows");
+  }
+  m->rows_mem = mem;
+  m->rows.map = map_dptr;
+  m->rows.seg_class = (const uint32_t*)mem;
+  m->rows.row_class = (const uint8_t*)(mem + seg_bytes);
+  m->rows.bc_rows = (const uint32_t*)(mem + seg_bytes + row_bytes);
+  m->rows.nseg = nseg;
+  m->rows.n_rows = (g.lat_ny - 2) * (g.dim == 3 ? g.lat_nz - 2 : 1);
+  m->rows.n_bc_rows = (int)h[0];
+  m->rows.n_fluid_segments = h[1];
+  m->rows.n_segments = (long long)m->rows.n_rows * nseg;
+  if (out_counts) {
+    out_counts[0] = m->rows.n_rows;
+    out_counts[1] = m->rows.n_bc_rows;
+    out_counts[2] = (int32_t)(m->rows.n_segments > 0x7fffffff ? 0x7fffffff : m->rows.n_segments);
+    out_counts[3] = (int32_t)(m->rows.n_fluid_segments > 0x7fffffff ? 0x7fffffff : m->rows.n_fluid_segments);
   }
   return SLF_OK;
 }
@@ -757,7 +846,7 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
   const bool any = send_low || send_high || recv_low || recv_high;
   if (any) {
     const slf::Geometry& g = m->geo;
-    if (m->sel.lattice != 1 || g.indirect || m->sc.enabled || !(g.variant & 8) || (g.variant & 512))
+    if (m->sel.lattice != 1 || g.indirect || m->sc.enabled || !(g.variant & 8))
       return fail(SLF_ERR_UNSUPPORTED, "x-face buffers: D3Q19 single-fluid modules with direct addressing (whole-row kernels) only");
     if (g.wrap[0]) return fail(SLF_ERR_INVALID, "x-face buffers make no sense with x wrapped inside the sweep");
     if (g.lat_nx - 2 > 1024) return fail(SLF_ERR_UNSUPPORTED, "x-face buffers: rows of at most 1024 nodes");
@@ -768,6 +857,18 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
   m->xsend[1] = send_high;
   m->xrecv[0] = recv_low;
   m->xrecv[1] = recv_high;
+  return SLF_OK;
+}
+
+// The ghost columns x = 0 (low) / x = nx + 1 (high) of this subdomain are never read: the face is a wall or open, not
+// periodic through the ghost-layer kernels and not connected to another subdomain.  The whole-row sweeps then leave
+// them alone (the reference pushes into them regardless, propagation.mako:384-421; nothing looks).  Refused for a
+// face the module itself needs: x periodic without in-sweep wrap.
+int slf_module_set_x_ghost_unused(slf_module* m, int low, int high) {
+  if (!m) return fail(SLF_ERR_INVALID, "module is NULL");
+  if ((low || high) && m->geo.axis_mode[0] == 1)
+    return fail(SLF_ERR_INVALID, "x is periodic through the ghost-layer kernels: its ghost columns are read");
+  m->geo.x_ghost_unused = (low ? 1 : 0) | (high ? 2 : 0);
   return SLF_OK;
 }
 
@@ -786,6 +887,7 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   else if (!strcmp(name, "ShanChenPrepareMacroFields")) kk = KK_SC_MACRO;
   else if (!strcmp(name, "ShanChenCollideAndPropagate0")) kk = KK_SC_SWEEP0;
   else if (!strcmp(name, "ShanChenCollideAndPropagate1")) kk = KK_SC_SWEEP1;
+  else if (!strcmp(name, "ShanChenCollideAndPropagateFused")) kk = KK_SC_FUSED;
   else if (!strcmp(name, "ApplyPeriodicBoundaryConditions")) kk = KK_PBC;
   else if (!strcmp(name, "ApplyPeriodicBoundaryConditionsWithSwap")) kk = KK_PBC_SWAP;
   else if (!strcmp(name, "ApplyMacroPeriodicBoundaryConditions")) kk = KK_MACRO_PBC;
@@ -797,7 +899,7 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   else return fail(SLF_ERR_NOT_FOUND, std::string("unknown kernel: ") + name);
   if (kk == KK_SCS_MACRO && m->sc.enabled != 2)
     return fail(SLF_ERR_NOT_FOUND, "PrepareMacroFields only exists in single-component Shan-Chen modules");
-  if ((kk == KK_SC_MACRO || kk == KK_SC_SWEEP0 || kk == KK_SC_SWEEP1) && m->sc.enabled != 1)
+  if ((kk == KK_SC_MACRO || kk == KK_SC_SWEEP0 || kk == KK_SC_SWEEP1 || kk == KK_SC_FUSED) && m->sc.enabled != 1)
     return fail(SLF_ERR_NOT_FOUND, "Shan-Chen kernels only exist in modules built with simtype = SLF_SIM_SHAN_CHEN_BINARY");
   if ((kk == KK_COLLIDE_AND_PROPAGATE || kk == KK_COMPUTE_MACRO) && m->sc.enabled == 1)
     return fail(SLF_ERR_NOT_FOUND, "single-fluid kernels do not exist in a Shan-Chen module");
@@ -845,10 +947,14 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_COLLECT_SPARSE:
     case KK_DISTRIBUTE_SPARSE: want_p = 3; want_i = 1; break;     // idx_array, dist, buffer, n
     case KK_COLLECT_BOX:
-    case KK_DISTRIBUTE_BOX: want_p = 2; want_i = 6; break;        // dist, buffer, dirs, base, col_stride, ncols, row_stride, nrows
+    case KK_DISTRIBUTE_BOX:                                       // dist, buffer, dirs, base, col_stride, ncols, row_stride, nrows
+      want_p = 2;                                                 // [, buffer stride between directions, between rows]
+      want_i = (k->ints.size() == 8) ? 8 : 6;
+      break;
     case KK_SC_MACRO:
     case KK_SC_SWEEP0:
     case KK_SC_SWEEP1: want_p = 5 + dim; want_i = 1; break;       // map, dist, dist, rho, phi, v.., options
+    case KK_SC_FUSED: want_p = 7 + dim; want_i = 1; break;        // map, dist0 in, out, dist1 in, out, rho, phi, v.., options
     case KK_SC_INIT: want_p = 5 + dim; want_i = 0; break;         // map, dist1, dist2, v.., rho, phi
     case KK_SCS_MACRO: want_p = 3; want_i = 1; break;             // map, dist, rho, options
     case KK_SCS_SWEEP: want_p = 4 + dim; want_i = 1; break;       // as CollideAndPropagate
@@ -898,6 +1004,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
         a.xsend[f] = m->xsend[f];
         a.xrecv[f] = m->xrecv[f];
       }
+      a.rows = m->rows.map ? &m->rows : nullptr;
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       if (g.indirect && !a.nodes) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
       slf::Prop prop = slf::PROP_AB;
@@ -953,6 +1060,38 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       if (k->kind == KK_SC_MACRO) e = slf::launch_sc_macro(m->sel, prop, g, m->phys, m->sc, a, y0, y1, z0, z1, s);
       else e = slf::launch_sc_sweep(m->sel, k->kind == KK_SC_SWEEP0 ? 0 : 1, prop, g, m->phys, m->sc, a, y0, y1, z0, z1,
                                     m->block_x, s);
+      break;
+    }
+    case KK_SC_FUSED: {
+      slf::SweepArgs a = {};
+      a.map = (const void*)k->ptrs[0];
+      a.dist_in = (void*)k->ptrs[1];
+      a.dist_out = (void*)k->ptrs[2];
+      a.dist_in2 = (void*)k->ptrs[3];
+      a.dist_out2 = (void*)k->ptrs[4];
+      a.rho = (void*)k->ptrs[5];
+      a.phi = (void*)k->ptrs[6];
+      a.v[0] = (void*)k->ptrs[7];
+      a.v[1] = (void*)k->ptrs[8];
+      a.v[2] = g.dim == 3 ? (void*)k->ptrs[9] : nullptr;
+      a.node_params = m->node_params;
+      a.status = m->status;
+      a.options = (uint32_t)k->ints[0];
+      if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
+      slf::Prop prop = slf::PROP_AB;
+      if (m->access_pattern == SLF_AA) {
+        if (!k->needs_iteration) return fail(SLF_ERR_INVALID, "AA kernels need the iteration argument");
+        prop = (k->iteration & 1u) ? slf::PROP_AA_ODD : slf::PROP_AA_EVEN;
+      }
+      int y0 = 1, y1 = g.lat_ny - 1, z0 = 1, z1 = g.lat_nz - 1;
+      if (g.dim == 2) { z0 = 0; z1 = 1; }
+      if (region) {
+        y0 = region->y0; y1 = region->y1;
+        if (g.dim == 3) { z0 = region->z0; z1 = region->z1; }
+        if (y0 < 1 || y1 > g.lat_ny - 1 || y0 > y1 || (g.dim == 3 && (z0 < 1 || z1 > g.lat_nz - 1 || z0 > z1)))
+          return fail(SLF_ERR_INVALID, "region outside the real nodes of the subdomain");
+      }
+      e = slf::launch_sc_fused(m->sel, prop, g, m->phys, m->sc, a, y0, y1, z0, z1, m->block_x, s);
       break;
     }
     case KK_SCS_MACRO:
@@ -1026,7 +1165,8 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     case KK_DISTRIBUTE_BOX:
       e = slf::launch_box(m->sel, g, k->kind == KK_COLLECT_BOX, (void*)k->ptrs[0], (void*)k->ptrs[1],
                           (unsigned int)k->ints[0], (unsigned long long)(uint32_t)k->ints[1], (long long)k->ints[2],
-                          (int)k->ints[3], (long long)k->ints[4], (int)k->ints[5], s);
+                          (int)k->ints[3], (long long)k->ints[4], (int)k->ints[5],
+                          k->ints.size() == 8 ? (long long)k->ints[6] : 0, k->ints.size() == 8 ? (long long)k->ints[7] : 0, s);
       break;
     case KK_COLLECT_SPARSE:
     case KK_DISTRIBUTE_SPARSE:

@@ -3,22 +3,22 @@
 // Same arithmetic (slf_node.h) and same memory layout as the general kernels in
 // slf_kernels.hip -- results are bit-identical; only the access shape differs.
 //
-// Geometry.variant bits (SLF_VARIANT):
-//   1   non-temporal loads / stores for the populations (streamed once per step)
-//   2,4 even AA step processes 2 / 4 consecutive x nodes per thread with 8 / 16-byte accesses
+// Geometry.variant bits:
+//   1   these kernels at all (0 = the general per-node kernels of slf_kernels.hip)
+//   2   even AA step processes 2 consecutive x nodes per thread with 8-byte accesses
 //       (the even step touches only the node's own slots -> every access is aligned)
 //   8   x-streaming steps (odd AA, AB) use the whole-row kernel with aligned accesses
+// Populations are streamed exactly once per step: every access carries the non-temporal hint (NT).
 #include "slf_sweep.h"
 
 namespace slf {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
-typedef float float4v __attribute__((ext_vector_type(4)));
+constexpr int NT = 3;   // non-temporal loads and stores
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { typedef float type; };
 template <> struct VecT<2> { typedef float2v type; };
-template <> struct VecT<4> { typedef float4v type; };
 
 template <int VEC>
 __device__ __forceinline__ float vget(const typename VecT<VEC>::type& v, int k) {
@@ -34,25 +34,16 @@ __device__ __forceinline__ void vset(typename VecT<VEC>::type& v, int k, float x
 // Even AA step (own node, opposite slot), VEC nodes per thread.  Thread 0 of a row starts at the first
 // real node x = 1; the launcher only selects VEC > 1 when x = 1 is VEC-element aligned in memory (the
 // backend allocates distribution arrays with that offset), so every access is an aligned 8 / 16-byte one.
-template <int MODEL, int VEC, int NT, bool FORCE>
-// (second launch bound: minimum waves per SIMD.  The force-free BGK instantiation needs 82 VGPRs when left alone,
-// two more than six resident waves allow.)
-__global__ void __launch_bounds__(VEC == 4 ? 256 : 512, (VEC == 2 && MODEL == 0 && !FORCE) ? 6 : 2) fast_even_kernel(const SweepParams<D3Q19, float> p) {
+template <int MODEL, int VEC, bool FORCE, bool XFACE>
+__device__ __forceinline__ void fast_even_body(const SweepParams<D3Q19, float>& p, int gy, int gz, uint32_t vi, int gx0) {
   using L = D3Q19;
   typedef typename VecT<VEC>::type V;
   const Geometry& g = p.g;
-  int by = (int)blockIdx.y, bz = (int)blockIdx.z;
-  row_of_block(g.row_order, (int)gridDim.y, (int)gridDim.z, by, bz);
-  const int gy = sgpr(p.y0 + by);
-  const int gz = sgpr(p.z0 + bz);
-  const uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;   // index of this thread's VEC-node group in the row
-  const int gx0 = 1 + (int)vi * VEC;
-  if (gx0 > g.lat_nx - 2) return;
   const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
   const uint32_t gi = row + (uint32_t)gx0;
   const uint32_t vb = vi * (uint32_t)sizeof(V);                // ... and its byte offset from x = 1
-  const size_t ds = g.dq;
-  const size_t drow = (size_t)(g.dsy * gy + g.dsz * gz);       // the row in distribution space (layout, slf_kernels.h)
+  const size_t ds = g.dist_size;
+  const size_t drow = row;
   V fv[L::Q];
   static_for<0, L::Q>([&](auto I) {
     fv[I] = ldg<NT>(at_byte(uniform_base((const V*)(p.din + ds * (size_t)I + drow + 1)), vb));
@@ -62,12 +53,20 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512, (VEC == 2 && MODEL == 0 
   for (int k = 0; k < VEC; k++) {
     float f[L::Q];
     static_for<0, L::Q>([&](auto I) { f[I] = vget<VEC>(fv[I], k); });
+    if constexpr (XFACE) {     // x faces connected through face buffers (x not wrapped): edge nodes only
+      const FaceRows fr = face_rows<L>(g, gy, gz);
+      x_face_receive<L, float, false>(p, f, gx0 + k, g.lat_nx - 2, fr);
+    }
     float rho, v[3];
     macro_standard<L, float>(f, p.cp.incompressible != 0, rho, v);
     if (gx0 + k <= g.lat_nx - 2) check_invalid<float>(p.status, p.options, rho, gx0 + k, gy, gz);
     if (p.relaxation_enabled) {
       if constexpr (MODEL == 0) bgk_relax<L, float, FORCE>(f, rho, v, p.cp);
       else mrt_relax<L, float, FORCE>(f, v, p.cp, false);
+    }
+    if constexpr (XFACE) {
+      const FaceRows fr = face_rows<L>(g, gy, gz);
+      x_face_send_own_row<L, float>(p, f, gx0 + k, g.lat_nx - 2, fr);
     }
     static_for<0, L::Q>([&](auto I) { vset<VEC>(fv[I], k, f[I]); });
     vset<VEC>(orho, k, rho);
@@ -87,14 +86,27 @@ __global__ void __launch_bounds__(VEC == 4 ? 256 : 512, (VEC == 2 && MODEL == 0 
     }
   }
   // nodes of the last group beyond x = nx are the high ghost / padding: their own slots are never read
-  // when x is wrapped in-sweep
+  // when x is wrapped in-sweep (without the wrap the launcher asks for nx % VEC == 0)
   static_for<0, L::Q>([&](auto I) {
     stg<NT>(at_byte(uniform_base((V*)(p.dout + ds * (size_t)L::opp(I) + drow + 1)), vb), fv[I]);
   });
 }
 
+template <int MODEL, int VEC, bool FORCE, bool XFACE>
+// (second launch bound: minimum waves per SIMD.  The force-free BGK instantiation needs 82 VGPRs when left alone,
+// two more than six resident waves allow.)
+__global__ void __launch_bounds__(512, (VEC == 2 && MODEL == 0 && !FORCE) ? 6 : 2) fast_even_kernel(const SweepParams<D3Q19, float> p) {
+  const Geometry& g = p.g;
+  const int gy = sgpr(p.y0 + (int)blockIdx.y);
+  const int gz = sgpr(p.z0 + (int)blockIdx.z);
+  const uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;   // index of this thread's VEC-node group in the row
+  const int gx0 = 1 + (int)vi * VEC;
+  if (gx0 > g.lat_nx - 2) return;
+  fast_even_body<MODEL, VEC, FORCE, XFACE>(p, gy, gz, vi, gx0);
+}
+
 // One node per thread, any propagation mode (scalar accesses), optional non-temporal hint.
-template <int MODEL, int PROP, int NT, bool FORCE>
+template <int MODEL, int PROP, bool FORCE>
 __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   const Geometry& g = p.g;
@@ -152,18 +164,16 @@ __global__ void __launch_bounds__(1024) fast_scalar_kernel(const SweepParams<D3Q
 // workgroup walks the row as two segments at once.  A 1024-node row is then 8 waves with 38 loads in flight each
 // instead of 16 waves that meet at every barrier (4.7 -> 6 TB/s on the odd step, profiles/r02/README.md); the
 // exchange is the same code with "virtual waves" vw = segment * waves + wave.
-template <int MODEL, int PROP, int NT, bool FORCE, int NSEG>
-__global__ void __launch_bounds__(NSEG == 1 ? 1024 : 512, (NSEG == 2 && MODEL == 0 && !FORCE) ? 6 : (NSEG == 1 ? 4 : 2))
+template <int MODEL, int PROP, bool FORCE, int NSEG>
+__global__ void __launch_bounds__(512, (NSEG == 2 && MODEL == 0 && !FORCE) ? 6 : (NSEG == 1 ? 4 : 2))
 fast_row_kernel(const SweepParams<D3Q19, float> p) {
   using L = D3Q19;
   constexpr int NW = 16;
   __shared__ float s_in_p[NW][5], s_in_m[NW][5], s_out_p[NW][5], s_out_m[NW][5];
   __shared__ float s_inw_p[5], s_inw_m[5], s_wrap_p[5], s_wrap_m[5];
   const Geometry& g = p.g;
-  int by = (int)blockIdx.y, bz = (int)blockIdx.z;
-  row_of_block(g.row_order, (int)gridDim.y, (int)gridDim.z, by, bz);
-  const int gy = sgpr(p.y0 + by);
-  const int gz = sgpr(p.z0 + bz);
+  const int gy = sgpr(p.y0 + (int)blockIdx.y);
+  const int gz = sgpr(p.z0 + (int)blockIdx.z);
   const int nx = g.lat_nx - 2;
   const int lane = (int)threadIdx.x & 63;
   const int nwave = (int)blockDim.x >> 6;                       // waves per segment
@@ -177,17 +187,18 @@ fast_row_kernel(const SweepParams<D3Q19, float> p) {
     xb[S] = (uint32_t)(live[S] ? x[S] : 1) * 4u;                // idle lanes: an in-row address, never stored
   });
   const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
-  const DistOff oy = dist_axis_off(gy, g.lat_ny, g.dsy, g.wrap[1]);
-  const DistOff oz = dist_axis_off(gz, g.lat_nz, g.dsz, g.wrap[2]);
-  const size_t ds = g.dq;
-  const long long drow = g.dsy * gy + g.dsz * gz;              // the row in distribution space (layout, slf_kernels.h)
+  AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  AxisOff oz = axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]);
+  oy.p = sgpr(oy.p); oy.m = sgpr(oy.m); oz.p = sgpr(oz.p); oz.m = sgpr(oz.m);
+  const AxisOff ox0 = {0, 0};
+  const size_t ds = g.dist_size;
 
   float f[NSEG][L::Q];
   if constexpr (PROP == PROP_AA_ODD) {
     // raw_i(x) = slot opp(i) at (x, y - e_y, z - e_z): the value node x + e_x will use as f_i
     static_for<0, L::Q>([&](auto I) {
-      const long long off = dist_dir_offset<L, I>(oy, oz, false);
-      const auto base = uniform_base(p.din + ds * (size_t)L::opp(I) + (size_t)(drow + off));
+      const int off = dir_offset<L, I>(ox0, oy, oz, false);
+      const auto base = uniform_base(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)row + off));
       static_for<0, NSEG>([&](auto S) { f[S][I] = ldg<NT>(at_byte(base, xb[S])); });
     });
     static_for<0, NSEG>([&](auto S) {
@@ -227,7 +238,7 @@ fast_row_kernel(const SweepParams<D3Q19, float> p) {
     });
   } else {
     static_for<0, L::Q>([&](auto I) {
-      const auto base = uniform_base(p.din + ds * (size_t)I + (size_t)drow);
+      const auto base = uniform_base(p.din + ds * (size_t)I + row);
       static_for<0, NSEG>([&](auto S) { f[S][I] = ldg<NT>(at_byte(base, xb[S])); });
     });
   }
@@ -269,8 +280,8 @@ fast_row_kernel(const SweepParams<D3Q19, float> p) {
   {
     int kp = 0, km = 0;
     static_for<0, L::Q>([&](auto I) {
-      const long long off = dist_dir_offset<L, I>(oy, oz, true);
-      const auto base = uniform_base(p.dout + ds * (size_t)I + (size_t)(drow + off));
+      const int off = dir_offset<L, I>(ox0, oy, oz, true);
+      const auto base = uniform_base(p.dout + ds * (size_t)I + (uint32_t)((int)row + off));
       static_for<0, NSEG>([&](auto S) {
         float t = f[S][I];
         if constexpr (L::ex(I) > 0) {
@@ -291,76 +302,57 @@ fast_row_kernel(const SweepParams<D3Q19, float> p) {
   }
 }
 
-template <int MODEL, int NT, bool FORCE>
-static bool launch_fast_nt(Prop prop, const Geometry& g, const SweepParams<D3Q19, float>& p, int ny, int nz,
-                           int block_x, hipStream_t s) {
+template <int MODEL, bool FORCE>
+static bool launch_fast_model(Prop prop, const Geometry& g, const SweepParams<D3Q19, float>& p, int ny, int nz,
+                              int block_x, hipStream_t s) {
   const int variant = g.variant;
-  const int vec = (variant & 4) ? 4 : ((variant & 2) ? 2 : 1);
   const int nx = g.lat_nx - 2;
-  // vector accesses need x = 1 on a vec-element boundary of both arrays
-  const bool vec_ok = (((uintptr_t)(p.din + 1)) % (sizeof(float) * vec) == 0) &&
-                      (((uintptr_t)(p.dout + 1)) % (sizeof(float) * vec) == 0) && (g.arr_nx % vec == 0) &&
-                      (g.dist_size % vec == 0);
-  if (prop == PROP_AA_EVEN && vec > 1 && vec_ok) {
-    const int threads_needed = (nx + vec - 1) / vec;
+  // 8-byte accesses need x = 1 on an 8-byte boundary of both arrays
+  const bool vec_ok = (variant & 2) && (((uintptr_t)(p.din + 1)) % 8 == 0) && (((uintptr_t)(p.dout + 1)) % 8 == 0) &&
+                      (g.arr_nx % 2 == 0) && (g.dist_size % 2 == 0);
+  if (prop == PROP_AA_EVEN && vec_ok) {
+    const int threads_needed = (nx + 1) / 2;
     int bx = ((threads_needed + 63) / 64) * 64;
     if (bx > block_x) bx = block_x;
-    if (bx > (vec == 4 ? 256 : 512)) bx = (vec == 4 ? 256 : 512);
+    if (bx > 512) bx = 512;
     dim3 block(bx, 1, 1);
     dim3 grid((threads_needed + bx - 1) / bx, ny, nz);
-    if (vec == 4) hipLaunchKernelGGL((fast_even_kernel<MODEL, 4, NT, FORCE>), grid, block, g.lds_pad, s, p);
-    else hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, NT, FORCE>), grid, block, g.lds_pad, s, p);
+    if (p.xsend[0] || p.xsend[1]) hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, FORCE, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, FORCE, false>), grid, block, 0, s, p);
     return true;
   }
+  if (!g.wrap[0]) return false;                  // everything below wraps x in-sweep
   if ((variant & 8) && prop != PROP_AA_EVEN) {
-    const int bx = ((nx + 63) / 64) * 64;
-    if ((variant & 512) && bx != 64 && bx != 128 && bx != 256 && bx != 512) return false;  // segmented rows (slf_row.hip)
-    if (bx <= 1024) {
-      dim3 grid(1, ny, nz);
-      if (bx > 512 && !(variant & 1024)) {       // two nodes per thread (variant bit 1024: one node per thread, 16 waves)
-        dim3 block((((nx + 1) / 2 + 63) / 64) * 64, 1, 1);
-        if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT, FORCE, 2>), grid, block, g.lds_pad, s, p);
-        else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT, FORCE, 2>), grid, block, g.lds_pad, s, p);
-        return true;
-      }
-      dim3 block(bx, 1, 1);
-      if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, NT, FORCE, 1>), grid, block, g.lds_pad, s, p);
-      else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, NT, FORCE, 1>), grid, block, g.lds_pad, s, p);
+    if (nx > 1024) return false;                 // long rows: segmented row kernel (slf_row.hip)
+    dim3 grid(1, ny, nz);
+    if (nx > 512) {                              // two nodes per thread
+      dim3 block((((nx + 1) / 2 + 63) / 64) * 64, 1, 1);
+      if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, FORCE, 2>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, FORCE, 2>), grid, block, 0, s, p);
       return true;
     }
+    dim3 block(((nx + 63) / 64) * 64, 1, 1);
+    if (prop == PROP_AB) hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AB, FORCE, 1>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((fast_row_kernel<MODEL, PROP_AA_ODD, FORCE, 1>), grid, block, 0, s, p);
+    return true;
   }
-  if (prop != PROP_AA_EVEN && (variant & 8) && nx > 1024) return false;  // long rows: segmented row kernel (slf_row.hip)
-  if (NT == 0) return false;  // plain scalar: the general kernel already does that
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, ny, nz);
   switch (prop) {
-    case PROP_AB: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AB, NT, FORCE>), grid, block, 0, s, p); break;
-    case PROP_AA_EVEN: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_EVEN, NT, FORCE>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_ODD, NT, FORCE>), grid, block, 0, s, p); break;
+    case PROP_AB: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AB, FORCE>), grid, block, 0, s, p); break;
+    case PROP_AA_EVEN: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_EVEN, FORCE>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((fast_scalar_kernel<MODEL, PROP_AA_ODD, FORCE>), grid, block, 0, s, p); break;
   }
   return true;
 }
 
-template <int MODEL, bool FORCE>
-static bool launch_fast_model(Prop prop, const Geometry& g, const SweepParams<D3Q19, float>& p, int ny, int nz,
-                              int block_x, hipStream_t s) {
-  // bit 1: NT loads + stores; bit 16: NT loads only; bit 32: NT stores only
-  int nt = 0;
-  if (g.variant & 1) nt = 3;
-  if (g.variant & 16) nt |= 1;
-  if (g.variant & 32) nt |= 2;
-  switch (nt) {
-    case 0: return launch_fast_nt<MODEL, 0, FORCE>(prop, g, p, ny, nz, block_x, s);
-    case 1: return launch_fast_nt<MODEL, 1, FORCE>(prop, g, p, ny, nz, block_x, s);
-    case 2: return launch_fast_nt<MODEL, 2, FORCE>(prop, g, p, ny, nz, block_x, s);
-    default: return launch_fast_nt<MODEL, 3, FORCE>(prop, g, p, ny, nz, block_x, s);
-  }
-}
-
 bool launch_sweep_fast(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const SweepArgs& a,
                        int y0, int y1, int z0, int z1, int block_x, hipStream_t s, hipError_t* err) {
-  if (sel.general || sel.lattice != 1 || sel.precision != 4 || !g.wrap[0] || g.variant == 0) return false;
-  if (g.variant & 256) return false;   // experiments: use the generic row kernels (slf_row.hip) instead
+  if (sel.general || sel.lattice != 1 || sel.precision != 4 || !(g.variant & 1)) return false;
+  // x not wrapped in-sweep (ghost columns or x-face buffers): the even step is local to the node, its two-nodes-per-
+  // thread form applies when no thread straddles the ghost column; the x-streaming steps go to slf_row.hip
+  if (!g.wrap[0] && !(prop == PROP_AA_EVEN && (g.variant & 2) && (g.lat_nx - 2) % 2 == 0)) return false;
+  if (g.variant & 256) return false;   // tests: route around these kernels, to the fluid-only instantiations of slf_row.hip
   if (y1 <= y0 || z1 <= z0) return false;
   const SweepParams<D3Q19, float> p = make_params<D3Q19, float>(g, ph, a, y0, z0);
   const int ny = y1 - y0, nz = z1 - z0;

@@ -26,20 +26,16 @@ struct Geometry {
   int use_link_tags;
   int variant;                 // tuned-kernel selection bits (SLF_VARIANT), see slf_fast.hip
   int indirect;                // distributions hold active nodes only, addressed through SweepArgs::nodes
-  // Distribution addressing: element (q, x, y, z) lives at q * dq + x + dsy * y + dsz * z.
-  //   direction-major (reference layout, kernel_common.mako:459-461):  dq = dist_size, dsy = arr_nx, dsz = arr_nxy
-  //   row-interleaved [z][y][q][x]:                                     dq = arr_nx, dsy = Q arr_nx, dsz = Q arr_nx arr_ny
-  unsigned long long dq;
-  long long dsy, dsz;
-  int layout;                  // 0 direction-major, 1 row-interleaved
-  int row_order;               // workgroup -> row mapping of the whole-row kernels (SLF_ROW_ORDER), see row_of_block()
-  int lds_pad;                 // extra dynamic LDS bytes per workgroup (SLF_LDS_PAD): occupancy throttle, experiments
   // What the module's node-type table contains (decided once, at module creation): 0 = nothing beyond fluid, ghost,
   // unused, propagation-only and full-way bounce-back nodes; 1 = boundary-condition nodes; 2 = also the outflow
   // nodes that read neighbouring nodes (two-copy pattern).  The f32 whole-row kernels are instantiated per level: the
   // code of conditions a simulation does not use costs registers (52 instead of 78-80 VGPRs at level 0) and, for
   // the outflow nodes, spills in the hot path of the two-copy kernel.
   int bc_level;
+  // bit 0 / 1: nothing ever reads the ghost column x = 0 / x = nx + 1 (the face is neither periodic through the
+  // ghost-layer kernels nor connected to another subdomain): the whole-row kernels do not store into it -- five
+  // partial-line writes per row and face that HBM turns into read-modify-writes (slf_module_set_x_ghost_unused)
+  int x_ghost_unused;
 };
 
 struct Physics {
@@ -60,11 +56,15 @@ struct ShanChen {
   double accel1[3]; // body-force acceleration on lattice 1 (Physics::accel acts on lattice 0)
 };
 
+struct RowClasses;
+
 struct SweepArgs {
   const void* nodes;   // indirect addressing: dense index -> slot table (uint32), else NULL
   const void* map;
   void* dist_in;
   void* dist_out;
+  void* dist_in2;   // second lattice (fused binary Shan-Chen sweep), else unused
+  void* dist_out2;
   void* rho;
   void* phi;        // second density field (binary Shan-Chen), else unused
   void* v[3];
@@ -74,6 +74,25 @@ struct SweepArgs {
   // x-face buffers (slf_module_set_xface_buffers): [0] low face (x = 1 side), [1] high face; NULL = not used
   void* xsend[2];
   const void* xrecv[2];
+  // row classes of the node map `map` (slf_module_classify_rows), NULL = not classified; see RowClasses
+  const RowClasses* rows;
+};
+
+// What slf_module_classify_rows() found in a node map, per 64-node x-segment (= one wavefront of a whole-row
+// workgroup) and per (y, z) row.  Segment class 0: every node of the segment is a plain fluid node -- the wave
+// does not read the map at all (4 of the 156 bytes per update) and runs the straight-line fluid body; 1: other
+// nodes that need no boundary-condition code (ghost, unused, propagation-only, full-way bounce-back); 2: nodes
+// with boundary conditions.  Rows whose worst segment is class 2 are listed in bc_rows and swept by the kernel
+// instantiated for the module's Geometry::bc_level; all other rows by the level-0 instantiation with its 8
+// resident waves per SIMD -- a lid-driven cavity has boundary-condition nodes in 0.2 % of its rows.
+struct RowClasses {
+  const void* map;             // the device node map the tables were built from
+  const uint32_t* seg_class;   // bytes [arr_nz * arr_ny][nseg], addressed as dwords (scalar loads)
+  const uint8_t* row_class;    // [arr_nz * arr_ny]
+  const uint32_t* bc_rows;     // y | z << 16 of the class-2 rows
+  int nseg;                    // segments per row = ceil(nx / 64)
+  int n_rows, n_bc_rows;       // real rows, class-2 rows
+  long long n_fluid_segments, n_segments;
 };
 
 // One module = one (lattice, model, precision, access pattern) specialisation.
@@ -98,10 +117,15 @@ hipError_t launch_sparse(const KernelSelector& sel, bool collect, const unsigned
 
 hipError_t launch_box(const KernelSelector& sel, const Geometry& g, bool collect, void* dist, void* buffer,
                       unsigned int dirs, unsigned long long base, long long col_stride, int ncols, long long row_stride,
-                      int nrows, hipStream_t s);
+                      int nrows, long long buf_k_stride, long long buf_row_stride, hipStream_t s);
 
 hipError_t launch_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
                         const SweepArgs& a, hipStream_t s);
+
+// Builds the tables of RowClasses for `map` (device buffers seg_class, row_class, bc_rows and the counters
+// {class-2 rows, class-0 segments} are the caller's); the counts are read back by the caller.
+hipError_t launch_classify_rows(const Geometry& g, const void* map, uint32_t* seg_class, uint8_t* row_class,
+                                uint32_t* bc_rows, uint32_t* counters, int nseg, hipStream_t s);
 
 // ---- binary Shan-Chen (slf_sc.hip) ----
 // macro pass: a.dist_in = lattice 0, a.dist_out = lattice 1 (both read), writes rho, phi, v
@@ -111,6 +135,9 @@ hipError_t launch_sc_macro(const KernelSelector& sel, Prop prop, const Geometry&
 hipError_t launch_sc_sweep(const KernelSelector& sel, int grid_idx, Prop prop, const Geometry& g, const Physics& ph,
                            const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                            hipStream_t s);
+// both lattices in one pass: a.dist_in / dist_out = lattice 0, a.dist_in2 / dist_out2 = lattice 1
+hipError_t launch_sc_fused(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const ShanChen& sc,
+                           const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s);
 // single-component Shan-Chen: density pass (a.dist_in -> a.rho) and the sweep with the force
 hipError_t launch_scs_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
                             const ShanChen& sc, const SweepArgs& a, hipStream_t s);

@@ -15,13 +15,14 @@
 // wave-uniform scalars and only the +-1 x shift is per lane.  Streaming is
 // "push" for AB and the odd AA step, in-place opposite-slot for the even AA step
 // (reference propagation.mako:170-174, 384-421; geo_helpers.mako:248-276).
+#include "../../include/sailfish_hip.h"
 #include "slf_kernels.h"
 #include "slf_node.h"
 #include "slf_sweep.h"
 
 namespace slf {
 
-template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false>
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool ROUNDOFF = false>
 __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
 
   R rho, v[3];
   bool wet = true;
-  node_update<L, R, MODEL, PROP, GENERAL, INDIRECT>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
+  node_update<L, R, MODEL, PROP, GENERAL, INDIRECT, FORCE_RUNTIME, 2, ROUNDOFF>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
 
   if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
   // ---- macroscopic output (save_macro_fields, kernel_common.mako:213-240)
@@ -109,13 +110,14 @@ __global__ void __launch_bounds__(256) init_kernel(R* dist, const R* __restrict_
     si = nodes[gi];
     if (si == INVALID_NODE) return;
   }
-  const R rho = irho[gi];
+  // incompressible = the module's density model: SLF_DENSITY_ROUNDOFF stores f_i - w_i (lb_single_fluid.mako:113)
+  const R rho = (incompressible == SLF_DENSITY_ROUNDOFF) ? irho[gi] - (R)1 : irho[gi];
   R v[3];
   v[0] = ivx[gi];
   v[1] = ivy[gi];
   v[2] = (R)0;
   if constexpr (L::dim == 3) v[2] = ivz[gi];
-  const R rho0 = incompressible ? (R)1 : rho;
+  const R rho0 = (incompressible == SLF_DENSITY_ROUNDOFF) ? rho + (R)1 : (incompressible ? (R)1 : rho);
   const R u15 = usq15<L, R>(v);
   static_for<0, L::Q>([&](auto I) { (dist + (size_t)g.dist_size * (size_t)I)[si] = feq<L, R, I>(rho, rho0, v, u15); });
 }
@@ -256,7 +258,8 @@ __global__ void __launch_bounds__(256) sparse_kernel(const unsigned long long* _
 // without the 8 bytes of index per 4 bytes of payload of the sparse kernels.
 template <class R, bool COLLECT>
 __global__ void __launch_bounds__(256) box_kernel(R* dist, R* buffer, size_t dq, unsigned int dirs, unsigned long long base,
-                                                  long long col_stride, int ncols, long long row_stride, int nrows) {
+                                                  long long col_stride, int ncols, long long row_stride, int nrows,
+                                                  long long buf_k_stride, long long buf_row_stride) {
   const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int r = (int)blockIdx.y;
   if (c >= ncols) return;
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(256) box_kernel(R* dist, R* buffer, size_t dq,
   for (int i = 0; i < (int)blockIdx.z; i++) m &= m - 1u;      // the blockIdx.z-th set bit
   const int q = __ffs(m) - 1;
   R* node = dist + dq * (size_t)q + base + (size_t)((long long)c * col_stride + (long long)r * row_stride);
-  R* slot = buffer + ((size_t)blockIdx.z * (size_t)nrows + (size_t)r) * (size_t)ncols + (size_t)c;
+  R* slot = buffer + (size_t)blockIdx.z * (size_t)buf_k_stride + (size_t)r * (size_t)buf_row_stride + (size_t)c;
   if constexpr (COLLECT) {
     *slot = *node;
   } else {
@@ -275,18 +278,20 @@ __global__ void __launch_bounds__(256) box_kernel(R* dist, R* buffer, size_t dq,
 
 hipError_t launch_box(const KernelSelector& sel, const Geometry& g, bool collect, void* dist, void* buffer,
                       unsigned int dirs, unsigned long long base, long long col_stride, int ncols, long long row_stride,
-                      int nrows, hipStream_t s) {
+                      int nrows, long long buf_k_stride, long long buf_row_stride, hipStream_t s) {
+  if (buf_k_stride <= 0) buf_k_stride = (long long)nrows * ncols;     // dense [k][r][c]
+  if (buf_row_stride <= 0) buf_row_stride = ncols;
   const int nd = __builtin_popcount(dirs);
   if (nd == 0 || ncols <= 0 || nrows <= 0) return hipSuccess;
   dim3 block(256, 1, 1);
   dim3 grid((ncols + 255) / 256, nrows, nd);
   const size_t dq = g.dist_size;
   if (sel.precision == 4) {
-    if (collect) hipLaunchKernelGGL((box_kernel<float, true>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
-    else hipLaunchKernelGGL((box_kernel<float, false>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
+    if (collect) hipLaunchKernelGGL((box_kernel<float, true>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
+    else hipLaunchKernelGGL((box_kernel<float, false>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
   } else {
-    if (collect) hipLaunchKernelGGL((box_kernel<double, true>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
-    else hipLaunchKernelGGL((box_kernel<double, false>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows);
+    if (collect) hipLaunchKernelGGL((box_kernel<double, true>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
+    else hipLaunchKernelGGL((box_kernel<double, false>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
   }
   return hipGetLastError();
 }
@@ -330,7 +335,8 @@ __global__ void __launch_bounds__(1024) macro_kernel(const SweepParams<L, R> p) 
     }
   });
   R rho, v[3];
-  macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
+  if (p.cp.incompressible == SLF_DENSITY_ROUNDOFF) macro_roundoff<L, R>(f, rho, v);
+  else macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
   p.rho[gi] = rho;
   p.vx[gi] = v[0];
   p.vy[gi] = v[1];
@@ -348,6 +354,14 @@ static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& 
   dim3 block(block_x, 1, 1);
   dim3 grid((g.lat_nx - 2 + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  if constexpr (MODEL == 0) {
+    if (ph.incompressible == SLF_DENSITY_ROUNDOFF) {       // --minimize_roundoff (BGK only; checked at module creation)
+      if (g.indirect) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, true, true>), grid, block, 0, s, p);
+      else if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, false, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false, false, true>), grid, block, 0, s, p);
+      return hipGetLastError();
+    }
+  }
   if (g.indirect) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, true>), grid, block, 0, s, p);
   else if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false>), grid, block, 0, s, p);

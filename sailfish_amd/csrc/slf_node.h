@@ -170,6 +170,61 @@ SLF_D void bgk_relax_accel(R (&f)[L::Q], R rho, R (&v)[3], R omega, R guo_pref, 
   }
 }
 
+// --minimize_roundoff (reference lb_base.py:72-76, "BGK-like models only"): the arrays hold f_i - w_i, so that the
+// O(1) rest-state part never meets the O(Ma) part in one floating-point sum.  The model's density variable is
+// drho = rho - 1 = sum_i (f_i - w_i) (sym.py:573-597); velocities divide by drho + 1 (sym.py:654-661); the equilibrium
+// is w_i (drho + (drho + 1) h_i(u)) (sym_equilibrium.py:100-118: rho0 = rho + 1); the Guo prefactor carries drho + 1
+// (sym_force.py:147-160); SetInitialConditions subtracts 1 from the density field (lb_single_fluid.mako:113) and the
+// density output is drho (kernel_common.mako:216-224).
+template <class L, class R>
+SLF_D void macro_roundoff(const R (&f)[L::Q], R& drho, R (&v)[3]) {
+  drho = density<L, R>(f);
+  const R rho0 = drho + (R)1;
+  v[0] = momentum<L, R, 0>(f) / rho0;
+  v[1] = momentum<L, R, 1>(f) / rho0;
+  v[2] = (R)0;
+  if constexpr (L::dim == 3) v[2] = momentum<L, R, 2>(f) / rho0;
+}
+
+template <class L, class R>
+SLF_D void bgk_relax_roundoff(R (&f)[L::Q], R drho, R (&v)[3], R omega, R guo_pref, bool has_force, const R (&a)[3],
+                              bool edm) {
+  const R rho0 = drho + (R)1;
+  if (has_force && edm) {
+    R vs[3] = {v[0] + a[0], v[1] + a[1], (R)0};
+    if constexpr (L::dim == 3) vs[2] = v[2] + a[2];
+    const R u15 = usq15<L, R>(v);
+    const R u15s = usq15<L, R>(vs);
+    static_for<0, L::Q>([&](auto I) {
+      const R fe = feq<L, R, I>(drho, rho0, v, u15);
+      const R fs = feq<L, R, I>(drho, rho0, vs, u15s);
+      f[I] = f[I] + omega * (fe - f[I]);
+      f[I] = f[I] + (fs - fe);
+    });
+    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * a[D]; });
+    return;
+  }
+  if (has_force) {
+    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * a[D]; });
+  }
+  const R u15 = usq15<L, R>(v);
+  static_for<0, L::Q>([&](auto I) {
+    const R fe = feq<L, R, I>(drho, rho0, v, u15);
+    f[I] = f[I] + omega * (fe - f[I]);
+  });
+  if (has_force) {
+    const R pref = rho0 * guo_pref;
+    R va = v[0] * a[0] + v[1] * a[1];
+    if constexpr (L::dim == 3) va = va + v[2] * a[2];
+    static_for<0, L::Q>([&](auto I) {
+      const R eu = edotv<L, R, I>(v);
+      const R ea = edotv<L, R, I>(a);
+      const R t = (ea - va) + (R)3 * eu * ea;
+      f[I] = f[I] + pref * Weights<L, R>::w(I) * t;
+    });
+  }
+}
+
 // FORCE: what the instantiation knows about the body force at compile time.
 //   0  the module has none: the Guo / exact-difference code (and the registers its merge points cost: 98 -> 48 VGPRs in
 //      the whole-row kernel, 4 -> 8 resident waves per SIMD) does not exist in the instantiation;

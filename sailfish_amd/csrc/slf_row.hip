@@ -28,15 +28,40 @@ namespace slf {
 // dependent round trip map -> loads costs 4-6 % of the odd step at 512^3 (profiles/r01/row_probe7.log,
 // row_probe8.log); loading for excluded nodes as well wastes their bytes, so the host asks for SPEC only when
 // few nodes are excluded.
-template <class L, class R, int MODEL, int PROP, bool GENERAL, int NT, bool FORCE, bool SPEC = false, int BCL = 2>
-// (second launch bound = minimum resident waves per SIMD: the f32 node-map instantiations fit 6 without spilling --
-// 77-80 VGPRs instead of 81-91 -- which is worth a wave of occupancy; checked with -Rpass-analysis=kernel-resource-usage.
-// Not the BGK instantiations with a body force: their Guo / exact-difference branches need ~94 and would spill 60-100 B)
-__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row_kernel(const SweepParams<L, R> p) {
+//
+// Row classes (RowClasses, slf_kernels.h; node-map instantiations): a wave whose 64 nodes are all plain fluid
+// (segment class 0, one scalar load) does not read the map -- its lanes are fluid nodes by construction (a second,
+// straight-line collision body for such waves was tried: two inlined collisions in one kernel cost 16-30 VGPRs and
+// spill, profiles/r03/row_classes_resources.txt); rows with
+// boundary-condition nodes are left to a second launch of the instantiation for the module's bc_level over the
+// list of those rows (launch_row(), slf_sweep.h), so that everything else -- 99.8 % of a lid-driven cavity -- runs
+// the BCL = 0 instantiation with its small register budget.
+constexpr int NT = 3;   // populations are streamed once per step: non-temporal loads and stores
+
+// Minimum resident waves per SIMD asked of the compiler (second launch bound; it budgets VGPRs *and* SGPRs for it --
+// 800 SGPRs per SIMD make 104 of them a 7-wave kernel however few VGPRs it has).  The f32 node-map instantiations fit
+// 6 without spilling (77-80 VGPRs instead of 81-91); those for tables without boundary-condition nodes and modules
+// without a body force fit 8 (BGK, 46-53 VGPRs); MRT is asked for 6 (73 VGPRs: one more than 7 waves allow, and squeezing it
+// there spills 12 bytes, which measured 2 % slower: profiles/r03/configs_v2.txt); checked with -Rpass-analysis=kernel-resource-usage
+// (tools/resource_usage.py, profiles/r03/row_kernels_resources.txt).
+#ifndef SLF_MRT_L0_WAVES
+#define SLF_MRT_L0_WAVES 6
+#endif
+template <class R, int MODEL, bool GENERAL, bool FORCE, int BCL>
+constexpr int row_min_waves() {
+  if (sizeof(R) != 4 || !GENERAL) return 4;
+  if (BCL == 0 && !FORCE) return MODEL == 0 ? 8 : SLF_MRT_L0_WAVES;
+  return 6;
+}
+
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool FORCE, bool SPEC = false, int BCL = 2>
+__global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE, BCL>())) row_kernel(const SweepParams<L, R> p) {
   static_assert(PROP == PROP_AB || PROP == PROP_AA_ODD, "the even AA step has no x shift");
   const Geometry& g = p.g;
-  const int gy = sgpr(p.y0 + (int)blockIdx.y);
-  const int gz = (L::dim == 3) ? sgpr(p.z0 + (int)blockIdx.z) : 0;
+  int ry, rz;
+  if (!launch_row(p, ry, rz)) return;          // the whole workgroup: before any barrier
+  const int gy = sgpr(ry);
+  const int gz = (L::dim == 3) ? sgpr(rz) : 0;
   const int nx = g.lat_nx - 2;
   const int x = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const bool live = x <= nx;
@@ -49,6 +74,9 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row
   oy.p = sgpr(oy.p); oy.m = sgpr(oy.m); oz.p = sgpr(oz.p); oz.m = sgpr(oz.m);
   const AxisOff ox0 = {0, 0};
   const size_t ds = g.dist_size;
+  // class of this wave's 64 nodes: 0 = all plain fluid (no map access)
+  int cls = 1;
+  if constexpr (GENERAL) cls = sgpr(segment_class(p, gy, gz, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
 
   // ---- load.  Every address = (wave-uniform row base of the direction, in SGPRs) + (this lane's byte offset in
   // the row): uniform_base(), slf_sweep.h.  Odd AA step: pull with plain x-shifted loads -- misaligned *reads*
@@ -78,15 +106,17 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row
   uint32_t code = 0;
   bool active = live;
   if constexpr (GENERAL) {
-    code = p.map[gi];
-    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
-    active = live && !kind_is_excluded(kind);
+    if (cls != 0) {
+      code = p.map[gi];
+      kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+      active = live && !kind_is_excluded(kind);
+    }
   }
   if constexpr (GENERAL && !SPEC) {
     static_for<0, L::Q>([&](auto I) { f[I] = active ? load(I) : (R)0; });
   }
 
-  const FaceRows fr = face_rows(g, gy, gz);
+  const FaceRows fr = face_rows<L>(g, gy, gz);
   if (active) x_face_receive<L, R, PROP == PROP_AA_ODD>(p, f, x, nx, fr);
   R rho, v[3];
   bool wet = true;
@@ -107,12 +137,16 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4) ? 6 : 4) row
 // Even AA step: every access is to the node's own slots (aligned); per-node kernel with cache hints.
 // SPEC (node-map instantiations, dense geometries): issue the 19 loads before the node map has arrived, as in
 // row_kernel -- the map -> loads dependency is the longest chain of this kernel; excluded nodes then load in vain.
-template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE, bool SPEC = false>
-__global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && MODEL == 1) ? 6 : 4) even_kernel(const SweepParams<L, R> p) {
+template <class L, class R, int MODEL, bool GENERAL, bool FORCE, bool SPEC = false, int BCL = 2>
+__global__ void __launch_bounds__(1024, (BCL == 0 ? row_min_waves<R, MODEL, GENERAL, FORCE, BCL>() : ((GENERAL && sizeof(R) == 4 && MODEL == 1) ? 6 : 4))) even_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
-  const int gy = sgpr(p.y0 + (int)blockIdx.y);
-  const int gz = (L::dim == 3) ? sgpr(p.z0 + (int)blockIdx.z) : 0;
+  int ry, rz;
+  if (!launch_row(p, ry, rz)) return;
+  const int gy = sgpr(ry);
+  const int gz = (L::dim == 3) ? sgpr(rz) : 0;
   const int gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  int cls = 1;
+  if constexpr (GENERAL) cls = sgpr(segment_class(p, gy, gz, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
   if (gx > g.lat_nx - 2) return;
   const uint32_t row = sgpr((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz);
   const uint32_t gi = row + (uint32_t)gx;
@@ -125,9 +159,11 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && MODEL == 1
     static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
   }
   if constexpr (GENERAL) {
-    code = p.map[gi];
-    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
-    if (kind_is_excluded(kind)) return;
+    if (cls != 0) {
+      code = p.map[gi];
+      kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+      if (kind_is_excluded(kind)) return;
+    }
   }
   const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
   const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
@@ -135,11 +171,11 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && MODEL == 1
   if constexpr (!(GENERAL && SPEC)) {
     static_for<0, L::Q>([&](auto I) { f[I] = ldg<NT>(at_byte(uniform_base(p.din + ds * (size_t)I + row), xb)); });
   }
-  const FaceRows fr = face_rows(g, gy, gz);
+  const FaceRows fr = face_rows<L>(g, gy, gz);
   x_face_receive<L, R, false>(p, f, gx, g.lat_nx - 2, fr);
   R rho, v[3];
   bool wet = true;
-  node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL, false, FORCE>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
+  node_update<L, R, MODEL, PROP_AA_EVEN, GENERAL, false, FORCE, BCL>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet);
   if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
   if ((p.options & 1u) && wet) {
     p.rho[gi] = rho;
@@ -151,62 +187,78 @@ __global__ void __launch_bounds__(1024, (GENERAL && sizeof(R) == 4 && MODEL == 1
   x_face_send_own_row<L, R>(p, f, gx, g.lat_nx - 2, fr);
 }
 
-template <class L, class R, int MODEL, bool GENERAL, int NT, bool FORCE>
-static void launch_row5(Prop prop, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
-  const int bx = row_block_x(nx, p.g.variant);
-  dim3 block(bx, 1, 1);
-  dim3 grid((nx + bx - 1) / bx, ny, nz);
-  // node-map kernels in single precision: one instantiation per Geometry::bc_level (slf_kernels.h)
-  constexpr bool LEVELS = GENERAL && sizeof(R) == 4;
-  const int bcl = LEVELS ? p.g.bc_level : 2;
+// One launch of the instantiation for boundary-condition level BCL.  variant bit 64 = the module descriptor says
+// "sparse geometry" (many excluded nodes): predicate the loads on the node map instead of issuing them first.
+template <class L, class R, int MODEL, bool GENERAL, bool FORCE, int BCL>
+static void launch_level(Prop prop, const SweepParams<L, R>& p, dim3 grid, dim3 block, hipStream_t s) {
+  const bool spec = GENERAL && !(p.g.variant & 64);
   switch (prop) {
     case PROP_AB:   // (no gain from SPEC here: row_probe8.log)
-      if constexpr (LEVELS) {
-        if (bcl == 0) { hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT, FORCE, false, 0>), grid, block, 0, s, p); break; }
-        if (bcl == 1) { hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT, FORCE, false, 1>), grid, block, 0, s, p); break; }
-      }
-      hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, NT, FORCE>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AB, GENERAL, FORCE, false, BCL>), grid, block, 0, s, p);
       break;
     case PROP_AA_ODD:
-      // variant bit 64 = the module descriptor says "sparse geometry" (many excluded nodes): predicate
-      if constexpr (LEVELS) {
-        if (bcl == 0) {
-          if (!(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, true, 0>), grid, block, 0, s, p);
-          else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, false, 0>), grid, block, 0, s, p);
-          break;
-        }
-      }
-      if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE, GENERAL>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, NT, FORCE>), grid, block, 0, s, p);
+      if (spec) hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, FORCE, GENERAL, BCL>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((row_kernel<L, R, MODEL, PROP_AA_ODD, GENERAL, FORCE, false, BCL>), grid, block, 0, s, p);
       break;
     default:
-      if (GENERAL && !(p.g.variant & 64)) hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT, FORCE, GENERAL>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, NT, FORCE>), grid, block, 0, s, p);
+      if (spec) hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, FORCE, GENERAL, BCL>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((even_kernel<L, R, MODEL, GENERAL, FORCE, false, BCL>), grid, block, 0, s, p);
       break;
   }
+}
+
+template <class L, class R, int MODEL, bool GENERAL, bool FORCE>
+static void launch_row5(Prop prop, SweepParams<L, R> p, int nx, int ny, int nz, const RowClasses* rc, hipStream_t s) {
+  const int bx = row_block_x(nx);
+  dim3 block(bx, 1, 1);
+  dim3 grid((nx + bx - 1) / bx, ny, nz);
+  p.y1 = p.y0 + ny;
+  p.z1 = p.z0 + nz;
+  // node-map kernels in single precision: one instantiation per Geometry::bc_level (slf_kernels.h)
+  if constexpr (GENERAL && sizeof(R) == 4) {
+    const int bcl = p.g.bc_level;
+    if (bcl == 0) {
+      launch_level<L, R, MODEL, GENERAL, FORCE, 0>(prop, p, grid, block, s);
+      return;
+    }
+    if (rc && p.seg_class) {
+      // rows without boundary-condition nodes: level 0; the others (listed): the module's level
+      if (rc->n_bc_rows < rc->n_rows) {
+        p.row_mode = rc->n_bc_rows ? 1 : 0;
+        launch_level<L, R, MODEL, GENERAL, FORCE, 0>(prop, p, grid, block, s);
+      }
+      if (rc->n_bc_rows) {
+        p.row_mode = 2;
+        grid = dim3(grid.x, rc->n_bc_rows, 1);
+        if (bcl == 1) launch_level<L, R, MODEL, GENERAL, FORCE, 1>(prop, p, grid, block, s);
+        else launch_level<L, R, MODEL, GENERAL, FORCE, 2>(prop, p, grid, block, s);
+      }
+      return;
+    }
+    if (bcl == 1) {
+      launch_level<L, R, MODEL, GENERAL, FORCE, 1>(prop, p, grid, block, s);
+      return;
+    }
+  }
+  launch_level<L, R, MODEL, GENERAL, FORCE, 2>(prop, p, grid, block, s);
 }
 
 template <class L, class R, int MODEL, bool GENERAL>
-static void launch_row4(Prop prop, int nt, const SweepParams<L, R>& p, int nx, int ny, int nz, hipStream_t s) {
-  const bool force = p.cp.has_force != 0;   // compile-time "no body force" instantiations: see bgk_relax, slf_node.h
-  if (nt == 3) {
-    if (force) launch_row5<L, R, MODEL, GENERAL, 3, true>(prop, p, nx, ny, nz, s);
-    else launch_row5<L, R, MODEL, GENERAL, 3, false>(prop, p, nx, ny, nz, s);
-  } else {
-    if (force) launch_row5<L, R, MODEL, GENERAL, 0, true>(prop, p, nx, ny, nz, s);
-    else launch_row5<L, R, MODEL, GENERAL, 0, false>(prop, p, nx, ny, nz, s);
-  }
+static void launch_row4(Prop prop, const SweepParams<L, R>& p, int nx, int ny, int nz, const RowClasses* rc, hipStream_t s) {
+  // compile-time "body force or not" instantiations: see bgk_relax, slf_node.h
+  if (p.cp.has_force != 0) launch_row5<L, R, MODEL, GENERAL, true>(prop, p, nx, ny, nz, rc, s);
+  else launch_row5<L, R, MODEL, GENERAL, false>(prop, p, nx, ny, nz, rc, s);
 }
 
 template <class L, class R>
-static void launch_row2(const KernelSelector& sel, Prop prop, int nt, const SweepParams<L, R>& p, int nx, int ny,
-                        int nz, hipStream_t s) {
+static void launch_row2(const KernelSelector& sel, Prop prop, const SweepParams<L, R>& p, int nx, int ny, int nz,
+                        const RowClasses* rc, hipStream_t s) {
   if (sel.model == 0) {
-    if (sel.general) launch_row4<L, R, 0, true>(prop, nt, p, nx, ny, nz, s);
-    else launch_row4<L, R, 0, false>(prop, nt, p, nx, ny, nz, s);
+    if (sel.general) launch_row4<L, R, 0, true>(prop, p, nx, ny, nz, rc, s);
+    else launch_row4<L, R, 0, false>(prop, p, nx, ny, nz, rc, s);
   } else {
-    if (sel.general) launch_row4<L, R, 1, true>(prop, nt, p, nx, ny, nz, s);
-    else launch_row4<L, R, 1, false>(prop, nt, p, nx, ny, nz, s);
+    if (sel.general) launch_row4<L, R, 1, true>(prop, p, nx, ny, nz, rc, s);
+    else launch_row4<L, R, 1, false>(prop, p, nx, ny, nz, rc, s);
   }
 }
 
@@ -218,11 +270,62 @@ bool launch_sweep_row(const KernelSelector& sel, Prop prop, const Geometry& g, c
   if (!(g.variant & 8) || sel.lattice != 1 || nx < 1) return false;
   const int ny = y1 - y0, nz = (g.dim == 3) ? z1 - z0 : 1;
   if (ny <= 0 || nz <= 0) return false;
-  const int nt = (g.variant & 1) ? 3 : 0;
-  if (sel.precision == 4) launch_row2<D3Q19, float>(sel, prop, nt, make_params<D3Q19, float>(g, ph, a, y0, z0), nx, ny, nz, s);
-  else launch_row2<D3Q19, double>(sel, prop, nt, make_params<D3Q19, double>(g, ph, a, y0, z0), nx, ny, nz, s);
+  const RowClasses* rc = (sel.general && a.rows && a.rows->map == a.map) ? a.rows : nullptr;
+  if (sel.precision == 4) launch_row2<D3Q19, float>(sel, prop, make_params<D3Q19, float>(g, ph, a, y0, z0), nx, ny, nz, rc, s);
+  else launch_row2<D3Q19, double>(sel, prop, make_params<D3Q19, double>(g, ph, a, y0, z0), nx, ny, nz, rc, s);
   *err = hipGetLastError();
   return true;
+}
+
+// ---- row classification (slf_module_classify_rows) ------------------------------------------------------------
+// One workgroup per real (y, z) row; wave w looks at the segments w, w + 4, ...: class of a segment = the worst
+// node kind among its live lanes (0 plain fluid, 1 no boundary-condition code, 2 boundary conditions).
+__global__ void __launch_bounds__(256) classify_rows_kernel(const uint32_t* __restrict__ map, Geometry g, uint8_t* seg_class,
+                                                            uint8_t* row_class, uint32_t* bc_rows, uint32_t* counters,
+                                                            int nseg) {
+  __shared__ int s_max, s_fluid;
+  const int gy = 1 + (int)blockIdx.y;
+  const int gz = (g.dim == 3) ? 1 + (int)blockIdx.z : 0;
+  const int nx = g.lat_nx - 2;
+  const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+  if (threadIdx.x == 0) { s_max = 0; s_fluid = 0; }
+  __syncthreads();
+  const uint32_t rowidx = (uint32_t)(gy + g.arr_ny * gz);
+  const uint32_t row = (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  int wmax = 0, wfluid = 0;
+  for (int sgm = w; sgm < nseg; sgm += 4) {
+    const int x = 1 + sgm * 64 + lane;
+    int level = 0;
+    if (x <= nx) {
+      const uint32_t code = map[row + (uint32_t)x];
+      const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+      const bool plain = kind_is_excluded(kind) || kind == NK_FULL_BB;
+      level = (kind == NK_FLUID) ? 0 : (plain ? 1 : 2);
+    }
+    const int c = __any(level == 2) ? 2 : (__any(level == 1) ? 1 : 0);
+    if (lane == 0) seg_class[rowidx * (uint32_t)nseg + (uint32_t)sgm] = (uint8_t)c;
+    wmax = c > wmax ? c : wmax;
+    wfluid += c == 0 ? 1 : 0;
+  }
+  if (lane == 0) {
+    atomicMax(&s_max, wmax);
+    atomicAdd(&s_fluid, wfluid);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    row_class[rowidx] = (uint8_t)s_max;
+    if (s_max == 2) bc_rows[atomicAdd(&counters[0], 1u)] = (uint32_t)gy | ((uint32_t)gz << 16);
+    atomicAdd(&counters[1], (uint32_t)s_fluid);
+  }
+}
+
+hipError_t launch_classify_rows(const Geometry& g, const void* map, uint32_t* seg_class, uint8_t* row_class,
+                                uint32_t* bc_rows, uint32_t* counters, int nseg, hipStream_t s) {
+  dim3 block(256, 1, 1);
+  dim3 grid(1, g.lat_ny - 2, g.dim == 3 ? g.lat_nz - 2 : 1);
+  hipLaunchKernelGGL(classify_rows_kernel, grid, block, 0, s, (const uint32_t*)map, g, (uint8_t*)seg_class, row_class,
+                     bc_rows, counters, nseg);
+  return hipGetLastError();
 }
 
 }  // namespace slf

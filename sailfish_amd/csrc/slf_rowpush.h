@@ -14,13 +14,6 @@
 
 namespace slf {
 
-template <class L>
-constexpr int count_x_dirs() {
-  int n = 0;
-  for (int i = 0; i < L::Q; i++) n += (L::ex(i) > 0) ? 1 : 0;
-  return n;
-}
-
 template <class R>
 __device__ __forceinline__ R shfl_up1(R v) { return __shfl_up(v, 1); }
 template <class R>
@@ -96,7 +89,9 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
         // around the periodic seam to x = 1
         if (edge_stores && x == xe && active) {
           if (xsend && xsend[1] && x == nx) {      // leaves through a connected high face: straight into the send buffer
-            xsend[1][(size_t)g.arr_ny * (size_t)g.arr_nz * x_dir_rank<L, I>() + (size_t)face_row_of<L, I>(*fr, true)] = f[I];
+            xsend[1][face_elem<L, I>(*fr, 1)] = f[I];
+          } else if (x == nx && !wrapx && (g.x_ghost_unused & 2)) {
+            // a ghost column nothing reads
           } else {
             stg<0>(dst + ((wrapx && x == nx) ? -(nx - 1) : 1), f[I]);
           }
@@ -110,7 +105,9 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
       if constexpr (L::ex(I) < 0) {
         if (edge_stores && x == xs && active) {
           if (xsend && xsend[0] && x == 1) {
-            xsend[0][(size_t)g.arr_ny * (size_t)g.arr_nz * x_dir_rank<L, I>() + (size_t)face_row_of<L, I>(*fr, true)] = f[I];
+            xsend[0][face_elem<L, I>(*fr, 1)] = f[I];
+          } else if (x == 1 && !wrapx && (g.x_ghost_unused & 1)) {
+            // a ghost column nothing reads
           } else {
             stg<0>(dst + ((wrapx && x == 1) ? (nx - 1) : -1), f[I]);
           }
@@ -126,23 +123,17 @@ __device__ __forceinline__ void row_push(const Geometry& g, const R (&f)[L::Q], 
   }
 }
 
-// Workgroup width for a row of nx nodes.  Up to 1024 nodes: the whole row.  Rows of 9-12 waves run 15-25 % below
-// the 8-wave rows of nx = 512, but cutting them into x-segments of 8 waves (row_push supports it: gridDim.x > 1,
-// variant bit 512) is slower still -- the partial-line stores of the segment edges cost more than the better fit buys
-// (profiles/r01/segmented_rows.log vs pad_rowshape.log).  Longer rows have no whole-row form: equal segments of at
-// most 8 waves, each a multiple of 64 nodes so that segment starts stay line aligned -- 5.9-6.1 TB/s on the
-// x-streaming steps where the per-node kernel with its misaligned stores reaches 5.2-5.5 (profiles/r02/long_rows.log).
-static inline int row_block_x(int nx, int variant) {
+// Workgroup width for a row of nx nodes.  Up to 1024 nodes: the whole row (rows of 9-12 waves run 15-25 % below the
+// 8-wave rows of nx = 512, but cutting them into x-segments of 8 waves is slower still -- the partial-line stores of
+// the segment edges cost more than the better fit buys: profiles/r01/segmented_rows.log vs pad_rowshape.log).  Longer
+// rows have no whole-row form: equal segments of at most 8 waves, each a multiple of 64 nodes so that segment starts
+// stay line aligned -- 5.9-6.1 TB/s on the x-streaming steps where the per-node kernel with its misaligned stores
+// reaches 5.2-5.5 (profiles/r02/long_rows.log).
+static inline int row_block_x(int nx) {
   const int waves = (nx + 63) / 64;
-  if (nx > 1024) {
-    const int nseg = (waves + 7) / 8;
-    return ((waves + nseg - 1) / nseg) * 64;
-  }
-  if (!(variant & 512)) return waves * 64;
-  if (waves == 1 || waves == 2 || waves == 4 || waves == 8) return waves * 64;
-  int seg = 512;
-  while (seg >= nx) seg >>= 1;
-  return seg < 64 ? 64 : seg;
+  if (nx <= 1024) return waves * 64;
+  const int nseg = (waves + 7) / 8;
+  return ((waves + nseg - 1) / nseg) * 64;
 }
 
 }  // namespace slf

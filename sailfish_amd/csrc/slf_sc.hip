@@ -2,6 +2,8 @@
 //
 //   sc_macro_kernel     ShanChenPrepareMacroFields      (reference templates/models/binary_shan_chen.mako:19-87)
 //   sc_sweep_kernel<K>  ShanChenCollideAndPropagate{0,1} (binary_shan_chen.mako:89-141, shan_chen.mako:9-84)
+//   sc_fused_kernel     both of them in one pass ("ShanChenCollideAndPropagateFused"): rho, phi, u and the 18-point
+//                       pseudopotential stencil of each field are read once for the two lattices
 //   sc_init_kernel      SetInitialConditions (binary)    (templates/models/lb_binary_fluid.mako:87-127)
 //
 // Same layout, streaming modes and launch shape as the single-fluid sweep (slf_kernels.hip).  The force
@@ -31,6 +33,12 @@ struct ScParams {
   R G[2];            // couplings of this lattice with field 0 and field 1 (sweep only)
   R accel[3];        // additional body-force acceleration
   int has_body_force;
+  // fused sweep of both lattices: the second lattice and its constants (d_in / d_out / G / accel = lattice 0)
+  const R* d_in2;
+  R* d_out2;
+  R G2[2];
+  R accel2[3];
+  int has_body_force2;
   int potential;
   int force_edm;
 };
@@ -39,7 +47,8 @@ template <class R>
 __device__ __forceinline__ R sc_psi(R rho, int potential) {
   // sym.py:896-908: linear psi = rho; classic psi = 1 - exp(-rho)
   if (potential == 0) return rho;
-  return (R)1 - (R)exp((double)((R)0 - rho));
+  if constexpr (sizeof(R) == 4) return 1.0f - expf(0.0f - rho);      // the reference's exp() on a float argument
+  else return (R)1 - exp((R)0 - rho);
 }
 
 // Cache hints for the populations: streamed once per kernel in 3-D (non-temporal); 2-D lattices live in the caches.
@@ -225,6 +234,90 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
   sc_store<L, R, PROP, GENERAL, ROW>(g, f, p.d_out, ds, n, nx, live, active);
 }
 
+// Both lattices in one pass.  The force on lattice k is  - psi(rho_k) sum_j G_kj S_j  with the stencil sums
+// S_j = sum_i w_i e_i psi(rho_j(x + e_i)): the two sweeps of the reference compute the same S_0, S_1 twice (and read
+// rho, phi, u twice); here they are formed once, in the operation order of sc_accel(), then lattice 0 and lattice 1 are
+// loaded, collided and streamed one after the other (the populations of only one lattice live in registers at a time).
+#ifndef SLF_SC_FUSED_WAVES
+#define SLF_SC_FUSED_WAVES 5
+#endif
+template <class L, class R, int PROP, bool GENERAL, bool ROW = false>
+__global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? SLF_SC_FUSED_WAVES : 4)
+sc_fused_kernel(const ScParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int nx = g.lat_nx - 2;
+  bool live;
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
+  if constexpr (!ROW) {
+    if (!live) return;
+  }
+  const uint32_t gi = n.gi;
+  int kind = NK_FLUID;
+  bool active = live;
+  if constexpr (GENERAL) {
+    const uint32_t code = p.map[gi];
+    kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    if constexpr (!ROW) {
+      if (kind_is_excluded(kind)) return;
+    } else {
+      active = live && !kind_is_excluded(kind);
+    }
+  }
+  const bool wet = kind_is_wet(kind) && active;
+  const size_t ds = g.dist_size;
+  const R rho[2] = {p.rho0[gi], p.rho1[gi]};
+  R vc[3];
+  vc[0] = p.vx[gi];
+  vc[1] = p.vy[gi];
+  vc[2] = (R)0;
+  if constexpr (L::dim == 3) vc[2] = p.vz[gi];
+  // stencil sums of the fields some lattice is coupled to
+  R S[2][3] = {{(R)0, (R)0, (R)0}, {(R)0, (R)0, (R)0}};
+  if (wet) {
+    const R* const fields[2] = {p.rho0, p.rho1};
+    static_for<0, 2>([&](auto J) {
+      if (p.G[J] != (R)0 || p.G2[J] != (R)0) {
+        static_for<1, L::Q>([&](auto I) {
+          const R psi = sc_psi<R>(*sc_neighbour<L, I>(fields[J], n, true), p.potential);
+          static_for<0, L::dim>([&](auto D) {
+            constexpr int e = e_comp<L>(I, D);
+            if constexpr (e > 0) S[J][D] = S[J][D] + psi * Weights<L, R>::w(I);
+            if constexpr (e < 0) S[J][D] = S[J][D] + psi * ((R)0 - Weights<L, R>::w(I));
+          });
+        });
+      }
+    });
+  }
+  static_for<0, 2>([&](auto K) {
+    // one lattice at a time: without the fence the scheduler starts the loads of lattice 1 under the collision of
+    // lattice 0, and two sets of populations in registers cost a resident wave
+    __builtin_amdgcn_sched_barrier(0);
+    R f[L::Q];
+    sc_load<L, R, PROP>(f, K == 0 ? p.d_in : p.d_in2, ds, n);
+    R a[3] = {(R)0, (R)0, (R)0};
+    if (wet) {
+      const R psi_loc = sc_psi<R>(rho[K], p.potential);
+      static_for<0, 2>([&](auto J) {
+        const R cc = (K == 0) ? p.G[J] : p.G2[J];
+        if (cc != (R)0) {
+          static_for<0, L::dim>([&](auto D) { a[D] = a[D] + S[J][D] * (((R)0 - psi_loc) * cc); });
+        }
+      });
+      static_for<0, L::dim>([&](auto D) { a[D] = a[D] / rho[K]; });
+      if (K == 0 ? p.has_body_force : p.has_body_force2) {
+        static_for<0, L::dim>([&](auto D) { a[D] = a[D] + (K == 0 ? p.accel[D] : p.accel2[D]); });
+      }
+    }
+    R v[3] = {vc[0], vc[1], vc[2]};
+    if constexpr (GENERAL) {
+      if (kind == NK_FULL_BB) bounce_back<L, R>(f);
+    }
+    if (wet) bgk_relax_accel<L, R>(f, rho[K], v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
+    if constexpr (ROW && PROP != PROP_AA_EVEN && K == 1) __syncthreads();     // row_push's LDS words are still being read
+    sc_store<L, R, PROP, GENERAL, ROW>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n, nx, live, active);
+  });
+}
+
 // ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
 // PrepareMacroFields: density of every wet node
 template <class L, class R, int PROP, bool GENERAL>
@@ -347,6 +440,15 @@ static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanCh
     if (p.accel[d] != (R)0) p.has_body_force = 1;
   }
   p.potential = sc.potential;
+  p.d_in2 = (const R*)a.dist_in2;
+  p.d_out2 = (R*)a.dist_out2;
+  p.G2[0] = (R)sc.G[2];
+  p.G2[1] = (R)sc.G[3];
+  p.has_body_force2 = 0;
+  for (int d = 0; d < 3; d++) {
+    p.accel2[d] = (R)sc.accel1[d];
+    if (p.accel2[d] != (R)0) p.has_body_force2 = 1;
+  }
   return p;
 }
 
@@ -404,7 +506,7 @@ static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometr
   const int nx = g.lat_nx - 2;
   // whole-row workgroups + aligned stores for the x-streaming steps in 3-D (as slf_row.hip)
   const bool row = L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
-  if (row) block_x = row_block_x(nx, g.variant);
+  if (row) block_x = row_block_x(nx);
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
@@ -437,6 +539,38 @@ hipError_t launch_sc_sweep(const KernelSelector& sel, int grid_idx, Prop prop, c
 }
 
 template <class L, class R>
+static hipError_t sc_fused2(Prop prop, bool general, const Geometry& g, const Physics& ph, const ShanChen& sc,
+                            const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s) {
+  const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
+  const int nx = g.lat_nx - 2;
+  const bool row = L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
+  if (row) block_x = row_block_x(nx);
+  dim3 block(block_x, 1, 1);
+  dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
+  if (grid.y == 0 || grid.z == 0) return hipSuccess;
+#define SLF_SCF(P, ROW)                                                                            \
+  do {                                                                                             \
+    if (general) hipLaunchKernelGGL((sc_fused_kernel<L, R, P, true, ROW>), grid, block, 0, s, p);   \
+    else hipLaunchKernelGGL((sc_fused_kernel<L, R, P, false, ROW>), grid, block, 0, s, p);          \
+  } while (0)
+  if constexpr (L::dim == 3) {
+    if (row && prop == PROP_AB) { SLF_SCF(PROP_AB, true); return hipGetLastError(); }
+    if (row && prop == PROP_AA_ODD) { SLF_SCF(PROP_AA_ODD, true); return hipGetLastError(); }
+  }
+  if (prop == PROP_AB) SLF_SCF(PROP_AB, false);
+  else if (prop == PROP_AA_EVEN) SLF_SCF(PROP_AA_EVEN, false);
+  else SLF_SCF(PROP_AA_ODD, false);
+#undef SLF_SCF
+  return hipGetLastError();
+}
+
+hipError_t launch_sc_fused(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph, const ShanChen& sc,
+                           const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (sc_fused2<L, R>(prop, sel.general, g, ph, sc, a, y0, y1, z0, z1, block_x, s)));
+  return hipErrorInvalidValue;
+}
+
+template <class L, class R>
 static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometry& g, const Physics& ph,
                               const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                               hipStream_t s) {
@@ -445,7 +579,7 @@ static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometr
   p.G[1] = (R)0;
   const int nx = g.lat_nx - 2;
   const bool row = !macro && L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
-  if (row) block_x = row_block_x(nx, g.variant);
+  if (row) block_x = row_block_x(nx);
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;

@@ -30,7 +30,42 @@ struct SweepParams {
   const R* xrecv[2];
   Geometry g;
   CollideParams<L, R> cp;
+  // (new members go to the END: the kernel-argument layout decides how the scalar loads group, and the headline
+  // kernels sit right at a VGPR boundary -- inserting these before `g` cost fast_even_kernel 12-20 bytes of scratch)
+  // row classes of the node map (RowClasses, slf_kernels.h); seg_class == NULL: not classified, every wave reads the map.
+  // row_mode 0: every row of the launch; 1: rows of class 2 are left to the list launch; 2: blockIdx.y indexes
+  // bc_rows, rows outside [y0, y1) x [z0, z1) are skipped.
+  const uint32_t* seg_class;
+  const uint8_t* row_class;
+  const uint32_t* bc_rows;
+  int nseg, row_mode, y1, z1;
 };
+
+// The (y, z) row a workgroup of a whole-row launch works on; false: nothing to do here (wave-uniform).
+template <class L, class R>
+__device__ __forceinline__ bool launch_row(const SweepParams<L, R>& p, int& gy, int& gz) {
+  if (p.row_mode == 2) {
+    const uint32_t yz = p.bc_rows[blockIdx.y];
+    gy = (int)(yz & 0xffffu);
+    gz = (int)(yz >> 16);
+    if (gy < p.y0 || gy >= p.y1 || (L::dim == 3 && (gz < p.z0 || gz >= p.z1))) return false;
+  } else {
+    gy = p.y0 + (int)blockIdx.y;
+    gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
+    if (p.row_mode == 1 && p.row_class[gy + p.g.arr_ny * gz] >= 2) return false;
+  }
+  return true;
+}
+
+// Class of the 64-node segment `seg` of row (gy, gz) through the scalar cache (the table is written once, by the
+// classification kernel of an earlier launch): 0 = all plain fluid.  Without a table every segment counts as mixed.
+template <class L, class R>
+__device__ __forceinline__ int segment_class(const SweepParams<L, R>& p, int gy, int gz, int seg) {
+  if (!p.seg_class) return 1;
+  const uint32_t idx = (uint32_t)(gy + p.g.arr_ny * gz) * (uint32_t)p.nseg + (uint32_t)seg;
+  const uint32_t word = ((const __attribute__((address_space(4))) uint32_t*)p.seg_class)[idx >> 2];
+  return (int)((word >> (8u * (idx & 3u))) & 0xffu);
+}
 
 // Offsets (in elements) to the +-1 neighbours along each axis, with the
 // optional in-kernel periodic wrap.  Real nodes are 1 .. lat-2.
@@ -116,76 +151,32 @@ __device__ __forceinline__ void stg(SLF_GLOBAL T* p, T v) {
   else *p = v;
 }
 
-// Distribution-space neighbour offsets along y and z (64-bit: in the row-interleaved layout a periodic wrap
-// spans the whole array) -- wave-uniform, they live in SGPRs.
-struct DistOff {
-  long long p, m;
-};
-__device__ __forceinline__ DistOff dist_axis_off(int c, int lat, long long stride, int wrap) {
-  DistOff o;
-  o.p = stride;
-  o.m = -stride;
-  if (wrap) {
-    if (c == lat - 2) o.p = -(long long)(lat - 3) * stride;
-    if (c == 1) o.m = (long long)(lat - 3) * stride;
-  }
-  return o;
-}
-// offset of (y, z) + e_i (forward) or - e_i in distribution space, y and z components only
-template <class L, int I>
-__device__ __forceinline__ long long dist_dir_offset(const DistOff& oy, const DistOff& oz, bool forward) {
-  long long off = 0;
-  constexpr int ey = L::ey(I), ez = L::ez(I);
-  if constexpr (ey != 0) off += ((ey > 0) == forward) ? oy.p : oy.m;
-  if constexpr (ez != 0) off += ((ez > 0) == forward) ? oz.p : oz.m;
-  return off;
-}
-
-// Which (y, z) row does workgroup (by, bz) of an (ny x nz)-row launch work on?  Workgroups are dispatched in
-// linear order and workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), so the mapping decides which rows are
-// in flight together and which XCD / L2 sees which addresses.
-//   0  row = block (y fastest): the 8 XCDs interleave row by row
-//   1  XCD-chunked: XCD k streams through its own contiguous eighth of the launch
-//   2  z fastest
-//   3  XCD-chunked in units of 8 consecutive rows per XCD (row-interleaved inside a 64-row tile)
-__device__ __forceinline__ void row_of_block(int order, int ny, int nz, int& y, int& z) {
-  if (order == 0) return;
-  const uint32_t n = (uint32_t)ny * (uint32_t)nz;
-  uint32_t l = (uint32_t)y + (uint32_t)ny * (uint32_t)z;
-  if (order == 1) {
-    if (n % 8u) return;
-    l = (l % 8u) * (n / 8u) + l / 8u;
-  } else if (order == 2) {
-    y = (int)(l / (uint32_t)nz);
-    z = (int)(l % (uint32_t)nz);
-    return;
-  } else if (order == 3) {
-    if (n % 64u) return;
-    const uint32_t tile = l / 64u, r = l % 64u;     // 64 consecutive blocks -> 8 rows on each of the 8 XCDs
-    l = tile * 64u + (r % 8u) * 8u + r / 8u;
-  }
-  y = (int)(l % (uint32_t)ny);
-  z = (int)(l / (uint32_t)ny);
-}
-
 // ---- x-face buffers ------------------------------------------------------------------------------------------
-// Row index of (y, z) in a face buffer and its +-1 neighbours along y / z with the same in-sweep wrap as the
-// distribution arrays (values that leave through a face land in the row the neighbour's edge node sits in).
-struct FaceRows {
-  int row;          // gy + arr_ny * gz
-  AxisOff oy, oz;   // strides 1 and arr_ny
-};
-__device__ __forceinline__ FaceRows face_rows(const Geometry& g, int gy, int gz) {
-  FaceRows fr;
-  fr.row = gy + g.arr_ny * gz;
-  fr.oy = axis_off(gy, g.lat_ny, 1, g.wrap[1]);
-  fr.oz = (g.dim == 3) ? axis_off(gz, g.lat_nz, g.arr_ny, g.wrap[2]) : AxisOff{0, 0};
-  return fr;
+// Dense face buffers [z][k][y] over the padded (arr_ny x arr_nz) plane, k = position of the direction among the NXD
+// with the same sign of e_x: a range of z-planes is one contiguous piece, which is what lets the halo stream send the
+// planes a z-chunk of the sweep has completed while the next chunk computes (sailfish_amd/xface.py).
+// Row of (y, z) and its +-1 neighbours along y / z with the same in-sweep wrap as the distribution arrays (values
+// that leave through a face land in the row the neighbour's edge node sits in).
+template <class L>
+constexpr int count_x_dirs() {
+  int n = 0;
+  for (int i = 0; i < L::Q; i++) n += (L::ex(i) > 0) ? 1 : 0;
+  return n;
 }
-template <class L, int I>
-__device__ __forceinline__ int face_row_of(const FaceRows& fr, bool forward) {
-  const AxisOff ox0 = {0, 0};
-  return fr.row + dir_offset<L, I>(ox0, fr.oy, fr.oz, forward);
+struct FaceRows {
+  int row;          // gy + NXD * arr_ny * gz
+  AxisOff oy, oz;   // strides 1 and NXD * arr_ny
+  int kstride;      // arr_ny
+};
+template <class L>
+__device__ __forceinline__ FaceRows face_rows(const Geometry& g, int gy, int gz) {
+  constexpr int NXD = count_x_dirs<L>();
+  FaceRows fr;
+  fr.row = gy + NXD * g.arr_ny * gz;
+  fr.oy = axis_off(gy, g.lat_ny, 1, g.wrap[1]);
+  fr.oz = (g.dim == 3) ? axis_off(gz, g.lat_nz, NXD * g.arr_ny, g.wrap[2]) : AxisOff{0, 0};
+  fr.kstride = g.arr_ny;
+  return fr;
 }
 // position of direction I among the directions with the same sign of e_x (ascending I)
 template <class L, int I>
@@ -194,25 +185,36 @@ constexpr int x_dir_rank() {
   for (int i = 1; i < I; i++) n += ((L::ex(i) > 0) == (L::ex(I) > 0) && L::ex(i) != 0) ? 1 : 0;
   return n;
 }
+// element of direction I in the row of (y, z) [own] / of (y, z) + e_I (forward) / - e_I
+template <class L, int I>
+__device__ __forceinline__ int face_elem(const FaceRows& fr, int shift) {     // shift: 0 own row, +1 forward, -1 backward
+  const AxisOff ox0 = {0, 0};
+  const int off = (shift == 0) ? 0 : dir_offset<L, I>(ox0, fr.oy, fr.oz, shift > 0);
+  return fr.row + off + fr.kstride * x_dir_rank<L, I>();
+}
+// "Nothing crossed the face here" = the all-ones bit pattern the buffers are cleared with (memset 0xFF), compared
+// bit for bit: a NaN or an infinity that a diverging neighbour really sent is delivered like any other value, so the
+// blow-up crosses the face and the invalid-value check trips on the receiving side too.
+__device__ __forceinline__ bool face_value_present(float v) { return __builtin_bit_cast(uint32_t, v) != 0xffffffffu; }
+__device__ __forceinline__ bool face_value_present(double v) { return __builtin_bit_cast(uint64_t, v) != ~0ull; }
 // Incoming populations of an edge node: f_I with e_x > 0 at x = 1 come from the low neighbour, e_x < 0 at x = nx from
 // the high one.  PULL = the odd AA step (the value sits in the row the pull reads from), otherwise the node's own row.
-// Non-finite entries (never written: the sender's edge node is excluded) leave f as loaded from the arrays.
+// Entries never written (the sender's edge node is excluded) leave f as loaded from the arrays.
 template <class L, class R, bool PULL>
 __device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
-  const size_t nrows = (size_t)p.g.arr_ny * (size_t)p.g.arr_nz;
   if (p.xrecv[0] && x == 1) {
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) > 0) {
-        const R val = p.xrecv[0][nrows * x_dir_rank<L, I>() + (size_t)(PULL ? face_row_of<L, I>(fr, false) : fr.row)];
-        if (__builtin_isfinite(val)) f[I] = val;
+        const R val = p.xrecv[0][face_elem<L, I>(fr, PULL ? -1 : 0)];
+        if (face_value_present(val)) f[I] = val;
       }
     });
   }
   if (p.xrecv[1] && x == nx) {
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) < 0) {
-        const R val = p.xrecv[1][nrows * x_dir_rank<L, I>() + (size_t)(PULL ? face_row_of<L, I>(fr, false) : fr.row)];
-        if (__builtin_isfinite(val)) f[I] = val;
+        const R val = p.xrecv[1][face_elem<L, I>(fr, PULL ? -1 : 0)];
+        if (face_value_present(val)) f[I] = val;
       }
     });
   }
@@ -221,15 +223,14 @@ __device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f
 template <class L, class R>
 __device__ __forceinline__ void x_face_send_own_row(const SweepParams<L, R>& p, const R (&f)[L::Q], int x, int nx,
                                                     const FaceRows& fr) {
-  const size_t nrows = (size_t)p.g.arr_ny * (size_t)p.g.arr_nz;
   if (p.xsend[1] && x == nx) {
     static_for<1, L::Q>([&](auto I) {
-      if constexpr (L::ex(I) > 0) p.xsend[1][nrows * x_dir_rank<L, I>() + (size_t)fr.row] = f[I];
+      if constexpr (L::ex(I) > 0) p.xsend[1][face_elem<L, I>(fr, 0)] = f[I];
     });
   }
   if (p.xsend[0] && x == 1) {
     static_for<1, L::Q>([&](auto I) {
-      if constexpr (L::ex(I) < 0) p.xsend[0][nrows * x_dir_rank<L, I>() + (size_t)fr.row] = f[I];
+      if constexpr (L::ex(I) < 0) p.xsend[0][face_elem<L, I>(fr, 0)] = f[I];
     });
   }
 }
@@ -257,7 +258,10 @@ __device__ __forceinline__ void check_invalid(uint32_t* status, uint32_t options
 
 // gi: dense node index; si: the node's slot in the distribution arrays (= gi unless INDIRECT).
 // BCL: the module's Geometry::bc_level the instantiation is for (2 = everything).
-template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, int FORCE = FORCE_RUNTIME, int BCL = 2>
+// ROUNDOFF: the --minimize_roundoff formulation (slf_node.h: macro_roundoff, bgk_relax_roundoff): BGK; fluid, full-way
+// and half-way bounce-back nodes (the module is refused otherwise); the per-node kernels only.
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, int FORCE = FORCE_RUNTIME, int BCL = 2,
+          bool ROUNDOFF = false>
 __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L::Q], uint32_t code, int kind,
                                             uint32_t gi, const AxisOff& ox, const AxisOff& oy, const AxisOff& oz,
                                             R& rho, R (&v)[3], bool& wet, uint32_t si = INVALID_NODE) {
@@ -265,6 +269,38 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
   const Geometry& g = p.g;
   const size_t ds = g.dist_size;
   (void)ds;
+  if constexpr (ROUNDOFF) {
+    wet = GENERAL ? kind_is_wet(kind) : true;
+    macro_roundoff<L, R>(f, rho, v);
+    if (GENERAL && kind == NK_FULL_BB) bounce_back<L, R>(f);
+    if (wet && p.relaxation_enabled)
+      bgk_relax_roundoff<L, R>(f, rho, v, p.cp.omega, p.cp.guo_pref, p.cp.has_force != 0, p.cp.accel, p.cp.force_edm != 0);
+    if (GENERAL && kind == NK_HALF_BB) {
+      const int orientation = (int)(code >> g.orient_shift);
+      static_for<1, L::Q>([&](auto I) {
+        bool missing;
+        if (g.use_link_tags) {
+          missing = ((orientation >> (I - 1)) & 1) == 0;
+        } else {
+          missing = false;
+          with_orientation<L>(orientation, [&](auto O) {
+            if constexpr (is_missing<L, L::opp(I), O>()) missing = true;
+          });
+        }
+        if (missing) {
+          if constexpr (PROP == PROP_AA_EVEN) {
+            const int off = dir_offset<L, I>(ox, oy, oz, true);
+            uint32_t t = (uint32_t)((int)gi + off);
+            if constexpr (INDIRECT) t = p.nodes[t];
+            if (!INDIRECT || t != INVALID_NODE) (p.dout + ds * (size_t)I)[t] = f[I];
+          } else {
+            (p.dout + ds * (size_t)L::opp(I))[si] = f[I];
+          }
+        }
+      });
+    }
+    return;
+  }
   if constexpr (GENERAL && BCL == 0) {
     wet = kind_is_wet(kind);
     macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
@@ -405,6 +441,18 @@ inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const
   }
   p.y0 = y0;
   p.z0 = z0;
+  p.y1 = p.z1 = 0;
+  p.seg_class = nullptr;
+  p.row_class = nullptr;
+  p.bc_rows = nullptr;
+  p.nseg = 0;
+  p.row_mode = 0;
+  if (a.rows && a.rows->map == a.map && a.map) {
+    p.seg_class = a.rows->seg_class;
+    p.row_class = a.rows->row_class;
+    p.bc_rows = a.rows->bc_rows;
+    p.nseg = a.rows->nseg;
+  }
   p.relaxation_enabled = ph.relaxation_enabled;
   p.g = g;
   p.cp.omega = (R)(1.0 / ph.tau);

@@ -63,6 +63,12 @@ def dist_stride(desc):
     return int(desc.dist_stride) or desc.arr_nx * desc.arr_ny * desc.arr_nz
 
 
+class SlfCommOp(Structure):
+    """Mirror of slf_comm_op."""
+    _fields_ = [('kind', c_int32), ('peer', c_int32), ('dptr', c_void_p), ('count', ctypes.c_uint64),
+                ('elem_bytes', c_int32), ('reserved', c_int32)]
+
+
 class SlfRegion(Structure):
     _fields_ = [('y0', c_int32), ('y1', c_int32), ('z0', c_int32), ('z1', c_int32)]
 
@@ -92,6 +98,7 @@ SIGNATURES = {
     'slf_comm_group_begin': (c_int, []),
     'slf_comm_group_end': (c_int, []),
     'slf_comm_sendrecv': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]),
+    'slf_comm_exchange': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'slf_host_alloc_pinned': (c_int, [c_size_t, POINTER(c_void_p)]),
     'slf_host_free': (c_int, [c_void_p]),
     'slf_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
@@ -114,6 +121,7 @@ SIGNATURES = {
     'slf_module_create': (c_int, [c_void_p, POINTER(SlfModuleDesc), POINTER(c_void_p)]),
     'slf_module_destroy': (c_int, [c_void_p]),
     'slf_module_set_xface_buffers': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'slf_module_set_x_ghost_unused': (c_int, [c_void_p, c_int, c_int]),
     'slf_module_block_size': (c_int, [c_void_p, POINTER(c_int)]),
     'slf_kernel_get': (c_int, [c_void_p, c_char_p, POINTER(c_void_p)]),
     'slf_kernel_destroy': (c_int, [c_void_p]),
@@ -121,6 +129,7 @@ SIGNATURES = {
     'slf_kernel_set_iteration': (c_int, [c_void_p, c_uint32]),
     'slf_kernel_launch': (c_int, [c_void_p, POINTER(SlfRegion), c_void_p]),
     'slf_module_poll_invalid': (c_int, [c_void_p, c_void_p, POINTER(c_int32 * 4)]),
+    'slf_module_classify_rows': (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int32 * 4)]),
     'slf_graph_capture_begin': (c_int, [c_void_p]),
     'slf_graph_capture_end': (c_int, [c_void_p, POINTER(c_void_p)]),
     'slf_graph_launch': (c_int, [c_void_p, c_void_p]),
@@ -129,6 +138,7 @@ SIGNATURES = {
 }
 
 SLF_ADDR_DIRECT, SLF_ADDR_INDIRECT = 0, 1
+SLF_DENSITY_COMPRESSIBLE, SLF_DENSITY_INCOMPRESSIBLE, SLF_DENSITY_ROUNDOFF = 0, 1, 2
 SLF_FORCE_GUO, SLF_FORCE_EDM = 0, 1
 SLF_INVALID_NODE = 0xffffffff
 

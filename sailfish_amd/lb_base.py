@@ -52,8 +52,9 @@ class LBSim(object):
                            help='Node addressing mode: direct (dense arrays) or indirect (populations stored for the active '
                                 'nodes only; single-fluid models).')
         group.add_argument('--minimize_roundoff', action='store_true', default=False,
-                           help='store rho - 1 / f - w instead of rho / f (reference sym.py:656-661); not implemented '
-                                'by the HIP backend: refused')
+                           help='tries to minimize round-off errors: the arrays hold f - w and the density field '
+                                'rho - 1, so that O(1) and O(Ma) quantities are never added (reference sym.py:573-661); '
+                                'BGK, fluid and bounce-back nodes')
         group.add_argument('--propagate_on_read', action='store_true', default=False,
                            help='(accepted for compatibility; the HIP kernels choose the streaming scheme)')
         group.add_argument('--propagate_with_shuffle', action='store_true', dest='propagate_with_shuffle',

@@ -1,4 +1,5 @@
 """Binary-fluid models (reference sailfish/lb_binary.py): the Shan-Chen mixture."""
+import os
 from collections import defaultdict, namedtuple
 
 import numpy as np
@@ -113,11 +114,22 @@ class LBBinaryFluidShanChen(LBBinaryFluidBase, LBForcedSim):
         def k(name, a, b):
             return runner.get_kernel(name, [gpu_map, a, b] + tail, sig, needs_iteration=ni)
 
+        # backends that have it sweep both lattices in ONE pass (rho, phi, u and the pseudopotential stencil are read
+        # once; C ABI kernel "ShanChenCollideAndPropagateFused"), otherwise the reference's two kernels
+        fused = getattr(runner.backend, 'supports_fused_shan_chen', False) and getattr(self.config, 'hip_sc_fused', True) and \
+            os.environ.get('SLF_SC_FUSED', '1') != '0'
+
+        def sweeps(in1, out1, in2, out2):
+            if fused:
+                return [runner.get_kernel('ShanChenCollideAndPropagateFused', [gpu_map, in1, out1, in2, out2] + tail,
+                                          'PP' + sig, needs_iteration=ni)]
+            return [k('ShanChenCollideAndPropagate0', in1, out1), k('ShanChenCollideAndPropagate1', in2, out2)]
+
         macro1 = k('ShanChenPrepareMacroFields', d1a, d2a)
-        primary = [k('ShanChenCollideAndPropagate0', d1a, d1b), k('ShanChenCollideAndPropagate1', d2a, d2b)]
+        primary = sweeps(d1a, d1b, d2a, d2b)
         if self.config.access_pattern == 'AB':
             macro2 = k('ShanChenPrepareMacroFields', d1b, d2b)
-            secondary = [k('ShanChenCollideAndPropagate0', d1b, d1a), k('ShanChenCollideAndPropagate1', d2b, d2a)]
+            secondary = sweeps(d1b, d1a, d2b, d2a)
         else:
             macro2, secondary = macro1, primary
         return [(macro1, primary), (macro2, secondary)]

@@ -32,7 +32,32 @@ class LBFluidSim(LBSim):
                   model=hipabi.SLF_MRT if cfg.model == 'mrt' else hipabi.SLF_BGK,
                   tau=sym.relaxation_time(cfg.visc), visc=cfg.visc,
                   mrt_rates=sym.mrt_rates(self.grid, cfg.visc),
-                  incompressible=int(bool(cfg.incompressible)))
+                  incompressible=self.density_model(cfg))
+
+    @staticmethod
+    def density_model(cfg):
+        """slf_module_desc::incompressible (SLF_DENSITY_*): the reference's three-way choice `incompressible` /
+        `minimize_roundoff` / neither (sym.py:573-661, sym_equilibrium.py:100-118)."""
+        if getattr(cfg, 'incompressible', False):
+            return hipabi.SLF_DENSITY_INCOMPRESSIBLE
+        if getattr(cfg, 'minimize_roundoff', False):
+            if cfg.model != 'bgk':
+                raise ValueError('--minimize_roundoff works with BGK-like models only (as in the reference)')
+            return hipabi.SLF_DENSITY_ROUNDOFF
+        return hipabi.SLF_DENSITY_COMPRESSIBLE
+
+    ROUNDOFF_KINDS = (hipabi.SLF_NK_FLUID, hipabi.SLF_NK_GHOST, hipabi.SLF_NK_UNUSED, hipabi.SLF_NK_PROPAGATION_ONLY,
+                      hipabi.SLF_NK_FULL_BB, hipabi.SLF_NK_HALF_BB)
+
+    @classmethod
+    def check_module_desc(cls, kw):
+        """Refuses, on the host and with a clear message, what the kernels of the chosen formulation do not cover
+        (the library refuses the same at module creation)."""
+        if kw.get('incompressible') == hipabi.SLF_DENSITY_ROUNDOFF:
+            bad = [k for k in kw.get('type_kind', []) if k not in cls.ROUNDOFF_KINDS]
+            if bad:
+                raise NotImplementedError('--minimize_roundoff: fluid and bounce-back nodes only (node kinds %s are not '
+                                          'covered; the reference says "BGK-like models")' % sorted(set(bad)))
 
     def initial_conditions(self, runner):
         """f = feq(rho, v) on every copy of the distributions (reference lb_single.py:72-94)."""

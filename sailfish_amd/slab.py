@@ -6,7 +6,8 @@ Per step (reference subdomain_runner.py:1028-1058 boundary / bulk split):
   halo stream : wait(event) -> pack the two faces -> RCCL send / recv with the two ring neighbours -> unpack -> event
 The other two axes are wrapped inside the sweep; the split axis is wrapped inside the sweep when there is a single
 slab, otherwise it goes through the ghost layers + halo.  x faces cannot be split off (a workgroup owns whole rows):
-with axis = 'x' the whole sweep runs before the pack.
+with axis = 'x' the sweep is cut into z-chunks instead, and the planes of the face buffers a chunk has completed
+travel while the next chunk computes (xface.ChunkPlan); a chunk of the next step waits only for the planes it reads.
 
 z and y faces are packed with the box kernels (Collect / DistributeContinuousData: no index lists; reference
 kernel_utils.mako:526-543, 629-645) and move contiguous row segments.  x faces are not packed at all: the edge lanes
@@ -111,12 +112,12 @@ class SlabSim(BoxSim):
     # -- halo machinery ------------------------------------------------------
     def _init_halo(self, exchanger):
         import torch
-        from sailfish_amd.connector import RingExchanger, init_distributed
+        from sailfish_amd.connector import init_distributed, make_ring_exchanger
         if exchanger is None:
             init_distributed()
         b = self.backend
         self.plan = SlabPlan(self.grid, self.desc, self.axis)
-        self.exchanger = exchanger or RingExchanger(self.rank, self.world)
+        self.exchanger = exchanger or make_ring_exchanger(self.rank, self.world, b)
         self.halo_stream = b.make_stream(high_priority=os.environ.get('SLF_HALO_PRIORITY', '1') != '0')
         self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
         tdtype = torch.float32 if self.desc.precision == 4 else torch.float64
@@ -130,9 +131,17 @@ class SlabSim(BoxSim):
                 tensors.append(torch.empty(n, dtype=tdtype, device=dev))
                 return tensors[-1].data_ptr()
             self.xface = xface.XFaceHalo.allocate(b, self.module, self.grid, self.desc, (True, True), alloc)
-            s_low, s_high, r_low, r_high = tensors
-            self.t_bufs = [s_high, s_low, r_low, r_high]            # s_up s_down r_low r_high
+            # per parity: send low, send high, receive low, receive high  ->  s_up s_down r_low r_high
+            self.t_sets = [[tensors[4 * p + 1], tensors[4 * p + 0], tensors[4 * p + 2], tensors[4 * p + 3]] for p in (0, 1)]
+            self.t_bufs = self.t_sets[0]
             self.xface.reset()
+            # overlap = every batch of planes is exchanged as soon as its chunks are done (needs an exchanger that can
+            # be called in the middle of a step: RCCL / gloo / ring of one); the three-phase protocol of exchangers that
+            # copy whole buffers between step_compute() and step_finish() (tests: two slabs in one process) stays
+            self.overlap = hasattr(self.exchanger, 'exchange_range')
+            self.chunks = xface.ChunkPlan(self.size[2], self.desc.periodic_fused[2], None if self.overlap else 1)
+            self._batch_events, self._prev_kind = None, None
+            self._event_pool = {}
             self.ev_halo = None
             self.regs_bnd, self.reg_bulk = self.plan.regions()
             self.time_halo = False
@@ -155,6 +164,8 @@ class SlabSim(BoxSim):
 
     def step_compute(self, save_macro=False):
         """Face layers, event, interior on the calc stream; halo pack on the halo stream."""
+        if self.xface is not None:
+            return self._step_compute_xface(save_macro)
         b = self.backend
         it = self.iteration
         if self.aa:
@@ -163,8 +174,6 @@ class SlabSim(BoxSim):
             k, out, swap = self.k_sweep[int(save_macro)][it & 1], 1 - (it & 1), False
         if self.ev_halo is not None:
             self.calc_stream.wait_for_event(self.ev_halo)
-        if self.xface is not None and self.xface.needs_clear:
-            self.xface.clear_send(self.calc_stream)
         for reg in self.regs_bnd:
             b.run_kernel(k, reg, self.calc_stream)
         if self.regs_bnd:
@@ -176,15 +185,64 @@ class SlabSim(BoxSim):
         self.halo_stream.wait_for_event(ev_bnd)
         if self.time_halo:
             self._ev_h0 = b.make_event(self.halo_stream, timing=True)
-        if self.xface is None:
-            self._ks = self.k_halo[(swap, out)]
-            b.run_kernel(self._ks[0], None, self.halo_stream)
-            b.run_kernel(self._ks[1], None, self.halo_stream)
+        self._ks = self.k_halo[(swap, out)]
+        b.run_kernel(self._ks[0], None, self.halo_stream)
+        b.run_kernel(self._ks[1], None, self.halo_stream)
         self.iteration += 1
         b.set_iteration(self.iteration)
 
+    def _step_compute_xface(self, save_macro):
+        """x-slabs: z-chunks of the sweep on the calc stream; after each, the planes of the send buffers it completed
+        travel on the halo stream (overlap mode) while the next chunk computes."""
+        b = self.backend
+        it = self.iteration
+        k = self.k_sweep[int(save_macro)][0] if self.aa else self.k_sweep[int(save_macro)][it & 1]
+        kind = 'own' if (self.aa and (it & 1) == 0) else 'push'
+        plan, ny = self.chunks, self.size[1]
+        par = self.xface.begin_step(it, self.calc_stream)
+        self.t_bufs = self.t_sets[par]
+        prev, need = self._batch_events, (plan.need[self._prev_kind] if self._prev_kind else None)
+        # event objects are kept and recorded again every other step (a wait refers to the record that preceded it)
+        pool = self._event_pool.setdefault(par, [(b.make_event(self.calc_stream), b.make_event(self.halo_stream))
+                                                 for _ in plan.order])
+        events = []
+        for pos, c in enumerate(plan.order):
+            if prev is not None and need[c] >= 0:
+                self.calc_stream.wait_for_event(prev[need[c]])
+            b.run_kernel(k, plan.region(c, ny), self.calc_stream)
+            ev_chunk, ev_batch = pool[pos]
+            ev_chunk.record(self.calc_stream)
+            self.halo_stream.wait_for_event(ev_chunk)
+            if self.time_halo and pos == 0:
+                self._ev_h0 = b.make_event(self.halo_stream, timing=True)
+            if self.overlap:
+                runs = plan.batches[kind][pos]
+                if runs:
+                    self._exchange_runs(runs)
+                ev_batch.record(self.halo_stream)
+                events.append(ev_batch)
+        self._batch_events, self._prev_kind = (events if self.overlap else None), kind
+        self.iteration += 1
+        b.set_iteration(self.iteration)
+
+    def _exchange_runs(self, runs):
+        """One group of transfers on the halo stream: the z-plane ranges `runs` of the four face buffers."""
+        plane = self.xface.plane
+        if getattr(self.exchanger, 'direct', False):       # straight to RCCL (connector.RcclRingExchanger)
+            self.exchanger.exchange_ranges(self.t_bufs, [(p0 * plane, (p1 - p0) * plane) for p0, p1 in runs], self.halo_stream)
+            return
+        import torch
+        with torch.cuda.stream(self.t_halo_stream):
+            for p0, p1 in runs:
+                self.exchanger.exchange_range(self.t_bufs, p0 * plane, (p1 - p0) * plane)
+
     def step_exchange(self):
         import torch
+        if self.xface is not None and self.overlap:
+            return                                    # done batch by batch inside step_compute()
+        if getattr(self.exchanger, 'direct', False):
+            self.exchanger.exchange_ranges(self.t_bufs, [(0, self.t_bufs[0].numel())], self.halo_stream)
+            return
         with torch.cuda.stream(self.t_halo_stream):
             self.exchanger.exchange(*self.t_bufs)
 
@@ -195,6 +253,11 @@ class SlabSim(BoxSim):
             b.run_kernel(self._ks[3], None, self.halo_stream)
         if self.time_halo:
             self._halo_events.append((self._ev_h0, b.make_event(self.halo_stream, timing=True)))
+        if self.xface is not None:
+            if not self.overlap:                      # whole buffers were moved by the caller: one event for every chunk
+                ev = b.make_event(self.halo_stream)
+                self._batch_events = [ev] * len(self.chunks.order)
+            return
         self.ev_halo = b.make_event(self.halo_stream)
 
     def step(self, save_macro=False, region=None):
@@ -210,9 +273,14 @@ class SlabSim(BoxSim):
         b = self.backend
         it = self.iteration
         k = self.k_sweep[0][0] if self.aa else self.k_sweep[0][it & 1]
-        for reg in getattr(self, 'regs_bnd', []):
-            b.run_kernel(k, reg, self.calc_stream)
-        b.run_kernel(k, getattr(self, 'reg_bulk', None), self.calc_stream)
+        if self.halo and self.xface is not None:
+            self.xface.begin_step(it, self.calc_stream)
+            for c in self.chunks.order:
+                b.run_kernel(k, self.chunks.region(c, self.size[1]), self.calc_stream)
+        else:
+            for reg in getattr(self, 'regs_bnd', []):
+                b.run_kernel(k, reg, self.calc_stream)
+            b.run_kernel(k, getattr(self, 'reg_bulk', None), self.calc_stream)
         self.iteration += 1
         b.set_iteration(self.iteration)
 
@@ -236,20 +304,28 @@ class SlabSim(BoxSim):
         BoxSim.initial_conditions(self)
         if self.halo and self.xface is not None:
             self.xface.reset(self.stream)
-            self.ev_halo = None
+            self._batch_events, self._prev_kind = None, None
 
     def materialise_faces(self):
         """With x-face buffers the arrays are stale at the faces: write the received values into them (before anything
         reads the arrays on the host)."""
         if self.halo and self.xface is not None and self.iteration > 0:
             self.sync()
-            pushed = (not self.aa) or ((self.iteration - 1) & 1) == 1
-            self.xface.materialise(self.gpu_dist[self.current_dist_index()], pushed, self.stream)
+            last = self.iteration - 1
+            pushed = (not self.aa) or (last & 1) == 1
+            self.xface.materialise(self.gpu_dist[self.current_dist_index()], pushed, self.stream, parity=last & 1)
             self.sync()
 
     def get_dist(self, which=None):
         self.materialise_faces()
         return BoxSim.get_dist(self, which)
+
+    def set_dist(self, host, which=None):
+        """A state written from the host: whatever crossed the x faces before no longer counts."""
+        BoxSim.set_dist(self, host, which)
+        if self.halo and self.xface is not None:
+            self.xface.reset(self.stream)
+            self._batch_events, self._prev_kind = None, None
 
     # -- initial state ---------------------------------------------------------
     def init_synthetic(self, seed=1234):

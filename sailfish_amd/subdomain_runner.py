@@ -183,6 +183,8 @@ class SubdomainRunner(object):
                   arr_nx=arr[0], arr_ny=arr[1], arr_nz=arr[2] if self.dim == 3 else 1)
         self._sim.fill_module_desc(kw)
         kw.update(self._subdomain._encoder.desc_fields())
+        if hasattr(self._sim, 'check_module_desc'):
+            self._sim.check_module_desc(kw)
         local = self._local_periodic()
         fused = [int(local[a] and getattr(cfg, 'hip_fused_periodic', True)) for a in range(self.dim)]
         kw['periodic_local'] = [int(x) for x in local] + [0] * (3 - self.dim)
@@ -252,6 +254,12 @@ class SubdomainRunner(object):
     def _init_compute(self):
         self._desc = self._module_desc()
         self.module = self.backend.build(self._desc)
+        spec = self._spec
+        if hasattr(self.backend, 'set_x_ghost_unused') and not self._local_periodic()[0] and \
+                not getattr(self.config, 'debug_dump_dists', False) and os.environ.get('SLF_X_GHOST_STORES', '0') != '1':
+            # ghost columns behind an x face that is neither periodic nor connected: nothing reads them (raw dumps of the
+            # arrays keep the reference's pushes: --debug_dump_dists)
+            self.backend.set_x_ghost_unused(self.module, not spec.has_face_conn(spec.X_LOW), not spec.has_face_conn(spec.X_HIGH))
         self._calc_stream = self.backend.make_stream()
         # the halo stream: ahead of the bulk sweep's queued workgroups where the backend can say so
         prio = getattr(self.backend, 'supports_stream_priority', False) and os.environ.get('SLF_HALO_PRIORITY', '1') != '0'
@@ -267,6 +275,12 @@ class SubdomainRunner(object):
             for comp in vec:
                 self._gpu_field_map[id(comp)] = b.alloc_buf(like=self._host_base[id(comp)])
         self._gpu_geo_map = b.alloc_buf(like=self._host_base[id(self._subdomain._type_map_ghost)])
+        self.row_classes = None
+        if getattr(b, 'supports_row_classes', None) and b.supports_row_classes(self._desc) and \
+                getattr(self.config, 'hip_row_classes', True) and os.environ.get('SLF_ROW_CLASSES', '1') != '0':
+            # which waves need the map at all, which rows need boundary-condition code (backend_hip.classify_rows)
+            self.row_classes = b.classify_rows(self.module, self._gpu_geo_map, self._calc_stream)
+            self.config.logger.debug('row classes: %s' % self.row_classes)
         if self.indirect:
             self._build_indirect_address_map()
 
@@ -281,6 +295,7 @@ class SubdomainRunner(object):
             # large arrays: physical backing spread over HBM (placement.py); all lattices and copies share the span
             n = len(self._sim.grids)
             bufs = b.alloc_placed([nbytes] * (n * (2 if ab else 1)), off)
+            self._placed = [pb for pb in bufs if hasattr(pb, 'detach')]
             self._gpu_grids_primary = [pb.addr for pb in bufs[:n]]
             self._gpu_grids_secondary = [pb.addr for pb in bufs[n:]]
             self.config.logger.debug('placed distributions: %s' % b.last_placement)
@@ -290,6 +305,38 @@ class SubdomainRunner(object):
                 if ab:
                     self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes, align_offset=off))
         self.config.logger.debug('distributions: %d MiB' % (nbytes * (2 if self._gpu_grids_secondary else 1) >> 20))
+
+    _placed = ()
+
+    def _tune_placement(self):
+        """Placement by measurement (placement.tune): a few steps of this simulation's own kernels are timed on the
+        placed distribution arrays, the arrays are placed again while the first chunks stay allocated, and the better
+        placement is kept.  The arrays' contents are scratch here: the initial state is set up again afterwards."""
+        from sailfish_amd import placement
+        cfg = self.config
+        if not self._placed or self._links or not getattr(cfg, 'hip_placement_tune', True) or \
+                os.environ.get('SLF_PLACEMENT_TUNE', '1') == '0' or (0 < cfg.max_iters < 200):
+            return None
+        b = self.backend
+        steps = 12
+
+        def measure():
+            self._sim.initial_conditions(self)
+            self._sim.iteration = 0
+            b.set_iteration(0)
+            for _ in range(4):
+                self.step_compute(False)
+            ev0 = b.make_event(self._calc_stream, timing=True)
+            for _ in range(steps):
+                self.step_compute(False)
+            ev1 = b.make_event(self._calc_stream, timing=True)
+            ev1.synchronize()
+            return ev1.time_since(ev0) * 1e-3 / steps
+        info = placement.tune(b, self._placed, measure, log=cfg.logger.debug)
+        self._sim.iteration = 0
+        b.set_iteration(0)
+        self.placement_tuning = info
+        return info
 
     def gpu_field(self, field):
         if isinstance(field, list):
@@ -417,24 +464,31 @@ class SubdomainRunner(object):
         return True
 
     def _init_xface_halo(self):
-        """One message per neighbour and step: [what leaves through my low face | through my high face] (the faces
-        that lead to this neighbour); it arrives as [its high-face input | its low-face input] on the other side."""
+        """Per neighbour and step parity one send and one receive buffer: [what leaves through my low face | through my
+        high face] (the faces that lead to this neighbour); it arrives as [its high-face input | its low-face input] on
+        the other side.  The sweep is cut into z-chunks and the planes a chunk completes travel at once
+        (xface.ChunkPlan)."""
         spec = self._spec
         n = xface.face_count(self._desc)
         isz = np.dtype(self.float).itemsize
         by_neighbour = {}
         for face, nid in sorted(spec.connecting_subdomains()):
             by_neighbour.setdefault(nid, []).append(xface.LOW if face == spec.X_LOW else xface.HIGH)
-        send, recv = [0, 0], [0, 0]
+        send, recv = [[0, 0], [0, 0]], [[0, 0], [0, 0]]
+        self._xface_routes = []          # (neighbour id, my face, parity -> send address, parity -> receive address)
         for nid in sorted(by_neighbour):
             faces = sorted(by_neighbour[nid])
             link = subdomain_connection.HaloLink(nid)
-            link.send_buf = self._connector.alloc_buffer(self, n * len(faces), self.float)
-            link.recv_buf = self._connector.alloc_buffer(self, n * len(faces), self.float)
-            for k, face in enumerate(faces):                       # my send order: low, high
-                send[face] = link.send_buf + k * n * isz
-            for k, face in enumerate(reversed(faces)):             # the neighbour's send order seen from here
-                recv[face] = link.recv_buf + k * n * isz
+            link.send_bufs = [self._connector.alloc_buffer(self, n * len(faces), self.float) for _ in (0, 1)]
+            link.recv_bufs = [self._connector.alloc_buffer(self, n * len(faces), self.float) for _ in (0, 1)]
+            link.send_buf, link.recv_buf = link.send_bufs[0], link.recv_bufs[0]
+            for par in (0, 1):
+                for k, face in enumerate(faces):                       # my send order: low, high
+                    send[par][face] = link.send_bufs[par] + k * n * isz
+                for k, face in enumerate(reversed(faces)):             # the neighbour's send order seen from here
+                    recv[par][face] = link.recv_bufs[par] + k * n * isz
+            for face in faces:            # pieces are posted in this order on both sides: my low <-> its high first
+                self._xface_routes.append((nid, face))
             link.kernels = {}
             for mode in ('push', 'pull'):
                 for copy in (0, 1):
@@ -442,6 +496,42 @@ class SubdomainRunner(object):
             self._links[nid] = link
         self._xface = xface.XFaceHalo(self.backend, self.module, self._sim.grid, self._desc, send, recv)
         self._xface.reset()
+        lat = list(reversed(self._lat_size))
+        # several launches per step pay off where the transfer is slow (another process / GPU: a connector that can be
+        # called in the middle of a step); runners stepped in lock-step by one Python process are bound by that process
+        # instead: one chunk (profiles/r03/xface_overlap_schemes.jsonl)
+        self._xchunks = xface.ChunkPlan(lat[2] - 2, self._fused[2],
+                                        None if getattr(self._connector, 'mid_step', False) else 1)
+        self._xface_events, self._xface_prev_kind = None, None
+
+    def xface_pieces(self, pos):
+        """[(neighbour id, send address, receive address, elements)] of batch `pos` of the step just enqueued: for every
+        connected face (send side: my faces low, high; the receive side of the same neighbour takes them as its high, low)
+        the runs of z-planes the chunks swept so far have completed."""
+        x, isz = self._xface, np.dtype(self.float).itemsize
+        par = self._xface_parity
+        out = []
+        # sends in my face order; receives of one neighbour in the order IT sends: its low face (= my high) first
+        by_n = {}
+        for nid, face in self._xface_routes:
+            by_n.setdefault(nid, []).append(face)
+        for nid in sorted(by_n):
+            s_faces = sorted(by_n[nid])
+            r_faces = list(reversed(s_faces))
+            for sf, rf in zip(s_faces, r_faces):
+                for p0, p1 in self._xchunks.batches[self._xface_kind][pos]:
+                    off, cnt = p0 * x.plane * isz, (p1 - p0) * x.plane
+                    out.append((nid, x.send[par][sf] + off, x.recv[par][rf] + off, cnt))
+        return out
+
+    def _reset_xface(self):
+        """Whatever state was just set up from the host (initial conditions, a checkpoint, a debug write): the arrays
+        count, nothing that crossed the x faces before does."""
+        if self._xface is not None:
+            self.backend.sync_stream(self._calc_stream, self._data_stream)
+            self._xface.reset(self._calc_stream)
+            self.__dict__.pop('_halo_mode', None)
+            self._xface_events, self._xface_prev_kind = None, None
 
     def _materialise_halo(self):
         """x-face buffers: the arrays are stale at the connected faces until the received values are written into
@@ -449,7 +539,8 @@ class SubdomainRunner(object):
         if self._xface is None or not hasattr(self, '_halo_mode'):
             return
         self.backend.sync_stream(self._calc_stream, self._data_stream)
-        self._xface.materialise(self.gpu_dist(0, self._halo_copy), self._halo_mode == 'push', self._calc_stream)
+        self._xface.materialise(self.gpu_dist(0, self._halo_copy), self._halo_mode == 'push', self._calc_stream,
+                                parity=self._xface_parity)
         self.backend.sync_stream(self._calc_stream)
 
     def halo_messages(self, kind='dist'):
@@ -538,6 +629,41 @@ class SubdomainRunner(object):
         prof.record_gpu_end(TimeProfile.BULK, self._calc_stream)
         return ev
 
+    def _run_sweep_xface(self, kernels, it):
+        """1-D x decomposition: the sweep in z-chunks; after each chunk the planes of the face buffers that are now
+        complete are handed to the transport (a connector that can be called in the middle of a step moves them at
+        once, on the data stream; a same-process group picks them up through xface_pieces() / the ready events), and
+        a chunk waits only for the transfers of the previous step it reads from."""
+        b, x, plan = self.backend, self._xface, self._xchunks
+        aa = self.config.access_pattern == 'AA'
+        kind = 'own' if (aa and (it & 1) == 0) else 'push'
+        # the send set of this parity was last read by the transfers of step it - 2
+        self._wait_send_buffers_free('dist%d' % (it & 1), self._calc_stream)
+        par = x.begin_step(it, self._calc_stream)
+        self._xface_parity, self._xface_kind = par, kind
+        prev = self._xface_events
+        need = plan.need[self._xface_prev_kind] if self._xface_prev_kind else None
+        ny = list(reversed(self._lat_size))[1] - 2
+        prof = self._profile
+        overlapped = getattr(self._connector, 'mid_step', False)
+        ready, events = [], []
+        prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
+        for pos, c in enumerate(plan.order):
+            if prev is not None and need[c] >= 0:
+                self._calc_stream.wait_for_event(prev[need[c]])
+            for k in kernels:
+                b.run_kernel(k, plan.region(c, ny), self._calc_stream)
+            ev = b.make_event(self._calc_stream)
+            ready.append(ev)
+            if overlapped:
+                self._data_stream.wait_for_event(ev)
+                self._connector.exchange_pieces(self, self.xface_pieces(pos))
+                events.append(b.make_event(self._data_stream))
+        prof.record_gpu_end(TimeProfile.BULK, self._calc_stream)
+        self._xface_ready = ready
+        self._xface_events = events if overlapped else None
+        self._xface_prev_kind = kind
+
     def step_compute(self, sync_req=False):
         """Sweep + local periodic boundaries + halo pack.  Returns the per-neighbour (send buffer, count)."""
         b = self.backend
@@ -545,14 +671,10 @@ class SubdomainRunner(object):
         kernels = self._kernels_full if sync_req else self._kernels_none
         kernels = kernels.primary if (it & 1) == 0 else kernels.secondary
         if self._xface is not None:
-            # the sweep itself writes the send buffers: whoever copies them (the neighbours of a same-process group on
-            # THEIR data streams, our own exchange on ours) must have read the previous step's values
-            self._wait_send_buffers_free('dist', self._calc_stream)
-            if self._ev_halo is not None:
-                self._calc_stream.wait_for_event(self._ev_halo)
-            if self._xface.needs_clear:
-                self._xface.clear_send(self._calc_stream)
-        ev_bnd = self._run_sweep(kernels, self._regions)
+            self._run_sweep_xface(kernels, it)
+            ev_bnd = None
+        else:
+            ev_bnd = self._run_sweep(kernels, self._regions)
         base = 1 - (it & 1)
         for axis in self._pbc_axes:
             for k in self._pbc_kernels[base][axis]:
@@ -568,8 +690,8 @@ class SubdomainRunner(object):
         aa = self.config.access_pattern == 'AA'
         self._halo_mode = 'pull' if (aa and (it & 1) == 0) else 'push'
         self._halo_copy = 0 if aa else 1 - (it & 1)
-        if self._links:
-            # x-connected or unsplit subdomains: the whole sweep (and the local PBC) must be done first
+        if self._links and self._xface is None:
+            # unsplit subdomains: the whole sweep (and the local PBC) must be done first
             ev = ev_bnd if (ev_bnd is not None and not self._pbc_axes) else b.make_event(self._calc_stream)
             self._data_stream.wait_for_event(ev)
             self._wait_send_buffers_free('dist')
@@ -582,7 +704,7 @@ class SubdomainRunner(object):
     def step_finish(self):
         """Unpack the received halos (the exchange has been enqueued on the data stream)."""
         b = self.backend
-        if not self._links:
+        if not self._links or self._xface is not None:
             return
         self._profile.record_gpu_start(TimeProfile.DISTRIB, self._data_stream)
         for nid, link in self._links.items():
@@ -600,7 +722,7 @@ class SubdomainRunner(object):
             self._connector.exchange(self, 'macro')
             self.step_macro_finish()
         self.step_compute(sync_req)
-        if self._links:
+        if self._links and self._xface is None:
             self._profile.record_cpu_start(TimeProfile.RECV_DISTS)
             self._connector.exchange(self)
             self._profile.record_cpu_end(TimeProfile.RECV_DISTS)
@@ -652,6 +774,7 @@ class SubdomainRunner(object):
         else:
             raw[:, :self._get_nodes()] = dense
         self.backend.to_buf(self.gpu_dist(grid_num, copy), raw)
+        self._reset_xface()
 
     def _debug_global_idx_to_tuple(self, gi):
         dist_num = gi // self._get_nodes()
@@ -729,6 +852,7 @@ class SubdomainRunner(object):
         self._init_gpu_data()
         self._init_halo()
         self._prepare_compute_kernels()
+        self._tune_placement()
         self._sim.initial_conditions(self)
         self.backend.set_iteration(0)
         if self._output is not None:
@@ -738,9 +862,7 @@ class SubdomainRunner(object):
             self.restore_checkpoint(fname)
         if getattr(cfg, 'debug_dump_node_type_map', False) and self._output is not None:
             self._output.dump_node_type(self._subdomain._type_vis_map)
-        if self._xface is not None:          # whatever state was set up (initial conditions, a checkpoint): the arrays count
-            self._xface.reset(self._calc_stream)
-            self.__dict__.pop('_halo_mode', None)
+        self._reset_xface()
         self._sim.before_main_loop(self)
         self.backend.sync_stream(self._calc_stream)
         self.num_fluid_nodes = self._subdomain.num_fluid_nodes

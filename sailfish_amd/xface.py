@@ -3,21 +3,34 @@
 A workgroup owns whole rows, so an x face is one node per row: pushing into the ghost columns costs a partial-line
 write per row and direction, packing / unpacking them a strided gather / scatter (64-byte sectors for 4-byte values).
 Here the two edge lanes of every row write what leaves the subdomain into dense send buffers and read what enters it
-from dense receive buffers ([k][z][y] over the padded plane, k = rank of the direction among the 5 with e_x > 0 resp.
-< 0); per step the host moves send_high -> the high neighbour's recv_low and send_low -> the low neighbour's
-recv_high, nothing else.  The distribution arrays are then stale at the face until `materialise()` copies the
-receive buffers into them (before a checkpoint / a debug dump); receive buffers full of NaN mean "the arrays count".
+from dense receive buffers ([z][k][y] over the padded plane, k = rank of the direction among the 5 with e_x > 0 resp.
+< 0: a range of z-planes is one contiguous piece); per step the host moves send_high -> the high neighbour's recv_low
+and send_low -> the low neighbour's recv_high, nothing else.  The distribution arrays are then stale at the face until
+`materialise()` copies the receive buffers into them (before a checkpoint / a debug dump); receive buffers whose bits
+are all ones (memset 0xFF) mean "the arrays count" -- the marker is compared bit for bit, so a NaN or an infinity a
+diverging neighbour really sent crosses the face like any other value.
+
+Overlap (the reference puts the x-face blocks into its boundary kernel and overlaps their transfer with the bulk,
+subdomain_runner.py:409-419, 1028-1058; a whole-row workgroup cannot split off an x face): the sweep is cut into
+z-chunks, one launch each (`ChunkPlan`; the chip drains at a launch boundary, which costs 1-2 % at 128 x 512 x 512 with
+four chunks); as soon as the chunks that write a range of face-buffer planes are done that range travels on the halo
+stream while the next chunk computes, and a chunk of the NEXT step waits only for the planes it reads.  Send and
+receive buffers exist twice and alternate by step parity, so a transfer never races with the following step's writes.
+(One launch that signals the completion of its chunks from inside the kernel was tried: the release fence a workgroup
+needs before it may count itself writes the L2 of its XCD back, 25 x slower -- profiles/r03/xface_overlap_schemes.jsonl.)
 
 Replaces, for 1-D decompositions along x (the reference's default axis, geo.py:100-135), the reference's
 CollectContinuousData / DistributeContinuousData on x faces (kernel_utils.mako:526-543, 692-708).
 """
 import ctypes
+import os
 
 import numpy as np
 
 from sailfish_amd import sym
 
 LOW, HIGH = 0, 1
+NXD = 5          # D3Q19 directions per sign of e_x
 
 
 def supported(grid, desc, indirect=False, simtype=0):
@@ -25,66 +38,161 @@ def supported(grid, desc, indirect=False, simtype=0):
 
 
 def face_count(desc):
-    """Elements of one face buffer: 5 directions x the padded (arr_ny x arr_nz) plane."""
-    return 5 * desc.arr_ny * desc.arr_nz
+    """Elements of one face buffer: the padded (arr_ny x arr_nz) plane x 5 directions."""
+    return NXD * desc.arr_ny * desc.arr_nz
+
+
+class ChunkPlan(object):
+    """Pure host logic: the z-chunks of the sweep of an x-connected subdomain, the order they are swept in, which
+    planes of the face buffers may travel after each, and which transfer a chunk of the following step waits for.
+
+    Step kinds: 'push' (AB, odd AA step): a node in plane z writes the send-buffer planes z-1 .. z+1 (the row its
+    target sits in) and the following step reads a node's own plane; 'own' (even AA step): writes the own plane,
+    and the following (odd) step pulls from the planes z-1 .. z+1.
+    """
+
+    def __init__(self, nz, wrap_z, nchunks=None, min_planes=8):
+        if nchunks is None:
+            nchunks = int(os.environ.get('SLF_XFACE_CHUNKS', '4'))
+        k = max(1, min(int(nchunks), nz // max(1, min_planes)))
+        self.nz, self.wrap_z = nz, bool(wrap_z)
+        bounds = [1 + (nz * i) // k for i in range(k + 1)]
+        self.chunks = [(bounds[i], bounds[i + 1]) for i in range(k)]        # real planes [z0, z1)
+        # z wrapped in-sweep: the chunks form a ring; the step must not END with a neighbour of the chunk the next
+        # step STARTS with (its planes would still be travelling)
+        self.order = [0, k - 1] + list(range(1, k - 1)) if (self.wrap_z and k >= 4) else list(range(k))
+        self.batches, self.need = {}, {}
+        for kind in ('push', 'own'):
+            self.batches[kind], self.need[kind] = self._plan(kind)
+
+    def _wrap(self, p):
+        if self.wrap_z:
+            return ((p - 1) % self.nz) + 1
+        return p
+
+    def writes(self, kind, c):
+        a, b = self.chunks[c]
+        ps = range(a - 1, b + 1) if kind == 'push' else range(a, b)
+        return sorted(set(self._wrap(p) for p in ps))
+
+    def reads_after(self, kind, c):
+        a, b = self.chunks[c]
+        ps = range(a, b) if kind == 'push' else range(a - 1, b + 1)
+        return sorted(set(self._wrap(p) for p in ps))
+
+    def _plan(self, kind):
+        done_at = {}                               # plane -> position in the order after which it is complete
+        for pos, c in enumerate(self.order):
+            for p in self.writes(kind, c):
+                done_at[p] = pos                   # the LAST writer decides
+        batches = []
+        for pos in range(len(self.order)):
+            planes = sorted(p for p, d in done_at.items() if d == pos)
+            runs = []
+            for p in planes:
+                if runs and runs[-1][1] == p:
+                    runs[-1][1] = p + 1
+                else:
+                    runs.append([p, p + 1])
+            batches.append([tuple(r) for r in runs])
+        need = []
+        for c in range(len(self.chunks)):
+            js = [done_at[p] for p in self.reads_after(kind, c) if p in done_at]
+            need.append(max(js) if js else -1)
+        return batches, need
+
+    def region(self, c, ny):
+        z0, z1 = self.chunks[c]
+        return (1, ny + 1, z0, z1)
 
 
 class XFaceHalo(object):
     def __init__(self, backend, module, grid, desc, send, recv):
-        """send / recv: device addresses [low face, high face] of buffers of face_count(desc) reals each, 0 for a
-        face that is not connected."""
+        """send / recv: [parity][face] device addresses of buffers of face_count(desc) reals each, 0 for a face that
+        is not connected (or one [face] list: no alternation)."""
         self.backend, self.module, self.grid, self.desc = backend, module, grid, desc
         self.dtype = np.float32 if desc.precision == 4 else np.float64
-        self.nrows = desc.arr_ny * desc.arr_nz
+        self.plane = NXD * desc.arr_ny                  # elements of one z-plane of a face buffer
         self.count = face_count(desc)
         self.nbytes = self.count * self.dtype().itemsize
-        self.send, self.recv = list(send), list(recv)
+        if not isinstance(send[0], (list, tuple)):
+            send, recv = [send, send], [recv, recv]
+        self.send, self.recv = [list(s) for s in send], [list(r) for r in recv]
         # directions entering through the low face have e_x > 0, through the high face e_x < 0 (ascending = rank order)
         self.enter = [sym.get_prop_dists(grid, 1, 0), sym.get_prop_dists(grid, -1, 0)]
         self._kernels = {}
-        lib = backend._lib
-        from sailfish_amd.backend_hip import _check
-        _check(lib, lib.slf_module_set_xface_buffers(module.handle, *[ctypes.c_void_p(a or None) for a in
-                                                                      (self.send[LOW], self.send[HIGH],
-                                                                       self.recv[LOW], self.recv[HIGH])]),
-               'slf_module_set_xface_buffers')
+        self._bound = None
+        self.bind(0, 1)
 
     @classmethod
     def allocate(cls, backend, module, grid, desc, faces, alloc):
         """faces: (low connected, high connected); alloc(n_elements) -> device address of a buffer the transport can
-        send from / receive into.  Allocation order: send low, send high, receive low, receive high."""
+        send from / receive into.  Allocation order, per parity: send low, send high, receive low, receive high."""
         n = face_count(desc)
-        send = [alloc(n) if faces[f] else 0 for f in (LOW, HIGH)]
-        recv = [alloc(n) if faces[f] else 0 for f in (LOW, HIGH)]
+        send, recv = [], []
+        for _ in range(2):
+            send.append([alloc(n) if faces[f] else 0 for f in (LOW, HIGH)])
+            recv.append([alloc(n) if faces[f] else 0 for f in (LOW, HIGH)])
         return cls(backend, module, grid, desc, send, recv)
 
+    def bind(self, send_parity, recv_parity):
+        """The sweeps launched from now on write send[send_parity] and read recv[recv_parity]."""
+        key = (send_parity, recv_parity)
+        if key == self._bound:
+            return
+        lib = self.backend._lib
+        from sailfish_amd.backend_hip import _check
+        s, r = self.send[send_parity], self.recv[recv_parity]
+        _check(lib, lib.slf_module_set_xface_buffers(self.module.handle, *[ctypes.c_void_p(a or None) for a in
+                                                                           (s[LOW], s[HIGH], r[LOW], r[HIGH])]),
+               'slf_module_set_xface_buffers')
+        self._bound = key
+
+    def begin_step(self, iteration, stream):
+        """Buffers of the step that starts at `iteration`: it writes the send set of its parity and reads what the
+        previous step's transfers delivered."""
+        par = iteration & 1
+        self.bind(par, 1 - par)
+        if self.needs_clear:
+            self.clear_send(stream, par)
+        return par
+
+    def _all(self):
+        seen = []
+        for group in self.send + self.recv:
+            for a in group:
+                if a and a not in seen:
+                    seen.append(a)
+        return seen
+
     def reset(self, stream=None):
-        """All entries NaN: nothing has crossed the faces yet, the kernels read the arrays."""
-        for a in self.send + self.recv:
-            if a:
-                self.backend.memset_buf(a, 0xFF, self.nbytes, stream)
+        """All bits set: nothing has crossed the faces yet, the kernels read the arrays."""
+        for a in self._all():
+            self.backend.memset_buf(a, 0xFF, self.nbytes, stream)
 
     @property
     def needs_clear(self):
-        """Without in-sweep wrap along y and z some rows of the send buffers are not written in every step (nothing
-        is pushed from a ghost row); they must read as 'nothing crossed here' (NaN), not as last step's value."""
+        """Rows of the send buffers that a step does not write must read as 'nothing crossed here', not as an older
+        step's value: without in-sweep wrap along y and z nothing is pushed from a ghost row, and with a node map an
+        excluded edge node pushes nothing."""
         d = self.desc
-        return not (d.periodic_fused[1] and d.periodic_fused[2])
+        return not (d.periodic_fused[1] and d.periodic_fused[2]) or not d.fluid_only
 
-    def clear_send(self, stream):
-        for a in self.send:
+    def clear_send(self, stream, parity=0):
+        for a in self.send[parity]:
             if a:
                 self.backend.memset_buf(a, 0xFF, self.nbytes, stream)
 
-    def materialise(self, dist, pushed, stream):
-        """Writes the receive buffers into the distribution array `dist`: pushed = True after a push step (AB, odd AA:
-        the values belong into the first real column, same slots), False after the even AA step (they belong into the
-        ghost column, opposite slots, where the next pull looks for them)."""
+    def materialise(self, dist, pushed, stream, parity=0):
+        """Writes the receive buffers of `parity` into the distribution array `dist`: pushed = True after a push step
+        (AB, odd AA: the values belong into the first real column, same slots), False after the even AA step (they
+        belong into the ghost column, opposite slots, where the next pull looks for them)."""
         b, d = self.backend, self.desc
         nx = d.lat_nx - 2
         isz = self.dtype().itemsize
+        recv = self.recv[parity]
         for face in (LOW, HIGH):
-            if not self.recv[face]:
+            if not recv[face]:
                 continue
             if pushed:
                 x = 1 if face == LOW else nx
@@ -94,11 +202,14 @@ class XFaceHalo(object):
                 jobs = [(mask, x, 0)]
             else:
                 x = 0 if face == LOW else nx + 1
-                jobs = [(1 << self.grid.idx_opposite[q], x, k * self.nrows * isz) for k, q in enumerate(self.enter[face])]
+                jobs = [(1 << self.grid.idx_opposite[q], x, k * d.arr_ny * isz) for k, q in enumerate(self.enter[face])]
             for mask, col, off in jobs:
-                key = (dist, face, pushed, mask)
+                key = (dist, recv[face], pushed, mask)
                 if key not in self._kernels:
+                    # node box: columns = y (stride arr_nx), rows = z; buffer [z][k][y]: directions arr_ny apart,
+                    # rows 5 arr_ny apart
                     self._kernels[key] = b.get_kernel(self.module, 'DistributeContinuousData', (64,),
-                                                      [dist, self.recv[face] + off, mask, col, d.arr_nx, d.arr_ny,
-                                                       d.arr_nx * d.arr_ny, d.arr_nz], 'PPiiiiii')
+                                                      [dist, recv[face] + off, mask, col, d.arr_nx, d.arr_ny,
+                                                       d.arr_nx * d.arr_ny, d.arr_nz, d.arr_ny, NXD * d.arr_ny],
+                                                      'PPiiiiiiii')
                 b.run_kernel(self._kernels[key], None, stream)

@@ -40,12 +40,38 @@ def test_rc_file(tmp_path, monkeypatch):
     assert cfg.precision == 'single'
 
 
-def test_minimize_roundoff_is_refused_not_ignored():
+def test_minimize_roundoff_is_a_density_model_and_refused_where_it_does_not_apply():
+    """--minimize_roundoff (reference lb_base.py:72-76, sym.py:573-661): the third value of the module's density
+    model; BGK with fluid and bounce-back nodes -- everything else is refused, never silently run as the standard
+    formulation."""
     import pytest
+    from sailfish_amd import hipabi
     from sailfish_amd.controller import LBSimulationController
     from sailfish_amd.geo import LBGeometry2D
+    from sailfish_amd.lb_single import LBFluidSim
     from tests import _host
+    cfg = _host.make_config(2, minimize_roundoff=True)
+    assert LBFluidSim.density_model(cfg) == hipabi.SLF_DENSITY_ROUNDOFF
+    assert LBFluidSim.density_model(_host.make_config(2)) == hipabi.SLF_DENSITY_COMPRESSIBLE
+    assert LBFluidSim.density_model(_host.make_config(2, incompressible=True)) == hipabi.SLF_DENSITY_INCOMPRESSIBLE
+    with pytest.raises(ValueError):
+        LBFluidSim.density_model(_host.make_config(2, minimize_roundoff=True, model='mrt'))
+    ok = dict(incompressible=hipabi.SLF_DENSITY_ROUNDOFF, type_kind=[hipabi.SLF_NK_FLUID, hipabi.SLF_NK_GHOST, hipabi.SLF_NK_FULL_BB])
+    LBFluidSim.check_module_desc(ok)
+    with pytest.raises(NotImplementedError):       # the lid of the cavity examples
+        LBFluidSim.check_module_desc(dict(ok, type_kind=ok['type_kind'] + [hipabi.SLF_NK_REGULARIZED_VELOCITY]))
+    # the geometry of examples/ldc_2d.py is refused on the host, before anything touches the device
     sim_cls = _host.load_sim_class('ldc_2d', 'LDCSim')
-    ctrl = LBSimulationController(sim_cls, LBGeometry2D, default_config=dict(minimize_roundoff=True, max_iters=1, quiet=True))
+    _, _, runners = _host.build_runners(sim_cls, 2, LBGeometry2D, dict(minimize_roundoff=True, lat_nx=32, lat_ny=32))
+    r = runners[0]
+    r._init_geometry()
+    r._sim.init_fields(r)
+    with pytest.raises(NotImplementedError):
+        r._module_desc()
+    # binary models: refused by the controller
+    from tests import _sc
+    sc_cls, geo = _sc.make_sim(2)
+    ctrl = LBSimulationController(sc_cls, geo, default_config=dict(_sc.config(2, (16, 16)), minimize_roundoff=True,
+                                                                  max_iters=1, quiet=True))
     with pytest.raises(NotImplementedError):
         ctrl.run(ignore_cmdline=True)

@@ -87,6 +87,41 @@ def collision_probe(backend, golden_dir, name, precision, fused, box_cls=None):
                G['mrt_force_post'][k], mrt_tol)
 
 
+@pytest.mark.parametrize('fused', [1, 0], ids=['in_sweep_wrap', 'ghost_pbc'])
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_minimize_roundoff_against_reference_fixtures(backend, golden_dir, name, precision, fused):
+    roundoff_probe(backend, golden_dir, name, precision, fused)
+
+
+def roundoff_probe(backend, golden_dir, name, precision, fused, box_cls=None):
+    """--minimize_roundoff (reference lb_base.py:72-76): the arrays hold f_i - w_i.  Fixtures evaluated from the
+    reference's sympy objects built with config.minimize_roundoff = True (tools/capture_goldens.py: ex_rho /
+    ex_velocity of the shifted populations, bgk_equilibrium with rho0 = rho + 1, the Guo term with its prefactor):
+    collision with and without a body force, the stored density delta / velocity, and SetInitialConditions."""
+    grid, size = GRIDS[name]
+    G = np.load(os.path.join(golden_dir, 'arith_%s.npz' % name))
+    tol = TOL[precision]
+    RO = hipabi.SLF_DENSITY_ROUNDOFF
+    for k in SAMPLES:
+        f = G['ro_f'][k]
+        for a, nu in enumerate(G['ro_visc']):
+            _check(_one_step(backend, grid, size, f, precision, fused, box_cls, model='bgk', visc=float(nu), incompressible=RO),
+                   G['ro_bgk_post'][a, k], tol, rho=float(G['ro_mom_rho'][k]), v=list(G['ro_mom_v'][k]))
+        _check(_one_step(backend, grid, size, f, precision, fused, box_cls, model='bgk', visc=float(G['ro_guo_visc'][0]),
+                         accel=list(G['ro_accel'][k]), incompressible=RO),
+               G['ro_guo_post'][k], tol, rho=float(G['ro_mom_rho'][k]), v=list(G['ro_guo_out_v'][k]))
+        desc = make_box_desc(grid, size, precision=precision, access_pattern='AB', periodic_fused=[fused] * 3, incompressible=RO)
+        s = (box_cls or BoxSim)(backend, desc, periodic=(True, True, True))
+        shape = tuple(reversed(size))
+        s.set_fields(np.full(shape, G['rho'][k]), [np.full(shape, G['v'][k][d]) for d in range(grid.dim)])
+        s.initial_conditions()
+        s.sync()
+        out = s.real_view(s.get_dist()).reshape(s.Q, -1).astype(np.float64)
+        assert float(np.max(np.abs(out - G['ro_feq'][k][:, None]))) < tol
+        s.release()
+
+
 BC_CASES = {    # kind: (type id in tests/_geometry.TYPE_KIND, parameter fixture, expected populations, expected rho, expected v)
     'regularized_velocity': ('T_REGVEL', 'bc_v', 'regvel_post', 'regvel_rho', 'bc_v'),
     'zouhe_velocity': ('T_ZHVEL', 'bc_v', 'zouhe_vel_post', 'regvel_rho', 'bc_v'),
@@ -103,7 +138,25 @@ def test_boundary_nodes_against_reference_fixtures(backend, golden_dir, name, pr
     boundary_probe(backend, golden_dir, name, precision, kind)
 
 
-def boundary_probe(backend, golden_dir, name, precision, kind, box_cls=None):
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_composed_step_with_boundary_condition_and_relaxation(backend, golden_dir, name, precision, model):
+    composed_probe(backend, golden_dir, name, precision, model)
+
+
+def composed_probe(backend, golden_dir, name, precision, model, box_cls=None):
+    """ONE node update with a boundary condition AND relaxation on, composed in the order of the reference's kernel
+    (lb_single_fluid.mako:175-228: getMacro -> pre-collision boundary condition -> relaxate with the same rho / u ->
+    stream): a regularized-velocity node (the lid of the cavity configurations) per orientation, BGK and MRT.  The
+    single-piece fixtures pin moments, boundary conditions and collisions separately; this one pins how the kernel
+    strings them together -- which density and velocity the collision sees after the boundary condition replaced the
+    populations."""
+    boundary_probe(backend, golden_dir, name, precision, 'regularized_velocity', box_cls=box_cls,
+                   relaxation=model, fkey='regvel_%s_step' % model)
+
+
+def boundary_probe(backend, golden_dir, name, precision, kind, box_cls=None, relaxation=None, fkey=None):
     """Single-node probes of the pre-collision boundary conditions (reference boundary.mako:343-382, 425-459, 784-878;
     fixtures from sym.noneq_bb / zouhe_fixup / reglb_flux_tensor / ex_rho): one boundary node per orientation in a
     box whose nodes all carry the fixture state f, relaxation switched off, one two-copy step through the node-map
@@ -112,14 +165,17 @@ def boundary_probe(backend, golden_dir, name, precision, kind, box_cls=None):
     grid, _ = GRIDS[name]
     dim = grid.dim
     G = np.load(os.path.join(golden_dir, 'arith_%s.npz' % name))
-    tname, pkey, fkey, rkey, vkey = BC_CASES[kind]
-    tol = TOL[precision] * 2
+    tname, pkey, fkey0, rkey, vkey = BC_CASES[kind]
+    fkey = fkey or fkey0
+    tol = TOL[precision] * (2 if relaxation != 'mrt' else (100 if precision == 'double' else 8))
     norient = 2 * dim
     size = (2 * norient + 3, 5) + ((5,) if dim == 3 else ())
     for k in SAMPLES[:3]:
         params = [float(x) for x in np.atleast_1d(G[pkey][k])]
         desc = make_box_desc(grid, size, precision=precision, access_pattern='AB', fluid_only=False,
-                             type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS, node_params=params, relaxation_enabled=False)
+                             type_kind=geo.TYPE_KIND, nt_bits=geo.NT_BITS, node_params=params,
+                             relaxation_enabled=relaxation is not None, model=relaxation or 'bgk',
+                             visc=float(G['step_visc'][0]))
         m = geo.empty_map(desc)
         probes = []
         for o in range(1, norient + 1):

@@ -266,9 +266,10 @@ def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
     """The reference's regression curve regtest/poiseuille.py: relative error of the maximum velocity of a
     127 x 128 force-driven channel (full-way bounce-back) after 100/visc iterations, 30 viscosities from
     1e-3 to 1e-1, against the numbers the reference recorded from its GPU path
-    (tests/golden/poiseuille_curves/).  Recorded by an older revision => envelope: our error may not be
-    larger than the recorded one (plus a small absolute slack); single precision is compared where round-off
-    does not dominate the recorded values (visc >= 0.02; they scatter by several 1e-3 there)."""
+    (tests/golden/poiseuille_curves/).  Recorded by an older revision => a two-sided bracket instead of equality: our
+    error at the centre nodes may not be larger than the recorded one, and the recorded one may not be larger than
+    ours one node off the centre (see below); single precision is compared where round-off does not dominate the
+    recorded values (visc >= 0.02; they scatter by several 1e-3 there)."""
     data = np.loadtxt(os.path.join(golden_dir, 'poiseuille_curves', 'D2Q9_%s_force_%s_fullbb.dat' % (model, precision)))
     assert data.shape == (30, 2)
     sim_cls = _host.load_sim_class('poiseuille', 'PoiseuilleSim')
@@ -284,11 +285,21 @@ def test_poiseuille_error_curve_envelope(model, precision, golden_dir):
         profile = vx[:, vx.shape[1] // 2]
         theory = sim_cls.subdomain.velocity_profile(r.config, np.arange(vx.shape[0]))
         err = np.nanmax(profile) / np.nanmax(theory) - 1.0
-        print('poiseuille %s %s visc %.5f: err %+.6e recorded %+.6e' % (model, precision, visc, err, recorded))
+        # the other side of the bracket: the same measure ONE NODE OFF the centre-line pair (the channel is 126
+        # lattice units wide between the half-way walls, the maximum sits between nodes 63 and 64).  The recorded
+        # plateau, -2.516e-4 = -4 / 126^2 to 0.1 %, lies between the value at the centre nodes and the value one node
+        # further out: that revision compared the same flow at a position up to one node away from where the current
+        # regtest/poiseuille.py (and this test) samples it -- a difference of set-up, not of the scheme.
+        centre = int(np.nanargmax(theory))
+        off = min(profile[centre - 1], profile[centre + 2]) / np.nanmax(theory) - 1.0
+        print('poiseuille %s %s visc %.5f: err %+.6e (one node off %+.6e) recorded %+.6e'
+              % (model, precision, visc, err, off, recorded))
         if precision == 'double':
             assert abs(err) <= abs(recorded) + 5e-5, (visc, err, recorded)
+            assert off - 5e-5 <= recorded <= err + 5e-5, (visc, off, recorded, err)
         else:
             assert abs(err) <= abs(recorded) + 1e-3, (visc, err, recorded)
+            assert off - 1e-3 <= recorded <= err + 1e-3, (visc, off, recorded, err)
         worst = max(worst, abs(err))
     assert worst < (3e-4 if precision == 'double' else 5e-3)
 

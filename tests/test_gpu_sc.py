@@ -46,6 +46,27 @@ def test_sc_vs_oracle(dim, size, pattern, fused):
         assert np.array_equal(gd, o.real(od)), 'lattice %d populations differ' % grid_num
 
 
+@pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (130, 9, 8))])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_fused_sweep_equals_the_two_kernels(dim, size, pattern):
+    """"ShanChenCollideAndPropagateFused" (both lattices in one pass, the stencil sums formed once) against the
+    reference's two kernels ShanChenCollideAndPropagate0 / 1: bit-identical populations, with self-coupling, the
+    classic (exponential) potential and a body force on one lattice."""
+    from sailfish_amd.controller import LBSimulationController
+    out = []
+    for fused in (True, False):
+        sim_cls, geo = _sc.make_forced_sim(dim, [1e-5, 0.0, 0.0][:dim], [0.0, -2e-5, 0.0][:dim])
+        cfg = _sc.config(dim, size, pattern=pattern, fused=True, G12=0.9, G11=-0.3, G22=-0.2, potential='classic',
+                         tau_phi=0.8)
+        cfg.update(max_iters=11, quiet=True, perf_stats_every=0, hip_sc_fused=fused)
+        ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
+        ctrl.run(ignore_cmdline=True)
+        r = ctrl.runners[0]
+        out.append([r._debug_get_dist(grid_num=g) for g in (0, 1)] + [r._sim.rho.copy(), r._sim.phi.copy()])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_sc_classic_potential_and_self_coupling():
     """exp() differs in the last bits between libm and the GPU: tolerance instead of bit equality."""
     kw = dict(pattern='AA', fused=True, G12=0.9, G11=-0.3, G22=-0.2, potential='classic', tau_phi=0.8)

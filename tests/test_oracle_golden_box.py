@@ -45,6 +45,20 @@ def test_oracle_sweep_boundary_nodes(golden_dir, name, precision, kind):
     probes.boundary_probe(None, golden_dir, name, precision, kind, box_cls=OracleProbeBox)
 
 
+@pytest.mark.parametrize('fused', [1, 0], ids=['in_sweep_wrap', 'ghost_pbc'])
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_oracle_minimize_roundoff(golden_dir, name, precision, fused):
+    probes.roundoff_probe(None, golden_dir, name, precision, fused, box_cls=OracleProbeBox)
+
+
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_oracle_composed_step(golden_dir, name, precision, model):
+    probes.composed_probe(None, golden_dir, name, precision, model, box_cls=OracleProbeBox)
+
+
 @pytest.mark.parametrize('precision', ['double', 'single'])
 @pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
 def test_oracle_initial_conditions(golden_dir, name, precision):

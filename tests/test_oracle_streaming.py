@@ -13,33 +13,7 @@ from sailfish_amd.box import make_box_desc
 from tests._oracle_box import OracleBox, synthetic_fields
 
 
-def numpy_twin(grid, rho, v, visc, steps):
-    """Textbook periodic BGK with np.roll streaming, float64."""
-    e = grid.basis_array
-    w = grid.weights_float
-    dim = grid.dim
-
-    def feq(rho, v):
-        usq = sum(c * c for c in v)
-        out = []
-        for i in range(grid.Q):
-            eu = sum(e[i][d] * v[d] for d in range(dim))
-            out.append(w[i] * rho * (1 + 3 * eu + 4.5 * eu * eu - 1.5 * usq))
-        return np.array(out)
-
-    f = feq(rho, v)
-    omega = 1.0 / sym.relaxation_time(visc)
-    for _ in range(steps):
-        r = f.sum(axis=0)
-        u = [sum(e[i][d] * f[i] for i in range(grid.Q)) / r for d in range(dim)]
-        f = f + omega * (feq(r, u) - f)
-        for i in range(grid.Q):
-            # numpy axis order is (z, y, x)
-            shift = tuple(int(e[i][d]) for d in reversed(range(dim)))
-            f[i] = np.roll(f[i], shift, axis=tuple(range(dim)))
-    r = f.sum(axis=0)
-    u = [sum(e[i][d] * f[i] for i in range(grid.Q)) / r for d in range(dim)]
-    return f, r, u
+from oracle.numpy_twin import run as numpy_twin  # noqa: E402  (the textbook np.roll scheme)
 
 
 CASES = [(sym.D2Q9, (12, 9)), (sym.D3Q19, (9, 7, 6))]

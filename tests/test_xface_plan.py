@@ -1,0 +1,55 @@
+"""Host logic of the overlapped x-face exchange (sailfish_amd/xface.py: ChunkPlan): which planes of the face buffers
+travel after which z-chunk of the sweep, and which transfer a chunk of the next step has to wait for."""
+import pytest
+
+from sailfish_amd.xface import ChunkPlan
+
+
+@pytest.mark.parametrize('nz', [8, 12, 33, 64, 512])
+@pytest.mark.parametrize('wrap', [True, False])
+@pytest.mark.parametrize('nchunks', [1, 2, 4, 7])
+def test_every_written_plane_travels_once_and_nothing_is_read_too_early(nz, wrap, nchunks):
+    p = ChunkPlan(nz, wrap, nchunks)
+    assert sorted(p.order) == list(range(len(p.chunks)))
+    assert p.chunks[0][0] == 1 and p.chunks[-1][1] == nz + 1
+    assert all(a[1] == b[0] for a, b in zip(p.chunks, p.chunks[1:]))
+    for kind in ('push', 'own'):
+        sent = {}
+        for pos, runs in enumerate(p.batches[kind]):
+            for p0, p1 in runs:
+                assert p0 < p1
+                for pl in range(p0, p1):
+                    assert pl not in sent
+                    sent[pl] = pos
+        written = set()
+        for c in range(len(p.chunks)):
+            written.update(p.writes(kind, c))
+        assert set(sent) == written
+        # a plane travels only after its last writer has been swept
+        done = {}
+        for pos, c in enumerate(p.order):
+            for pl in p.writes(kind, c):
+                done[pl] = pos
+        assert sent == done
+        # the next step: chunk c may start once batch need[c] has arrived -- everything it reads is in it or earlier
+        for c in range(len(p.chunks)):
+            for pl in p.reads_after(kind, c):
+                if pl in sent:
+                    assert sent[pl] <= p.need[kind][c]
+        assert set(range(1, nz + 1)) <= written
+
+
+def test_the_first_chunk_of_a_step_never_waits_for_the_last_transfer_of_the_previous_one():
+    """That is the point of the sweep order 0, K-1, 1, .. K-2 on a ring of chunks: the last batch travels while the
+    next step's first chunk computes."""
+    for nz in (64, 512):
+        for wrap in (True, False):
+            p = ChunkPlan(nz, wrap, 4)
+            last = len(p.order) - 1
+            for kind in ('push', 'own'):
+                assert p.need[kind][p.order[0]] < last, (nz, wrap, kind, p.need[kind])
+
+
+def test_thin_subdomains_are_not_cut():
+    p = ChunkPlan(6, True, 4)
+    assert p.chunks == [(1, 7)] and p.order == [0] and p.need['push'] == [0]

@@ -118,6 +118,54 @@ def arithmetic_goldens(grid, rng, n=48):
                 res[k, i] = _evalf(e, subs)
         out['feq_inc%d' % int(inc)] = res
 
+    # --- the --minimize_roundoff formulation (reference lb_base.py:72-76): every expression built with
+    #     config.minimize_roundoff = True -- equilibrium at (delta rho, v) (sym_equilibrium.py:100-118, rho0 = rho + 1),
+    #     moments of the shifted populations f - w (sym.py:573-597, 654-661), BGK collision, Guo forcing with the
+    #     prefactor of sym_force.py:147-160
+    cfg_ro = _Cfg(minimize_roundoff=True)
+    wts = np.array([float(w) for w in grid.weights])
+    f_ro = f - wts[None, :]
+    eq_ro = sym_equilibrium.bgk_equilibrium(grid, cfg_ro)
+    ro_rho = np.zeros(n)
+    ro_v = np.zeros((n, dim))
+    ro_feq = np.zeros((n, Q))
+    for k in range(n):
+        subs = _fi_subs(grid, f_ro[k])
+        ro_rho[k] = _evalf(sym.ex_rho(grid, 'fi', False, minimize_roundoff=True), subs)
+        subs2 = dict(subs)
+        subs2.update({'g0m0': ro_rho[k], 'rho': ro_rho[k]})
+        for d in range(dim):
+            ro_v[k, d] = _evalf(sym.ex_velocity(grid, 'fi', d, cfg_ro), subs2)
+        subs = _macro_subs(grid, rho[k] - 1.0, v[k])
+        for i, e in enumerate(eq_ro.expression):
+            ro_feq[k, i] = _evalf(e, subs)
+    out['ro_f'], out['ro_mom_rho'], out['ro_mom_v'], out['ro_feq'] = f_ro, ro_rho, ro_v, ro_feq
+    ro_visc = np.array([1.0 / 6.0, 0.01])
+    ro_post = np.zeros((len(ro_visc), n, Q))
+    for a, nu in enumerate(ro_visc):
+        omega = 1.0 / sym.relaxation_time(nu)
+        for k in range(n):
+            subs = _macro_subs(grid, ro_rho[k], ro_v[k])
+            for i, e in enumerate(eq_ro.expression):
+                ro_post[a, k, i] = f_ro[k, i] + omega * (_evalf(e, subs) - f_ro[k, i])
+    out['ro_visc'], out['ro_bgk_post'] = ro_visc, ro_post
+    ro_accel = np.random.RandomState(77).uniform(-1e-4, 1e-4, (n, dim))
+    ro_guo = np.zeros((n, Q))
+    nu = 0.02
+    tau = sym.relaxation_time(nu)
+    guo_e = sym_force.guo_external_force(grid, grid_num=0)
+    pref_ro = sym_force.guo_external_force_pref(grid, cfg_ro, grid_num=0)
+    for k in range(n):
+        v0 = ro_v[k] + 0.5 * ro_accel[k]
+        subs = _macro_subs(grid, ro_rho[k], v0)
+        subs.update({'g0ea' + c: ro_accel[k, j] for j, c in enumerate('xyz'[:dim])})
+        subs['tau0'] = tau
+        subs['pref'] = _evalf(pref_ro, subs)
+        for i, e in enumerate(eq_ro.expression):
+            ro_guo[k, i] = f_ro[k, i] + (1.0 / tau) * (_evalf(e, subs) - f_ro[k, i]) + _evalf(guo_e[i], subs)
+    out['ro_accel'], out['ro_guo_post'], out['ro_guo_out_v'] = ro_accel, ro_guo, ro_v + 0.5 * ro_accel
+    out['ro_guo_visc'] = np.array([nu])
+
     cfg = _Cfg()
     # --- moments: sym.py:573-682
     ex_rho = sym.ex_rho(grid, 'fi', False)
@@ -354,6 +402,33 @@ def arithmetic_goldens(grid, rng, n=48):
                 regd[o - 1, k, i] = max(1e-7, _evalf(eqx[i], subs_r) + _evalf(reg[i], subs_r))
             del nvec[:]
     out['regvel_rho'], out['regvel_post'] = regv_rho, regv
+    # --- one COMPOSED node update with a boundary condition and relaxation on, in the order of
+    #     lb_single_fluid.mako:175-228: getMacro (rho from ex_rho(missing_dir), v = the node's parameters) ->
+    #     precollisionBoundaryConditions (noneq_bb + regularisation: regv above) -> relaxate with the SAME g0m0 / v
+    #     (BGK: relaxation.mako:127-132; MRT: moments of the regularised populations, relaxation_mrt.mako:31-97)
+    nu_step = 0.02
+    omega = 1.0 / sym.relaxation_time(nu_step)
+    step_bgk = np.zeros((2 * dim, n, Q))
+    step_mrt = np.zeros((2 * dim, n, Q))
+    for o in range(1, 2 * dim + 1):
+        for k in range(n):
+            g = regv[o - 1, k]
+            subs = _macro_subs(grid, regv_rho[o - 1, k], bc_v[k])
+            for i in range(Q):
+                step_bgk[o - 1, k, i] = g[i] + omega * (_evalf(eqx[i], subs) - g[i])
+            if hasattr(grid, 'mrt_matrix'):
+                m = M.dot(g)
+                subs = {'rho': m[0], 'g0m0': m[0], 'rho0': m[0], 'visc': nu_step}
+                subs.update({'m' + c: m[grid.mrt_names.index('m' + c)] for c in 'xyz'[:dim]})
+                for lv in grid.mrt_eq_symbols:
+                    subs[lv.lhs.name] = _evalf(lv.rhs, subs)
+                for i in range(Q):
+                    c = grid.mrt_collision[i]
+                    cval = _evalf(c, subs) if isinstance(c, sympy.Basic) else float(c)
+                    if cval != 0:
+                        m[i] -= cval * (m[i] - _evalf(grid.mrt_equilibrium[i], subs))
+                step_mrt[o - 1, k] = Minv.dot(m)
+    out['regvel_bgk_step'], out['regvel_mrt_step'], out['step_visc'] = step_bgk, step_mrt, np.array([nu_step])
     out['eqdens_v'], out['eqdens_post'] = eqd_v, eqd
     out['zouhe_vel_post'], out['zouhe_dens_post'], out['zouhe_dens_v'] = zhv, zhd, zhd_v
     out['regdens_post'] = regd
