@@ -171,7 +171,11 @@ def make_ring_exchanger(rank, world, backend):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and \
             os.environ.get('SLF_HALO_TRANSPORT', 'rccl') != 'torch':
-        return RcclRingExchanger(rank, world, backend)
+        try:
+            return RcclRingExchanger(rank, world, backend)
+        except Exception as e:  # noqa: BLE001 -- no communicator of our own: torch.distributed carries the halo instead
+            import sys
+            sys.stderr.write('sailfish_amd: RCCL through the C ABI unavailable (%s); halo through torch.distributed\n' % e)
     return RingExchanger(rank, world)
 
 

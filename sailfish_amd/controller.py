@@ -123,9 +123,12 @@ class LocalGroup(object):
     def run(self):
         runners = self.runners
         from sailfish_amd import placement
-        with placement.holding():       # several subdomains on one GPU: every one gets its own stretch of HBM
-            for r in runners:
-                r.prepare()
+        if len(runners) > 1:
+            with placement.holding():   # several subdomains on one GPU: every one gets its own stretch of HBM
+                for r in runners:
+                    r.prepare()
+        else:
+            runners[0].prepare()
         cfg = runners[0].config
         t_prev, it_prev = time.time(), runners[0]._sim.iteration
         t0, it0 = t_prev, it_prev

@@ -214,8 +214,10 @@ static void launch_row5(Prop prop, SweepParams<L, R> p, int nx, int ny, int nz, 
   dim3 grid((nx + bx - 1) / bx, ny, nz);
   p.y1 = p.y0 + ny;
   p.z1 = p.z0 + nz;
-  // node-map kernels in single precision: one instantiation per Geometry::bc_level (slf_kernels.h)
-  if constexpr (GENERAL && sizeof(R) == 4) {
+  // node-map kernels: one instantiation per Geometry::bc_level (slf_kernels.h).  (Double precision too: the 64 bytes
+  // of scratch per lane of its two-copy kernels are the outflow-node code of level 2, not the 128-VGPR cap of a
+  // 1024-thread workgroup -- they stay with 512-thread workgroups: profiles/r03/f64_row_kernels_resources.txt)
+  if constexpr (GENERAL) {
     const int bcl = p.g.bc_level;
     if (bcl == 0) {
       launch_level<L, R, MODEL, GENERAL, FORCE, 0>(prop, p, grid, block, s);

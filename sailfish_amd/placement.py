@@ -54,21 +54,6 @@ class PlacedBuffer(object):
         self.backend.vmm_map(self.va + i * self.part_bytes, self.part_bytes, handle)
         self.mapped[i] = handle
 
-    def detach(self):
-        """Unmaps the physical chunks (the address range stays reserved) and returns their handles: the caller either
-        gives them back with attach() or releases them (placement by measurement, tune())."""
-        handles = list(self.mapped)
-        for i, h in enumerate(handles):
-            if h is not None:
-                self.backend.vmm_unmap(self.va + i * self.part_bytes, self.part_bytes)
-                self.mapped[i] = None
-        return handles
-
-    def attach(self, handles):
-        for i, h in enumerate(handles):
-            if h is not None:
-                self.map_part(i, h)
-
     def release(self):
         """Unmaps and releases the chunks and the address range."""
         b = self.backend
@@ -110,6 +95,11 @@ class holding(object):
         return False
 
 
+def holding_now():
+    """Inside a holding() block (several simulations being set up on one GPU)?"""
+    return _held is not None
+
+
 def place(backend, buffers, span=None):
     """Backs `buffers` (PlacedBuffer with equal part counts) with physical chunks spread over `span` bytes: part i of
     every buffer, then a spacer, for i = 0 .. parts-1; the spacers are released at the end (or when the enclosing
@@ -147,43 +137,31 @@ def place(backend, buffers, span=None):
             'spacer_gib': round(spacer / 2.0 ** 30, 3), 'span_gib': round((payload + spacer * (parts - 1)) / 2.0 ** 30, 1)}
 
 
-def tune(backend, buffers, measure, attempts=4, agree=0.02, log=None):
+def choose(make_set, measure, release, attempts=3, agree=0.02, log=None):
     """Placement by measurement.  The rule of place() -- spread the chunks over the span -- removes the 15 % bimodality
     of large arrays, but what a placement is worth still varies between processes and boxes (arrays of 1-2 GB: 35-41
-    GMLUPS, profiles/r02/runner_path_placement.log).  So: `measure()` (seconds per step of the real kernels on the
-    placed arrays; their contents are scratch at this point) is taken for the current placement, then the arrays are
-    placed again -- the previous chunks stay allocated meanwhile, so the new ones land elsewhere -- until two
-    placements agree with the best within `agree` or `attempts` are used up; the best one is mapped back and everything
-    else released.  Returns {'times': [...], 'chosen': index}."""
-    tried = []                       # [(seconds, [handles per buffer])]
-    t = measure()
-    times = [t]
-    best_t, best_i = t, 0
-    for k in range(1, attempts):
-        tried.append((times[-1], [b.detach() for b in buffers]))
-        place(backend, buffers)
-        t = measure()
-        times.append(t)
-        if t < best_t:
-            best_t, best_i = t, k
+    GMLUPS, profiles/r02/runner_path_placement.log).  So: make_set() places a set of arrays, measure(set) times the
+    many-stream sweep on it (seconds per step); a second set is placed while the first is still allocated -- so it
+    lands elsewhere -- and so on until two sets agree with the best within `agree` or `attempts` are used up.  The
+    best set is returned, the others are released.  (Swapping the physical chunks under ONE address range instead was
+    tried and is not safe on this stack: kernels launched after hipMemUnmap / hipMemMap of a range they had used before
+    produced non-finite values -- profiles/r03/placement_remap_failure.txt.)"""
+    sets, times = [], []
+    for _ in range(attempts):
+        bufs = make_set()
+        sets.append(bufs)
+        times.append(measure(bufs))
         close = sorted(times)[:2]
-        if close[1] <= close[0] * (1.0 + agree):
+        if len(times) > 1 and close[1] <= close[0] * (1.0 + agree):
             break
-    if best_i != len(times) - 1:     # an earlier placement was better: map it back
-        current = [b.detach() for b in buffers]
-        for b, hs in zip(buffers, tried[best_i][1]):
-            b.attach(hs)
-        tried[best_i] = (tried[best_i][0], None)
-        tried.append((times[-1], current))
-    for _, per_buffer in tried:
-        for hs in per_buffer or []:
-            for h in hs:
-                if h is not None:
-                    backend.vmm_chunk_release(h)
-    info = {'times_ms': [round(x * 1e3, 4) for x in times], 'chosen': best_i}
+    best = min(range(len(times)), key=lambda i: times[i])
+    for i, bufs in enumerate(sets):
+        if i != best:
+            release(bufs)
+    info = {'times_ms': [round(x * 1e3, 4) for x in times], 'chosen': best}
     if log:
         log('placement by measurement: %s' % info)
-    return info
+    return sets[best], info
 
 
 def _check(lib, status, what):

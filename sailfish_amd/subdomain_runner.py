@@ -294,8 +294,16 @@ class SubdomainRunner(object):
                 getattr(self.config, 'hip_placement', True):
             # large arrays: physical backing spread over HBM (placement.py); all lattices and copies share the span
             n = len(self._sim.grids)
-            bufs = b.alloc_placed([nbytes] * (n * (2 if ab else 1)), off)
-            self._placed = [pb for pb in bufs if hasattr(pb, 'detach')]
+            sizes = [nbytes] * (n * (2 if ab else 1))
+            cfg = self.config
+            if getattr(cfg, 'hip_placement_tune', True) and os.environ.get('SLF_PLACEMENT_TUNE', '1') != '0' and \
+                    not (0 < cfg.max_iters < 200) and not placement.holding_now():
+                # placement by measurement: a second set is placed while the first is allocated, the faster one stays
+                bufs, self.placement_tuning = placement.choose(
+                    lambda: b.alloc_placed(sizes, off), lambda bs: self._probe_placement(bs, n, ab),
+                    lambda bs: [b.free_buf(pb.addr) for pb in bs], log=cfg.logger.debug)
+            else:
+                bufs = b.alloc_placed(sizes, off)
             self._gpu_grids_primary = [pb.addr for pb in bufs[:n]]
             self._gpu_grids_secondary = [pb.addr for pb in bufs[n:]]
             self.config.logger.debug('placed distributions: %s' % b.last_placement)
@@ -306,37 +314,37 @@ class SubdomainRunner(object):
                     self._gpu_grids_secondary.append(b.alloc_buf(size=nbytes, align_offset=off))
         self.config.logger.debug('distributions: %d MiB' % (nbytes * (2 if self._gpu_grids_secondary else 1) >> 20))
 
-    _placed = ()
+    placement_tuning = None
 
-    def _tune_placement(self):
-        """Placement by measurement (placement.tune): a few steps of this simulation's own kernels are timed on the
-        placed distribution arrays, the arrays are placed again while the first chunks stay allocated, and the better
-        placement is kept.  The arrays' contents are scratch here: the initial state is set up again afterwards."""
-        from sailfish_amd import placement
-        cfg = self.config
-        if not self._placed or self._links or not getattr(cfg, 'hip_placement_tune', True) or \
-                os.environ.get('SLF_PLACEMENT_TUNE', '1') == '0' or (0 < cfg.max_iters < 200):
-            return None
+    def _probe_placement(self, bufs, n_grids, ab, steps=12):
+        """Seconds per step of the plain fluid sweep (same lattice, precision, sizes and access pattern as this
+        simulation; BGK, every axis wrapped in-sweep, no node map) on the first lattice of the placed set `bufs`: what
+        placement.choose() compares.  The arrays are scratch: filled with one positive value, i.e. a fluid at rest."""
         b = self.backend
-        steps = 12
-
-        def measure():
-            self._sim.initial_conditions(self)
-            self._sim.iteration = 0
-            b.set_iteration(0)
-            for _ in range(4):
-                self.step_compute(False)
-            ev0 = b.make_event(self._calc_stream, timing=True)
-            for _ in range(steps):
-                self.step_compute(False)
-            ev1 = b.make_event(self._calc_stream, timing=True)
-            ev1.synchronize()
-            return ev1.time_since(ev0) * 1e-3 / steps
-        info = placement.tune(b, self._placed, measure, log=cfg.logger.debug)
-        self._sim.iteration = 0
+        d = hipabi.SlfModuleDesc.from_buffer_copy(self._desc)
+        d.model, d.simtype, d.fluid_only, d.n_types, d.has_force = hipabi.SLF_BGK, 0, 1, 0, 0
+        d.incompressible, d.node_addressing, d.relaxation_enabled, d.tau = 0, 0, 1, 1.0
+        for a in range(3):
+            d.periodic_fused[a] = d.periodic_local[a] = int(a < self.dim)
+        module = b.build(d)
+        nbytes = self._sim.grid.Q * self._dist_stride * self.float().itemsize
+        src, dst = bufs[0].addr, (bufs[n_grids].addr if ab else bufs[0].addr)
+        for addr in set((src, dst)):
+            b.memset_buf(addr, 0x3D, nbytes, self._calc_stream)        # 0x3d3d3d3d = 0.046 as a float, 4.2e-14 as a double
+        sig = 'P' * (4 + self.dim) + 'i'
+        pairs = [(src, dst), (dst, src)] if ab else [(src, src)]
+        ks = [b.get_kernel(module, 'CollideAndPropagate', (64,), [0, i, o, i] + [i] * self.dim + [0], sig,
+                           needs_iteration=not ab) for i, o in pairs]
+        ev0 = None
+        for it in range(4 + steps):
+            if it == 4:
+                ev0 = b.make_event(self._calc_stream, timing=True)
+            b.set_iteration(it)
+            b.run_kernel(ks[it % len(ks)], None, self._calc_stream)
+        ev1 = b.make_event(self._calc_stream, timing=True)
+        ev1.synchronize()
         b.set_iteration(0)
-        self.placement_tuning = info
-        return info
+        return ev1.time_since(ev0) * 1e-3 / steps
 
     def gpu_field(self, field):
         if isinstance(field, list):
@@ -852,7 +860,6 @@ class SubdomainRunner(object):
         self._init_gpu_data()
         self._init_halo()
         self._prepare_compute_kernels()
-        self._tune_placement()
         self._sim.initial_conditions(self)
         self.backend.set_iteration(0)
         if self._output is not None:

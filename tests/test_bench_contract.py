@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'bench_final.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'bench_final.json')))
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -27,9 +27,15 @@ def test_committed_bench_line_has_every_contract_field():
     assert abs(d['value'] - 512 ** 3 / (d['ms_per_step'] * 1e-3) * 1e-6) / d['value'] < 1e-3
     assert r['kernel_ms'] <= d['ms_per_step'] * 1.001
     assert r['traffic'] is None or 0.9 < r['traffic'] / (512 ** 3 * 152) < 1.2
+    # round 3: the line validates itself and carries the runner-path leg
+    assert c['validated'] is True and all(v['populations_bit_identical'] and v['ok'] for v in c['validation'].values())
+    assert all(v['populations_compared'] > 2e7 and v['mass_rel_drift'] < 1e-5 for v in c['validation'].values())
+    rp = c['runner_path']
+    assert 'SubdomainRunner.step()' in rp['through'] and abs(rp['vs_value'] - 1.0) < 0.03, rp
+    assert abs(d['median_value'] - c['median_mlups']) < 1.0
     b = d['cpu_baseline']
     assert b['kind'] == 'port' and b['unit'] == 'MLUPS' and b['cores'] >= 1 and 'oracle/lbm_fast.c' in b['sample']
-    assert b['single_thread_mlups'] > 0 and b['config1_d2q9_256x256_mlups'] > 0
+    assert b['single_thread_mlups'] > 0 and b['config1_d2q9_256x256_mlups'] > 0 and 0 < b['numpy_twin_mlups'] < b['value']
 
 
 def test_strong_scaling_arguments_are_checked_before_any_gpu_work():

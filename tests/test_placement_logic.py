@@ -117,27 +117,28 @@ def test_spacers_of_a_group_are_held_until_every_member_is_placed():
     assert len(b1.live) == 32
 
 
-@pytest.mark.parametrize('times,chosen', [([3.3, 3.31], 0), ([3.8, 3.3, 3.31], 1), ([3.8, 3.7, 3.3, 3.5], 2),
-                                          ([3.3, 3.9, 3.8, 3.7], 0)])
+@pytest.mark.parametrize('times,chosen', [([3.3, 3.31], 0), ([3.8, 3.3, 3.31], 1), ([3.8, 3.7, 3.3], 2), ([3.3, 3.9, 3.8], 0)])
 def test_placement_by_measurement_keeps_the_best_and_gives_everything_else_back(times, chosen):
-    """placement.tune(): place again while the previous chunks stay allocated, stop when two placements agree with the
-    best within 2 % (or after 4), map the best one back, release the rest -- the address ranges never change."""
+    """placement.choose(): place a second set while the first stays allocated, stop when two sets agree with the best
+    within 2 % (or after 3), return the best, release the rest."""
     b = FakeVmm()
     nbytes = 19 * 288 * 258 * 258 * 4
-    bufs = [placement.PlacedBuffer(b, nbytes, align_offset=124) for _ in range(2)]
-    placement.place(b, bufs)
-    vas = [pb.va for pb in bufs]
-    seq = iter(times)
-    seen = []
+    made, released = [], []
 
-    def measure():
-        seen.append(sorted(h for pb in bufs for h in pb.mapped))
-        assert all(h in b.live for pb in bufs for h in pb.mapped)
-        return next(seq) * 1e-3
-    info = placement.tune(b, bufs, measure)
-    assert info['times_ms'] == times[:len(info['times_ms'])] and info['chosen'] == chosen
-    assert len(seen) == len(info['times_ms']) and all(a != c for a, c in zip(seen, seen[1:]))    # new chunks every time
-    assert [pb.va for pb in bufs] == vas
-    mapped = sorted(h for pb in bufs for h in pb.mapped)
-    assert mapped == seen[chosen]                                      # the best placement is the one left mapped
+    def make_set():
+        bufs = [placement.PlacedBuffer(b, nbytes, align_offset=124) for _ in range(2)]
+        placement.place(b, bufs)
+        assert all(set(o.mapped).isdisjoint(pb.mapped) for old in made for o in old for pb in bufs)
+        made.append(bufs)
+        return bufs
+    seq = iter(times)
+
+    def release(bufs):
+        released.append(bufs)
+        for pb in bufs:
+            pb.release()
+    best, info = placement.choose(make_set, lambda bufs: next(seq) * 1e-3, release)
+    assert info['times_ms'] == times[:len(info['times_ms'])] and info['chosen'] == chosen and best is made[chosen]
+    assert len(made) == len(info['times_ms']) and len(released) == len(made) - 1 and best not in released
+    mapped = sorted(h for pb in best for h in pb.mapped)
     assert sorted(b.live) == mapped and len(b.mapped) == len(mapped)   # nothing else survives

@@ -52,6 +52,9 @@ def _run(label, sim_cls, geo, settings, bytes_per_update):
         out['step_ms'] = [dict(id=r._spec.id, mean=round(r.summary[0].total * 1e3, 4), min=round(r.summary[1].total * 1e3, 4),
                                max=round(r.summary[2].total * 1e3, 4), comp=round(r.summary[0].comp * 1e3, 4),
                                coll=round(r.summary[0].coll * 1e3, 4)) for r in ctrl.runners if r.summary]
+    tun = [getattr(r, 'placement_tuning', None) for r in ctrl.runners]
+    if any(tun):
+        out['placement_tuning'] = tun
     if bytes_per_update:
         out['bytes_per_update'] = bytes_per_update
         out['GBps_comp'] = round(ctrl.mlups_comp * bytes_per_update / 1e3, 1)   # sweep kernels only

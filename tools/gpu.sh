@@ -5,7 +5,7 @@
 #   host            CPU model / core count / rocm-smi product line
 #   smoke           __graft_entry__.smoke()
 #   tests [expr]    pytest -m gpu (optionally -k expr via $TEST_K)
-#   probe           tools/box_probe.py (clocks + per-launch series; $PROBE_ARGS)
+#   probe           tools/probe/box_probe.py (clocks + per-launch series; $PROBE_ARGS)
 #   bench           python bench.py $BENCH_ARGS
 #   trace           rocprofv3 --kernel-trace --stats of bench.py --steps 100 --warmup 10 ($BENCH_ARGS)
 #   pmc             separate rocprofv3 --pmc passes of bench.py (HBM traffic; $BENCH_ARGS)
@@ -32,32 +32,32 @@ while [ $# -gt 0 ]; do
       if [ -n "$TEST_K" ]; then timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q -k "$TEST_K" 2>&1 | tee $O/pytest_gpu.log | tail -15
       else timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q 2>&1 | tee $O/pytest_gpu.log | tail -15; fi ;;
     probe)
-      timeout 900 python tools/box_probe.py --out $O/box_probe $PROBE_ARGS 2>&1 | tee $O/box_probe.log | tail -60 ;;
+      timeout 900 python tools/probe/box_probe.py --out $O/box_probe $PROBE_ARGS 2>&1 | tee $O/box_probe.log | tail -60 ;;
     bench)
       timeout 900 python bench.py $BENCH_ARGS 2>&1 | tail -1 | tee $O/bench.json | cut -c1-1500 ;;
     trace)
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- \
-          python $R/bench.py --steps 100 --warmup 10 --no_cpu_baseline $BENCH_ARGS > $O/trace.log 2>&1 )
+          python $R/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_runner_path --no_validate $BENCH_ARGS > $O/trace.log 2>&1 )
       summarise_trace $O/trace $O/kernel_stats.csv; tail -1 $O/trace.log | cut -c1-400 ;;
     pmc)
       i=0
       for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
         i=$((i+1))
         ( cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/pmc/p$i -o pmc -- \
-            python $R/bench.py --steps 20 --warmup 4 --no_cpu_baseline --repeats 1 --prewarm_steps 0 $BENCH_ARGS > $O/pmc_p$i.log 2>&1 )
+            python $R/bench.py --steps 20 --warmup 4 --no_cpu_baseline --no_runner_path --no_validate --repeats 1 --prewarm_steps 0 $BENCH_ARGS > $O/pmc_p$i.log 2>&1 )
       done
       python tools/pmc_summary.py $O/pmc | tee $O/pmc_summary.txt ;;
     torchrun)
       for mode in "--scaling weak" "--scaling strong --domain 1024x512x512 --axis z" "--scaling strong --domain 1024x512x512 --axis x"; do
         timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
-          bench.py --gpus 1 --steps 50 --warmup 10 --no_cpu_baseline --force_distributed $mode 2>&1 | tail -1 | tee -a $O/torchrun.jsonl | cut -c1-1200
+          bench.py --gpus 1 --steps 100 --warmup 10 --no_cpu_baseline --force_distributed $mode 2>&1 | tail -1 | tee -a $O/torchrun.jsonl | cut -c1-1200
       done ;;
     configs)
       timeout 1500 python tools/bench_configs.py $CONFIG_ARGS 2>&1 | tee $O/configs.jsonl | tail -12 ;;
     tracecfg)
       for c in ${TRACE_CONFIGS:-4}; do
         ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg$c -o trace -- \
-            python $R/tools/bench_configs.py --quick --only $c > $O/trace_cfg$c.log 2>&1 )
+            env SLF_PLACEMENT_TUNE=0 python $R/tools/bench_configs.py --quick --only $c > $O/trace_cfg$c.log 2>&1 )
         summarise_trace $O/trace_cfg$c $O/kernel_stats_cfg$c.csv; tail -1 $O/trace_cfg$c.log | cut -c1-300
       done ;;
     pmccfg)
@@ -66,7 +66,7 @@ while [ $# -gt 0 ]; do
         for C in "FETCH_SIZE" "WRITE_SIZE"; do
           i=$((i+1))
           ( cd /tmp && timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/pmc_cfg$c/p$i -o pmc -- \
-              python $R/tools/bench_configs.py --quick --only $c > $O/pmc_cfg${c}_p$i.log 2>&1 )
+              env SLF_PLACEMENT_TUNE=0 python $R/tools/bench_configs.py --quick --only $c > $O/pmc_cfg${c}_p$i.log 2>&1 )
         done
         python tools/pmc_summary.py $O/pmc_cfg$c | tee $O/pmc_summary_cfg$c.txt
       done ;;

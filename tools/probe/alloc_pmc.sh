@@ -1,12 +1,12 @@
 #!/bin/bash
-# Counters of the SAME kernel on fast and slow allocations inside one process (tools/alloc_probe.py, 8 arrays).
+# Counters of the SAME kernel on fast and slow allocations inside one process (tools/probe/alloc_probe.py, 8 arrays).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/${GPU_TAG:-alloc_pmc}; mkdir -p $O; export TMPDIR=/tmp
 i=0
 while read -r C; do
   i=$((i+1))
   ( cd /tmp && timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/s$i -o pmc -- \
-      python $R/tools/alloc_probe.py --arrays 8 --rounds 1 --reps 8 > $O/s$i.log 2>&1 )
+      python $R/tools/probe/alloc_probe.py --arrays 8 --rounds 1 --reps 8 > $O/s$i.log 2>&1 )
   grep "^round" $O/s$i.log | cut -c1-140
   python - <<PY
 import csv, glob, collections

@@ -4,7 +4,7 @@ allocated distribution arrays (each 19 x 544 x 514 x 514 x 4 B = 10.9 GB at 512^
 timed on every array in turn (several rounds), then the AB kernel on pairs.  Optional gaps of G bytes are allocated
 between the arrays so that they land at different offsets.
 
-    python tools/alloc_probe.py --dims 512x512x512 --arrays 6 --rounds 3
+    python tools/probe/alloc_probe.py --dims 512x512x512 --arrays 6 --rounds 3
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from sailfish_amd import sym
 from sailfish_amd.backend_hip import HIPBackend
 from sailfish_amd.box import make_box_desc

@@ -12,7 +12,7 @@ In ONE process, on the same allocations, records
 
 Output: one JSON file (summary statistics + the raw series) and a readable text summary.
 
-    python tools/box_probe.py --size 512 --launches 400 --out gpurun_out/box_probe
+    python tools/probe/box_probe.py --size 512 --launches 400 --out gpurun_out/box_probe
 """
 import argparse
 import ctypes
@@ -26,7 +26,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, ROOT)
 
 

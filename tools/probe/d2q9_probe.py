@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """D2Q9 sweep rate on large 2-D boxes (GPU box only): periodic box through BoxSim, HIP events.
 
-    python tools/d2q9_probe.py --sizes 1024,4096,8192 [--general]
+    python tools/probe/d2q9_probe.py --sizes 1024,4096,8192 [--general]
 """
 import argparse
 import os
@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from sailfish_amd import sym  # noqa: E402
 from sailfish_amd.backend_hip import HIPBackend  # noqa: E402
 from sailfish_amd.box import BoxSim, make_box_desc  # noqa: E402

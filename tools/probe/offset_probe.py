@@ -3,7 +3,7 @@
 offsets k * step inside a single hipMalloc'ed block and the in-place (AA) kernels are timed at every offset.  A periodic
 pattern over the offset exposes which address bits decide the mode.
 
-    python tools/offset_probe.py --dims 512x512x512 --steps_mib 2,128 --count 48
+    python tools/probe/offset_probe.py --dims 512x512x512 --steps_mib 2,128 --count 48
 """
 import argparse
 import os
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from sailfish_amd import hipabi, sym
 from sailfish_amd.backend_hip import HIPBackend
 from sailfish_amd.box import make_box_desc

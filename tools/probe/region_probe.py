@@ -9,7 +9,7 @@ import ctypes
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from sailfish_amd.backend_hip import HIPBackend
 from tools.box_probe import build_probe_lib
 

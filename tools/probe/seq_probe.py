@@ -4,7 +4,7 @@ Alternates a small placed box (256^3, or two 128x512x512 slabs) with a large one
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from sailfish_amd import sym  # noqa: E402
 from sailfish_amd.backend_hip import HIPBackend  # noqa: E402
 from sailfish_amd.slab import SlabSim  # noqa: E402

@@ -3,7 +3,7 @@
 every offset (GiB) in --offsets the distribution array is placed there and the in-place even/odd kernels are timed for
 every dist_stride padding in --pads (elements added to arr_nx*arr_ny*arr_nz).
 
-    python tools/stride_probe.py --offsets 0,8,27 --pads 0,32,1024,65536
+    python tools/probe/stride_probe.py --offsets 0,8,27 --pads 0,32,1024,65536
 """
 import argparse
 import os
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from sailfish_amd import hipabi, sym
 from sailfish_amd.backend_hip import HIPBackend
 from sailfish_amd.box import make_box_desc
