@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument('--cpu_seconds', type=float, default=10.0)
     ap.add_argument('--repeats', type=int, default=2,
                     help='each candidate access pattern is timed this many times (K steps each)')
+    ap.add_argument('--no_placement_tune', action='store_true',
+                    help='place the distribution arrays once instead of by measurement (sailfish_amd/placement.py choose())')
     ap.add_argument('--prewarm_steps', type=int, default=300,
                     help='untimed steps before the W warm-up steps (same count on every rank): about 1 s at 512^3')
     ap.add_argument('--no_gpu_state', action='store_true', help='do not sample amd-smi before / after')
@@ -260,8 +262,11 @@ def main():
     def measure(pattern, check=False):
         sim = SlabSim(backend, sym.D3Q19, tuple(local), rank=rank, world=world, model=args.model,
                       precision=args.precision, access_pattern=pattern, visc=args.visc,
-                      fused_periodic=not args.no_fused_periodic, axis=args.axis, force_halo=args.force_distributed)
+                      fused_periodic=not args.no_fused_periodic, axis=args.axis, force_halo=args.force_distributed,
+                      tune_placement=not args.no_placement_tune)
         res = {'pattern': pattern, 'block': sim.block_size, 'placement': sim.placement_info}
+        if sim.placement_tuning:
+            res['placement'] = dict(sim.placement_info or {}, tuning=sim.placement_tuning)
         sim.init_synthetic(seed=1234)
         if check:
             r64 = sim.real_view(sim.rho).astype(np.float64)

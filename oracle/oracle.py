@@ -164,15 +164,21 @@ class OracleSim(object):
         self.L.orc_sparse(int(collect), _vp(idx), _vp(dist), _vp(buf), len(idx))
 
     def sc_init(self, d1, d2, rho, phi, vx, vy, vz):
+        self._install_nodes()
         self.L.orc_sc_init(ctypes.byref(self.desc), _vp(d1), _vp(d2), _vp(rho), _vp(phi), _vp(vx), _vp(vy), _vp(vz))
+        self.L.orc_set_nodes(None)
 
     def sc_macro(self, prop, nmap, d1, d2, rho, phi, vx, vy, vz):
+        self._install_nodes()
         self.L.orc_sc_macro(ctypes.byref(self.desc), prop, _vp(nmap), _vp(d1), _vp(d2), _vp(rho), _vp(phi), _vp(vx),
                             _vp(vy), _vp(vz))
+        self.L.orc_set_nodes(None)
 
     def sc_step(self, grid_idx, prop, nmap, din, dout, rho, phi, vx, vy, vz):
+        self._install_nodes()
         self.L.orc_sc_step(ctypes.byref(self.desc), grid_idx, prop, _vp(nmap), _vp(din), _vp(dout), _vp(rho),
                            _vp(phi), _vp(vx), _vp(vy), _vp(vz))
+        self.L.orc_set_nodes(None)
 
     def scs_macro(self, prop, nmap, din, rho):
         self.L.orc_scs_macro(ctypes.byref(self.desc), prop, _vp(nmap), _vp(din), _vp(rho))

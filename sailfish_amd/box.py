@@ -59,7 +59,7 @@ def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='A
 class BoxSim(object):
     """One subdomain, no neighbours, on one GPU through the backend interface."""
 
-    def __init__(self, backend, desc, periodic=(False, False, False), node_map=None):
+    def __init__(self, backend, desc, periodic=(False, False, False), node_map=None, tune_placement=False):
         self.backend = backend
         self.desc = desc
         self.dim = 2 if desc.lattice == hipabi.SLF_D2Q9 else 3
@@ -81,8 +81,18 @@ class BoxSim(object):
         # large distribution arrays are *placed*: spread over physical HBM (placement.py)
         self.placed = []
         self.placement_info = None
+        self.placement_tuning = None
         if placement.enabled() and self.Q * fbytes >= placement.MIN_BYTES and not int(desc.node_addressing):
-            self.placed = b.alloc_placed([self.Q * fbytes] * (1 if self.aa else 2), off)
+            sizes = [self.Q * fbytes] * (1 if self.aa else 2)
+            if tune_placement and os.environ.get('SLF_PLACEMENT_TUNE', '1') != '0' and not placement.holding_now():
+                # placement by measurement (placement.choose): what SubdomainRunner does for its arrays
+                probe_stream = b.make_stream()
+                self.placed, self.placement_tuning = placement.choose(
+                    lambda: b.alloc_placed(sizes, off),
+                    lambda bs: placement.probe_sweep(b, desc, self.dim, bs[0].addr, bs[-1].addr, self.Q * fbytes, probe_stream),
+                    lambda bs: [b.free_buf(pb.addr) for pb in bs])
+            else:
+                self.placed = b.alloc_placed(sizes, off)
             self.placement_info = b.last_placement
             self.gpu_dist = [pb.addr for pb in self.placed]
         else:

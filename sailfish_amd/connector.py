@@ -102,6 +102,7 @@ class DirectRccl(object):
         import torch.distributed as dist
         from sailfish_amd.backend_hip import _check
         self._ctypes, self._check, self.lib = ctypes, _check, backend._lib
+        self._backend = backend          # the communicator refers to the backend's context: keep it alive
         uid = ctypes.create_string_buffer(128)
         if rank == 0:
             _check(self.lib, self.lib.slf_comm_unique_id(uid), 'slf_comm_unique_id')
@@ -137,13 +138,25 @@ class DirectRccl(object):
             self.comm = None
 
 
+_process_rccl = {}
+
+
+def process_rccl(backend, rank, world):
+    """The one DirectRccl communicator of this process (creating one is a collective over all ranks: once, not per
+    simulation)."""
+    key = (int(backend.gpu_id), int(rank), int(world))
+    if key not in _process_rccl:
+        _process_rccl[key] = DirectRccl(backend, rank, world)
+    return _process_rccl[key]
+
+
 class RcclRingExchanger(RingExchanger):
     """RingExchanger whose transfers go straight to RCCL (DirectRccl) on a stream of the backend."""
     direct = True
 
     def __init__(self, rank, world, backend):
         RingExchanger.__init__(self, rank, world)
-        self.rccl = DirectRccl(backend, rank, world)
+        self.rccl = process_rccl(backend, rank, world)
         self._batches = {}
 
     def exchange_ranges(self, bufs, ranges, stream):
@@ -266,7 +279,7 @@ class TorchDistConnector(object):
             self._rccl = False
             if dist.get_backend() == 'nccl' and os.environ.get('SLF_HALO_TRANSPORT', 'rccl') != 'torch' and \
                     hasattr(runner.backend, '_ctx'):
-                self._rccl = DirectRccl(runner.backend, dist.get_rank(), dist.get_world_size())
+                self._rccl = process_rccl(runner.backend, dist.get_rank(), dist.get_world_size())
         return self._rccl or None
 
     def exchange_pieces(self, runner, pieces):

@@ -610,7 +610,10 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   }
   if (d->node_addressing == SLF_ADDR_INDIRECT) {
     if (d->fluid_only) { delete m; return fail(SLF_ERR_INVALID, "indirect addressing needs the node map (fluid_only = 0)"); }
-    if (d->simtype != SLF_SIM_LBM) { delete m; return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: single-fluid modules only"); }
+    if (d->simtype != SLF_SIM_LBM && d->simtype != SLF_SIM_SHAN_CHEN_BINARY) {
+      delete m;
+      return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: single-fluid and binary Shan-Chen modules only");
+    }
   }
   m->access_pattern = d->access_pattern;
   slf::Geometry& g = m->geo;
@@ -959,8 +962,11 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_SCS_MACRO: want_p = 3; want_i = 1; break;             // map, dist, rho, options
     case KK_SCS_SWEEP: want_p = 4 + dim; want_i = 1; break;       // as CollideAndPropagate
   }
+  if (k->mod->geo.indirect && k->kind == KK_SC_FUSED)
+    return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: the binary model runs its two per-lattice sweeps");
   if (k->mod->geo.indirect && (k->kind == KK_COLLIDE_AND_PROPAGATE || k->kind == KK_COMPUTE_MACRO ||
-                               k->kind == KK_SET_INITIAL_CONDITIONS))
+                               k->kind == KK_SET_INITIAL_CONDITIONS || k->kind == KK_SC_MACRO ||
+                               k->kind == KK_SC_SWEEP0 || k->kind == KK_SC_SWEEP1 || k->kind == KK_SC_INIT))
     want_p += 1;   // leading `nodes` table (reference _add_indirect_args, subdomain_runner.py:1153-1157)
   if (k->ptrs.size() != want_p || k->ints.size() != want_i)
     return fail(SLF_ERR_INVALID, "argument list does not match the kernel's signature");
@@ -1031,15 +1037,17 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     case KK_SC_SWEEP0:
     case KK_SC_SWEEP1: {
       slf::SweepArgs a = {};
-      a.nodes = nullptr;
-      a.map = (const void*)k->ptrs[0];
-      a.dist_in = (void*)k->ptrs[1];
-      a.dist_out = (void*)k->ptrs[2];
-      a.rho = (void*)k->ptrs[3];
-      a.phi = (void*)k->ptrs[4];
-      a.v[0] = (void*)k->ptrs[5];
-      a.v[1] = (void*)k->ptrs[6];
-      a.v[2] = g.dim == 3 ? (void*)k->ptrs[7] : nullptr;
+      const int b0 = g.indirect ? 1 : 0;     // indirect: (nodes, map, dist, dist, rho, phi, v.., options), lb_binary.py:457-465
+      a.nodes = g.indirect ? (const void*)k->ptrs[0] : nullptr;
+      if (g.indirect && !a.nodes) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
+      a.map = (const void*)k->ptrs[b0 + 0];
+      a.dist_in = (void*)k->ptrs[b0 + 1];
+      a.dist_out = (void*)k->ptrs[b0 + 2];
+      a.rho = (void*)k->ptrs[b0 + 3];
+      a.phi = (void*)k->ptrs[b0 + 4];
+      a.v[0] = (void*)k->ptrs[b0 + 5];
+      a.v[1] = (void*)k->ptrs[b0 + 6];
+      a.v[2] = g.dim == 3 ? (void*)k->ptrs[b0 + 7] : nullptr;
       a.node_params = m->node_params;
       a.status = m->status;
       a.options = (uint32_t)k->ints[0];
@@ -1137,11 +1145,14 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       break;
     }
     case KK_SC_INIT: {
-      // (map, dist1, dist2, vx, vy[, vz], rho, phi)  -- reference lb_binary.py:107-127
-      const void* v[3] = {(const void*)k->ptrs[3], (const void*)k->ptrs[4],
-                          g.dim == 3 ? (const void*)k->ptrs[5] : nullptr};
-      e = slf::launch_sc_init(m->sel, g, m->phys, (void*)k->ptrs[1], (void*)k->ptrs[2],
-                              (const void*)k->ptrs[3 + g.dim], (const void*)k->ptrs[4 + g.dim], v, s);
+      // ([nodes,] map, dist1, dist2, vx, vy[, vz], rho, phi)  -- reference lb_binary.py:107-127
+      const int b0 = g.indirect ? 1 : 0;
+      if (g.indirect && !k->ptrs[0]) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
+      const void* v[3] = {(const void*)k->ptrs[b0 + 3], (const void*)k->ptrs[b0 + 4],
+                          g.dim == 3 ? (const void*)k->ptrs[b0 + 5] : nullptr};
+      e = slf::launch_sc_init(m->sel, g, m->phys, (void*)k->ptrs[b0 + 1], (void*)k->ptrs[b0 + 2],
+                              (const void*)k->ptrs[b0 + 3 + g.dim], (const void*)k->ptrs[b0 + 4 + g.dim], v,
+                              g.indirect ? (const void*)k->ptrs[0] : nullptr, s);
       break;
     }
     case KK_SET_INITIAL_CONDITIONS: {

@@ -145,6 +145,6 @@ hipError_t launch_scs_sweep(const KernelSelector& sel, Prop prop, const Geometry
                             const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                             hipStream_t s);
 hipError_t launch_sc_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist1, void* dist2,
-                          const void* rho, const void* phi, const void* const v[3], hipStream_t s);
+                          const void* rho, const void* phi, const void* const v[3], const void* nodes, hipStream_t s);
 
 }  // namespace slf

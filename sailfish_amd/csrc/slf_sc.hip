@@ -17,6 +17,7 @@ namespace slf {
 
 template <class L, class R>
 struct ScParams {
+  const uint32_t* __restrict__ nodes;   // indirect addressing: dense node -> slot of the distribution arrays, else NULL
   const uint32_t* __restrict__ map;
   const R* d_in;     // sweep: lattice in      | macro: lattice 0
   R* d_out;          // sweep: lattice out     | macro: lattice 1 (read)
@@ -90,8 +91,23 @@ __device__ __forceinline__ const SLF_GLOBAL T* sc_neighbour(const T* base, const
   return at_byte(uniform_base(base + (uint32_t)((int)n.row + off)), (uint32_t)((int)n.xi + xs) * (uint32_t)sizeof(T));
 }
 
-template <class L, class R, int PROP>
-__device__ __forceinline__ void sc_load(R (&f)[L::Q], const R* din, size_t ds, const ScNode& n) {
+// INDIRECT (reference subdomain_runner.py:829-878, kernel_common.mako:140-167; serves NNSubdomainRunner too): the
+// distribution arrays hold the active nodes only; the node's own slot and the slots of its neighbours come from the
+// dense table `nodes`, the fields rho / phi / v and the node map stay dense.
+template <class L, class R, int PROP, bool INDIRECT = false>
+__device__ __forceinline__ void sc_load(R (&f)[L::Q], const R* din, size_t ds, const ScNode& n,
+                                        const uint32_t* nodes = nullptr, uint32_t si = 0) {
+  if constexpr (INDIRECT) {
+    static_for<0, L::Q>([&](auto I) {
+      if constexpr (PROP == PROP_AA_ODD) {
+        const uint32_t sn = nodes[(uint32_t)((int)n.gi + dir_offset<L, I>(n.ox, n.oy, n.oz, false))];
+        f[I] = (sn != INVALID_NODE) ? (din + ds * (size_t)L::opp(I))[sn] : (R)0;
+      } else {
+        f[I] = (din + ds * (size_t)I)[si];
+      }
+    });
+    return;
+  }
   static_for<0, L::Q>([&](auto I) {
     if constexpr (PROP == PROP_AA_ODD) {
       constexpr int nt = (L::ex(I) != 0) ? (sc_nt<L>() & ~1) : sc_nt<L>();     // shifted pulls share their lines
@@ -129,10 +145,19 @@ __device__ __forceinline__ void sc_accel(const R* const (&fields)[2], const R (&
 }
 
 // the streaming part of a sweep: whole-row push (3-D x-streaming steps), own slots (even AA step), or per-node push
-template <class L, class R, int PROP, bool GENERAL, bool ROW>
+template <class L, class R, int PROP, bool GENERAL, bool ROW, bool INDIRECT = false>
 __device__ __forceinline__ void sc_store(const Geometry& g, R (&f)[L::Q], R* dout, size_t ds, const ScNode& n, int nx,
-                                         bool live, bool active) {
-  if constexpr (ROW && PROP != PROP_AA_EVEN) {
+                                         bool live, bool active, const uint32_t* nodes = nullptr, uint32_t si = 0) {
+  if constexpr (INDIRECT) {
+    static_for<0, L::Q>([&](auto I) {
+      if constexpr (PROP == PROP_AA_EVEN) {
+        (dout + ds * (size_t)L::opp(I))[si] = f[I];
+      } else {
+        const uint32_t t = nodes[(uint32_t)((int)n.gi + dir_offset<L, I>(n.ox, n.oy, n.oz, true))];
+        if (t != INVALID_NODE) (dout + ds * (size_t)I)[t] = f[I];
+      }
+    });
+  } else if constexpr (ROW && PROP != PROP_AA_EVEN) {
     row_push<L, R, GENERAL, sc_nt<L>()>(g, f, dout, ds, n.row, n.xi, n.gx, nx, live, active, n.oy, n.oz);
   } else {
     static_for<0, L::Q>([&](auto I) {
@@ -146,13 +171,18 @@ __device__ __forceinline__ void sc_store(const Geometry& g, R (&f)[L::Q], R* dou
   }
 }
 
-template <class L, class R, int PROP, bool GENERAL>
+template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false>
 __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   bool live;
   const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live);
   if (!live) return;
   const uint32_t gi = n.gi;
+  uint32_t si = gi;
+  if constexpr (INDIRECT) {
+    si = p.nodes[gi];
+    if (si == INVALID_NODE) return;
+  }
   if constexpr (GENERAL) {
     const uint32_t code = p.map[gi];
     const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
@@ -161,7 +191,7 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   const size_t ds = g.dist_size;
   R f[L::Q];
   // lattice 0
-  sc_load<L, R, PROP>(f, p.d_in, ds, n);
+  sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
   const R rho0 = density<L, R>(f);
   R v[3];
   v[0] = p.omega[0] * momentum<L, R, 0>(f);
@@ -169,7 +199,7 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   v[2] = (R)0;
   if constexpr (L::dim == 3) v[2] = p.omega[0] * momentum<L, R, 2>(f);
   // lattice 1
-  sc_load<L, R, PROP>(f, (const R*)p.d_out, ds, n);
+  sc_load<L, R, PROP, INDIRECT>(f, (const R*)p.d_out, ds, n, p.nodes, si);
   const R rho1 = density<L, R>(f);
   v[0] = v[0] + p.omega[1] * momentum<L, R, 0>(f);
   v[1] = v[1] + p.omega[1] * momentum<L, R, 1>(f);
@@ -185,8 +215,9 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
 
 // ROW: one workgroup = one whole row, streaming through row_push() (aligned stores, slf_rowpush.h); every
 // thread stays until the end (barrier inside), excluded nodes and idle lanes are merely inactive.
-template <class L, class R, int K, int PROP, bool GENERAL, bool ROW = false>
+template <class L, class R, int K, int PROP, bool GENERAL, bool ROW = false, bool INDIRECT = false>
 __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) {
+  static_assert(!(ROW && INDIRECT), "indirect addressing: per-node kernels only");
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
@@ -195,6 +226,11 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
     if (!live) return;
   }
   const uint32_t gi = n.gi;
+  uint32_t si = gi;
+  if constexpr (INDIRECT) {
+    si = p.nodes[gi];
+    if (si == INVALID_NODE) return;
+  }
   int kind = NK_FLUID;
   bool active = live;
   if constexpr (GENERAL) {
@@ -210,7 +246,7 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
   const size_t ds = g.dist_size;
 
   R f[L::Q];
-  sc_load<L, R, PROP>(f, p.d_in, ds, n);
+  sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
   const R* own = (K == 0) ? p.rho0 : p.rho1;
   const R rho = own[gi];
   R a[3] = {(R)0, (R)0, (R)0};
@@ -231,7 +267,7 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
     if (kind == NK_FULL_BB) bounce_back<L, R>(f);
   }
   if (wet) bgk_relax_accel<L, R>(f, rho, v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
-  sc_store<L, R, PROP, GENERAL, ROW>(g, f, p.d_out, ds, n, nx, live, active);
+  sc_store<L, R, PROP, GENERAL, ROW, INDIRECT>(g, f, p.d_out, ds, n, nx, live, active, p.nodes, si);
 }
 
 // Both lattices in one pass.  The force on lattice k is  - psi(rho_k) sum_j G_kj S_j  with the stencil sums
@@ -390,12 +426,17 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
 template <class L, class R>
 __global__ void __launch_bounds__(256) sc_init_kernel(R* d1, R* d2, const R* __restrict__ irho, const R* __restrict__ iphi,
                                                      const R* __restrict__ ivx, const R* __restrict__ ivy,
-                                                     const R* __restrict__ ivz, Geometry g) {
+                                                     const R* __restrict__ ivz, Geometry g, const uint32_t* __restrict__ nodes) {
   const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int gy = (int)blockIdx.y;
   const int gz = (int)blockIdx.z;
   if (gx > g.lat_nx - 1) return;
   const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  uint32_t si = gi;       // indirect addressing: the node's slot, if it is active
+  if (nodes) {
+    si = nodes[gi];
+    if (si == INVALID_NODE) return;
+  }
   R v[3];
   v[0] = ivx[gi];
   v[1] = ivy[gi];
@@ -404,8 +445,8 @@ __global__ void __launch_bounds__(256) sc_init_kernel(R* d1, R* d2, const R* __r
   const R u15 = usq15<L, R>(v);
   const R r0 = irho[gi], r1 = iphi[gi];
   static_for<0, L::Q>([&](auto I) {
-    (d1 + (size_t)g.dist_size * (size_t)I)[gi] = feq<L, R, I>(r0, r0, v, u15);
-    (d2 + (size_t)g.dist_size * (size_t)I)[gi] = feq<L, R, I>(r1, r1, v, u15);
+    (d1 + (size_t)g.dist_size * (size_t)I)[si] = feq<L, R, I>(r0, r0, v, u15);
+    (d2 + (size_t)g.dist_size * (size_t)I)[si] = feq<L, R, I>(r1, r1, v, u15);
   });
 }
 
@@ -414,6 +455,7 @@ template <class L, class R>
 static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanChen& sc, const SweepArgs& a, int grid_idx,
                               int y0, int z0) {
   ScParams<L, R> p;
+  p.nodes = (const uint32_t*)a.nodes;
   p.map = (const uint32_t*)a.map;
   p.d_in = (const R*)a.dist_in;
   p.d_out = (R*)a.dist_out;
@@ -464,7 +506,8 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
 #define SLF_SCM(P)                                                                        \
   do {                                                                                    \
-    if (general) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true>), grid, block, 0, s, p); \
+    if (g.indirect) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true, true>), grid, block, 0, s, p); \
+    else if (general) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((sc_macro_kernel<L, R, P, false>), grid, block, 0, s, p);        \
   } while (0)
   if (prop == PROP_AA_ODD) SLF_SCM(PROP_AA_ODD);
@@ -476,6 +519,12 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
 template <class L, class R, int K>
 static hipError_t sc_sweep3(Prop prop, bool general, bool row, const ScParams<L, R>& p, dim3 grid, dim3 block,
                             hipStream_t s) {
+  if (p.g.indirect) {      // active-node slots: per-node kernels with translated neighbours
+    if (prop == PROP_AB) hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, PROP_AB, true, false, true>), grid, block, 0, s, p);
+    else if (prop == PROP_AA_EVEN) hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, PROP_AA_EVEN, true, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, PROP_AA_ODD, true, false, true>), grid, block, 0, s, p);
+    return hipGetLastError();
+  }
 #define SLF_SCS(P)                                                                           \
   do {                                                                                       \
     if (general) hipLaunchKernelGGL((sc_sweep_kernel<L, R, K, P, true>), grid, block, 0, s, p); \
@@ -505,7 +554,7 @@ static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometr
   const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, grid_idx, y0, z0);
   const int nx = g.lat_nx - 2;
   // whole-row workgroups + aligned stores for the x-streaming steps in 3-D (as slf_row.hip)
-  const bool row = L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
+  const bool row = L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN && !g.indirect;
   if (row) block_x = row_block_x(nx);
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
@@ -630,17 +679,17 @@ hipError_t launch_scs_sweep(const KernelSelector& sel, Prop prop, const Geometry
 
 template <class L, class R>
 static hipError_t sc_init2(const Geometry& g, void* d1, void* d2, const void* rho, const void* phi,
-                           const void* const v[3], hipStream_t s) {
+                           const void* const v[3], const void* nodes, hipStream_t s) {
   dim3 block(256, 1, 1);
   dim3 grid((g.lat_nx + 255) / 256, g.lat_ny, g.lat_nz);
   hipLaunchKernelGGL((sc_init_kernel<L, R>), grid, block, 0, s, (R*)d1, (R*)d2, (const R*)rho, (const R*)phi,
-                     (const R*)v[0], (const R*)v[1], (const R*)v[2], g);
+                     (const R*)v[0], (const R*)v[1], (const R*)v[2], g, (const uint32_t*)nodes);
   return hipGetLastError();
 }
 
 hipError_t launch_sc_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist1, void* dist2,
-                          const void* rho, const void* phi, const void* const v[3], hipStream_t s) {
-  SLF_DISPATCH_LR(sel, return (sc_init2<L, R>(g, dist1, dist2, rho, phi, v, s)));
+                          const void* rho, const void* phi, const void* const v[3], const void* nodes, hipStream_t s) {
+  SLF_DISPATCH_LR(sel, return (sc_init2<L, R>(g, dist1, dist2, rho, phi, v, nodes, s)));
   return hipErrorInvalidValue;
 }
 

@@ -55,10 +55,10 @@ class LBBinaryFluidBase(LBSim):
         gpu_v = runner.gpu_field(self.v)
         gpu_map = runner.gpu_geo_map()
         args1 = [gpu_map, runner.gpu_dist(0, 0), runner.gpu_dist(1, 0)] + gpu_v + [gpu_rho, gpu_phi]
-        runner.exec_kernel('SetInitialConditions', args1, 'P' * len(args1))
+        runner.exec_kernel('SetInitialConditions', *runner.add_indirect_args(args1, 'P' * len(args1)))
         if self.config.access_pattern == 'AB':
             args2 = [gpu_map, runner.gpu_dist(0, 1), runner.gpu_dist(1, 1)] + gpu_v + [gpu_rho, gpu_phi]
-            runner.exec_kernel('SetInitialConditions', args2, 'P' * len(args2))
+            runner.exec_kernel('SetInitialConditions', *runner.add_indirect_args(args2, 'P' * len(args2)))
 
     def fill_module_desc(self, kw):
         super(LBBinaryFluidBase, self).fill_module_desc(kw)
@@ -112,12 +112,14 @@ class LBBinaryFluidShanChen(LBBinaryFluidBase, LBForcedSim):
         ni = self.config.needs_iteration_num
 
         def k(name, a, b):
-            return runner.get_kernel(name, [gpu_map, a, b] + tail, sig, needs_iteration=ni)
+            # indirect addressing: the dense-node -> slot table leads the list (reference lb_binary.py:457-465)
+            args, s = runner.add_indirect_args([gpu_map, a, b] + tail, sig)
+            return runner.get_kernel(name, args, s, needs_iteration=ni)
 
         # backends that have it sweep both lattices in ONE pass (rho, phi, u and the pseudopotential stencil are read
         # once; C ABI kernel "ShanChenCollideAndPropagateFused"), otherwise the reference's two kernels
         fused = getattr(runner.backend, 'supports_fused_shan_chen', False) and getattr(self.config, 'hip_sc_fused', True) and \
-            os.environ.get('SLF_SC_FUSED', '1') != '0'
+            os.environ.get('SLF_SC_FUSED', '1') != '0' and not runner.indirect
 
         def sweeps(in1, out1, in2, out2):
             if fused:

@@ -164,6 +164,39 @@ def choose(make_set, measure, release, attempts=3, agree=0.02, log=None):
     return sets[best], info
 
 
+def probe_sweep(backend, desc, dim, src, dst, nbytes, stream, steps=12):
+    """Seconds per step of the plain fluid sweep (same lattice, precision, sizes and access pattern as the module
+    described by `desc`; BGK, every axis wrapped in-sweep, no node map) between the distribution arrays at `src` and
+    `dst` (the same address for the AA pattern): the many-stream access pattern whose speed depends on the placement.
+    The arrays are scratch: filled with one positive value, i.e. a fluid at rest."""
+    from sailfish_amd import hipabi
+    b = backend
+    d = hipabi.SlfModuleDesc.from_buffer_copy(desc)
+    d.model, d.simtype, d.fluid_only, d.n_types, d.has_force = hipabi.SLF_BGK, 0, 1, 0, 0
+    d.incompressible, d.node_addressing, d.relaxation_enabled, d.tau = 0, 0, 1, 1.0
+    for a in range(3):
+        d.periodic_fused[a] = d.periodic_local[a] = int(a < dim)
+    ab = src != dst
+    d.access_pattern = hipabi.SLF_AB if ab else hipabi.SLF_AA
+    module = b.build(d)
+    for addr in set((src, dst)):
+        b.memset_buf(addr, 0x3D, nbytes, stream)        # 0x3d3d3d3d = 0.046 as a float, 4.2e-14 as a double
+    sig = 'P' * (4 + dim) + 'i'
+    pairs = [(src, dst), (dst, src)] if ab else [(src, src)]
+    ks = [b.get_kernel(module, 'CollideAndPropagate', (64,), [0, i, o, i] + [i] * dim + [0], sig,
+                       needs_iteration=not ab) for i, o in pairs]
+    ev0 = None
+    for it in range(4 + steps):
+        if it == 4:
+            ev0 = b.make_event(stream, timing=True)
+        b.set_iteration(it)
+        b.run_kernel(ks[it % len(ks)], None, stream)
+    ev1 = b.make_event(stream, timing=True)
+    ev1.synchronize()
+    b.set_iteration(0)
+    return ev1.time_since(ev0) * 1e-3 / steps
+
+
 def _check(lib, status, what):
     if status != 0:
         from sailfish_amd.backend_hip import HIPFatalError

@@ -87,8 +87,9 @@ class SlabPlan(object):
 class SlabSim(BoxSim):
     def __init__(self, backend, grid, size, rank=0, world=1, model='bgk', precision='single',
                  access_pattern='AA', visc=1.0 / 6.0, fused_periodic=True, exchanger=None, axis='z',
-                 force_halo=False):
-        """size: the LOCAL slab (nx, ny, nz); the global box is `world` slabs stacked along `axis`."""
+                 force_halo=False, tune_placement=False):
+        """size: the LOCAL slab (nx, ny, nz); the global box is `world` slabs stacked along `axis`.
+        tune_placement: place the distribution arrays by measurement (placement.choose)."""
         self.grid, self.size, self.rank, self.world = grid, size, rank, world
         self.axis = AXES[axis] if isinstance(axis, str) else int(axis)
         assert grid.dim == 3
@@ -102,7 +103,7 @@ class SlabSim(BoxSim):
                              periodic_fused=fused, fluid_only=True)
         periodic = [True, True, True]
         periodic[self.axis] = not self.halo
-        BoxSim.__init__(self, backend, desc, periodic=tuple(periodic))
+        BoxSim.__init__(self, backend, desc, periodic=tuple(periodic), tune_placement=tune_placement)
         self.calc_stream = self.stream
         self.block_size = self.module.block_size
         self.halo_ms = []

@@ -317,34 +317,12 @@ class SubdomainRunner(object):
     placement_tuning = None
 
     def _probe_placement(self, bufs, n_grids, ab, steps=12):
-        """Seconds per step of the plain fluid sweep (same lattice, precision, sizes and access pattern as this
-        simulation; BGK, every axis wrapped in-sweep, no node map) on the first lattice of the placed set `bufs`: what
-        placement.choose() compares.  The arrays are scratch: filled with one positive value, i.e. a fluid at rest."""
-        b = self.backend
-        d = hipabi.SlfModuleDesc.from_buffer_copy(self._desc)
-        d.model, d.simtype, d.fluid_only, d.n_types, d.has_force = hipabi.SLF_BGK, 0, 1, 0, 0
-        d.incompressible, d.node_addressing, d.relaxation_enabled, d.tau = 0, 0, 1, 1.0
-        for a in range(3):
-            d.periodic_fused[a] = d.periodic_local[a] = int(a < self.dim)
-        module = b.build(d)
+        """Seconds per step of the plain fluid sweep on the first lattice of the placed set `bufs`: what
+        placement.choose() compares (placement.probe_sweep)."""
+        from sailfish_amd import placement
         nbytes = self._sim.grid.Q * self._dist_stride * self.float().itemsize
         src, dst = bufs[0].addr, (bufs[n_grids].addr if ab else bufs[0].addr)
-        for addr in set((src, dst)):
-            b.memset_buf(addr, 0x3D, nbytes, self._calc_stream)        # 0x3d3d3d3d = 0.046 as a float, 4.2e-14 as a double
-        sig = 'P' * (4 + self.dim) + 'i'
-        pairs = [(src, dst), (dst, src)] if ab else [(src, src)]
-        ks = [b.get_kernel(module, 'CollideAndPropagate', (64,), [0, i, o, i] + [i] * self.dim + [0], sig,
-                           needs_iteration=not ab) for i, o in pairs]
-        ev0 = None
-        for it in range(4 + steps):
-            if it == 4:
-                ev0 = b.make_event(self._calc_stream, timing=True)
-            b.set_iteration(it)
-            b.run_kernel(ks[it % len(ks)], None, self._calc_stream)
-        ev1 = b.make_event(self._calc_stream, timing=True)
-        ev1.synchronize()
-        b.set_iteration(0)
-        return ev1.time_since(ev0) * 1e-3 / steps
+        return placement.probe_sweep(self.backend, self._desc, self.dim, src, dst, nbytes, self._calc_stream, steps)
 
     def gpu_field(self, field):
         if isinstance(field, list):

@@ -180,6 +180,10 @@ class _OracleNN(object):
         self.pbc_axes = [a for a in range(self.dim) if local[a] and not r._fused[a]]
         self.iteration = 0
         self.links, self.macro_links = {}, {}
+        self.indirect, self.addr = r.indirect, None
+        if self.indirect:          # distributions: [Q, stride] arrays of active-node slots (fields stay dense)
+            self.addr = r._indirect_address_host()
+            self.o.set_nodes(self.addr)
         if r._all_specs is not None and len(r._all_specs) > 1:
             arr = list(reversed(r._physical_size))
             cfg = r.config
@@ -188,9 +192,13 @@ class _OracleNN(object):
                 return [int(bool(spec._periodicity[a]) and getattr(cfg, 'hip_fused_periodic', True))
                         for a in range(self.dim)]
 
+            dense_nodes = int(np.prod(self.o.shape))
+            stride = hipabi.dist_stride(self.desc)
             self.links = subdomain_connection.build_halo_links(
                 r._spec, r._all_specs, r._global_size, r._global_periodic, r._sim.grid, arr,
-                hipabi.dist_stride(self.desc), fused=r._fused)
+                dense_nodes if self.indirect else stride, fused=r._fused)
+            if self.indirect:
+                r._translate_halo_links(self.links, self.addr, dense_nodes, stride)
             self.macro_links = subdomain_connection.build_macro_links(
                 r._spec, r._all_specs, r._global_size, r._global_periodic, arr, fused_of)
 
@@ -261,6 +269,19 @@ class _OracleNN(object):
             return arr[(Ellipsis, 0) + tuple(ng)]
         return arr[(Ellipsis,) + tuple(ng)]
 
+    def new_dist(self):
+        return self.o.new_sparse_dist() if self.indirect else self.o.new_dist()
+
+    def dense(self, dist):
+        """[Q, nz, ny, nx] view / copy of a distribution array (indirect: slots scattered to their nodes)."""
+        if not self.indirect:
+            return dist
+        addr = self.addr.reshape(-1)
+        act = addr != hipabi.SLF_INVALID_NODE
+        out = np.zeros((self.o.Q, addr.size), dtype=self.o.dtype)
+        out[:, act] = dist[:, addr[act]]
+        return out.reshape((self.o.Q,) + self.o.shape)
+
 
 class OracleSCSubdomain(_OracleNN):
     """Oracle twin of NNSubdomainRunner for the binary Shan-Chen model."""
@@ -270,8 +291,8 @@ class OracleSCSubdomain(_OracleNN):
         r, dt = runner, self.o.dtype
         self.phi = np.ascontiguousarray(r.field_base(r._sim.phi), dtype=dt).reshape(self.o.shape)
         ncopy = 1 if self.aa else 2
-        self.d1 = [self.o.new_dist() for _ in range(ncopy)]
-        self.d2 = [self.o.new_dist() for _ in range(ncopy)]
+        self.d1 = [self.new_dist() for _ in range(ncopy)]
+        self.d2 = [self.new_dist() for _ in range(ncopy)]
         with np.errstate(all='ignore'):
             for a, b in zip(self.d1, self.d2):
                 self.o.sc_init(a, b, self.rho, self.phi, *self.v)

@@ -80,3 +80,25 @@ def make_forced_sim(dim, a0, a1, seed=7):
                 self.add_body_force(tuple(a1), grid=1)
 
     return Forced, geo
+
+
+def make_wall_sim(dim, seed=11, amplitude=1e-3, wall=4):
+    """Binary mixture between two solid slabs (`wall` nodes thick each, so that their inner layers are neither fluid
+    nor next to fluid: inactive under --node_addressing=indirect) with a solid block in the channel."""
+    from sailfish_amd.node_type import NTFullBBWall
+    base, geo = make_sim(dim, seed=seed, amplitude=amplitude)
+    sub = base.subdomain
+
+    class Walled(sub):
+        def boundary_conditions(self, *h):
+            hy, hx = h[1], h[0]
+            solid = (hy < wall) | (hy >= self.gy - wall)
+            block = (hx >= 5) & (hx < 9) & (hy >= wall + 2) & (hy < wall + 6)
+            if dim == 3:
+                block = block & (h[2] >= 1) & (h[2] < 5)
+            self.set_node(solid | block, NTFullBBWall)
+
+    class Sim(base):
+        subdomain = Walled
+
+    return Sim, geo

@@ -361,3 +361,34 @@ def test_sc_kernels_against_reference_composition(grid, potential, pattern, gold
         for addr in set(dev_in + dev_out + dev_f):
             b.free_buf(addr)
     assert worst < 1e-13, worst
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('dim,size,nsub,axis', [(2, (70, 26), 1, 'x'), (3, (40, 22, 8), 1, 'x'), (3, (40, 22, 8), 2, 'x'),
+                                                (3, (24, 22, 12), 2, 'z')])
+def test_sc_indirect_addressing(dim, size, nsub, axis, pattern):
+    """--node_addressing=indirect with the binary model (reference lb_binary.py:457-465, subdomain_runner.py:829-878
+    serves NNSubdomainRunner too): both lattices hold the active nodes only, rho / phi / u stay dense.  Equal to the
+    oracle group run with sparse arrays, which tests/test_indirect_oracle.py shows to equal the dense run."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from tests._oracle_group import OracleNNGroup
+    steps = 11
+    sim_cls, _ = _sc.make_wall_sim(dim)
+    cfg = _sc.config(dim, size, pattern=pattern)
+    cfg.update(periodic_y=False, subdomains=nsub, conn_axis=axis, node_addressing='indirect')
+    geo_name = 'EqualSubdomainsGeometry%dD' % dim
+    og = OracleNNGroup(sim_cls, dim, geo_name, dict(cfg))
+    og.run(steps)
+    ctrl = LBSimulationController(sim_cls, getattr(geo_mod, geo_name),
+                                  default_config=dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0))
+    ctrl.run(ignore_cmdline=True)
+    assert len(ctrl.runners) == nsub
+    for r, o in zip(ctrl.runners, og.subs):
+        assert r._desc.node_addressing == 1 and r._dist_stride < 0.85 * int(np.prod(r._physical_size))
+        wet = r._subdomain.fluid_map()
+        assert np.array_equal(r._sim.rho[wet], o.real(o.rho)[wet])
+        assert np.array_equal(r._sim.phi[wet], o.real(o.phi)[wet])
+        for grid_num, od in enumerate(o.current()):
+            gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+            assert np.array_equal(gd[:, wet], o.real(o.dense(od))[:, wet]), 'subdomain %d lattice %d' % (r._spec.id, grid_num)

@@ -66,3 +66,43 @@ def test_indirect_equals_direct(pattern, model, nsub, axis):
     fd, fi = res['direct'][2], res['indirect'][2]
     assert np.array_equal(fd[:, wet], fi[:, wet])
     assert np.abs(res['indirect'][1][wet]).max() > 1e-6      # the body force has set the fluid in motion
+
+
+# ---- binary Shan-Chen model (reference lb_binary.py:457-465: the nodes table leads every kernel's argument list) ----
+def _sc_group(dim, size, addressing, nsub, axis, pattern, steps):
+    from tests import _sc
+    from tests._oracle_group import OracleNNGroup
+    sim_cls, _ = _sc.make_wall_sim(dim)
+    cfg = _sc.config(dim, size, pattern=pattern)
+    cfg.update(periodic_y=False, subdomains=nsub, conn_axis=axis, node_addressing=addressing)
+    g = OracleNNGroup(sim_cls, dim, 'EqualSubdomainsGeometry%dD' % dim, cfg)
+    g.run(steps)
+    return g
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('dim,size,nsub,axis', [(2, (24, 22), 1, 'x'), (3, (16, 20, 6), 1, 'x'), (3, (16, 20, 6), 2, 'x'),
+                                                (3, (16, 20, 8), 2, 'z')])
+def test_binary_shan_chen_indirect_equals_direct(pattern, dim, size, nsub, axis):
+    """Sparse distribution arrays of both lattices, dense rho / phi / u: every field and every population of a wet
+    node equals the dense run, bit for bit, on one and on two subdomains (population halo through translated links)."""
+    d = _sc_group(dim, size, 'direct', nsub, axis, pattern, 9)
+    i = _sc_group(dim, size, 'indirect', nsub, axis, pattern, 9)
+    wet = np.zeros(tuple(reversed(d.subs[0].runner._global_size)), dtype=bool)
+    for sub in d.subs:
+        sp = sub.runner._spec
+        sl = tuple(slice(o, o + n) for o, n in zip(reversed(sp.location), reversed(sp.size)))
+        wet[sl] = sub.runner._subdomain.fluid_map()
+    assert 0.3 < wet.mean() < 0.8
+    for sub in i.subs:
+        assert sub.indirect and sub.d1[0].shape == (sub.o.Q, sub.desc.dist_stride)
+        assert sub.desc.dist_stride < 0.85 * np.prod(sub.o.shape)
+    for get in (lambda s: s.rho, lambda s: s.phi, lambda s: s.v[0], lambda s: s.v[1]):
+        a, b = d.merged(get), i.merged(get)
+        assert np.array_equal(a[wet], b[wet])
+    for k in (0, 1):
+        a = d.merged(lambda s: s.dense(s.current()[k]))
+        b = i.merged(lambda s: s.dense(s.current()[k]))
+        assert np.array_equal(a[:, wet], b[:, wet])
+    rho = d.merged(lambda s: s.rho)[wet]
+    assert np.isfinite(rho).all() and rho.std() > 1e-5
