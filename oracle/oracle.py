@@ -52,6 +52,8 @@ def lib(precision=4):
         fn.restype = None
     L.orc_set_nodes.argtypes = [vp]
     L.orc_set_nodes.restype = None
+    L.orc_set_mrt_form.argtypes = [ctypes.c_int]
+    L.orc_set_mrt_form.restype = None
     for fn in (L.orc_node_feq, L.orc_node_macro, L.orc_node_update, L.orc_init, L.orc_step, L.orc_pbc,
                L.orc_macro_pbc, L.orc_sparse, L.orc_compute_macro):
         fn.restype = None
@@ -93,6 +95,12 @@ def node_update(desc, kind, orientation, par, f, precision=8):
         pp[:len(par)] = par
     lib(precision).orc_node_update(ctypes.byref(desc), kind, orientation, _dp(pp), _dp(f), _dp(rho), _dp(v))
     return f, rho[0], v
+
+
+def set_mrt_form(matrix_form, precision=8):
+    """D3Q19 MRT: False = products through the pairs of opposite directions (the arithmetic of the HIP kernels, the
+    default), True = plain row-by-row products with the integer matrix (the definition; tests compare the two)."""
+    lib(precision).orc_set_mrt_form(int(bool(matrix_form)))
 
 
 def sc_force_node(lattice, potential, cc, rho_local, neigh, precision=8):

@@ -267,6 +267,68 @@ SLF_D R mrt_col(const R (&m)[L::Q]) {
   return acc;
 }
 
+// D3Q19: the same two products M f and M^T (m / |row|^2), evaluated through the sums and differences of the nine pairs of
+// opposite directions -- the even moments (rho, en, eps, the stresses) need only the sums, the odd ones (j, q, the
+// third-order m) only the differences: 62 + 85 operations instead of 2 x 270.  (The sweep with the row-by-row product
+// kept the vector ALUs 72 % busy on a 512^3 cavity, profiles/r03/sq_summary_cfg2.txt: the collision, not HBM, set its
+// pace.)  The order of the operations below is the arithmetic contract with oracle/lbm_oracle.c (mrt_forward_d3q19 /
+// mrt_inverse_d3q19): identical, with the same fused multiply-adds; tests/test_oracle_golden.py holds it against the
+// matrix form and the reference's sympy values.
+template <class R>
+SLF_D R fma_(R a, R b, R c) {
+  if constexpr (sizeof(R) == 4) return __builtin_fmaf(a, b, c);
+  else return __builtin_fma(a, b, c);
+}
+
+template <class R>
+SLF_D void mrt_forward_d3q19(const R (&f)[19], R (&m)[19]) {
+  const R sx = f[1] + f[2], dx = f[1] - f[2], sy = f[3] + f[4], dy = f[3] - f[4], sz = f[5] + f[6], dz = f[5] - f[6];
+  const R sA = f[7] + f[10], dA = f[7] - f[10], sB = f[8] + f[9], dB = f[9] - f[8];
+  const R sC = f[11] + f[14], dC = f[11] - f[14], sD = f[12] + f[13], dD = f[13] - f[12];
+  const R sE = f[15] + f[18], dE = f[15] - f[18], sF = f[16] + f[17], dF = f[17] - f[16];
+  // odd moments
+  const R xab = dA + dB, yab = dA - dB, ycd = dC + dD, zcd = dC - dD, xef = dE + dF, zef = dE - dF;
+  const R X = xab + xef, Y = yab + ycd, Z = zcd + zef;
+  m[3] = dx + X;  m[4] = fma_<R>((R)-4, dx, X);  m[16] = xab - xef;
+  m[5] = dy + Y;  m[6] = fma_<R>((R)-4, dy, Y);  m[17] = ycd - yab;
+  m[7] = dz + Z;  m[8] = fma_<R>((R)-4, dz, Z);  m[18] = zef - zcd;
+  // even moments
+  const R Sxy = sA + sB, Syz = sC + sD, Szx = sE + sF;
+  const R A1 = (sx + sy) + sz, B1 = (Sxy + Syz) + Szx;
+  m[0] = (f[0] + A1) + B1;
+  m[1] = fma_<R>((R)8, B1, fma_<R>((R)-11, A1, (R)-30 * f[0]));
+  m[2] = fma_<R>((R)-4, A1, fma_<R>((R)12, f[0], B1));
+  const R P = fma_<R>((R)2, sx, (R)0 - (sy + sz)), Qd = fma_<R>((R)-2, Syz, Sxy + Szx);
+  m[9] = P + Qd;   m[10] = fma_<R>((R)-2, P, Qd);
+  const R W = sy - sz, V = Sxy - Szx;
+  m[11] = W + V;   m[12] = fma_<R>((R)-2, W, V);
+  m[13] = sA - sB; m[14] = sC - sD; m[15] = sE - sF;
+}
+
+// f = M^T m for moments m already divided by the squared row norms.
+template <class R>
+SLF_D void mrt_inverse_d3q19(const R (&m)[19], R (&f)[19]) {
+  const R K0 = fma_<R>((R)-4, m[2], fma_<R>((R)-11, m[1], m[0]));
+  const R K1 = fma_<R>((R)8, m[1], m[0]) + m[2];
+  f[0] = fma_<R>((R)12, m[2], fma_<R>((R)-30, m[1], m[0]));
+  const R G = fma_<R>((R)2, m[10], (R)0 - m[9]), H = fma_<R>((R)-2, m[12], m[11]);
+  const R Ex = fma_<R>((R)-2, G, K0), KG = K0 + G, Ey = KG + H, Ez = KG - H;
+  const R Ox = fma_<R>((R)-4, m[4], m[3]), Oy = fma_<R>((R)-4, m[6], m[5]), Oz = fma_<R>((R)-4, m[8], m[7]);
+  f[1] = Ex + Ox; f[2] = Ex - Ox; f[3] = Ey + Oy; f[4] = Ey - Oy; f[5] = Ez + Oz; f[6] = Ez - Oz;
+  const R S9 = m[9] + m[10], S11 = m[11] + m[12];
+  const R K19 = K1 + S9, Txy = K19 + S11, Tzx = K19 - S11, Tyz = fma_<R>((R)-2, S9, K1);
+  const R ax = m[3] + m[4], ay = m[5] + m[6], az = m[7] + m[8];
+  R ep = Txy + m[13], em = Txy - m[13];
+  const R oA = (ax + ay) + (m[16] - m[17]), oB = (ax - ay) + (m[16] + m[17]);
+  f[7] = ep + oA; f[10] = ep - oA; f[9] = em + oB; f[8] = em - oB;
+  ep = Tyz + m[14]; em = Tyz - m[14];
+  const R oC = (ay + az) + (m[17] - m[18]), oD = (ay - az) + (m[17] + m[18]);
+  f[11] = ep + oC; f[14] = ep - oC; f[13] = em + oD; f[12] = em - oD;
+  ep = Tzx + m[15]; em = Tzx - m[15];
+  const R oE = (ax + az) + (m[18] - m[16]), oF = (ax - az) - (m[16] + m[18]);
+  f[15] = ep + oE; f[18] = ep - oE; f[17] = em + oF; f[16] = em - oF;
+}
+
 template <class L, class R>
 SLF_D void mrt_equilibrium(const R (&m)[L::Q], R inv_rho, R (&meq)[L::Q]) {
   static_for<0, L::Q>([&](auto K) { meq[K] = (R)0; });
@@ -305,7 +367,8 @@ SLF_D void mrt_equilibrium(const R (&m)[L::Q], R inv_rho, R (&meq)[L::Q]) {
 template <class L, class R, int FORCE = FORCE_RUNTIME>
 SLF_D void mrt_relax(R (&f)[L::Q], R (&v)[3], const CollideParams<L, R>& cp, bool force_eq) {
   R m[L::Q];
-  static_for<0, L::Q>([&](auto K) { m[K] = mrt_row<L, R, K>(f); });
+  if constexpr (L::id == D3Q19::id) mrt_forward_d3q19<R>(f, m);
+  else static_for<0, L::Q>([&](auto K) { m[K] = mrt_row<L, R, K>(f); });
   const bool has_force = (FORCE == 1) ? true : ((FORCE == 0) ? false : (cp.has_force != 0));
   if (has_force) {
     m[L::M_MX] = m[L::M_MX] + (R)0.5 * cp.accel[0];
@@ -329,7 +392,8 @@ SLF_D void mrt_relax(R (&f)[L::Q], R (&v)[3], const CollideParams<L, R>& cp, boo
     if constexpr (L::dim == 3) m[L::M_MZ] = m[L::M_MZ] + (R)0.5 * cp.accel[2];
   }
   static_for<0, L::Q>([&](auto K) { m[K] = m[K] * (R)(1.0 / (double)L::mrt_norm(K)); });
-  static_for<0, L::Q>([&](auto I) { f[I] = mrt_col<L, R, I>(m); });
+  if constexpr (L::id == D3Q19::id) mrt_inverse_d3q19<R>(m, f);
+  else static_for<0, L::Q>([&](auto I) { f[I] = mrt_col<L, R, I>(m); });
   if (has_force) {
     static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * cp.accel[D]; });
   }

@@ -41,11 +41,12 @@ constexpr int NT = 3;   // populations are streamed once per step: non-temporal 
 // Minimum resident waves per SIMD asked of the compiler (second launch bound; it budgets VGPRs *and* SGPRs for it --
 // 800 SGPRs per SIMD make 104 of them a 7-wave kernel however few VGPRs it has).  The f32 node-map instantiations fit
 // 6 without spilling (77-80 VGPRs instead of 81-91); those for tables without boundary-condition nodes and modules
-// without a body force fit 8 (BGK, 46-53 VGPRs); MRT is asked for 6 (73 VGPRs: one more than 7 waves allow, and squeezing it
-// there spills 12 bytes, which measured 2 % slower: profiles/r03/configs_v2.txt); checked with -Rpass-analysis=kernel-resource-usage
+// without a body force fit 8 (BGK, 46-53 VGPRs); MRT with the pair-form moment transform (slf_node.h) needs 54-58 VGPRs, 70
+// in the load-first odd-step instantiation: asked for 7, everything but that one reaches 8 and nothing spills (asked for
+// 8, the load-first instantiation spills 32 bytes); checked with -Rpass-analysis=kernel-resource-usage
 // (tools/resource_usage.py, profiles/r03/row_kernels_resources.txt).
 #ifndef SLF_MRT_L0_WAVES
-#define SLF_MRT_L0_WAVES 6
+#define SLF_MRT_L0_WAVES 7
 #endif
 template <class R, int MODEL, bool GENERAL, bool FORCE, int BCL>
 constexpr int row_min_waves() {

@@ -28,10 +28,12 @@ class LBBinaryFluidBase(LBSim):
 
     def get_pbc_kernels(self, runner):
         """(distributions, macro) : copy -> axis -> kernels (reference lb_binary.py:40-105)."""
-        d1a, d1b = runner.gpu_dist(0, 0), runner.gpu_dist(0, 1)
-        d2a, d2b = runner.gpu_dist(1, 0), runner.gpu_dist(1, 1)
         dist_kernels = defaultdict(lambda: defaultdict(list))
         macro_kernels = defaultdict(lambda: defaultdict(list))
+        if runner.indirect:      # periodic axes are wrapped inside the kernels; no ghost-layer kernels exist
+            return MacroKernels(macro=macro_kernels, distributions=dist_kernels)
+        d1a, d1b = runner.gpu_dist(0, 0), runner.gpu_dist(0, 1)
+        d2a, d2b = runner.gpu_dist(1, 0), runner.gpu_dist(1, 1)
         nn_fields = [fp.buffer for fp in self._scalar_fields if fp.abstract.need_nn]
         for i in range(0, self.dim):
             dist_kernels[0][i] = [runner.get_kernel('ApplyPeriodicBoundaryConditions', [d1a, np.uint32(i)], 'Pi'),

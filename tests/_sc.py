@@ -90,13 +90,19 @@ def make_wall_sim(dim, seed=11, amplitude=1e-3, wall=4):
     sub = base.subdomain
 
     class Walled(sub):
-        def boundary_conditions(self, *h):
+        def _solid(self, *h):
             hy, hx = h[1], h[0]
             solid = (hy < wall) | (hy >= self.gy - wall)
             block = (hx >= 5) & (hx < 9) & (hy >= wall + 2) & (hy < wall + 6)
             if dim == 3:
                 block = block & (h[2] >= 1) & (h[2] < 5)
-            self.set_node(solid | block, NTFullBBWall)
+            return solid | block
+
+        def boundary_conditions(self, *h):
+            self.set_node(self._solid(*h), NTFullBBWall)
+
+        def load_active_node_map(self, *h):               # --node_addressing=indirect: all nodes incl. ghosts
+            self.set_active_node_map_from_wall_map(self._solid(*h))
 
     class Sim(base):
         subdomain = Walled

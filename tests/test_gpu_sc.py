@@ -386,6 +386,7 @@ def test_sc_indirect_addressing(dim, size, nsub, axis, pattern):
     assert len(ctrl.runners) == nsub
     for r, o in zip(ctrl.runners, og.subs):
         assert r._desc.node_addressing == 1 and r._dist_stride < 0.85 * int(np.prod(r._physical_size))
+        assert 0.5 < r._subdomain.active_node_mask.mean() < 0.9
         wet = r._subdomain.fluid_map()
         assert np.array_equal(r._sim.rho[wet], o.real(o.rho)[wet])
         assert np.array_equal(r._sim.phi[wet], o.real(o.phi)[wet])

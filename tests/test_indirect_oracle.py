@@ -96,7 +96,8 @@ def test_binary_shan_chen_indirect_equals_direct(pattern, dim, size, nsub, axis)
     assert 0.3 < wet.mean() < 0.8
     for sub in i.subs:
         assert sub.indirect and sub.d1[0].shape == (sub.o.Q, sub.desc.dist_stride)
-        assert sub.desc.dist_stride < 0.85 * np.prod(sub.o.shape)
+        assert sub.desc.dist_stride < 0.85 * np.prod(sub.runner._physical_size)
+        assert 0.5 < sub.runner._subdomain.active_node_mask.mean() < 0.9
     for get in (lambda s: s.rho, lambda s: s.phi, lambda s: s.v[0], lambda s: s.v[1]):
         a, b = d.merged(get), i.merged(get)
         assert np.array_equal(a[wet], b[wet])

@@ -113,6 +113,33 @@ def test_mrt_collision(gold, precision):
 
 
 @pytest.mark.parametrize('precision', [8, 4])
+def test_mrt_pair_form_equals_matrix_form(gold, precision):
+    """D3Q19: the moment transform evaluated through the pairs of opposite directions (what the oracle and the HIP
+    kernels run) against the row-by-row products with the integer matrix of sym.py:331-378: the same numbers up to the
+    rounding of a differently ordered sum, and both within the tolerance of the reference's sympy values."""
+    grid, G = gold
+    if grid.Q != 19:
+        pytest.skip('D2Q9 keeps the matrix form')
+    worst = 0.0
+    try:
+        for a, nu in enumerate(G['bgk_visc']):
+            d = _desc(grid, precision, visc=float(nu), model='mrt')
+            for k in range(len(G['rho'])):
+                oracle.set_mrt_form(False, precision)
+                f_pair, _, _ = oracle.node_update(d, hipabi.SLF_NK_FLUID, 0, None, G['f'][k], precision)
+                oracle.set_mrt_form(True, precision)
+                f_mat, _, _ = oracle.node_update(d, hipabi.SLF_NK_FLUID, 0, None, G['f'][k], precision)
+                worst = max(worst, float(np.max(np.abs(f_pair - f_mat))))
+                _close(f_mat, G['mrt_post'][a, k], TOL[precision] * (4 if precision == 4 else 50))
+                _close(f_pair, G['mrt_post'][a, k], TOL[precision] * (4 if precision == 4 else 50))
+    finally:
+        oracle.set_mrt_form(False, precision)
+    assert 0.0 < worst < (2e-6 if precision == 4 else 2e-14)       # different rounding, same transform
+    # the pair form is the more accurate of the two: fewer, smaller intermediate sums
+    print('max |pair - matrix| = %.3e' % worst)
+
+
+@pytest.mark.parametrize('precision', [8, 4])
 def test_mrt_collision_with_body_force(gold, precision):
     """Moment-space forcing (reference relaxation_mrt.mako:10-27, 45-46, 91: half of sym_force.accel_vector in the
     momentum moments before the equilibrium, half after the relaxation; output velocity u + a / 2)."""

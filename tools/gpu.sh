@@ -11,6 +11,7 @@
 #   pmc             separate rocprofv3 --pmc passes of bench.py (HBM traffic; $BENCH_ARGS)
 #   torchrun        the N>1 code paths on one GPU: torch.distributed.run --nproc-per-node 1, weak + strong
 #   configs         tools/bench_configs.py (all single-GPU BASELINE configs through the host stack)
+#   sqcfg           SQ instruction / issue counters of bench_configs.py --quick --only <id>, for id in $TRACE_CONFIGS
 #   pmccfg          FETCH_SIZE / WRITE_SIZE passes of bench_configs.py --quick --only <id>, for id in $TRACE_CONFIGS
 #   tracecfg        rocprofv3 --kernel-trace --stats of bench_configs.py --quick --only <id>, for id in $TRACE_CONFIGS
 #   py <file> ...   python <file> ... (rest of the line)
@@ -69,6 +70,20 @@ while [ $# -gt 0 ]; do
               env SLF_PLACEMENT_TUNE=0 python $R/tools/bench_configs.py --quick --only $c > $O/pmc_cfg${c}_p$i.log 2>&1 )
         done
         python tools/pmc_summary.py $O/pmc_cfg$c | tee $O/pmc_summary_cfg$c.txt
+      done ;;
+    sqcfg)
+      # instruction issue: what the waves of each kernel execute (per-wave VALU / SALU / memory instruction counts) and
+      # how busy the issue ports are -- is a kernel bound by HBM or by the instruction stream?
+      for c in ${TRACE_CONFIGS:-4}; do
+        i=0
+        for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM" \
+                 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+                 "GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"; do
+          i=$((i+1))
+          ( cd /tmp && timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/sq_cfg$c/p$i -o pmc -- \
+              env SLF_PLACEMENT_TUNE=0 python $R/tools/bench_configs.py --quick --only $c > $O/sq_cfg${c}_p$i.log 2>&1 )
+        done
+        python tools/pmc_summary.py $O/sq_cfg$c | tee $O/sq_summary_cfg$c.txt
       done ;;
     py)
       timeout ${PY_TIMEOUT:-900} python "$@" 2>&1 | tee -a $O/py.log | tail -${PY_TAIL:-40}; break ;;

@@ -37,6 +37,15 @@ def main(root):
             w64 = c.get('TCC_EA0_WRREQ_64B_sum', 0.0)
             print('    write bytes/launch (WRREQ: 64B x 64 + rest x 32):                    %.4f GB'
                   % ((w64 * 64 + (c['TCC_EA0_WRREQ_sum'] - w64) * 32) / 1e9))
+        if 'SQ_WAVES' in c and c['SQ_WAVES'] > 0:
+            w = c['SQ_WAVES']
+            print('    per wave: ' + ', '.join('%s %.0f' % (cn[9:], c[cn] / w) for cn in sorted(c) if cn.startswith('SQ_INSTS_')))
+        if 'SQ_BUSY_CYCLES' in c and c['SQ_BUSY_CYCLES'] > 0:
+            print('    of SQ_BUSY_CYCLES: ' + ', '.join('%s %.3f' % (cn[3:], c[cn] / c['SQ_BUSY_CYCLES']) for cn in sorted(c)
+                                                      if cn.startswith(('SQ_ACTIVE_', 'SQ_WAIT', 'SQ_INST_CYCLES'))))
+        if 'SQ_WAVE_CYCLES' in c and c['SQ_WAVE_CYCLES'] > 0:
+            print('    of SQ_WAVE_CYCLES: ' + ', '.join('%s %.3f' % (cn[3:], c[cn] / c['SQ_WAVE_CYCLES']) for cn in sorted(c)
+                                                      if cn.startswith(('SQ_ACTIVE_', 'SQ_WAIT'))))
 
 
 if __name__ == '__main__':
