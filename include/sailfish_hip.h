@@ -49,8 +49,10 @@ enum { SLF_SIM_LBM = 0, SLF_SIM_SHAN_CHEN_BINARY = 1, SLF_SIM_SHAN_CHEN_SINGLE =
  * distribution arrays hold the *active* nodes only (dist_stride >= number of active nodes); a dense
  * uint32 table `nodes` maps a node's dense index to its slot or SLF_INVALID_NODE.  Node map and
  * macroscopic fields stay dense.  In an indirect module CollideAndPropagate, SetInitialConditions and
- * ComputeMacroFields take that table as an additional FIRST pointer argument (as the reference's
- * _add_indirect_args, subdomain_runner.py:1153-1157); periodic boundaries must be wrapped in-sweep. */
+ * ComputeMacroFields -- and, for SLF_SIM_SHAN_CHEN_BINARY, ShanChenPrepareMacroFields and
+ * ShanChenCollideAndPropagate0 / 1 (lb_binary.py:121-123, 457-465; the fused sweep is not offered) -- take that table
+ * as an additional FIRST pointer argument (as the reference's _add_indirect_args, subdomain_runner.py:1153-1157);
+ * periodic boundaries must be wrapped in-sweep.  SLF_SIM_SHAN_CHEN_SINGLE modules are direct only. */
 enum { SLF_ADDR_DIRECT = 0, SLF_ADDR_INDIRECT = 1 };
 
 /* How a body-force / Shan-Chen acceleration a enters the BGK collision (relaxation_common.mako:56-99):
