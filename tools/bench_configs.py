@@ -70,14 +70,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--quick', action='store_true')
-    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,4)')
+    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,4)')
     args = ap.parse_args()
     if not args.only:
         # one fresh process per configuration: what a configuration measures must not depend on what ran before it in
         # the same process (stream -> hardware-queue mapping, allocator state; profiles/r02/README.md "config 3")
         import subprocess
         lines = []
-        for cid in ('0', '1', '2', '2b', '2c', '5a', '5b', '3', '4'):
+        for cid in ('0', '1', '2', '2b', '2c', '5a', '5b', '3', '3b', '4'):
             cmd = [sys.executable, os.path.abspath(__file__), '--only', cid] + (['--quick'] if args.quick else [])
             out = subprocess.run(cmd, stdout=subprocess.PIPE).stdout.decode(errors='replace')
             for ln in out.splitlines():
@@ -129,11 +129,12 @@ def main():
                             max_iters=int(1500 * it), benchmark_sample_from=int(500 * it)), 152))
     # config 3 (8 GPUs) is bench.py --gpus 8; here its per-GPU shape for both decompositions, 2 subdomains
     # of the reference's x-split layout on this one GPU (halo path exercised, no xGMI)
-    res.append(run('3: D3Q19 BGK 1024x512x512 / 8: one 128x512x512 x-slab pair on one GPU', BoxSim,
-                   EqualSubdomainsGeometry3D,
-                   dict(lat_nx=256, lat_ny=512, lat_nz=512, subdomains=2, conn_axis='x', periodic_x=True,
-                        periodic_y=True, periodic_z=True, visc=1.0 / 6.0, access_pattern='AA', grid='D3Q19',
-                        max_iters=int(600 * it), benchmark_sample_from=int(200 * it)), 152))
+    for cid, pattern in (('3', 'AA'), ('3b', 'AB')):
+        res.append(run('%s: D3Q19 BGK 1024x512x512 / 8: one 128x512x512 x-slab pair on one GPU (%s)' % (cid, pattern), BoxSim,
+                       EqualSubdomainsGeometry3D,
+                       dict(lat_nx=256, lat_ny=512, lat_nz=512, subdomains=2, conn_axis='x', periodic_x=True,
+                            periodic_y=True, periodic_z=True, visc=1.0 / 6.0, access_pattern=pattern, grid='D3Q19',
+                            max_iters=int(600 * it), benchmark_sample_from=int(200 * it)), 152))
     # config 4: binary Shan-Chen 256^3 (3 passes per step: 516 B per node update)
     res.append(run('4: binary Shan-Chen D3Q19 256^3', SeparationSim, LBGeometry3D,
                    dict(lat_nx=256, lat_ny=256, lat_nz=256, access_pattern='AA', max_iters=int(1500 * it),
