@@ -100,7 +100,24 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
     constexpr int nt = (PROP == PROP_AA_ODD && L::ex(I) != 0) ? (NT & ~1) : NT;
     return ldg<nt>(src_of(I));
   };
-  if constexpr (SPEC || !GENERAL) {
+  // Odd AA step next to a CONNECTED x face: what the edge node would pull out of the ghost column arrives through the
+  // face buffer instead (x_face_receive), so its lane does not load it -- the ghost column sits in a line of its own
+  // behind the row, which the pull would fetch from HBM for one value nothing uses: ten lines per row, +13 % reads on
+  // the 128-node rows of an eight-way x split (profiles/r03/pmc_summary_cfg3.txt).
+  // (Fluid-only instantiations: in the node-map ones the two extra predicated blocks push the plain-fluid level over its
+  // eight-wave register budget -- 20 bytes of scratch in the kernel a cavity spends half its time in.)
+  constexpr bool SKIP_GHOST_PULL = PROP == PROP_AA_ODD && !GENERAL;
+  bool pull_lo = true, pull_hi = true;
+  if constexpr (SKIP_GHOST_PULL) {
+    pull_lo = !(p.xrecv[0] && x == 1);
+    pull_hi = !(p.xrecv[1] && x == nx);
+  }
+  if constexpr (SKIP_GHOST_PULL) {
+    static_for<0, L::Q>([&](auto I) { if constexpr (L::ex(I) == 0) f[I] = load(I); });
+    static_for<1, L::Q>([&](auto I) { if constexpr (L::ex(I) != 0) f[I] = (R)0; });
+    if (pull_lo) static_for<1, L::Q>([&](auto I) { if constexpr (L::ex(I) > 0) f[I] = load(I); });
+    if (pull_hi) static_for<1, L::Q>([&](auto I) { if constexpr (L::ex(I) < 0) f[I] = load(I); });
+  } else if constexpr (SPEC || !GENERAL) {
     static_for<0, L::Q>([&](auto I) { f[I] = load(I); });
   }
   int kind = NK_FLUID;
@@ -118,7 +135,11 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
   }
 
   const FaceRows fr = face_rows<L>(g, gy, gz);
-  if (active) x_face_receive<L, R, PROP == PROP_AA_ODD>(p, f, x, nx, fr);
+  if constexpr (SKIP_GHOST_PULL) {
+    if (active) x_face_receive<L, R, true>(p, f, x, nx, fr, load);
+  } else {
+    if (active) x_face_receive<L, R, PROP == PROP_AA_ODD>(p, f, x, nx, fr);
+  }
   R rho, v[3];
   bool wet = true;
   if (active) {

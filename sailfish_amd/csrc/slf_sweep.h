@@ -199,14 +199,19 @@ __device__ __forceinline__ bool face_value_present(float v) { return __builtin_b
 __device__ __forceinline__ bool face_value_present(double v) { return __builtin_bit_cast(uint64_t, v) != ~0ull; }
 // Incoming populations of an edge node: f_I with e_x > 0 at x = 1 come from the low neighbour, e_x < 0 at x = nx from
 // the high one.  PULL = the odd AA step (the value sits in the row the pull reads from), otherwise the node's own row.
-// Entries never written (the sender's edge node is excluded) leave f as loaded from the arrays.
-template <class L, class R, bool PULL>
-__device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
+// Entries never written (the sender's edge node is excluded) leave f as loaded from the arrays -- or, when the caller
+// has not loaded them (`from_arrays` given: the whole-row odd step skips the pull out of the ghost column), load them now.
+struct NoArrayLoad {};
+template <class L, class R, bool PULL, class A = NoArrayLoad>
+__device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f)[L::Q], int x, int nx, const FaceRows& fr,
+                                               A from_arrays = A()) {
+  constexpr bool RELOAD = PULL && !__is_same(A, NoArrayLoad);
   if (p.xrecv[0] && x == 1) {
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) > 0) {
         const R val = p.xrecv[0][face_elem<L, I>(fr, PULL ? -1 : 0)];
         if (face_value_present(val)) f[I] = val;
+        else if constexpr (RELOAD) f[I] = from_arrays(I);
       }
     });
   }
@@ -215,6 +220,7 @@ __device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f
       if constexpr (L::ex(I) < 0) {
         const R val = p.xrecv[1][face_elem<L, I>(fr, PULL ? -1 : 0)];
         if (face_value_present(val)) f[I] = val;
+        else if constexpr (RELOAD) f[I] = from_arrays(I);
       }
     });
   }
