@@ -5,7 +5,7 @@
 //   * one workgroup = one (y, z) row (or, opt-in, an x-segment of it: row_block_x), thread t of workgroup b
 //     owns node x = 1 + b * blockDim.x + t; the distribution arrays are allocated so that x = 1 starts a
 //     128-byte line  =>  every global access of a wave is line aligned;
-//   * the +-1 x shift of the push (AB and odd AA step) happens in registers: __shfl_up/down inside a
+//   * the +-1 x shift of the push (AB and odd AA step) happens in registers: a DPP wave shift inside a
 //     wave64, one LDS word per direction between neighbouring waves, the periodic wrap as the cyclic
 //     continuation (x = nx <-> x = 1)  =>  every *store* is aligned (partial-line writes are what hurts
 //     HBM); the pull of the odd AA step uses plain shifted loads (misaligned reads are served from cache);
