@@ -84,11 +84,24 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
   // cost little (the neighbouring wave uses the rest of the line; measured equal to an LDS exchange of aligned
   // loads, profiles/r01/row_probe4.log) and save a barrier; the push below is what must be aligned.
   R f[L::Q];
+  // Odd AA step next to a CONNECTED x face (fluid-only instantiations): what the edge node would pull out of the ghost
+  // column arrives through the face buffer instead (x_face_receive overrides it), so its lane pulls from its own x -- a
+  // line the wave fetches anyway -- rather than from the ghost column, which sits in a line of its own behind the row:
+  // ten lines per row fetched from HBM for values nothing uses, +13 % reads on the 128-node rows of an eight-way x
+  // split (profiles/r03/pmc_summary_cfg3*.txt).  Branch-free on purpose: predicating the loads instead made every wave
+  // wait for all of its loads before the edge lanes' block (s_waitcnt vmcnt(0) at the join), 10 % slower on 1024-node rows.
+  // (Not in the node-map instantiations: there a missing face entry legitimately falls back to the arrays.)
+  constexpr bool SKIP_GHOST_PULL = PROP == PROP_AA_ODD && !GENERAL;
+  AxisOff oxl = ox;
+  if constexpr (SKIP_GHOST_PULL) {
+    if (p.xrecv[0] && x == 1) oxl.m = 0;
+    if (p.xrecv[1] && x == nx) oxl.p = 0;
+  }
   auto src_of = [&](auto I) -> const SLF_GLOBAL R* {
     if constexpr (PROP == PROP_AA_ODD) {
       const int off = dir_offset<L, I>(ox0, oy, oz, false);                     // y, z part: uniform
       constexpr int ex = L::ex(I);
-      const int xs = (ex == 0) ? 0 : ((ex > 0) ? ox.m : ox.p);                  // x part of x - e_i: per lane
+      const int xs = (ex == 0) ? 0 : ((ex > 0) ? oxl.m : oxl.p);                // x part of x - e_i: per lane
       return at_byte(uniform_base(p.din + ds * (size_t)L::opp(I) + (uint32_t)((int)row + off)),
                      (uint32_t)((int)xi + xs) * (uint32_t)sizeof(R));
     } else {
@@ -100,24 +113,7 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
     constexpr int nt = (PROP == PROP_AA_ODD && L::ex(I) != 0) ? (NT & ~1) : NT;
     return ldg<nt>(src_of(I));
   };
-  // Odd AA step next to a CONNECTED x face: what the edge node would pull out of the ghost column arrives through the
-  // face buffer instead (x_face_receive), so its lane does not load it -- the ghost column sits in a line of its own
-  // behind the row, which the pull would fetch from HBM for one value nothing uses: ten lines per row, +13 % reads on
-  // the 128-node rows of an eight-way x split (profiles/r03/pmc_summary_cfg3.txt).
-  // (Fluid-only instantiations: in the node-map ones the two extra predicated blocks push the plain-fluid level over its
-  // eight-wave register budget -- 20 bytes of scratch in the kernel a cavity spends half its time in.)
-  constexpr bool SKIP_GHOST_PULL = PROP == PROP_AA_ODD && !GENERAL;
-  bool pull_lo = true, pull_hi = true;
-  if constexpr (SKIP_GHOST_PULL) {
-    pull_lo = !(p.xrecv[0] && x == 1);
-    pull_hi = !(p.xrecv[1] && x == nx);
-  }
-  if constexpr (SKIP_GHOST_PULL) {
-    static_for<0, L::Q>([&](auto I) { if constexpr (L::ex(I) == 0) f[I] = load(I); });
-    static_for<1, L::Q>([&](auto I) { if constexpr (L::ex(I) != 0) f[I] = (R)0; });
-    if (pull_lo) static_for<1, L::Q>([&](auto I) { if constexpr (L::ex(I) > 0) f[I] = load(I); });
-    if (pull_hi) static_for<1, L::Q>([&](auto I) { if constexpr (L::ex(I) < 0) f[I] = load(I); });
-  } else if constexpr (SPEC || !GENERAL) {
+  if constexpr (SPEC || !GENERAL) {
     static_for<0, L::Q>([&](auto I) { f[I] = load(I); });
   }
   int kind = NK_FLUID;
@@ -136,7 +132,7 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
 
   const FaceRows fr = face_rows<L>(g, gy, gz);
   if constexpr (SKIP_GHOST_PULL) {
-    if (active) x_face_receive<L, R, true>(p, f, x, nx, fr, load);
+    if (active) x_face_receive<L, R, true, true>(p, f, x, nx, fr);
   } else {
     if (active) x_face_receive<L, R, PROP == PROP_AA_ODD>(p, f, x, nx, fr);
   }
