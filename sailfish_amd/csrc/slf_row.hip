@@ -44,12 +44,13 @@ constexpr int NT = 3;   // populations are streamed once per step: non-temporal 
 // without a body force fit 8 (BGK, 46-53 VGPRs); MRT with the pair-form moment transform (slf_node.h) needs 54-58 VGPRs, 70
 // in the load-first odd-step instantiation: asked for 7, everything but that one reaches 8 and nothing spills (asked for
 // 8, the load-first instantiation spills 32 bytes); checked with -Rpass-analysis=kernel-resource-usage
-// (tools/resource_usage.py, profiles/r03/row_kernels_resources.txt).
+// (tools/resource_usage.py, profiles/r03/kernels_resources_final.txt).
 #ifndef SLF_MRT_L0_WAVES
 #define SLF_MRT_L0_WAVES 7
 #endif
 template <class R, int MODEL, bool GENERAL, bool FORCE, int BCL>
 constexpr int row_min_waves() {
+  if (sizeof(R) == 4 && !GENERAL && MODEL == 0 && !FORCE) return 8;   // 46 VGPRs; the bound keeps it under 96 SGPRs too
   if (sizeof(R) != 4 || !GENERAL) return 4;
   if (BCL == 0 && !FORCE) return MODEL == 0 ? 8 : SLF_MRT_L0_WAVES;
   return 6;
@@ -90,12 +91,19 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
   // ten lines per row fetched from HBM for values nothing uses, +13 % reads on the 128-node rows of an eight-way x
   // split (profiles/r03/pmc_summary_cfg3*.txt).  Branch-free on purpose: predicating the loads instead made every wave
   // wait for all of its loads before the edge lanes' block (s_waitcnt vmcnt(0) at the join), 10 % slower on 1024-node rows.
-  // (Not in the node-map instantiations: there a missing face entry legitimately falls back to the arrays.)
+  // Only where every entry the row reads is sure to have been written: fluid-only instantiations (with a node map the
+  // sender's edge node may be excluded) and rows whose y and z neighbours are real or wrapped rows (the rows next to a
+  // non-periodic y / z face pull from ghost rows, which no sweep of the neighbour has sent: those entries stay unset and
+  // x_face_receive leaves what was pulled from the arrays -- the reference's behaviour, pinned by the propagation KATs).
   constexpr bool SKIP_GHOST_PULL = PROP == PROP_AA_ODD && !GENERAL;
   AxisOff oxl = ox;
   if constexpr (SKIP_GHOST_PULL) {
-    if (p.xrecv[0] && x == 1) oxl.m = 0;
-    if (p.xrecv[1] && x == nx) oxl.p = 0;
+    const bool inner = (g.wrap[1] || (gy > 1 && gy < g.lat_ny - 2)) &&
+                       (L::dim < 3 || g.wrap[2] || (gz > 1 && gz < g.lat_nz - 2));
+    if (inner) {
+      if (p.xrecv[0] && x == 1) oxl.m = 0;
+      if (p.xrecv[1] && x == nx) oxl.p = 0;
+    }
   }
   auto src_of = [&](auto I) -> const SLF_GLOBAL R* {
     if constexpr (PROP == PROP_AA_ODD) {
@@ -131,11 +139,7 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
   }
 
   const FaceRows fr = face_rows<L>(g, gy, gz);
-  if constexpr (SKIP_GHOST_PULL) {
-    if (active) x_face_receive<L, R, true, true>(p, f, x, nx, fr);
-  } else {
-    if (active) x_face_receive<L, R, PROP == PROP_AA_ODD>(p, f, x, nx, fr);
-  }
+  if (active) x_face_receive<L, R, PROP == PROP_AA_ODD>(p, f, x, nx, fr);
   R rho, v[3];
   bool wet = true;
   if (active) {

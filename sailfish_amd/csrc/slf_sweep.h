@@ -199,20 +199,15 @@ __device__ __forceinline__ bool face_value_present(float v) { return __builtin_b
 __device__ __forceinline__ bool face_value_present(double v) { return __builtin_bit_cast(uint64_t, v) != ~0ull; }
 // Incoming populations of an edge node: f_I with e_x > 0 at x = 1 come from the low neighbour, e_x < 0 at x = nx from
 // the high one.  PULL = the odd AA step (the value sits in the row the pull reads from), otherwise the node's own row.
-// Entries never written (the sender's edge node is excluded) leave f as loaded from the arrays.  UNLOADED: what the
-// caller loaded there is not the ghost column's value (the fluid-only whole-row odd step pulls from a line it fetches
-// anyway, slf_row.hip) -- in a fluid-only module every edge node sends, so a missing entry means the buffers were not
-// exchanged: the population becomes NaN (f + the all-ones sentinel) and the invalid-value check trips, as it did when
-// the never-written ghost column was pulled.  (Written as a select on f, not as a plain assignment: with the plain
-// assignment the compiler waits for ALL loads of the wave before the edge lanes' block.)
-template <class L, class R, bool PULL, bool UNLOADED = false>
+// Entries never written (the sender's edge node is excluded, or the entry belongs to a ghost row the neighbour does not
+// sweep) leave f as loaded from the arrays.
+template <class L, class R, bool PULL>
 __device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
   if (p.xrecv[0] && x == 1) {
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) > 0) {
         const R val = p.xrecv[0][face_elem<L, I>(fr, PULL ? -1 : 0)];
-        if constexpr (UNLOADED) f[I] = face_value_present(val) ? val : f[I] + val;
-        else if (face_value_present(val)) f[I] = val;
+        if (face_value_present(val)) f[I] = val;
       }
     });
   }
@@ -220,8 +215,7 @@ __device__ __forceinline__ void x_face_receive(const SweepParams<L, R>& p, R (&f
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) < 0) {
         const R val = p.xrecv[1][face_elem<L, I>(fr, PULL ? -1 : 0)];
-        if constexpr (UNLOADED) f[I] = face_value_present(val) ? val : f[I] + val;
-        else if (face_value_present(val)) f[I] = val;
+        if (face_value_present(val)) f[I] = val;
       }
     });
   }
