@@ -61,6 +61,11 @@ def parse_args():
     ap.add_argument('--no_gpu_state', action='store_true', help='do not sample amd-smi before / after')
     ap.add_argument('--no_runner_path', action='store_true',
                     help='skip the leg through LBSimulationController / SubdomainRunner.step() (N = 1 only)')
+    ap.add_argument('--min_seconds', type=float, default=0.5,
+                    help='the block of exactly K timed steps is repeated until at least this much time has been timed '
+                         '(every block bracketed by barrier + synchronize; best block = value, the median is reported too)')
+    ap.add_argument('--halo_timing_steps', type=int, default=20,
+                    help='N > 1: steps of the separate leg that brackets the halo stream with timing events')
     ap.add_argument('--no_validate', action='store_true',
                     help='skip the check of the final state against the CPU oracle after the timed region')
     return ap.parse_args()
@@ -164,36 +169,79 @@ def runner_path(args, gpu_id):
     return out
 
 
-def validate(sim, backend, mass0, distributed, axis):
+def ring_swapper(rank, world):
+    """swap(low, high) -> (from_down, from_up) for oracle.window.SeamCheck: the edge layers of the ring neighbours, moved
+    with the same point-to-point pattern as the halo itself (connector.RingExchanger: torch.distributed isend / irecv,
+    RCCL for device tensors; a plain copy for a ring of one without a process group)."""
+    import torch
+    from sailfish_amd.connector import RingExchanger
+
+    def flatten(tree):
+        if isinstance(tree, (list, tuple)):
+            return [a for t in tree for a in flatten(t)]
+        return [tree]
+
+    def rebuild(tree, flat):
+        if isinstance(tree, (list, tuple)):
+            return [rebuild(t, flat) for t in tree]
+        return flat.pop(0)
+
+    def swap(low, high):
+        ex = RingExchanger(rank, world)
+        fl, fh = flatten(low), flatten(high)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        t_low = torch.from_numpy(np.concatenate([a.ravel() for a in fl])).to(dev)
+        t_high = torch.from_numpy(np.concatenate([a.ravel() for a in fh])).to(dev)
+        r_down, r_up = torch.empty_like(t_high), torch.empty_like(t_low)
+        ex.exchange(t_high, t_low, r_down, r_up)      # my high layers travel up and arrive as the neighbour's "from down"
+        torch.cuda.synchronize()
+        out = []
+        for flat_t, like in ((r_down, fh), (r_up, fl)):
+            host, parts, o = flat_t.cpu().numpy(), [], 0
+            for a in like:
+                parts.append(host[o:o + a.size].reshape(a.shape).copy())
+                o += a.size
+            out.append(parts)
+        return rebuild(high, out[0]), rebuild(low, out[1])
+    return swap
+
+
+def validate(sim, backend, mass0, distributed, axis, rank=0, world=1):
     """AFTER the timed region, on the state the timed steps left behind: (a) sampled z-planes of the next two steps
     against the CPU oracle (7-plane windows seeded from the device, oracle/window.py: bit-identical populations
-    expected), (b) total mass and momentum against the initial state (periodic BGK box without forcing: conserved
-    up to f32 round-off).  The oracle is the checker here, never part of what is timed."""
+    expected) -- for a slab with ring neighbours the windows reach three layers into the NEIGHBOURS' slabs
+    (window.SeamCheck: their edge layers are fetched over the same point-to-point pattern as the halo), so the seam
+    layers -- planes z = 1, z = nz of a z-slab, columns x = 1, x = nx of an x-slab -- are compared bit for bit;
+    (b) total mass and momentum against the initial state (periodic BGK box without forcing: conserved up to f32
+    round-off).  The oracle is the checker here, never part of what is timed."""
     from oracle import window
+    from sailfish_amd.slab import AXES
     import torch
     out = {}
     nz = sim.desc.lat_nz - 2
+    fields = [sim.gpu_rho] + list(sim.gpu_v)
+    sim.sync()
     if not sim.halo:
         zs = [1, nz // 3, nz]
         zs += [z for z in window.chunk_boundary_planes(sim.placed, sim.desc, sim.stride, limit=2) if z not in zs]
-    elif axis == 'z' and nz >= 16:
-        zs = [8, nz // 2, nz - 7]         # interior planes: the windows do not model the neighbours' halo
+        chk = window.PlaneCheck(backend, sim.desc, None, zs, sim.gpu_dist, sim.stride, fields)
     else:
-        zs = []
-    chk = None
-    sim.sync()
-    if zs:
-        chk = window.PlaneCheck(backend, sim.desc, None, zs, sim.gpu_dist, sim.stride,
-                                [sim.gpu_rho] + list(sim.gpu_v))
-        chk.seed(sim.iteration)
+        sim.materialise_faces()         # x-face buffers: what crossed the faces goes into the arrays
+        zs = sorted(set([1, nz // 2, nz] if axis == 'z' else [1, nz // 3, nz]))
+        chk = window.SeamCheck(backend, sim.desc, zs, sim.gpu_dist, sim.stride, fields, AXES[axis], ring_swapper(rank, world))
+        out['seam_layers_checked'] = ({'z': 'planes z = 1 and z = nz', 'y': 'rows y = 1 and y = ny',
+                                       'x': 'columns x = 1 and x = nx'}[axis] + ' of every sampled plane (windows reach 3 layers '
+                                      'into the ring neighbours)')
+    chk.seed(sim.iteration)
     sim.step()
     sim.step(save_macro=True)
     sim.sync()
-    if chk is not None:
-        chk.advance(2, save_last=True)
-        r = chk.compare()
-        out.update(planes=r['planes'], populations_compared=r['compared_values'], populations_bit_identical=r['dist_exact'],
-                   max_abs_err=r['dist_err'], rho_rel_err=r['rho_err'], u_abs_err=r['v_abs_err'])
+    if sim.halo:
+        sim.materialise_faces()
+    chk.advance(2, save_last=True)
+    r = chk.compare()
+    out.update(planes=r['planes'], populations_compared=r['compared_values'], populations_bit_identical=r['dist_exact'],
+               max_abs_err=r['dist_err'], rho_rel_err=r['rho_err'], u_abs_err=r['v_abs_err'])
     rho, v = sim.fetch_fields()
     r64 = sim.real_view(rho).astype(np.float64)
     tot = [float(r64.sum())] + [float((r64 * sim.real_view(c)).sum()) for c in v]
@@ -207,10 +255,29 @@ def validate(sim, backend, mass0, distributed, axis):
     out['ok'] = bool(out['mass_rel_drift'] < 1e-5 and out['momentum_drift_over_mass_u'] < 1e-4 and
                      out.get('populations_bit_identical', True) and out.get('rho_rel_err', 0.0) < 1e-6)
     if distributed:                      # every rank checked its own planes: all of them must agree
-        t = torch.tensor([1.0 if out['ok'] else 0.0], dtype=torch.float64, device='cuda')
+        flags = [1.0 if out['ok'] else 0.0, 1.0 if out.get('populations_bit_identical', True) else 0.0]
+        t = torch.tensor(flags, dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
-        out['ok'] = bool(t.item() > 0.5)
+        out['ok'] = bool(t[0].item() > 0.5)
+        out['populations_bit_identical'] = bool(t[1].item() > 0.5)
+        out['ranks_checked'] = world
     return out
+
+
+def device_report(local_rank):
+    """What this rank runs on and which other devices of the node it can reach directly (RCCL's xGMI paths)."""
+    import torch
+    rep = {'device': local_rank}
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        rep['name'] = p.name
+        rep['uuid'] = str(getattr(p, 'uuid', ''))
+        rep['pci_bus_id'] = '%04x:%02x:%02x.0' % (getattr(p, 'pci_domain_id', 0), getattr(p, 'pci_bus_id', 0), getattr(p, 'pci_device_id', 0))
+        n = torch.cuda.device_count()
+        rep['peer_access'] = [int(i == local_rank or torch.cuda.can_device_access_peer(local_rank, i)) for i in range(n)]
+    except Exception as e:  # noqa: BLE001
+        rep['error'] = str(e)[:100]
+    return rep
 
 
 def main():
@@ -287,28 +354,53 @@ def main():
             sim.step()
         for _ in range(args.warmup):
             sim.step()
-        barrier(sim)
+        # timed region: blocks of EXACTLY K steps, each bracketed by barrier + synchronize, max over ranks; repeated until
+        # --min_seconds have been timed (the driver's K = 20 is 64 ms at 512^3: too short a sample on its own)
+        blocks, host, kernel = [], [], []
+        total = 0.0
+        while True:
+            barrier(sim)
+            ev0 = backend.make_event(sim.calc_stream, timing=True)
+            t0 = time.perf_counter()
+            per_step = []
+            for _ in range(args.steps):
+                t1 = time.perf_counter()
+                sim.step()
+                per_step.append(time.perf_counter() - t1)
+            ev1 = backend.make_event(sim.calc_stream, timing=True)
+            barrier(sim)
+            elapsed = time.perf_counter() - t0
+            if distributed:
+                t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                elapsed = float(t.item())
+            ev1.synchronize()
+            blocks.append(elapsed)
+            kernel.append(ev1.time_since(ev0) / args.steps)   # HIP events on the sweep's own stream
+            host.append(per_step)
+            total += elapsed
+            if total >= args.min_seconds or len(blocks) >= 200:
+                break
+        best = int(np.argmin(blocks))
+        res['elapsed'] = blocks[best]
+        res['blocks'] = blocks
+        res['kernel_ms'] = kernel[best]
+        # enqueueing time per step.  mean: includes the stretches in which the runtime / RCCL made the host wait because
+        # their queues were full (the host runs far ahead of the GPU: that wait is harmless); median: what a step costs
+        # the host when nothing holds it back
+        flat = np.array([x for b in host for x in b]) * 1e3
+        res['host_ms'] = float(flat.mean())
+        res['host_ms_median'] = float(np.median(flat))
         if sim.halo:
+            # a separate short leg with timing events around the halo stream's work (entry-by-entry enqueue: the timed
+            # region above replays step plans, which carry no timing events)
             sim.start_halo_timing()
-        ev0 = backend.make_event(sim.calc_stream, timing=True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sim.step()
-        ev1 = backend.make_event(sim.calc_stream, timing=True)
-        res['host_ms'] = (time.perf_counter() - t0) / args.steps * 1e3    # enqueueing only: near ms_per_step = host-bound
-        barrier(sim)
-        elapsed = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
-        ev1.synchronize()
-        res['elapsed'] = elapsed
-        res['kernel_ms'] = ev1.time_since(ev0) / args.steps   # HIP events on the sweep's own stream
-        if sim.halo:
+            for _ in range(args.halo_timing_steps + (args.halo_timing_steps & 1)):
+                sim.step()
             res['halo_ms'] = sim.stop_halo_timing()
+            res['step_plans'] = sorted(str(k) for k in getattr(sim, '_plans', {}))
         if check:
-            res['validation'] = validate(sim, backend, mass0[0], distributed, args.axis)
+            res['validation'] = validate(sim, backend, mass0[0], distributed, args.axis, rank, world)
         sim.release()
         return res
 
@@ -327,8 +419,10 @@ def main():
     args.access_pattern = best['pattern']
     per_rank = None
     if distributed:
-        mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms', 'host_ms') if k in best)
+        mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms', 'host_ms', 'host_ms_median') if k in best)
         mine['rank'] = rank
+        mine['step_plans'] = best.get('step_plans')
+        mine.update(device_report(local_rank))
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, mine)
         per_rank = gathered
@@ -343,7 +437,7 @@ def main():
         wkey = 'D3Q19_%s_f%d_%s_%s_%s' % (args.model, prec * 8, args.access_pattern,
                                           str(local[0]) if len(set(local)) == 1 else shape,
                                           'ghostpbc' if args.no_fused_periodic else 'fused')
-        all_mlups = sorted(to_mlups(r['elapsed']) for r in runs[args.access_pattern])
+        all_mlups = sorted(to_mlups(b) for r in runs[args.access_pattern] for b in r['blocks'])
         if args.scaling == 'weak':
             what = 'D3Q19 %s %s^3 per GPU' % (args.model.upper(), args.size)
         else:
@@ -354,8 +448,10 @@ def main():
                'periodic': 'in-sweep wrap' if not args.no_fused_periodic else 'ghost-layer PBC kernels',
                'decomposition': ('%s-slabs x%d, RCCL halo' % (args.axis, world)) if distributed else 'single subdomain',
                'visc': args.visc, 'block_x': best['block'], 'repeats': max(1, args.repeats),
-               'value_is': 'best of repeats', 'median_mlups': round(float(np.median(all_mlups)), 1),
-               'runs_mlups': [round(v, 1) for v in all_mlups],
+               'value_is': 'best block of exactly K steps (blocks repeated until --min_seconds are timed, per repeat)',
+               'timed_blocks': len(all_mlups), 'timed_seconds': round(sum(b for r in runs[args.access_pattern] for b in r['blocks']), 3),
+               'median_mlups': round(float(np.median(all_mlups)), 1),
+               'runs_mlups': [round(v, 1) for v in (all_mlups if len(all_mlups) <= 12 else all_mlups[:4] + all_mlups[-8:])],
                'candidates_mlups': dict((p, round(to_mlups(r['elapsed']), 1)) for p, r in best_of.items()),
                'placement': best['placement']}
         checks = dict((p, rs[-1]['validation']) for p, rs in runs.items() if 'validation' in rs[-1])
@@ -369,6 +465,9 @@ def main():
             exposed = max(0.0, step_ms - so)
             cfg.update({'rccl_ranks': torch.distributed.get_world_size(),
                         'dist_backend': torch.distributed.get_backend(),
+                        'halo_transport': 'RCCL through the C ABI (slf_comm_exchange inside the step plan)'
+                        if best.get('step_plans') else 'torch.distributed',
+                        'host_ms_median': round(max(r.get('host_ms_median', 0.0) for r in per_rank), 4),
                         'per_rank': per_rank,
                         'halo_overlap_frac': round(max(0.0, min(1.0, 1.0 - exposed / hm)), 3) if hm > 0 else None,
                         'halo_exposed_ms': round(exposed, 4)})

@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root (the `sailfish` alias)
 
 from sailfish.controller import LBSimulationController
+from sailfish.geo import EqualSubdomainsGeometry3D
 from sailfish.lb_single import LBFluidSim
 from sailfish.node_type import NTFullBBWall, NTRegularizedVelocity
 from sailfish.subdomain import Subdomain3D
@@ -34,4 +35,4 @@ class CavitySim(LBFluidSim):
 
 
 if __name__ == '__main__':
-    LBSimulationController(CavitySim).run()
+    LBSimulationController(CavitySim, EqualSubdomainsGeometry3D).run()     # --subdomains / --conn_axis; --gpus 0 1 ...: one process per GPU

@@ -151,6 +151,10 @@ typedef struct slf_region {
  *      to_buf/from_buf(_async)  (backend_cuda.py:67-191) ---- */
 int slf_abi_version(void);
 int slf_device_count(int* count);
+int slf_device_pci_bus_id(int device, char* out, size_t len);    /* "0000:05:00.0": which NUMA node the GPU hangs off
+                                                                    (the controller pins each subdomain process to
+                                                                    cores of its GPU's node; reference master.py:106-117
+                                                                    only deals the GPUs out) */
 int slf_ctx_create(int device, slf_ctx** out);
 int slf_ctx_destroy(slf_ctx* ctx);
 int slf_ctx_sync(slf_ctx* ctx);                                  /* backend.sync() */
@@ -311,14 +315,46 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
  * switch a face back to ghost columns.  D3Q19 single-fluid modules, direct addressing, x not wrapped in-sweep. */
 int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high);
 
-/* The ghost columns x = 0 (low) / x = nx + 1 (high) of this subdomain are never read -- the face is a wall or open,
- * neither periodic through the ghost-layer kernels nor connected to another subdomain through ghost columns: the
- * whole-row sweeps stop pushing into them (five partial-line writes per row and face).  The reference pushes into
- * ghost nodes regardless (propagation.mako:384-421); only raw dumps of the arrays can tell the difference. */
+/* The ghost columns x = 0 (low) / x = nx + 1 (high) of this subdomain carry nothing the simulation uses -- the face is
+ * a wall or open, neither periodic through the ghost-layer kernels nor connected to another subdomain through ghost
+ * columns, and (in-place pattern) the first / last real column holds no wet node: the odd in-place step of a WET node
+ * next to an open face pulls out of the ghost column what its even step pushed there, so such a face must keep its
+ * ghost column; what a dry (bounce-back) node pulls out of it only ever travels back into it.  The whole-row sweeps
+ * then neither push into these columns (five partial-line writes per row and face) nor pull out of them (five lines
+ * per row and face fetched for one value each).  The reference pushes into ghost nodes regardless
+ * (propagation.mako:384-421); only raw dumps of the arrays can tell the difference.  The caller decides (it owns the
+ * node map): sailfish_amd/subdomain_runner.py _init_compute. */
 int slf_module_set_x_ghost_unused(slf_module* m, int low, int high);
 
 /* number of x-threads per workgroup the sweep uses for this module (diagnostics) */
 int slf_module_block_size(slf_module* m, int* threads);
+
+/* ---- step plans (extension): the launch list of ONE time step, built once, enqueued with one call.
+ *      The reference enqueues every kernel, event and copy of a step from Python (SubdomainRunner.step(),
+ *      subdomain_runner.py:960-974; the boundary / bulk overlap with its event chain, :1028-1058; _send_dists /
+ *      _recv_dists, :1064-1139) -- fine at its 15 ms per step, most of a 0.9 ms MI355X step once a halo-connected
+ *      subdomain needs ~20 runtime calls per step (z-chunks of the sweep, an event and an RCCL batch after each).
+ *      A plan holds that list: kernel launches with their regions and streams, event records, stream waits, RCCL
+ *      batches (the ops are copied), buffer fills and device-to-device copies, and the x-face buffer set the sweeps use
+ *      from there on.  slf_plan_run(plan, iteration) performs the entries in order on the calling thread; kernels bound
+ *      with needs_iteration get `iteration` (as slf_kernel_set_iteration) before they are launched.  Kernels, events,
+ *      streams, communicators and modules named in a plan must outlive it.  Events recorded by a plan may be waited
+ *      for by another plan or by direct calls (a wait refers to the most recent record at the time it is enqueued;
+ *      waiting for an event that was never recorded is a no-op).  A runner keeps one plan per (step parity, with /
+ *      without field output): four plans cover every step of a run.  On error the run stops at the failing entry. ---- */
+typedef struct slf_plan slf_plan;
+int slf_plan_create(slf_ctx* ctx, slf_plan** out);
+int slf_plan_destroy(slf_plan* plan);
+int slf_plan_size(slf_plan* plan, int* n_ops);
+int slf_plan_add_launch(slf_plan* plan, slf_kernel* k, const slf_region* region, slf_stream* stream);   /* run_kernel */
+int slf_plan_add_record(slf_plan* plan, slf_event* ev, slf_stream* stream);                             /* make_event */
+int slf_plan_add_wait(slf_plan* plan, slf_stream* stream, slf_event* ev);                               /* wait_for_event */
+int slf_plan_add_exchange(slf_plan* plan, slf_comm* comm, const slf_comm_op* ops, int n, slf_stream* stream);
+int slf_plan_add_memset(slf_plan* plan, void* dptr, int value, size_t bytes, slf_stream* stream);
+int slf_plan_add_copy(slf_plan* plan, void* dst, const void* src, size_t bytes, slf_stream* stream);    /* same device */
+int slf_plan_add_xface_buffers(slf_plan* plan, slf_module* m, void* send_low, void* send_high, void* recv_low,
+                               void* recv_high);                                /* slf_module_set_xface_buffers */
+int slf_plan_run(slf_plan* plan, uint32_t iteration);
 
 const char* slf_last_error(void);
 

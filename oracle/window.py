@@ -55,6 +55,7 @@ class PlaneWindow(object):
         self.aa = desc.access_pattern == hipabi.SLF_AA
         self.pbc_axes = [a for a in (0, 1) if desc.periodic_local[a] and not desc.periodic_fused[a]]
         self.dist = None
+        self.off_y = self.off_x = 0          # where the subdomain's node (y, x) sits in the window's arrays
 
     def runs(self):
         """[(first global plane, count, first local plane)]: stretches of consecutive planes (one copy each)."""
@@ -109,9 +110,8 @@ class PlaneCheck(object):
     def advance(self, steps=2, save_last=True):
         if steps > RADIUS:
             raise ValueError('a window is exact for at most %d steps' % RADIUS)
-        ny = self.desc.lat_ny - 2
-        region = (1, ny + 1, 1, W - 1)
         for w in self.windows:
+            region = (1, w.desc.lat_ny - 1, 1, W - 1)
             it = self.iteration
             for s in range(steps):
                 opts = 1 if (save_last and s == steps - 1) else 0
@@ -137,9 +137,11 @@ class PlaneCheck(object):
         res = {'planes': [w.z for w in self.windows], 'nodes': 0, 'dist_exact': True, 'dist_err': 0.0,
                'rho_err': 0.0, 'v_abs_err': 0.0, 'compared_values': 0}
         for w in self.windows:
+            wys = slice(ys.start + w.off_y, ys.stop + w.off_y)
+            wxs = slice(xs.start + w.off_x, xs.stop + w.off_x)
             for q in range(19):
                 dev = self._fetch_planes(self.dist_addrs[cur] + q * self.stride * self.isz, w.z, 1)[0][ys, xs]
-                ref = w.dist[cur][q, w.t][ys, xs]
+                ref = w.dist[cur][q, w.t][wys, wxs]
                 ok = np.isfinite(ref)
                 res['compared_values'] += int(ok.sum())
                 if not np.array_equal(dev[ok], ref[ok]):
@@ -148,15 +150,114 @@ class PlaneCheck(object):
                         res['dist_err'] = max(res['dist_err'], float(np.nanmax(np.abs(dev[ok] - ref[ok]))))
             res['nodes'] += (d.lat_ny - 2) * (d.lat_nx - 2)
             if fields and self.field_addrs is not None:
-                ref_rho = w.rho[w.t][ys, xs]
+                ref_rho = w.rho[w.t][wys, wxs]
                 wet = np.isfinite(ref_rho)
                 dev_rho = self._fetch_planes(self.field_addrs[0], w.z, 1)[0][ys, xs]
                 if wet.any():
                     res['rho_err'] = max(res['rho_err'], float(np.max(np.abs(dev_rho[wet] - ref_rho[wet]) / np.abs(ref_rho[wet]))))
                     for c in range(3):
                         dev_v = self._fetch_planes(self.field_addrs[1 + c], w.z, 1)[0][ys, xs]
-                        res['v_abs_err'] = max(res['v_abs_err'], float(np.max(np.abs(dev_v[wet] - w.v[c][w.t][ys, xs][wet]))))
+                        res['v_abs_err'] = max(res['v_abs_err'], float(np.max(np.abs(dev_v[wet] - w.v[c][w.t][wys, wxs][wet]))))
         return res
+
+
+class SeamCheck(PlaneCheck):
+    """Plane windows of ONE SLAB of a box that is cut into slabs along `axis` (0 = x, 1 = y, 2 = z) and exchanges its
+    face layers with ring neighbours every step: the windows reach E = RADIUS + 1 layers beyond the slab along the split
+    axis and hold there what the NEIGHBOURS' arrays hold -- a window is then a piece of the global box that straddles the
+    seam, the oracle advances it with no notion of slabs, and the sampled planes are compared over the slab's full
+    extent: the seam layers (x = 1, x = nx columns of an x-slab; planes z = 1, z = nz of a z-slab) are checked bit for
+    bit against what a transfer that failed or arrived late would have spoilt.
+
+    swap(low, high) -> (from_down, from_up): `low` / `high` are this slab's first / last E real layers along the split
+    axis (numpy, [copy][19, ...]); the call returns the last E layers of the down neighbour and the first E layers of
+    the up neighbour (a ring of one: (high, low)).  The slab itself is a fluid-only periodic box (bench.py's slabs):
+    the unsplit axes are wrapped in-sweep.  Seed with the device idle and the x-face buffers materialised."""
+
+    def __init__(self, backend, desc, zs, dist_addrs, stride, field_addrs, axis, swap):
+        PlaneCheck.__init__(self, backend, desc, None, [], dist_addrs, stride, field_addrs)
+        self.axis, self.swap, self.E = int(axis), swap, RADIUS + 1
+        E = self.E
+        n = [desc.lat_nx - 2, desc.lat_ny - 2, desc.lat_nz - 2]
+        if n[self.axis] < E:
+            raise ValueError('slab thinner than %d layers along the split axis' % E)
+        for z in zs:
+            if self.axis == 2:
+                w = PlaneWindow.__new__(PlaneWindow)
+                w.z, w.t = z, E
+                w.planes = [z - E + k for k in range(W)]        # local plane indices, may leave [1, nz]
+                wd = _clone_desc(desc, lat_nz=W, arr_nz=W, dist_stride=0)
+                wd.periodic_fused[2] = wd.periodic_local[2] = 0
+                w.off_y = w.off_x = 0
+            else:
+                w = PlaneWindow(desc, None, z)
+                ext = 2 * (E - 1)
+                if self.axis == 0:
+                    lat = desc.lat_nx + ext
+                    wd = _clone_desc(w.desc, lat_nx=lat, arr_nx=(lat + 31) // 32 * 32)
+                    w.off_y, w.off_x = 0, E - 1
+                else:
+                    lat = desc.lat_ny + ext
+                    wd = _clone_desc(w.desc, lat_ny=lat, arr_ny=lat)
+                    w.off_y, w.off_x = E - 1, 0
+                wd.periodic_fused[self.axis] = wd.periodic_local[self.axis] = 0
+            w.desc, w.full = wd, desc
+            w.o = OracleSim(wd)
+            w.map, w.dist = None, None
+            w.aa = desc.access_pattern == hipabi.SLF_AA
+            w.pbc_axes = []
+            self.windows.append(w)
+
+    def _edge(self, block, lo):
+        """The first (lo) / last E real layers of a [19, W, y, x] block along the split axis."""
+        n = [self.desc.lat_nx - 2, self.desc.lat_ny - 2][self.axis]
+        sl = slice(1, 1 + self.E) if lo else slice(n - self.E + 1, n + 1)
+        return np.ascontiguousarray(block[:, :, :, sl] if self.axis == 0 else block[:, :, sl, :])
+
+    def seed(self, iteration):
+        self.iteration = int(iteration)
+        d, E = self.desc, self.E
+        if self.axis == 2:
+            nz = d.lat_nz - 2
+            mine = [(np.stack([self._fetch_planes(a + q * self.stride * self.isz, 1, E) for q in range(19)]),
+                     np.stack([self._fetch_planes(a + q * self.stride * self.isz, nz - E + 1, E) for q in range(19)]))
+                    for a in self.dist_addrs]
+            down, up = self.swap([m[0] for m in mine], [m[1] for m in mine])
+            for w in self.windows:
+                w.dist = []
+                for c, a in enumerate(self.dist_addrs):
+                    blk = np.empty((19, W, d.arr_ny, d.arr_nx), dtype=self.dtype)
+                    for k, p in enumerate(w.planes):
+                        if p < 1:
+                            blk[:, k] = down[c][:, p + E - 1]
+                        elif p > nz:
+                            blk[:, k] = up[c][:, p - nz - 1]
+                        else:
+                            for q in range(19):
+                                blk[q, k] = self._fetch_planes(a + q * self.stride * self.isz, p, 1)[0]
+                    w.dist.append(blk)
+        else:
+            local = [[self._fetch_window(w, a) for a in self.dist_addrs] for w in self.windows]
+            down, up = self.swap([[self._edge(b, True) for b in per_w] for per_w in local],
+                                 [[self._edge(b, False) for b in per_w] for per_w in local])
+            n = [d.lat_nx - 2, d.lat_ny - 2][self.axis]
+            for i, w in enumerate(self.windows):
+                w.dist = []
+                for c in range(len(self.dist_addrs)):
+                    blk = np.zeros((19, W, w.desc.arr_ny, w.desc.arr_nx), dtype=self.dtype)
+                    src = local[i][c]
+                    if self.axis == 0:
+                        blk[:, :, :d.arr_ny, E:E + n] = src[:, :, :, 1:n + 1]
+                        blk[:, :, :d.arr_ny, 0:E] = down[i][c]
+                        blk[:, :, :d.arr_ny, E + n:E + n + E] = up[i][c]
+                    else:
+                        blk[:, :, E:E + n, :] = src[:, :, 1:n + 1, :]
+                        blk[:, :, 0:E, :] = down[i][c]
+                        blk[:, :, E + n:E + n + E, :] = up[i][c]
+                    w.dist.append(blk)
+        for w in self.windows:
+            w.rho = np.full(w.o.shape, np.inf, dtype=self.dtype)
+            w.v = [np.full(w.o.shape, np.inf, dtype=self.dtype) for _ in range(3)]
 
 
 def chunk_boundary_planes(placed, desc, stride, limit=4):

@@ -22,11 +22,11 @@ Everything calls libsailfish_hip.so through ctypes; there is no CPU fallback.
 """
 import ctypes
 import gc
-import weakref
 
 import numpy as np
 
 from sailfish_amd import hipabi, placement
+from sailfish_amd.stepqueue import DirectQueue, NotPlannable  # noqa: F401  (re-exported)
 
 
 class HIPFatalError(RuntimeError):
@@ -176,6 +176,82 @@ class HIPKernel(object):
             pass
 
 
+class HIPPlan(object):
+    """The launch list of one time step, built once and enqueued with ONE C-ABI call per step (slf_plan_*,
+    include/sailfish_hip.h "step plans"): same methods as stepqueue.DirectQueue, but every entry is appended to the plan;
+    run(iteration) performs them in order inside the library.  Keeps the Python owners of everything it names alive."""
+    planned = True
+
+    def __init__(self, backend):
+        self.backend = backend
+        self._lib = backend._lib
+        h = ctypes.c_void_p()
+        _check(self._lib, self._lib.slf_plan_create(backend._ctx, ctypes.byref(h)), 'slf_plan_create')
+        self.handle = h
+        self._keep = []
+
+    def _h(self, stream):
+        return stream.handle if stream is not None else None
+
+    def launch(self, kernel, region, stream):
+        reg = None
+        if region is not None:
+            y0, y1, z0, z1 = region
+            reg = ctypes.byref(hipabi.SlfRegion(int(y0), int(y1), int(z0), int(z1)))
+        _check(self._lib, self._lib.slf_plan_add_launch(self.handle, kernel.handle, reg, self._h(stream)),
+               'slf_plan_add_launch(%s)' % kernel.name)
+        self._keep += [kernel, stream]
+
+    def record(self, event, stream):
+        _check(self._lib, self._lib.slf_plan_add_record(self.handle, event.handle, self._h(stream)), 'slf_plan_add_record')
+        self._keep += [event, stream]
+
+    def wait(self, stream, event):
+        _check(self._lib, self._lib.slf_plan_add_wait(self.handle, self._h(stream), event.handle), 'slf_plan_add_wait')
+        self._keep += [event, stream]
+
+    def exchange(self, rccl, batch, stream):
+        arr, n = batch
+        _check(self._lib, self._lib.slf_plan_add_exchange(self.handle, rccl.comm, arr, n, self._h(stream)),
+               'slf_plan_add_exchange')
+        self._keep += [rccl, stream]
+
+    def memset(self, addr, value, nbytes, stream):
+        for a, _, n in self.backend._segments(addr, nbytes):
+            _check(self._lib, self._lib.slf_plan_add_memset(self.handle, ctypes.c_void_p(a), int(value), n, self._h(stream)),
+                   'slf_plan_add_memset')
+        self._keep.append(stream)
+
+    def copy(self, dst, src, nbytes, stream):
+        _check(self._lib, self._lib.slf_plan_add_copy(self.handle, ctypes.c_void_p(dst), ctypes.c_void_p(src), int(nbytes),
+                                                      self._h(stream)), 'slf_plan_add_copy')
+        self._keep.append(stream)
+
+    def xface(self, module, send_low, send_high, recv_low, recv_high):
+        _check(self._lib, self._lib.slf_plan_add_xface_buffers(self.handle, module.handle,
+                                                               *[ctypes.c_void_p(a or None) for a in
+                                                                 (send_low, send_high, recv_low, recv_high)]),
+               'slf_plan_add_xface_buffers')
+        self._keep.append(module)
+
+    def call(self, fn):
+        raise NotPlannable('this step needs Python between its launches')
+
+    def __len__(self):
+        n = ctypes.c_int()
+        _check(self._lib, self._lib.slf_plan_size(self.handle, ctypes.byref(n)), 'slf_plan_size')
+        return n.value
+
+    def run(self, iteration):
+        _check(self._lib, self._lib.slf_plan_run(self.handle, int(iteration) & 0xFFFFFFFF), 'slf_plan_run')
+
+    def __del__(self):
+        try:
+            self._lib.slf_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class HIPBackend(placement.VmmMixin):
     name = 'hip'
     supports_xface = True      # slf_module_set_xface_buffers (sailfish_amd/xface.py)
@@ -191,11 +267,23 @@ class HIPBackend(placement.VmmMixin):
         return n.value
 
     @classmethod
+    def pci_bus_id(cls, device):
+        """PCI address of HIP device `device` ('0000:05:00.0'), '' if it cannot be had."""
+        lib = hipabi.load()
+        buf = ctypes.create_string_buffer(32)
+        if lib.slf_device_pci_bus_id(int(device), buf, 32) != 0:
+            return ''
+        return buf.value.decode().lower()
+
+    @classmethod
     def add_options(cls, group):
         group.add_argument('--hip-kernel-stats', dest='hip_kernel_stats', action='store_true', default=False,
                            help='print the workgroup shape chosen for the sweep kernels')
         group.add_argument('--nohip_graphs', dest='hip_graphs', action='store_false', default=True,
                            help='do not replay stretches of steps without host interaction as HIP graphs')
+        group.add_argument('--nohip_step_plans', dest='hip_step_plans', action='store_false', default=True,
+                           help='enqueue every kernel, event and halo exchange of a step from Python instead of replaying '
+                                'the step from a C-ABI step plan (one runtime call per step)')
         group.add_argument('--nohip_xface', dest='hip_xface', action='store_false', default=True,
                            help='1-D decompositions along x: exchange the x faces through ghost columns and pack / '
                                 'unpack kernels (the reference\'s scheme) instead of the face buffers the sweep writes '
@@ -228,10 +316,8 @@ class HIPBackend(placement.VmmMixin):
         self._raw = {}
         self._placed = {}
         self._pinned = []
-        # kernels whose trailing iteration argument set_iteration() rewrites; weak: a kernel that its owner
-        # dropped (a released simulation) must not be kept alive -- or updated -- by this registry
-        self._iteration_kernels = weakref.WeakSet()
         self._total_memory_bytes = 0
+        self._iteration = 0
         ctx = ctypes.c_void_p()
         _check(self._lib, self._lib.slf_ctx_create(int(gpu_id), ctypes.byref(ctx)), 'slf_ctx_create')
         self._ctx = ctx
@@ -467,20 +553,20 @@ class HIPBackend(placement.VmmMixin):
         ``shared`` are accepted for compatibility and ignored."""
         kern = HIPKernel(self._lib, prog, name)
         kern.set_args(args, args_format, needs_iteration)
-        if needs_iteration:
-            self._iteration_kernels.add(kern)
         return kern
 
     def set_iteration(self, it):
-        for kern in list(self._iteration_kernels):
-            _check(self._lib, self._lib.slf_kernel_set_iteration(kern.handle, int(it) & 0xFFFFFFFF),
-                   'slf_kernel_set_iteration')
+        """The iteration number the AA kernels see (reference backend_cuda.py:128-130 rewrites the trailing kernel
+        argument of every registered kernel); applied when a kernel that takes it is launched."""
+        self._iteration = int(it) & 0xFFFFFFFF
 
     def run_kernel(self, kernel, grid_size=None, stream=None):
         region = None
         if grid_size is not None:
             y0, y1, z0, z1 = grid_size
             region = ctypes.byref(hipabi.SlfRegion(int(y0), int(y1), int(z0), int(z1)))
+        if kernel.needs_iteration:
+            self._lib.slf_kernel_set_iteration(kernel.handle, self._iteration)
         _check(self._lib, self._lib.slf_kernel_launch(kernel.handle, region, stream.handle if stream else None),
                'slf_kernel_launch(%s)' % kernel.name)
 
@@ -532,6 +618,18 @@ class HIPBackend(placement.VmmMixin):
                 gc.enable()
         _check(self._lib, rc, 'slf_graph_capture_end')
         return HIPGraph(self, h)
+
+    def make_plan(self):
+        """An empty step plan (HIPPlan)."""
+        return HIPPlan(self)
+
+    def set_xface_buffers(self, module, send_low, send_high, recv_low, recv_high):
+        """x-face buffers the CollideAndPropagate kernels of `module` use from now on (0 / None: face not connected)."""
+        _check(self._lib, self._lib.slf_module_set_xface_buffers(module.handle, *[ctypes.c_void_p(a or None) for a in
+                                                                                   (send_low, send_high, recv_low, recv_high)]),
+               'slf_module_set_xface_buffers')
+
+    supports_step_plans = True
 
     def make_stream(self, high_priority=False):
         """high_priority (no counterpart in backend_cuda.py:291-296): for the halo stream, see slf_api.hip."""

@@ -90,7 +90,7 @@ class BoxSim(object):
                 self.placed, self.placement_tuning = placement.choose(
                     lambda: b.alloc_placed(sizes, off),
                     lambda bs: placement.probe_sweep(b, desc, self.dim, bs[0].addr, bs[-1].addr, self.Q * fbytes, probe_stream),
-                    lambda bs: [b.free_buf(pb.addr) for pb in bs])
+                    lambda bs: [b.free_buf(pb.addr) for pb in bs], room=lambda: placement.room_for(b, sum(sizes)))
             else:
                 self.placed = b.alloc_placed(sizes, off)
             self.placement_info = b.last_placement

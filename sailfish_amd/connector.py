@@ -60,6 +60,11 @@ class RingExchanger(object):
         self.up = (rank + 1) % world
         self.down = (rank - 1) % world
 
+    def plain_copy(self):
+        """A ring of one without a process group: the exchange is two device copies (which a step plan can hold)."""
+        import torch.distributed as dist
+        return self.world == 1 and not (dist.is_available() and dist.is_initialized())
+
     def exchange_range(self, bufs, start, count):
         """The same exchange for the elements [start, start + count) of the four buffers (x-face buffers: a range of
         z-planes that the sweep has completed, sailfish_amd/xface.py)."""
@@ -160,6 +165,9 @@ class RcclRingExchanger(RingExchanger):
         self._batches = {}
 
     def exchange_ranges(self, bufs, ranges, stream):
+        self.rccl.run(self.batch(bufs, ranges), stream)
+
+    def batch(self, bufs, ranges):
         """bufs = (send_up, send_down, recv_low, recv_high) tensors; ranges = [(first element, count)]: one group.
         Posting order = the matching order between a pair of ranks: up first, then down (a ring of two has both
         messages going to the same peer).  The batch is built once per (buffers, ranges)."""
@@ -174,7 +182,7 @@ class RcclRingExchanger(RingExchanger):
                 ops += [('send', self.up, s_up.data_ptr() + off, count, isz), ('send', self.down, s_down.data_ptr() + off, count, isz),
                         ('recv', self.down, r_low.data_ptr() + off, count, isz), ('recv', self.up, r_high.data_ptr() + off, count, isz)]
             batch = self._batches[key] = self.rccl.prepare(ops)
-        self.rccl.run(batch, stream)
+        return batch
 
 
 def make_ring_exchanger(rank, world, backend):
@@ -203,6 +211,14 @@ class LocalConnector(object):
 
     def exchange(self, runner):
         raise RuntimeError('LocalConnector exchanges are driven by controller.LocalGroup')
+
+    def enqueue_exchange(self, q, runner, kind='dist'):
+        if runner.halo_messages(kind):
+            raise RuntimeError('LocalConnector exchanges are driven by controller.LocalGroup')
+
+    def enqueue_pieces(self, q, runner, pieces):
+        if pieces:
+            raise RuntimeError('LocalConnector exchanges are driven by controller.LocalGroup')
 
 
 class TorchDistConnector(object):
@@ -281,6 +297,43 @@ class TorchDistConnector(object):
                     hasattr(runner.backend, '_ctx'):
                 self._rccl = process_rccl(runner.backend, dist.get_rank(), dist.get_world_size())
         return self._rccl or None
+
+    def enqueue_exchange(self, q, runner, kind='dist'):
+        """The exchange of `kind` that is due now as an entry of the step program `q` (stepqueue.py): one RCCL group
+        through the C ABI where the process group is RCCL -- something a step plan can hold -- otherwise a call back
+        into exchange() (torch.distributed; entry-by-entry queues only)."""
+        msgs = runner.halo_messages(kind)
+        if not msgs:
+            return
+        rccl = self.direct(runner)
+        if rccl is None:
+            q.call(lambda: self.exchange(runner, kind))
+            return
+        key = (kind, tuple(msgs))
+        batch = self._batches.get(key)
+        if batch is None:
+            isz = runner.float().itemsize
+            ops = [('send', self.id_to_rank[nid], sb, ns, isz) for nid, sb, ns, _, _ in msgs if ns]
+            ops += [('recv', self.id_to_rank[nid], rb, nr, isz) for nid, _, _, rb, nr in msgs if nr]
+            batch = self._batches[key] = rccl.prepare(ops)
+        q.exchange(rccl, batch, runner._data_stream)
+
+    def enqueue_pieces(self, q, runner, pieces):
+        """exchange_pieces() as an entry of the step program `q`."""
+        if not pieces:
+            return
+        rccl = self.direct(runner)
+        if rccl is None:
+            q.call(lambda: self.exchange_pieces(runner, pieces))
+            return
+        key = tuple(pieces)
+        batch = self._batches.get(key)
+        if batch is None:
+            isz = runner.float().itemsize
+            ops = [('send', self.id_to_rank[nid], s, n, isz) for nid, s, _, n in pieces]
+            ops += [('recv', self.id_to_rank[nid], r, n, isz) for nid, _, r, n in pieces]
+            batch = self._batches[key] = rccl.prepare(ops)
+        q.exchange(rccl, batch, runner._data_stream)
 
     def exchange_pieces(self, runner, pieces):
         """pieces: [(neighbour id, send address, receive address, elements)] -- ranges of the x-face buffers that a

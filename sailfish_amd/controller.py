@@ -2,15 +2,19 @@
 domain decomposition, process / GPU mapping and the run loop.
 
 Process model (MI355X-first, one node):
-  * default: this process drives every subdomain; subdomain i runs on GPU
-    gpus[i % len(gpus)] (reference master.py:106-117 round-robin) and the group is
-    stepped in lock-step with device-to-device halo copies (LocalGroup).  With a
-    single subdomain this is the reference's --debug_single_process path.
-  * under ``python -m torch.distributed.run`` (WORLD_SIZE > 1): one process per
-    GPU, subdomain i is owned by rank i, halos travel over RCCL/xGMI
-    (connector.TorchDistConnector).  This replaces the reference's machine master
-    + zmq connectors (master.py, connector.py); cluster launch (PBS/LSF/execnet)
-    is out of scope.
+  * ``--gpus`` names ONE device (the default): this process drives every subdomain
+    on it, stepped in lock-step with device-to-device halo copies (LocalGroup);
+    a single subdomain runs its own loop (SubdomainRunner.main).
+  * ``--gpus`` names SEVERAL devices and there are several subdomains: the
+    controller starts one process per subdomain itself (sailfish_amd/launch.py;
+    reference master.py:242-312), subdomain i on GPU gpus[i % len(gpus)]
+    (master.py:106-117), each rank pinned to cores of its GPU's NUMA node; halos
+    travel over RCCL/xGMI (connector.TorchDistConnector).  ``--debug_single_process``
+    keeps everything in this process instead.
+  * under ``python -m torch.distributed.run`` (WORLD_SIZE > 1) the same branch is
+    entered directly: rank i owns subdomain i.  This replaces the reference's
+    machine master + zmq connectors (master.py, connector.py); cluster launch
+    (PBS/LSF/execnet) is out of scope.
 """
 import logging
 import math
@@ -123,20 +127,19 @@ class LocalGroup(object):
     def run(self):
         runners = self.runners
         from sailfish_amd import placement
-        if len(runners) > 1:
-            with placement.holding():   # several subdomains on one GPU: every one gets its own stretch of HBM
-                for r in runners:
-                    r.prepare()
-        else:
-            runners[0].prepare()
+        if len(runners) == 1:
+            # one subdomain: the runner's own loop (SubdomainRunner.main: HIP graphs for stretches without host
+            # interaction, every other step replayed from its step plan)
+            return runners[0].run()
+        with placement.holding():   # several subdomains on one GPU: every one gets its own stretch of HBM
+            for r in runners:
+                r.prepare()
         cfg = runners[0].config
         t_prev, it_prev = time.time(), runners[0]._sim.iteration
         t0, it0 = t_prev, it_prev
         for r in runners:
             r._profile.record_start()
         while not any(r.need_quit() for r in runners):
-            if len(runners) == 1 and runners[0].fast_forward():
-                continue
             reqs = [r.pre_step() for r in runners]
             for r in runners:
                 r._profile.start_step()
@@ -159,7 +162,7 @@ class LocalGroup(object):
             it = runners[0]._sim.iteration
             if cfg.perf_stats_every > 0 and it % cfg.perf_stats_every == 0:
                 for r in runners:
-                    r.backend.sync_stream(r._calc_stream, r._data_stream)
+                    r.backend.sync_stream(*r._all_streams())
                 now = time.time()
                 nodes = sum(r.num_fluid_nodes for r in runners)
                 cfg.logger.info('iteration:{0}  speed:{1:.2f} MLUPS'.format(
@@ -207,7 +210,8 @@ class LBSimulationController(object):
         group.add_argument('--debug_dump_dists', action='store_true', default=False,
                            help='dump the contents of the distribution arrays to files')
         group.add_argument('--debug_single_process', action='store_true', default=False,
-                           help='(accepted for compatibility: a single process is the default here)')
+                           help='run every subdomain in this process even when --gpus names several devices '
+                                '(one process drives all of them in lock-step)')
         group.add_argument('--debug_dump_node_type_map', action='store_true', default=False,
                            help='dump the node type map into a file')
         group.add_argument('--base_name', type=str, default='',
@@ -344,6 +348,18 @@ class LBSimulationController(object):
             return runner
 
         t0 = time.time()
+        if world == 1 and len(subdomains) > 1 and len(gpus) > 1 and not cfg.debug_single_process:
+            # several GPUs named, several subdomains: one process per subdomain, started here (reference
+            # master.py:242-312 _run_subprocesses, GPUs dealt out round-robin as master.py:106-117); the children take
+            # the WORLD_SIZE > 1 branch below.  --debug_single_process keeps everything in this process.
+            from sailfish_amd import launch
+            summary = launch.run_processes(self._lb_class, self._lb_geo, cfg, len(subdomains), gpus, log=cfg.logger.info)
+            self.runners = []
+            if cfg.mode == 'benchmark' and summary:
+                self.mlups_total, self.mlups_comp = summary['mlups_total'], summary['mlups_comp']
+                self.timing_infos = None
+                return tuple(summary['timing']) + (subdomains,)
+            return None, None
         if world > 1:
             rank, world = init_distributed()
             if len(subdomains) != world:

@@ -115,6 +115,12 @@ int slf_device_count(int* count) {
   return SLF_OK;
 }
 
+int slf_device_pci_bus_id(int device, char* out, size_t len) {
+  if (!out || len < 13) return fail(SLF_ERR_INVALID, "buffer of at least 13 bytes needed");
+  SLF_HIP(hipDeviceGetPCIBusId(out, (int)len, device));
+  return SLF_OK;
+}
+
 int slf_ctx_create(int device, slf_ctx** out) {
   if (!out) return fail(SLF_ERR_INVALID, "out is NULL");
   int n = 0;
@@ -863,10 +869,9 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
   return SLF_OK;
 }
 
-// The ghost columns x = 0 (low) / x = nx + 1 (high) of this subdomain are never read: the face is a wall or open, not
-// periodic through the ghost-layer kernels and not connected to another subdomain.  The whole-row sweeps then leave
-// them alone (the reference pushes into them regardless, propagation.mako:384-421; nothing looks).  Refused for a
-// face the module itself needs: x periodic without in-sweep wrap.
+// The ghost columns x = 0 (low) / x = nx + 1 (high) of this subdomain carry nothing the simulation uses (contract:
+// include/sailfish_hip.h): the whole-row sweeps neither push into them nor pull out of them.  Refused for a face the
+// module itself needs: x periodic without in-sweep wrap.
 int slf_module_set_x_ghost_unused(slf_module* m, int low, int high) {
   if (!m) return fail(SLF_ERR_INVALID, "module is NULL");
   if ((low || high) && m->geo.axis_mode[0] == 1)
@@ -1186,6 +1191,166 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       break;
   }
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  return SLF_OK;
+}
+
+// ---- step plans: the launch list of one time step, built once, enqueued with ONE call ----------------------------
+// (include/sailfish_hip.h "step plans".)  Every entry is what the corresponding slf_* call would do; slf_plan_run()
+// walks the list on the calling thread -- no Python, no argument marshalling between the entries.
+namespace {
+enum PlanKind { PL_LAUNCH, PL_RECORD, PL_WAIT, PL_EXCHANGE, PL_MEMSET, PL_COPY, PL_XFACE };
+struct PlanOp {
+  PlanKind kind;
+  slf_kernel* k = nullptr;
+  bool has_region = false;
+  slf_region region = {0, 0, 0, 0};
+  slf_stream* stream = nullptr;
+  slf_event* ev = nullptr;
+  slf_comm* comm = nullptr;
+  std::vector<slf_comm_op> ops;
+  void* dst = nullptr;
+  const void* src = nullptr;
+  int value = 0;
+  size_t bytes = 0;
+  slf_module* mod = nullptr;
+  void* xf[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+}  // namespace
+
+struct slf_plan {
+  slf_ctx* ctx;
+  std::vector<PlanOp> ops;
+};
+
+int slf_plan_create(slf_ctx* ctx, slf_plan** out) {
+  if (!ctx || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  slf_plan* p = new slf_plan;
+  p->ctx = ctx;
+  *out = p;
+  return SLF_OK;
+}
+
+int slf_plan_destroy(slf_plan* p) {
+  delete p;
+  return SLF_OK;
+}
+
+int slf_plan_size(slf_plan* p, int* n_ops) {
+  if (!p || !n_ops) return fail(SLF_ERR_INVALID, "NULL argument");
+  *n_ops = (int)p->ops.size();
+  return SLF_OK;
+}
+
+int slf_plan_add_launch(slf_plan* p, slf_kernel* k, const slf_region* region, slf_stream* stream) {
+  if (!p || !k) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (!k->bound) return fail(SLF_ERR_INVALID, "kernel arguments not set");
+  PlanOp o;
+  o.kind = PL_LAUNCH;
+  o.k = k;
+  o.has_region = region != nullptr;
+  if (region) o.region = *region;
+  o.stream = stream;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_add_record(slf_plan* p, slf_event* ev, slf_stream* stream) {
+  if (!p || !ev) return fail(SLF_ERR_INVALID, "NULL argument");
+  PlanOp o;
+  o.kind = PL_RECORD;
+  o.ev = ev;
+  o.stream = stream;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_add_wait(slf_plan* p, slf_stream* stream, slf_event* ev) {
+  if (!p || !ev) return fail(SLF_ERR_INVALID, "NULL argument");
+  PlanOp o;
+  o.kind = PL_WAIT;
+  o.ev = ev;
+  o.stream = stream;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_add_exchange(slf_plan* p, slf_comm* comm, const slf_comm_op* ops, int n, slf_stream* stream) {
+  if (!p || !comm || (!ops && n > 0)) return fail(SLF_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < n; i++) {
+    if (ops[i].elem_bytes != 4 && ops[i].elem_bytes != 8 && ops[i].elem_bytes != 1)
+      return fail(SLF_ERR_INVALID, "elem_bytes must be 1, 4 or 8");
+    if (ops[i].kind != SLF_COMM_SEND && ops[i].kind != SLF_COMM_RECV) return fail(SLF_ERR_INVALID, "bad slf_comm_op kind");
+  }
+  PlanOp o;
+  o.kind = PL_EXCHANGE;
+  o.comm = comm;
+  o.ops.assign(ops, ops + (n > 0 ? n : 0));
+  o.stream = stream;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_add_memset(slf_plan* p, void* dptr, int value, size_t bytes, slf_stream* stream) {
+  if (!p || !dptr) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (!stream) return fail(SLF_ERR_INVALID, "plan entries are asynchronous: a stream is needed");
+  PlanOp o;
+  o.kind = PL_MEMSET;
+  o.dst = dptr;
+  o.value = value;
+  o.bytes = bytes;
+  o.stream = stream;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_add_copy(slf_plan* p, void* dst, const void* src, size_t bytes, slf_stream* stream) {
+  if (!p || !dst || !src) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (!stream) return fail(SLF_ERR_INVALID, "plan entries are asynchronous: a stream is needed");
+  PlanOp o;
+  o.kind = PL_COPY;
+  o.dst = dst;
+  o.src = src;
+  o.bytes = bytes;
+  o.stream = stream;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_add_xface_buffers(slf_plan* p, slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high) {
+  if (!p || !m) return fail(SLF_ERR_INVALID, "NULL argument");
+  // validated now, with the module's rules, so that slf_plan_run cannot fail on it
+  void* keep[4] = {m->xsend[0], m->xsend[1], m->xrecv[0], m->xrecv[1]};
+  if (int e = slf_module_set_xface_buffers(m, send_low, send_high, recv_low, recv_high)) return e;
+  m->xsend[0] = keep[0]; m->xsend[1] = keep[1]; m->xrecv[0] = keep[2]; m->xrecv[1] = keep[3];
+  PlanOp o;
+  o.kind = PL_XFACE;
+  o.mod = m;
+  o.xf[0] = send_low; o.xf[1] = send_high; o.xf[2] = recv_low; o.xf[3] = recv_high;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_run(slf_plan* p, uint32_t iteration) {
+  if (!p) return fail(SLF_ERR_INVALID, "plan is NULL");
+  for (PlanOp& o : p->ops) {
+    int e = SLF_OK;
+    switch (o.kind) {
+      case PL_LAUNCH:
+        if (o.k->needs_iteration) o.k->iteration = iteration;
+        e = slf_kernel_launch(o.k, o.has_region ? &o.region : nullptr, o.stream);
+        break;
+      case PL_RECORD: e = slf_event_record(o.ev, o.stream); break;
+      case PL_WAIT: e = slf_stream_wait_event(o.stream, o.ev); break;
+      case PL_EXCHANGE: e = slf_comm_exchange(o.comm, o.ops.data(), (int)o.ops.size(), o.stream); break;
+      case PL_MEMSET: e = slf_memset(p->ctx, o.dst, o.value, o.bytes, o.stream); break;
+      case PL_COPY: e = slf_memcpy_d2d_async(p->ctx, o.dst, o.src, o.bytes, o.stream); break;
+      case PL_XFACE:
+        o.mod->xsend[0] = o.xf[0]; o.mod->xsend[1] = o.xf[1];
+        o.mod->xrecv[0] = o.xf[2]; o.mod->xrecv[1] = o.xf[3];
+        break;
+    }
+    if (e) return e;
+  }
   return SLF_OK;
 }
 

@@ -95,8 +95,18 @@ __global__ void __launch_bounds__(1024, (row_min_waves<R, MODEL, GENERAL, FORCE,
   // sender's edge node may be excluded) and rows whose y and z neighbours are real or wrapped rows (the rows next to a
   // non-periodic y / z face pull from ghost rows, which no sweep of the neighbour has sent: those entries stay unset and
   // x_face_receive leaves what was pulled from the arrays -- the reference's behaviour, pinned by the propagation KATs).
+  // The same select serves ghost columns that nothing stores into (slf_module_set_x_ghost_unused: the face is a wall or
+  // open and its first real column holds no wet node): what a dry node pulls out of them only ever travels back into
+  // them, and each of the ten x-moving directions fetched a line of its own for it -- 10 lines per row, +3.3 % reads on
+  // a 512^3 cavity (profiles/r03/pmc_summary_cfg2b.txt).
   constexpr bool SKIP_GHOST_PULL = PROP == PROP_AA_ODD && !GENERAL;
   AxisOff oxl = ox;
+  if constexpr (PROP == PROP_AA_ODD) {
+    if (!g.wrap[0]) {
+      if ((g.x_ghost_unused & 1) && x == 1) oxl.m = 0;
+      if ((g.x_ghost_unused & 2) && x == nx) oxl.p = 0;
+    }
+  }
   if constexpr (SKIP_GHOST_PULL) {
     const bool inner = (g.wrap[1] || (gy > 1 && gy < g.lat_ny - 2)) &&
                        (L::dim < 3 || g.wrap[2] || (gz > 1 && gz < g.lat_nz - 2));

@@ -77,6 +77,7 @@ class SlfRegion(Structure):
 SIGNATURES = {
     'slf_abi_version': (c_int, []),
     'slf_device_count': (c_int, [POINTER(c_int)]),
+    'slf_device_pci_bus_id': (c_int, [c_int, c_char_p, c_size_t]),
     'slf_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
     'slf_ctx_destroy': (c_int, [c_void_p]),
     'slf_ctx_sync': (c_int, [c_void_p]),
@@ -134,6 +135,17 @@ SIGNATURES = {
     'slf_graph_capture_end': (c_int, [c_void_p, POINTER(c_void_p)]),
     'slf_graph_launch': (c_int, [c_void_p, c_void_p]),
     'slf_graph_destroy': (c_int, [c_void_p]),
+    'slf_plan_create': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'slf_plan_destroy': (c_int, [c_void_p]),
+    'slf_plan_size': (c_int, [c_void_p, POINTER(c_int)]),
+    'slf_plan_add_launch': (c_int, [c_void_p, c_void_p, POINTER(SlfRegion), c_void_p]),
+    'slf_plan_add_record': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'slf_plan_add_wait': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'slf_plan_add_exchange': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'slf_plan_add_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    'slf_plan_add_copy': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'slf_plan_add_xface_buffers': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'slf_plan_run': (c_int, [c_void_p, c_uint32]),
     'slf_last_error': (c_char_p, []),
 }
 

@@ -137,20 +137,38 @@ def place(backend, buffers, span=None):
             'spacer_gib': round(spacer / 2.0 ** 30, 3), 'span_gib': round((payload + spacer * (parts - 1)) / 2.0 ** 30, 1)}
 
 
-def choose(make_set, measure, release, attempts=3, agree=0.02, log=None):
+def choose(make_set, measure, release, attempts=3, agree=0.02, log=None, room=None):
     """Placement by measurement.  The rule of place() -- spread the chunks over the span -- removes the 15 % bimodality
     of large arrays, but what a placement is worth still varies between processes and boxes (arrays of 1-2 GB: 35-41
     GMLUPS, profiles/r02/runner_path_placement.log).  So: make_set() places a set of arrays, measure(set) times the
     many-stream sweep on it (seconds per step); a second set is placed while the first is still allocated -- so it
     lands elsewhere -- and so on until two sets agree with the best within `agree` or `attempts` are used up.  The
-    best set is returned, the others are released.  (Swapping the physical chunks under ONE address range instead was
+    best set is returned, the others are released.  room() (optional) says whether another set fits next to the ones
+    held; a further set that cannot be placed or probed ends the search with the best so far.  (Swapping the physical chunks under ONE address range instead was
     tried and is not safe on this stack: kernels launched after hipMemUnmap / hipMemMap of a range they had used before
     produced non-finite values -- profiles/r03/placement_remap_failure.txt.)"""
-    sets, times = [], []
-    for _ in range(attempts):
-        bufs = make_set()
+    sets, times, note = [], [], None
+    for n in range(attempts):
+        if n > 0 and room is not None and not room():
+            note = 'no room for another set'
+            break
+        try:
+            bufs = make_set()
+        except Exception as e:  # noqa: BLE001 -- a further set that does not fit must not end a run that fitted before
+            if n == 0:
+                raise
+            note = 'placing set %d failed: %s' % (n, str(e)[:100])
+            break
+        try:
+            t = measure(bufs)
+        except Exception as e:  # noqa: BLE001
+            release(bufs)
+            if n == 0:
+                raise
+            note = 'probing set %d failed: %s' % (n, str(e)[:100])
+            break
         sets.append(bufs)
-        times.append(measure(bufs))
+        times.append(t)
         close = sorted(times)[:2]
         if len(times) > 1 and close[1] <= close[0] * (1.0 + agree):
             break
@@ -159,6 +177,8 @@ def choose(make_set, measure, release, attempts=3, agree=0.02, log=None):
         if i != best:
             release(bufs)
     info = {'times_ms': [round(x * 1e3, 4) for x in times], 'chosen': best}
+    if note:
+        info['note'] = note
     if log:
         log('placement by measurement: %s' % info)
     return sets[best], info
@@ -194,7 +214,20 @@ def probe_sweep(backend, desc, dim, src, dst, nbytes, stream, steps=12):
     ev1 = b.make_event(stream, timing=True)
     ev1.synchronize()
     b.set_iteration(0)
-    return ev1.time_since(ev0) * 1e-3 / steps
+    seconds = ev1.time_since(ev0) * 1e-3 / steps
+    for addr in set((src, dst)):                        # back to what alloc_placed() handed out: zeros
+        b.memset_buf(addr, 0, nbytes, stream)
+    stream.synchronize()
+    del ks, module                                      # the probe's module and kernels go with it
+    return seconds
+
+
+def room_for(backend, nbytes, slack=1.15):
+    """True when another set of `nbytes` of distribution arrays fits into the device memory that is free right now."""
+    try:
+        return backend.free_memory() >= int(nbytes * slack)
+    except Exception:  # noqa: BLE001
+        return False
 
 
 def _check(lib, status, what):

@@ -10,6 +10,7 @@ minibatch boundaries, wall time / n gives the mean step time of the batch; HIP t
 recorded on every step (asynchronously) and read back at the end of the batch to split the steps
 into bulk / boundary / pack / unpack time.
 """
+import os
 import time
 
 from sailfish_amd import util
@@ -50,6 +51,7 @@ class TimeProfile(object):
         self._open = {}
         self._in_batch = 0
         self._active = False
+        self._all_steps = os.environ.get('SLF_PROFILE_ALL_STEPS', '0') == '1'
         self.samples = 0
         self.summary = None
         self.t_start = self.t_end = 0.0
@@ -92,7 +94,7 @@ class TimeProfile(object):
     # ------------------------------------------------------------------ steps
     def _sync(self):
         r = self._runner
-        r.backend.sync_stream(r._calc_stream, r._data_stream)
+        r.backend.sync_stream(*r._all_streams())
 
     def start_step(self):
         it = self._runner._sim.iteration
@@ -135,20 +137,33 @@ class TimeProfile(object):
         per = dur / n
         self._account(self.STEP, dur, per)
         self._timings[self.STEP_SQ] += n * per * per
-        sums = {}
+        sums, covered = {}, {}
         for i, ev0, ev1, steps in self._events:
             d = ev1.time_since(ev0) / 1e3
             sums[i] = sums.get(i, 0.0) + d
+            covered[i] = covered.get(i, 0) + steps
             self._min_timings[i] = min(self._min_timings[i], d / steps)
             self._max_timings[i] = max(self._max_timings[i], d / steps)
+        # an event id is recorded at most once per step (or once per graph replay of `steps` steps); where only some of
+        # the batch's steps were timed (wants_gpu_events) their mean stands for the others
+        timed = max(covered.values()) if covered else 0          # steps of this batch that carried timing events
         for i, total in sums.items():
-            self._timings[i] += total
+            self._timings[i] += total * (float(n) / timed if 0 < timed < n else 1.0)
         del self._events[:]
         for i in (self.SEND_DISTS, self.RECV_DISTS, self.SEND_MACRO, self.RECV_MACRO, self.NET_RECV):
             if self._cpu_batch[i] > 0.0:
                 self._account(i, self._cpu_batch[i], self._cpu_batch[i] / n)
         self.samples += n
         self._in_batch = 0
+
+    def wants_gpu_events(self):
+        """Does the coming step record HIP timing events?  A runner that replays its steps from a C-ABI plan
+        (SubdomainRunner.step) takes the entry-by-entry route for such a step.  In an active benchmark batch: the first
+        step of every minibatch (SLF_PROFILE_ALL_STEPS=1: every step); the split of a step into bulk / boundary /
+        pack / unpack time is then scaled from the steps that were timed to the whole batch (_close_batch)."""
+        if not self._active:
+            return False
+        return self._in_batch == 0 or self._all_steps
 
     # ------------------------------------------------------------------ events
     def record_gpu_start(self, event, stream):

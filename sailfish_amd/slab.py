@@ -24,6 +24,7 @@ import os
 import numpy as np
 
 from sailfish_amd import hipabi, sym, xface
+from sailfish_amd.backend_hip import DirectQueue, HIPEvent, NotPlannable
 from sailfish_amd.box import BoxSim, make_box_desc
 
 AXES = {'x': 0, 'y': 1, 'z': 2}
@@ -121,9 +122,22 @@ class SlabSim(BoxSim):
         self.exchanger = exchanger or make_ring_exchanger(self.rank, self.world, b)
         self.halo_stream = b.make_stream(high_priority=os.environ.get('SLF_HALO_PRIORITY', '1') != '0')
         self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
+        # a second calc stream: z / y slabs sweep their face layers on it, so that the stream of the interior sweep never
+        # waits for a halo; x slabs alternate their z-chunks between the two, so that the chip does not drain at every
+        # chunk boundary (SLF_CALC_STREAMS=1: everything on one stream, the round-3 scheme)
+        self.calc_stream2 = b.make_stream() if os.environ.get('SLF_CALC_STREAMS', '2') != '1' else self.stream
+        # an exchanger that can be called in the middle of a step (RCCL / gloo / ring of one): the step is one program
+        # (_program), replayed from a C-ABI step plan where the transport allows; exchangers that move whole buffers
+        # between step_compute() and step_finish() (tests: two slabs in one process) keep the three-phase protocol
+        self.mid_step = hasattr(self.exchanger, 'exchange_range')
+        self._plans = {}
+        self._plan_ok = getattr(b, 'supports_step_plans', False) and os.environ.get('SLF_STEP_PLAN', '1') != '0'
         tdtype = torch.float32 if self.desc.precision == 4 else torch.float64
         dev = torch.device('cuda', b.gpu_id)
         self.xface = None
+        self.ev_halo = None
+        self.regs_bnd, self.reg_bulk = self.plan.regions()
+        self.time_halo = False
         if self.axis == 0 and xface.supported(self.grid, self.desc) and os.environ.get('SLF_XFACE', '1') != '0':
             # x faces: the sweep's edge lanes write / read dense face buffers themselves (xface.py) -- no pack / unpack
             tensors = []
@@ -136,16 +150,14 @@ class SlabSim(BoxSim):
             self.t_sets = [[tensors[4 * p + 1], tensors[4 * p + 0], tensors[4 * p + 2], tensors[4 * p + 3]] for p in (0, 1)]
             self.t_bufs = self.t_sets[0]
             self.xface.reset()
-            # overlap = every batch of planes is exchanged as soon as its chunks are done (needs an exchanger that can
-            # be called in the middle of a step: RCCL / gloo / ring of one); the three-phase protocol of exchangers that
-            # copy whole buffers between step_compute() and step_finish() (tests: two slabs in one process) stays
-            self.overlap = hasattr(self.exchanger, 'exchange_range')
+            # overlap = every batch of planes is exchanged as soon as its chunks are done
+            self.overlap = self.mid_step
             self.chunks = xface.ChunkPlan(self.size[2], self.desc.periodic_fused[2], None if self.overlap else 1)
             self._batch_events, self._prev_kind = None, None
             self._event_pool = {}
-            self.ev_halo = None
-            self.regs_bnd, self.reg_bulk = self.plan.regions()
-            self.time_halo = False
+            n = len(self.chunks.order)
+            self._ev_chunk = [[HIPEvent(b) for _ in range(n)] for _ in (0, 1)]
+            self._ev_batch = [[HIPEvent(b) for _ in range(n)] for _ in (0, 1)]
             return
         n = self.plan.count
         self.t_bufs = [torch.empty(n, dtype=tdtype, device=dev) for _ in range(4)]  # s_up s_down r_low r_high
@@ -159,12 +171,126 @@ class SlabSim(BoxSim):
                     ks.append(b.get_kernel(self.module, name, (64,), [dbuf, self.t_bufs[j].data_ptr()] + list(boxes[j]),
                                            'PPiiiiii'))
                 self.k_halo[(swap, di)] = ks
-        self.ev_halo = None
-        self.regs_bnd, self.reg_bulk = self.plan.regions()
-        self.time_halo = False
+        self._ev = [dict((name, HIPEvent(b)) for name in ('bnd', 'bulk', 'halo')) for _ in (0, 1)]
+
+    # -- one step as a program: written once against the DirectQueue / HIPPlan interface (backend_hip.py) -------------
+    def _exchange(self, q, ranges):
+        """One group of transfers on the halo stream: the element ranges [(first, count)] of the four face buffers
+        (send up, send down, receive low, receive high)."""
+        ex = self.exchanger
+        bufs = self.t_bufs
+        if getattr(ex, 'direct', False):                    # straight to RCCL (connector.RcclRingExchanger)
+            q.exchange(ex.rccl, ex.batch(bufs, ranges), self.halo_stream)
+            return
+        if ex.plain_copy():                                 # a ring of one without a process group
+            isz = bufs[0].element_size()
+            for first, count in ranges:
+                for src, dst in ((bufs[0], bufs[2]), (bufs[1], bufs[3])):
+                    q.copy(dst.data_ptr() + first * isz, src.data_ptr() + first * isz, count * isz, self.halo_stream)
+            return
+
+        def run():                                          # torch.distributed (gloo in the tests): needs Python
+            import torch
+            with torch.cuda.stream(self.t_halo_stream):
+                for first, count in ranges:
+                    ex.exchange_range(bufs, first, count)
+        q.call(run)
+
+    def _program(self, q, it, save_macro):
+        if self.xface is not None:
+            return self._program_xface(q, it, save_macro)
+        return self._program_box(q, it, save_macro)
+
+    def _program_box(self, q, it, save_macro):
+        """z / y slabs.  Boundary stream: wait(previous halo, previous interior) -> the two face layers -> event;
+        interior stream: wait(previous face layers) -> interior; halo stream: wait(face layers) -> pack -> exchange ->
+        unpack -> event.  The interior sweep depends on the neighbours only through the face layers of the step before
+        (what the unpack writes -- the first real layer after a push step, the ghost layer after the even in-place
+        step -- is read by the face layers alone), so its stream never waits for a transfer."""
+        if self.aa:
+            k, out, swap = self.k_sweep[int(save_macro)][0], 0, (it & 1) == 0
+        else:
+            k, out, swap = self.k_sweep[int(save_macro)][it & 1], 1 - (it & 1), False
+        ev, pev = self._ev[it & 1], self._ev[1 - (it & 1)]
+        sk, sb, sh = self.calc_stream, self.calc_stream2, self.halo_stream
+        if self.regs_bnd:
+            q.wait(sb, pev['halo'])
+            if sb is not sk:
+                q.wait(sb, pev['bulk'])
+            for reg in self.regs_bnd:
+                q.launch(k, reg, sb)
+            q.record(ev['bnd'], sb)
+            if sb is not sk:
+                q.wait(sk, pev['bnd'])
+            q.launch(k, self.reg_bulk, sk)
+            q.record(ev['bulk'], sk)
+        else:       # a layer that cannot be split off: the whole sweep first
+            q.wait(sk, pev['halo'])
+            q.launch(k, self.reg_bulk, sk)
+            q.record(ev['bnd'], sk)
+        q.wait(sh, ev['bnd'])
+        ks = self.k_halo[(swap, out)]
+        t0 = self.backend.make_event(sh, timing=True) if (self.time_halo and not q.planned) else None
+        q.launch(ks[0], None, sh)
+        q.launch(ks[1], None, sh)
+        self._exchange(q, [(0, self.t_bufs[0].numel())])
+        q.launch(ks[2], None, sh)
+        q.launch(ks[3], None, sh)
+        q.record(ev['halo'], sh)
+        if t0 is not None:
+            self._halo_events.append((t0, self.backend.make_event(sh, timing=True)))
+
+    def _program_xface(self, q, it, save_macro):
+        """x slabs: the sweep in z-chunks, alternating between the two calc streams (a chunk starts while the one
+        before it drains); after each chunk the planes of the send buffers it completed travel on the halo stream.  A
+        chunk waits for (a) the transfers of the previous step that carry the planes it reads and (b) the chunks of the
+        previous step that touched its planes or their neighbours and ran on the other stream."""
+        x, plan, ny = self.xface, self.chunks, self.size[1]
+        k = self.k_sweep[int(save_macro)][0] if self.aa else self.k_sweep[int(save_macro)][it & 1]
+        kind = 'own' if (self.aa and (it & 1) == 0) else 'push'
+        prev_kind = 'push' if (not self.aa or kind == 'own') else 'own'
+        par = it & 1
+        self.t_bufs = self.t_sets[par]
+        # the z-chunks alternate between the two calc streams only on request (SLF_XFACE_STREAMS=2): a chunk that starts
+        # while the one before it drains was measured SLOWER than the drain it avoids (profiles/r04/NOTES.md)
+        streams = [self.calc_stream, self.calc_stream2 if os.environ.get('SLF_XFACE_STREAMS', '1') == '2' else self.calc_stream]
+        if x.needs_clear:
+            streams[1] = streams[0]
+        snd, rcv = x.send[par], x.recv[1 - par]
+        q.xface(self.module, snd[xface.LOW], snd[xface.HIGH], rcv[xface.LOW], rcv[xface.HIGH])
+        if x.needs_clear:
+            for a in snd:
+                if a:
+                    q.memset(a, 0xFF, x.nbytes, streams[0])
+        evc, evb = self._ev_chunk[par], self._ev_batch[par]
+        pevc, pevb = self._ev_chunk[1 - par], self._ev_batch[1 - par]
+        need = plan.need[prev_kind]
+        pos_of = dict((c, pos) for pos, c in enumerate(plan.order))
+        sh = self.halo_stream
+        t0 = None
+        for pos, c in enumerate(plan.order):
+            st = streams[pos & 1]
+            if need[c] >= 0:
+                q.wait(st, pevb[need[c]])
+            for c2 in plan.neighbours(c):
+                if streams[pos_of[c2] & 1] is not st:
+                    q.wait(st, pevc[pos_of[c2]])
+            q.launch(k, plan.region(c, ny), st)
+            q.record(evc[pos], st)
+            q.wait(sh, evc[pos])
+            if self.time_halo and not q.planned and pos == 0:
+                t0 = self.backend.make_event(sh, timing=True)
+            runs = plan.batches[kind][pos]
+            if runs:
+                self._exchange(q, [(p0 * x.plane, (p1 - p0) * x.plane) for p0, p1 in runs])
+            q.record(evb[pos], sh)
+        if t0 is not None:
+            self._halo_events.append((t0, self.backend.make_event(sh, timing=True)))
 
     def step_compute(self, save_macro=False):
-        """Face layers, event, interior on the calc stream; halo pack on the halo stream."""
+        """Three-phase protocol (exchangers that move whole buffers between step_compute() and step_finish()): face
+        layers, event, interior on the calc stream; halo pack on the halo stream."""
+        self.backend.set_iteration(self.iteration)
         if self.xface is not None:
             return self._step_compute_xface(save_macro)
         b = self.backend
@@ -184,66 +310,30 @@ class SlabSim(BoxSim):
             b.run_kernel(k, self.reg_bulk, self.calc_stream)
             ev_bnd = b.make_event(self.calc_stream)
         self.halo_stream.wait_for_event(ev_bnd)
-        if self.time_halo:
-            self._ev_h0 = b.make_event(self.halo_stream, timing=True)
         self._ks = self.k_halo[(swap, out)]
         b.run_kernel(self._ks[0], None, self.halo_stream)
         b.run_kernel(self._ks[1], None, self.halo_stream)
         self.iteration += 1
-        b.set_iteration(self.iteration)
 
     def _step_compute_xface(self, save_macro):
-        """x-slabs: z-chunks of the sweep on the calc stream; after each, the planes of the send buffers it completed
-        travel on the halo stream (overlap mode) while the next chunk computes."""
+        """x-slabs, three-phase protocol: one launch of the whole sweep (ChunkPlan with a single chunk); the caller
+        moves the face buffers between step_compute() and step_finish()."""
         b = self.backend
         it = self.iteration
         k = self.k_sweep[int(save_macro)][0] if self.aa else self.k_sweep[int(save_macro)][it & 1]
-        kind = 'own' if (self.aa and (it & 1) == 0) else 'push'
         plan, ny = self.chunks, self.size[1]
         par = self.xface.begin_step(it, self.calc_stream)
         self.t_bufs = self.t_sets[par]
-        prev, need = self._batch_events, (plan.need[self._prev_kind] if self._prev_kind else None)
-        # event objects are kept and recorded again every other step (a wait refers to the record that preceded it)
-        pool = self._event_pool.setdefault(par, [(b.make_event(self.calc_stream), b.make_event(self.halo_stream))
-                                                 for _ in plan.order])
-        events = []
+        prev = self._batch_events
         for pos, c in enumerate(plan.order):
-            if prev is not None and need[c] >= 0:
-                self.calc_stream.wait_for_event(prev[need[c]])
+            if prev is not None:
+                self.calc_stream.wait_for_event(prev[pos])
             b.run_kernel(k, plan.region(c, ny), self.calc_stream)
-            ev_chunk, ev_batch = pool[pos]
-            ev_chunk.record(self.calc_stream)
-            self.halo_stream.wait_for_event(ev_chunk)
-            if self.time_halo and pos == 0:
-                self._ev_h0 = b.make_event(self.halo_stream, timing=True)
-            if self.overlap:
-                runs = plan.batches[kind][pos]
-                if runs:
-                    self._exchange_runs(runs)
-                ev_batch.record(self.halo_stream)
-                events.append(ev_batch)
-        self._batch_events, self._prev_kind = (events if self.overlap else None), kind
+            self.halo_stream.wait_for_event(b.make_event(self.calc_stream))
         self.iteration += 1
-        b.set_iteration(self.iteration)
-
-    def _exchange_runs(self, runs):
-        """One group of transfers on the halo stream: the z-plane ranges `runs` of the four face buffers."""
-        plane = self.xface.plane
-        if getattr(self.exchanger, 'direct', False):       # straight to RCCL (connector.RcclRingExchanger)
-            self.exchanger.exchange_ranges(self.t_bufs, [(p0 * plane, (p1 - p0) * plane) for p0, p1 in runs], self.halo_stream)
-            return
-        import torch
-        with torch.cuda.stream(self.t_halo_stream):
-            for p0, p1 in runs:
-                self.exchanger.exchange_range(self.t_bufs, p0 * plane, (p1 - p0) * plane)
 
     def step_exchange(self):
         import torch
-        if self.xface is not None and self.overlap:
-            return                                    # done batch by batch inside step_compute()
-        if getattr(self.exchanger, 'direct', False):
-            self.exchanger.exchange_ranges(self.t_bufs, [(0, self.t_bufs[0].numel())], self.halo_stream)
-            return
         with torch.cuda.stream(self.t_halo_stream):
             self.exchanger.exchange(*self.t_bufs)
 
@@ -252,27 +342,51 @@ class SlabSim(BoxSim):
         if self.xface is None:
             b.run_kernel(self._ks[2], None, self.halo_stream)
             b.run_kernel(self._ks[3], None, self.halo_stream)
-        if self.time_halo:
-            self._halo_events.append((self._ev_h0, b.make_event(self.halo_stream, timing=True)))
-        if self.xface is not None:
-            if not self.overlap:                      # whole buffers were moved by the caller: one event for every chunk
-                ev = b.make_event(self.halo_stream)
-                self._batch_events = [ev] * len(self.chunks.order)
+            self.ev_halo = b.make_event(self.halo_stream)
             return
-        self.ev_halo = b.make_event(self.halo_stream)
+        ev = b.make_event(self.halo_stream)      # whole buffers were moved by the caller: one event for every chunk
+        self._batch_events = [ev] * len(self.chunks.order)
 
     def step(self, save_macro=False, region=None):
         if not self.halo:
             return BoxSim.step(self, save_macro)
-        self.step_compute(save_macro)
-        self.step_exchange()
-        self.step_finish()
+        if not self.mid_step:
+            self.step_compute(save_macro)
+            self.step_exchange()
+            self.step_finish()
+            return
+        b = self.backend
+        it = self.iteration
+        if self._plan_ok and not self.time_halo:
+            key = (it & 1, int(bool(save_macro)))
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = b.make_plan()
+                try:
+                    self._program(plan, it, save_macro)
+                    self._plans[key] = plan
+                except NotPlannable:            # the transport needs Python between the launches
+                    self._plan_ok, plan = False, None
+            if plan is not None:
+                if self.xface is not None:
+                    self.t_bufs = self.t_sets[it & 1]
+                plan.run(it)
+                self.iteration += 1
+                if self.xface is not None:
+                    self.xface._bound = None        # the plan set the module's face buffers itself
+                return
+        b.set_iteration(it)
+        self._program(DirectQueue(b), it, save_macro)
+        self.iteration += 1
+        if self.xface is not None:
+            self.xface._bound = None
 
     def step_sweep_only(self):
         """The sweep launches of one step without any halo traffic (timing reference: what the calc stream costs
         when nothing has to be waited for).  Leaves the slab faces stale -- re-initialise afterwards."""
         b = self.backend
         it = self.iteration
+        b.set_iteration(it)
         k = self.k_sweep[0][0] if self.aa else self.k_sweep[0][it & 1]
         if self.halo and self.xface is not None:
             self.xface.begin_step(it, self.calc_stream)
@@ -283,7 +397,6 @@ class SlabSim(BoxSim):
                 b.run_kernel(k, reg, self.calc_stream)
             b.run_kernel(k, getattr(self, 'reg_bulk', None), self.calc_stream)
         self.iteration += 1
-        b.set_iteration(self.iteration)
 
     def start_halo_timing(self):
         self.time_halo, self._halo_events = True, []
@@ -299,6 +412,8 @@ class SlabSim(BoxSim):
     def sync(self):
         self.stream.synchronize()
         if self.halo:
+            if self.calc_stream2 is not self.stream:
+                self.calc_stream2.synchronize()
             self.halo_stream.synchronize()
 
     def initial_conditions(self):
@@ -306,6 +421,8 @@ class SlabSim(BoxSim):
         if self.halo and self.xface is not None:
             self.xface.reset(self.stream)
             self._batch_events, self._prev_kind = None, None
+        if self.halo:
+            self.sync()          # the first step starts on several streams
 
     def materialise_faces(self):
         """With x-face buffers the arrays are stale at the faces: write the received values into them (before anything
@@ -317,6 +434,13 @@ class SlabSim(BoxSim):
             self.xface.materialise(self.gpu_dist[self.current_dist_index()], pushed, self.stream, parity=last & 1)
             self.sync()
 
+    def _prime_pull(self):
+        """A state written from the host at an odd in-place iteration: the next step pulls, and its edge lanes take what
+        enters through a connected x face from the receive buffers alone (no pull out of the ghost column, slf_row.hip)
+        -- so the ghost columns of the state just written go into those buffers."""
+        if self.aa and (self.iteration & 1):
+            self.xface.prime_pull(self.gpu_dist[0], self.stream, parity=1 - (self.iteration & 1))
+
     def get_dist(self, which=None):
         self.materialise_faces()
         return BoxSim.get_dist(self, which)
@@ -327,6 +451,9 @@ class SlabSim(BoxSim):
         if self.halo and self.xface is not None:
             self.xface.reset(self.stream)
             self._batch_events, self._prev_kind = None, None
+            self._prime_pull()
+        if self.halo:
+            self.sync()
 
     # -- initial state ---------------------------------------------------------
     def init_synthetic(self, seed=1234):

@@ -1,0 +1,50 @@
+"""One time step as a program: the entries of a step (kernel launches with their regions and streams, event records,
+stream waits, halo exchanges, buffer fills and copies) are issued against ONE interface, so that the step is written
+once (`SlabSim._program`, `SubdomainRunner._program`) and is either
+
+  * performed entry by entry through the backend calls (`DirectQueue`: transports that need Python in the middle of a
+    step -- torch.distributed / gloo in the tests -- and steps that record timing events), or
+  * recorded once into a C-ABI step plan (`backend_hip.HIPPlan`, include/sailfish_hip.h "step plans") and replayed
+    with one call per step.
+
+The reference enqueues every step from Python (subdomain_runner.py:960-974, 1028-1058) at ~15 ms per step; a
+halo-connected MI355X subdomain steps in under a millisecond with ~20 runtime calls per step.
+"""
+
+
+class NotPlannable(RuntimeError):
+    """An entry that only Python can perform (a torch.distributed exchange) was put into a step plan."""
+
+
+class DirectQueue(object):
+    """Performs every entry at once through the backend interface (any backend: the CPU test backend too)."""
+    planned = False
+
+    def __init__(self, backend):
+        self.backend = backend
+
+    def launch(self, kernel, region, stream):
+        self.backend.run_kernel(kernel, region, stream)
+
+    def record(self, event, stream):
+        event.record(stream)
+
+    def wait(self, stream, event):
+        stream.wait_for_event(event)
+
+    def exchange(self, rccl, batch, stream):
+        """batch: DirectRccl.prepare(ops) -- one RCCL group"""
+        rccl.run(batch, stream)
+
+    def memset(self, addr, value, nbytes, stream):
+        self.backend.memset_buf(addr, value, nbytes, stream)
+
+    def copy(self, dst, src, nbytes, stream):
+        self.backend.copy_buf_async(dst, src, nbytes, stream)
+
+    def xface(self, module, send_low, send_high, recv_low, recv_high):
+        self.backend.set_xface_buffers(module, send_low, send_high, recv_low, recv_high)
+
+    def call(self, fn):
+        """Arbitrary host code between the entries (what a plan cannot hold)."""
+        fn()

@@ -28,6 +28,7 @@ from sailfish_amd import hipabi, io, subdomain_connection, util, xface
 from sailfish_amd import node_type as nt
 from sailfish_amd.lb_base import LBSim  # noqa: F401  (type reference)
 from sailfish_amd.profile import TimeProfile
+from sailfish_amd.stepqueue import DirectQueue, NotPlannable
 
 
 class GPUBuffer(object):
@@ -257,9 +258,17 @@ class SubdomainRunner(object):
         spec = self._spec
         if hasattr(self.backend, 'set_x_ghost_unused') and not self._local_periodic()[0] and \
                 not getattr(self.config, 'debug_dump_dists', False) and os.environ.get('SLF_X_GHOST_STORES', '0') != '1':
-            # ghost columns behind an x face that is neither periodic nor connected: nothing reads them (raw dumps of the
-            # arrays keep the reference's pushes: --debug_dump_dists)
-            self.backend.set_x_ghost_unused(self.module, not spec.has_face_conn(spec.X_LOW), not spec.has_face_conn(spec.X_HIGH))
+            # ghost columns behind an x face that is neither periodic nor connected.  Two-copy pattern: nothing ever
+            # reads them.  In-place pattern: the odd step of the first / last real column PULLS out of them what its even
+            # step pushed there two steps earlier (the reference's behaviour for a wet node next to an open face), so the
+            # stores may only go where that column holds no wet node -- a wall, as in every cavity / channel / pipe: what
+            # a dry node pulls out of the ghost column only ever travels back into it.  (Raw dumps of the arrays keep the
+            # reference's pushes: --debug_dump_dists.)
+            wet = self._subdomain.fluid_map(wet=True)
+            ab = self.config.access_pattern == 'AB'
+            low = not spec.has_face_conn(spec.X_LOW) and (ab or not wet[..., 0].any())
+            high = not spec.has_face_conn(spec.X_HIGH) and (ab or not wet[..., -1].any())
+            self.backend.set_x_ghost_unused(self.module, low, high)
         self._calc_stream = self.backend.make_stream()
         # the halo stream: ahead of the bulk sweep's queued workgroups where the backend can say so
         prio = getattr(self.backend, 'supports_stream_priority', False) and os.environ.get('SLF_HALO_PRIORITY', '1') != '0'
@@ -301,7 +310,8 @@ class SubdomainRunner(object):
                 # placement by measurement: a second set is placed while the first is allocated, the faster one stays
                 bufs, self.placement_tuning = placement.choose(
                     lambda: b.alloc_placed(sizes, off), lambda bs: self._probe_placement(bs, n, ab),
-                    lambda bs: [b.free_buf(pb.addr) for pb in bs], log=cfg.logger.debug)
+                    lambda bs: [b.free_buf(pb.addr) for pb in bs], log=cfg.logger.debug,
+                    room=lambda: placement.room_for(b, sum(sizes)))
             else:
                 bufs = b.alloc_placed(sizes, off)
             self._gpu_grids_primary = [pb.addr for pb in bufs[:n]]
@@ -514,7 +524,7 @@ class SubdomainRunner(object):
         """Whatever state was just set up from the host (initial conditions, a checkpoint, a debug write): the arrays
         count, nothing that crossed the x faces before does."""
         if self._xface is not None:
-            self.backend.sync_stream(self._calc_stream, self._data_stream)
+            self.backend.sync_stream(*self._all_streams())
             self._xface.reset(self._calc_stream)
             self.__dict__.pop('_halo_mode', None)
             self._xface_events, self._xface_prev_kind = None, None
@@ -524,7 +534,7 @@ class SubdomainRunner(object):
         them (before anything reads the arrays on the host)."""
         if self._xface is None or not hasattr(self, '_halo_mode'):
             return
-        self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self.backend.sync_stream(*self._all_streams())
         self._xface.materialise(self.gpu_dist(0, self._halo_copy), self._halo_mode == 'push', self._calc_stream,
                                 parity=self._xface_parity)
         self.backend.sync_stream(self._calc_stream)
@@ -702,20 +712,200 @@ class SubdomainRunner(object):
     has_macro_exchange = False
 
     def step(self, sync_req=False):
-        """One time step of a runner whose neighbours live in other processes."""
-        if self.has_macro_exchange and self._macro_links:
-            self.step_macro()
-            self._connector.exchange(self, 'macro')
-            self.step_macro_finish()
-        self.step_compute(sync_req)
-        if self._links and self._xface is None:
-            self._profile.record_cpu_start(TimeProfile.RECV_DISTS)
-            self._connector.exchange(self)
-            self._profile.record_cpu_end(TimeProfile.RECV_DISTS)
-        self.step_finish()
+        """One time step of a runner that owns its process (neighbours, if any, live in other processes): the step is
+        ONE program (_program, stepqueue.py), replayed from a C-ABI step plan -- a single runtime call -- where the
+        transport can be part of it (RCCL through the C ABI), performed entry by entry otherwise (torch.distributed) and
+        on the steps that record timing events."""
+        b = self.backend
+        it = self._sim.iteration
+        if self._plan_ok and not self._profile.wants_gpu_events():
+            key = (it & 1, bool(sync_req))
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = b.make_plan()
+                try:
+                    self._program(plan, it, sync_req)
+                    self._plans[key] = plan
+                except NotPlannable:            # the transport needs Python between the launches
+                    self._plan_ok, plan = False, None
+            if plan is not None:
+                self._set_step_state(it)
+                plan.run(it)
+                if self._xface is not None:
+                    self._xface._bound = None       # the plan set the module's face buffers itself
+                self._sim.iteration += 1
+                b.set_iteration(self._sim.iteration)
+                return
+        b.set_iteration(it)
+        self._program(DirectQueue(b), it, sync_req)
+        if self._xface is not None:
+            self._xface._bound = None
+        self._sim.iteration += 1
+        b.set_iteration(self._sim.iteration)
+
+    # ------------------------------------------------------------------ the step as a program (stepqueue.py)
+    _plan_ok = False
+
+    def _init_step_program(self):
+        """Events, streams and plan table of step() (runners that own their process; a same-process group keeps the
+        three-phase step_compute / exchange / step_finish protocol of controller.LocalGroup)."""
+        b = self.backend
+        self._plans = {}
+        self._plan_ok = bool(getattr(b, 'supports_step_plans', False)) and getattr(self.config, 'hip_step_plans', True) and \
+            os.environ.get('SLF_STEP_PLAN', '1') != '0'
+        names = ('bnd', 'bulk', 'halo', 'macro', 'macro_halo')
+        self._pev = [dict((n, b.make_event(self._calc_stream)) for n in names) for _ in (0, 1)]
+        # a second calc stream (SLF_CALC_STREAMS=1: off).  z / y decompositions sweep their face layers on it: the
+        # interior depends on the neighbours only through the face layers of the step before, so its stream never waits
+        # for a transfer.  x decompositions alternate their z-chunks between the two streams: a chunk starts while the
+        # one before it drains.  Ghost-layer PBC kernels and the macro pass of the non-local models work on whole
+        # arrays: one stream there.
+        two = os.environ.get('SLF_CALC_STREAMS', '2') != '1' and not self._pbc_axes and not self.has_macro_exchange and \
+            bool(self._links) and hasattr(b, 'supports_step_plans')
+        if self._xface is not None:
+            # z-chunks on alternating streams only on request: measured slower than the drain at the chunk boundaries
+            # it avoids (profiles/r04/NOTES.md)
+            two = two and not self._xface.needs_clear and os.environ.get('SLF_XFACE_STREAMS', '1') == '2'
+            n = len(self._xchunks.order)
+            self._ev_chunk = [[b.make_event(self._calc_stream) for _ in range(n)] for _ in (0, 1)]
+            self._ev_batch = [[b.make_event(self._data_stream) for _ in range(n)] for _ in (0, 1)]
+        else:
+            two = two and bool(self._regions[0])
+        self._bnd_stream = b.make_stream() if two else self._calc_stream
+
+    def _sweep_kernels(self, it, sync_req):
+        kernels = self._kernels_full if sync_req else self._kernels_none
+        return kernels.primary if (it & 1) == 0 else kernels.secondary
+
+    def _set_step_state(self, it):
+        """What the rest of the runner reads about the step being enqueued (halo_messages, xface_pieces, materialise)."""
+        aa = self.config.access_pattern == 'AA'
+        self._halo_mode = 'pull' if (aa and (it & 1) == 0) else 'push'
+        self._halo_copy = 0 if aa else 1 - (it & 1)
+        if self._xface is not None:
+            self._xface_parity = it & 1
+            self._xface_kind = 'own' if (aa and (it & 1) == 0) else 'push'
+            self._xface_prev_kind = self._xface_kind
+
+    def _program(self, q, it, sync_req):
+        """Single-fluid step: [face layers -> event] -> interior -> ghost-layer PBC kernels; halo stream: pack ->
+        exchange -> unpack -> event (reference subdomain_runner.py:960-1058)."""
+        prof, timed = self._profile, not q.planned
+        self._set_step_state(it)
+        ev, pev = self._pev[it & 1], self._pev[1 - (it & 1)]
+        kernels = self._sweep_kernels(it, sync_req)
+        if self._xface is not None:
+            return self._program_xface(q, it, kernels)
+        sk, sb = self._calc_stream, self._bnd_stream
+        bnd, bulk = self._regions
+        ready = None
+        if bnd:
+            if self._links:
+                q.wait(sb, pev['halo'])
+            if sb is not sk:
+                q.wait(sb, pev['bulk'])
+            if timed:
+                prof.record_gpu_start(TimeProfile.BOUNDARY, sb)
+            for reg in bnd:
+                for k in kernels:
+                    q.launch(k, reg, sb)
+            if timed:
+                prof.record_gpu_end(TimeProfile.BOUNDARY, sb)
+            q.record(ev['bnd'], sb)
+            if sb is not sk:
+                q.wait(sk, pev['bnd'])
+            ready = ev['bnd']
+        elif self._links:
+            q.wait(sk, pev['halo'])
+        if timed:
+            prof.record_gpu_start(TimeProfile.BULK, sk)
+        for k in kernels:
+            q.launch(k, bulk, sk)
+        if timed:
+            prof.record_gpu_end(TimeProfile.BULK, sk)
+        base = 1 - (it & 1)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels[base][axis]:
+                q.launch(k, None, sk)
+        q.record(ev['bulk'], sk)
+        if ready is None or self._pbc_axes:
+            ready = ev['bulk']       # unsplit subdomains: the whole sweep (and the local PBC) must be done first
+        self._program_halo(q, ready, ev)
+
+    def _program_halo(self, q, ready, ev):
+        """Halo stream: wait(`ready`) -> pack -> exchange -> unpack -> event 'halo'."""
+        if not self._links:
+            return
+        prof, timed, sh = self._profile, not q.planned, self._data_stream
+        q.wait(sh, ready)
+        key = (self._halo_mode, self._halo_copy)
+        if timed:
+            prof.record_gpu_start(TimeProfile.COLLECTION, sh)
+        for nid in sorted(self._links):
+            for pack in self._links[nid].kernels[key][0]:
+                q.launch(pack, None, sh)
+        if timed:
+            prof.record_gpu_end(TimeProfile.COLLECTION, sh)
+            prof.record_cpu_start(TimeProfile.RECV_DISTS)
+        self._connector.enqueue_exchange(q, self, 'dist')
+        if timed:
+            prof.record_cpu_end(TimeProfile.RECV_DISTS)
+            prof.record_gpu_start(TimeProfile.DISTRIB, sh)
+        for nid in sorted(self._links):
+            for unpack in self._links[nid].kernels[key][1]:
+                q.launch(unpack, None, sh)
+        if timed:
+            prof.record_gpu_end(TimeProfile.DISTRIB, sh)
+        q.record(ev['halo'], sh)
+
+    def _program_xface(self, q, it, kernels):
+        """1-D x decomposition: the sweep in z-chunks, alternating between the two calc streams; after each chunk the
+        planes of the face buffers that are now complete travel on the data stream.  A chunk waits for the transfers of
+        the previous step that carry the planes it reads and for the chunks of the previous step that touched its
+        planes or their neighbours and ran on the other stream (xface.ChunkPlan)."""
+        prof, timed = self._profile, not q.planned
+        x, plan = self._xface, self._xchunks
+        par = it & 1
+        kind = self._xface_kind
+        prev_kind = 'push' if (self.config.access_pattern != 'AA' or kind == 'own') else 'own'
+        ny = list(reversed(self._lat_size))[1] - 2
+        streams = [self._calc_stream, self._bnd_stream]
+        snd, rcv = x.send[par], x.recv[1 - par]
+        q.xface(self.module, snd[xface.LOW], snd[xface.HIGH], rcv[xface.LOW], rcv[xface.HIGH])
+        if x.needs_clear:
+            for a in snd:
+                if a:
+                    q.memset(a, 0xFF, x.nbytes, streams[0])
+        evc, evb = self._ev_chunk[par], self._ev_batch[par]
+        pevc, pevb = self._ev_chunk[1 - par], self._ev_batch[1 - par]
+        need = plan.need[prev_kind]
+        pos_of = dict((c, pos) for pos, c in enumerate(plan.order))
+        sh = self._data_stream
+        if timed:
+            prof.record_gpu_start(TimeProfile.BULK, streams[0])
+        for pos, c in enumerate(plan.order):
+            st = streams[pos & 1]
+            if need[c] >= 0:
+                q.wait(st, pevb[need[c]])
+            for c2 in plan.neighbours(c):
+                if streams[pos_of[c2] & 1] is not st:
+                    q.wait(st, pevc[pos_of[c2]])
+            for k in kernels:
+                q.launch(k, plan.region(c, ny), st)
+            q.record(evc[pos], st)
+            q.wait(sh, evc[pos])
+            self._connector.enqueue_pieces(q, self, self.xface_pieces(pos))
+            q.record(evb[pos], sh)
+        if timed:
+            if streams[1] is not streams[0]:
+                streams[0].wait_for_event(evc[len(plan.order) - 1])
+            prof.record_gpu_end(TimeProfile.BULK, streams[0])
 
     # ------------------------------------------------------------------ data movement
     def _fields_to_host(self, sync=True):
+        bs = getattr(self, '_bnd_stream', None)
+        if bs is not None and bs is not self._calc_stream:
+            bs.synchronize()            # the face layers / every other z-chunk stored their fields on the second stream
         for field in self._scalar_fields:
             self.backend.from_buf_async(self.gpu_field(field), self._calc_stream)
         for vec in self._vector_fields:
@@ -734,7 +924,7 @@ class SubdomainRunner(object):
     def _debug_get_dist(self, output=True, grid_num=0, copy=None):
         """Distributions as [Q, (nz,) ny, arr_nx] (reference subdomain_runner.py:1363-1381); with indirect
         addressing the slots are scattered back to their nodes (inactive nodes: 0)."""
-        self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self.backend.sync_stream(*self._all_streams())
         self._materialise_halo()
         if copy is None:
             copy = 0 if not self._gpu_grids_secondary else (self._sim.iteration & 1)
@@ -838,6 +1028,7 @@ class SubdomainRunner(object):
         self._init_gpu_data()
         self._init_halo()
         self._prepare_compute_kernels()
+        self._init_step_program()
         self._sim.initial_conditions(self)
         self.backend.set_iteration(0)
         if self._output is not None:
@@ -981,8 +1172,15 @@ class SubdomainRunner(object):
     def _quit_requested(self):
         return self._quit_event is not None and self._quit_event.is_set()
 
+    def _all_streams(self):
+        out = [self._calc_stream, self._data_stream]
+        bs = getattr(self, '_bnd_stream', None)
+        if bs is not None and bs is not self._calc_stream:
+            out.append(bs)
+        return out
+
     def finish(self):
-        self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self.backend.sync_stream(*self._all_streams())
         self.check_gpu_invalid()
         if getattr(self.config, 'final_checkpoint', False) and self.config.checkpoint_file:
             self.save_checkpoint()
@@ -994,7 +1192,7 @@ class SubdomainRunner(object):
         """Gives the device memory of this subdomain back (fields, populations, node map, halo buffers).  The
         runner must not be stepped or queried for device data afterwards; the host copies of the output fields
         (sim.rho, sim.v) stay valid."""
-        self.backend.sync_stream(self._calc_stream, self._data_stream)
+        self.backend.sync_stream(*self._all_streams())
         self._kernels_full = self._kernels_none = self._pbc_kernels = None
         self._links, self._macro_links = {}, {}
         self.backend.close()
@@ -1014,7 +1212,7 @@ class SubdomainRunner(object):
             self.post_step(sync_req, output_req)
             self._profile.end_step()
             if cfg.perf_stats_every > 0 and self._sim.iteration % cfg.perf_stats_every == 0:
-                self.backend.sync_stream(self._calc_stream, self._data_stream)
+                self.backend.sync_stream(*self._all_streams())
                 now = time.time()
                 mlups = self.num_fluid_nodes * (self._sim.iteration - it_prev) / (now - t_prev) * 1e-6
                 cfg.logger.info('iteration:{0}  speed:{1:.2f} MLUPS'.format(self._sim.iteration, mlups))
@@ -1162,6 +1360,58 @@ class NNSubdomainRunner(SubdomainRunner):
         self._pack_halo(it)
         self._sim.iteration += 1
         b.set_iteration(self._sim.iteration)
+
+    def _program(self, q, it, sync_req):
+        """Non-local models: macro pass -> [exchange of the macroscopic fields] -> sweeps of every lattice -> population
+        halo (reference NNSubdomainRunner.step, subdomain_runner.py:2102-2197), on one calc stream."""
+        prof, timed = self._profile, not q.planned
+        self._set_step_state(it)
+        ev, pev = self._pev[it & 1], self._pev[1 - (it & 1)]
+        sk, sh = self._calc_stream, self._data_stream
+        macro_kernel = self._kernels_none[it & 1][0]
+        sim_kernels = (self._kernels_full if sync_req else self._kernels_none)[it & 1][1]
+        base = 1 - (it & 1)
+        if self._links:
+            q.wait(sk, pev['halo'])                          # populations received after the last step
+        if timed:
+            prof.record_gpu_start(TimeProfile.MACRO_BULK, sk)
+        q.launch(macro_kernel, None, sk)
+        if timed:
+            prof.record_gpu_end(TimeProfile.MACRO_BULK, sk)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels.macro[base][axis]:
+                q.launch(k, None, sk)
+        if self._macro_links:
+            q.record(ev['macro'], sk)
+            q.wait(sh, ev['macro'])
+            if timed:
+                prof.record_gpu_start(TimeProfile.MACRO_COLLECTION, sh)
+            for nid in sorted(self._macro_links):
+                for k in self._macro_links[nid].packs:
+                    q.launch(k, None, sh)
+            if timed:
+                prof.record_gpu_end(TimeProfile.MACRO_COLLECTION, sh)
+            self._connector.enqueue_exchange(q, self, 'macro')
+            if timed:
+                prof.record_gpu_start(TimeProfile.MACRO_DISTRIB, sh)
+            for nid in sorted(self._macro_links):
+                for k in self._macro_links[nid].unpacks:
+                    q.launch(k, None, sh)
+            if timed:
+                prof.record_gpu_end(TimeProfile.MACRO_DISTRIB, sh)
+            q.record(ev['macro_halo'], sh)
+            q.wait(sk, ev['macro_halo'])
+        if timed:
+            prof.record_gpu_start(TimeProfile.BULK, sk)
+        for k in sim_kernels:
+            q.launch(k, None, sk)
+        if timed:
+            prof.record_gpu_end(TimeProfile.BULK, sk)
+        for axis in self._pbc_axes:
+            for k in self._pbc_kernels.distributions[base][axis]:
+                q.launch(k, None, sk)
+        q.record(ev['bulk'], sk)
+        self._program_halo(q, ev['bulk'], ev)
 
     def _debug_get_dist(self, output=True, grid_num=0, copy=None):
         return SubdomainRunner._debug_get_dist(self, output, grid_num, copy)

@@ -24,10 +24,11 @@ def get_grid_from_config(config):
 
 def get_backends(backends=('hip',)):
     """Yields the `backend` class of every importable sailfish.backend_<name> module
-    (reference util.py:52-59).  Only the HIP backend exists here."""
+    (reference util.py:52-59).  Only the HIP backend exists here; a dotted name is the full path of a module that
+    provides a `backend` class (out-of-tree backends: the CPU test backend of tests/)."""
     for backend in backends:
         try:
-            module = importlib.import_module('sailfish_amd.backend_{0}'.format(backend))
+            module = importlib.import_module(backend if '.' in backend else 'sailfish_amd.backend_{0}'.format(backend))
             yield module.backend
         except ImportError:
             pass

@@ -34,6 +34,16 @@ NXD = 5          # D3Q19 directions per sign of e_x
 
 
 def supported(grid, desc, indirect=False, simtype=0):
+    """Can a module built from `desc` take x-face buffers (slf_module_set_xface_buffers)?  D3Q19 single fluid, direct
+    addressing, rows of at most 1024 nodes -- and the whole-row kernels must be what runs: the --minimize_roundoff
+    formulation lives in the per-node kernels only (slf_api.hip: variant = 0), and so does everything under an
+    SLF_VARIANT without bit 8."""
+    from sailfish_amd import hipabi
+    if int(desc.incompressible) == hipabi.SLF_DENSITY_ROUNDOFF:
+        return False
+    variant = os.environ.get('SLF_VARIANT')
+    if variant is not None and not (int(variant) & 8):
+        return False
     return grid.dim == 3 and grid.Q == 19 and not indirect and not simtype and desc.lat_nx - 2 <= 1024
 
 
@@ -105,6 +115,20 @@ class ChunkPlan(object):
         z0, z1 = self.chunks[c]
         return (1, ny + 1, z0, z1)
 
+    def neighbours(self, c):
+        """Chunks whose sweep touches planes that chunk c reads or writes (itself and the chunks next to it; around the
+        ring when z is wrapped in-sweep): what a chunk of the next step has to wait for when the chunks do not all
+        run on one stream."""
+        k = len(self.chunks)
+        out = []
+        for d in (-1, 0, 1):
+            n = c + d
+            if self.wrap_z:
+                n %= k
+            if 0 <= n < k and n not in out:
+                out.append(n)
+        return out
+
 
 class XFaceHalo(object):
     def __init__(self, backend, module, grid, desc, send, recv):
@@ -140,12 +164,8 @@ class XFaceHalo(object):
         key = (send_parity, recv_parity)
         if key == self._bound:
             return
-        lib = self.backend._lib
-        from sailfish_amd.backend_hip import _check
         s, r = self.send[send_parity], self.recv[recv_parity]
-        _check(lib, lib.slf_module_set_xface_buffers(self.module.handle, *[ctypes.c_void_p(a or None) for a in
-                                                                           (s[LOW], s[HIGH], r[LOW], r[HIGH])]),
-               'slf_module_set_xface_buffers')
+        self.backend.set_xface_buffers(self.module, s[LOW], s[HIGH], r[LOW], r[HIGH])
         self._bound = key
 
     def begin_step(self, iteration, stream):
@@ -182,6 +202,32 @@ class XFaceHalo(object):
         for a in self.send[parity]:
             if a:
                 self.backend.memset_buf(a, 0xFF, self.nbytes, stream)
+
+    def prime_pull(self, dist, stream, parity=0):
+        """The inverse of materialise(pushed=False): copies the ghost columns of `dist` (opposite slots -- what the odd
+        in-place step pulls across a connected face) into the receive buffers of `parity`.  Needed when a state is
+        written from the host at an odd in-place iteration (checkpoint restore, set_dist): rows whose edge lanes skip
+        the pull out of the ghost column (fluid-only row kernels, slf_row.hip SKIP_GHOST_PULL) rely on the receive
+        buffers alone."""
+        self._ghost_columns('CollectContinuousData', dist, stream, parity)
+
+    def _ghost_columns(self, name, dist, stream, parity):
+        b, d = self.backend, self.desc
+        nx = d.lat_nx - 2
+        isz = self.dtype().itemsize
+        recv = self.recv[parity]
+        for face in (LOW, HIGH):
+            if not recv[face]:
+                continue
+            x = 0 if face == LOW else nx + 1
+            for k, q in enumerate(self.enter[face]):
+                key = (name, dist, recv[face], k)
+                if key not in self._kernels:
+                    self._kernels[key] = b.get_kernel(self.module, name, (64,),
+                                                      [dist, recv[face] + k * d.arr_ny * isz, 1 << self.grid.idx_opposite[q],
+                                                       x, d.arr_nx, d.arr_ny, d.arr_nx * d.arr_ny, d.arr_nz, d.arr_ny,
+                                                       NXD * d.arr_ny], 'PPiiiiiiii')
+                b.run_kernel(self._kernels[key], None, stream)
 
     def materialise(self, dist, pushed, stream, parity=0):
         """Writes the receive buffers of `parity` into the distribution array `dist`: pushed = True after a push step

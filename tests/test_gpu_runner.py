@@ -476,3 +476,16 @@ def test_runner_with_placed_distribution_arrays(pattern, monkeypatch, tmp_path):
         for r in c.runners:
             r.release()
             assert not r.backend._placed
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+def test_minimize_roundoff_split_along_x(pattern):
+    """--minimize_roundoff modules run the per-node kernels, which have no x-face buffers: a run split along
+    x (the default axis) must take the ordinary halo links -- and equal the undivided run bit for bit."""
+    cfg = dict(lat_nx=18, lat_ny=18, lat_nz=16, visc=0.1, flow_direction='z', stationary=False, drive='force',
+               force_implementation='guo', access_pattern=pattern, minimize_roundoff=True, conn_axis='x')
+    two = run_gpu('poiseuille_3d', 'PoiseuilleSim', 3, dict(cfg, subdomains=2), 8)
+    assert all(r._xface is None for r in two.runners)
+    one = run_gpu('poiseuille_3d', 'PoiseuilleSim', 3, dict(cfg, subdomains=1), 8)
+    assert np.array_equal(merged_gpu(two, 'dist'), merged_gpu(one, 'dist'), equal_nan=True)
+    assert np.array_equal(merged_gpu(two, 'rho'), merged_gpu(one, 'rho'), equal_nan=True)

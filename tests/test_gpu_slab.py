@@ -108,3 +108,62 @@ def test_single_slab_ring_of_one(pattern, axis):
         s.sync()
         res.append(s.real_view(s.get_dist()))
     assert np.array_equal(res[0], res[1])
+
+
+def _ring_of_one(axis, pattern, n, steps, env=None, model='bgk', restore_at=None):
+    """Populations after `steps` steps of one slab that is its own ring neighbour (plain device copies: a transport a
+    step plan can hold), under the environment switches `env`."""
+    import os
+    from sailfish_amd.backend_hip import HIPBackend
+    from sailfish_amd.connector import RingExchanger
+    from sailfish_amd.slab import SlabSim
+
+    class Opt(object):
+        pass
+    old = dict((k, os.environ.get(k)) for k in (env or {}))
+    os.environ.update(env or {})
+    try:
+        s = SlabSim(HIPBackend(Opt(), 0), sym.D3Q19, n, rank=0, world=1, access_pattern=pattern, visc=0.02, axis=axis,
+                    model=model, force_halo=True, exchanger=RingExchanger(0, 1))
+        s.init_synthetic(seed=3)
+        for i in range(steps):
+            if restore_at is not None and i == restore_at:
+                s.set_dist(s.get_dist())        # a state written from the host in the middle of the run
+            s.step(save_macro=(i == steps - 1))
+        s.sync()
+        planned = sorted(s._plans)
+        rho, v = s.fetch_fields()
+        return s.real_view(s.get_dist()), s.real_view(rho).copy(), planned
+    finally:
+        for k, v_ in old.items():
+            if v_ is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v_
+
+
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+@pytest.mark.parametrize('axis', ['x', 'y', 'z'])
+def test_step_plan_equals_direct_enqueue(pattern, axis):
+    """The step replayed from a C-ABI plan (slf_plan_run), enqueued entry by entry from Python, and on one calc stream
+    instead of two: the same populations and fields, bit for bit (four z-chunks along x)."""
+    n = (64, 10, 40)
+    ref, ref_rho, planned = _ring_of_one(axis, pattern, n, 9)
+    assert planned == [(0, 0), (0, 1), (1, 0)]           # both parities, the last step with field output
+    for env in ({'SLF_STEP_PLAN': '0'}, {'SLF_STEP_PLAN': '0', 'SLF_CALC_STREAMS': '1'}, {'SLF_CALC_STREAMS': '1'},
+                {'SLF_XFACE_CHUNKS': '2'}, {'SLF_XFACE_CHUNKS': '1'}, {'SLF_XFACE_STREAMS': '2'}):
+        got, got_rho, planned = _ring_of_one(axis, pattern, n, 9, env)
+        assert (planned == []) == (env.get('SLF_STEP_PLAN') == '0')
+        assert np.array_equal(got, ref), env
+        assert np.array_equal(got_rho, ref_rho), env
+
+
+@pytest.mark.parametrize('restore_at', [3, 4])
+def test_x_slab_state_written_at_odd_iteration(restore_at):
+    """a state written from the host (checkpoint restore, set_dist) at an ODD in-place iteration: the next
+    step pulls, and the edge lanes of the fluid-only row kernel do not look into the ghost columns -- the receive
+    buffers are primed from them (XFaceHalo.prime_pull)."""
+    n = (64, 10, 16)
+    ref, _, _ = _ring_of_one('x', 'AA', n, 8)
+    got, _, _ = _ring_of_one('x', 'AA', n, 8, restore_at=restore_at)
+    assert np.array_equal(got, ref)

@@ -110,3 +110,28 @@ def test_controller_branch_two_processes_on_the_gpu(case, monkeypatch):
     got_f, got_rho = _merge(parts, ref_f, ref_rho)
     assert np.array_equal(got_f, ref_f, equal_nan=True)
     assert np.array_equal(got_rho, ref_rho, equal_nan=True)
+
+
+@pytest.mark.parametrize('pattern,axis', [('AA', 'x'), ('AB', 'z')])
+def test_example_starts_its_own_ranks(pattern, axis, tmp_path):
+    """`python examples/ldc_3d.py --subdomains=2 --gpus 0 0` with NO launcher: the controller starts one process per
+    subdomain itself (sailfish_amd/launch.py; reference master.py:242-312) -- two ranks on the one GPU of the box, hence
+    a gloo group -- and the merged output equals the single-subdomain run of the same script."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from utils.merge_subdomains import merge_subdomains
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'SLF_DIST_BACKEND', 'SLF_FORCE_DEVICE'):
+        env.pop(k, None)
+    steps = 9
+    common = ['--lat_nx=40', '--lat_ny=12', '--lat_nz=10', '--visc=0.03', '--max_iters=%d' % steps, '--every=%d' % steps,
+              '--access_pattern=' + pattern, '--conn_axis=' + axis, '--quiet', '--nooutput_compress', '--perf_stats_every=0']
+    for name, extra in (('two', ['--subdomains=2', '--gpus', '0', '0']), ('one', ['--subdomains=1', '--gpus', '0'])):
+        cmd = [sys.executable, os.path.join(ROOT, 'examples', 'ldc_3d.py'), '--output=' + str(tmp_path / name)] + common + extra
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+        assert res.returncode == 0, res.stdout.decode(errors='replace')[-3000:]
+    got = merge_subdomains(str(tmp_path / 'two'), 1, steps, save=False)
+    ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
+    assert set(got) == set(ref) and 'rho' in ref and 'v' in ref
+    for name in ref:
+        assert np.array_equal(got[name], ref[name], equal_nan=True), name

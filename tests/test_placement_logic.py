@@ -142,3 +142,27 @@ def test_placement_by_measurement_keeps_the_best_and_gives_everything_else_back(
     assert len(made) == len(info['times_ms']) and len(released) == len(made) - 1 and best not in released
     mapped = sorted(h for pb in best for h in pb.mapped)
     assert sorted(b.live) == mapped and len(b.mapped) == len(mapped)   # nothing else survives
+
+
+@pytest.mark.parametrize('fail', ['make', 'measure', 'room'])
+def test_placement_by_measurement_survives_a_second_set_that_does_not_fit(fail):
+    """arrays above half of the device memory -- the second set cannot be placed (or probed).  The first,
+    valid set stays and nothing leaks; a failure of the FIRST set is still an error."""
+    made, released = [], []
+
+    def make_set():
+        if fail == 'make' and made:
+            raise RuntimeError('out of memory')
+        made.append(object())
+        return made[-1]
+
+    def measure(bufs):
+        if fail == 'measure' and len(made) > 1:
+            raise RuntimeError('probe failed')
+        return 3.3e-3 if len(made) == 1 else 3.0e-3
+
+    best, info = placement.choose(make_set, measure, released.append, room=(lambda: False) if fail == 'room' else None)
+    assert best is made[0] and info['chosen'] == 0 and info['times_ms'] == [3.3] and 'note' in info
+    assert released == ([made[1]] if fail == 'measure' else [])
+    with pytest.raises(RuntimeError):
+        placement.choose(lambda: (_ for _ in ()).throw(RuntimeError('oom')), measure, released.append)

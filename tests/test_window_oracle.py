@@ -73,3 +73,82 @@ def test_window_detects_a_wrong_value():
     chk.advance(2, save_last=False)
     res = chk.compare(fields=False)
     assert not res['dist_exact'] and res['dist_err'] > 0
+
+
+def _cut(global_box, desc_l, axis, r, n_l, copies, ghost=np.nan):
+    """The arrays slab r of the global oracle box would hold: real nodes copied, ghost layers filled with `ghost`
+    (a seam window must not look at them)."""
+    out = []
+    for c in copies:
+        g = global_box.real_view(global_box.dist[c])
+        sl = [slice(None)] * 4
+        sl[3 - axis] = slice(r * n_l, (r + 1) * n_l)
+        loc = np.full((19, desc_l.arr_nz, desc_l.arr_ny, desc_l.arr_nx), ghost, dtype=np.float32)
+        loc[:, 1:desc_l.lat_nz - 1, 1:desc_l.lat_ny - 1, 1:desc_l.lat_nx - 1] = g[tuple(sl)]
+        out.append(np.ascontiguousarray(loc))
+    return out
+
+
+@pytest.mark.parametrize('axis', [0, 1, 2])
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+@pytest.mark.parametrize('start', [4, 5])
+def test_seam_windows_reach_into_the_neighbouring_slabs(axis, pattern, start):
+    """window.SeamCheck (bench.py's validation of N > 1 runs): a periodic box cut into two slabs; the windows of one
+    slab take three layers of the other through swap() and reproduce the undivided oracle run on the seam layers."""
+    from oracle.window import SeamCheck
+    size_l = [12, 10, 14]
+    size_g = list(size_l)
+    size_g[axis] *= 2
+    kw = dict(model='bgk', precision='single', access_pattern=pattern, visc=0.02)
+    desc_g = make_box_desc(sym.D3Q19, tuple(size_g), periodic_fused=[1, 1, 1], **kw)
+    fused_l = [1, 1, 1]
+    fused_l[axis] = 0
+    desc_l = make_box_desc(sym.D3Q19, tuple(size_l), periodic_fused=fused_l, **kw)
+    o = OracleBox(desc_g, periodic=(True, True, True))
+    rho, v = synthetic_fields(tuple(size_g), 3)
+    o.set_fields(rho, v)
+    o.initial_conditions()
+    o.run(start, save_last=False)
+    copies = range(len(o.dist))
+    before = [_cut(o, desc_l, axis, r, size_l[axis], copies) for r in (0, 1)]
+    E = 3
+    n = size_l[axis]
+
+    def edges(arrs, lo):
+        sl = [slice(None)] * 4
+        sl[3 - axis] = slice(1, 1 + E) if lo else slice(n - E + 1, n + 1)
+        return [np.ascontiguousarray(a[tuple(sl)]) for a in arrs]
+
+    zs = [1, 7, size_l[2]]
+    checks = []
+    for r in (0, 1):
+        other = before[1 - r]
+
+        def swap(low, high, other=other):
+            # a ring of two: both neighbours are the other slab; z: whole layers, x / y: per window [19, W, ...] blocks
+            if axis == 2:
+                return edges(other, False), edges(other, True)
+            down, up = [], []
+            for w in chk.windows:
+                pl = w.planes
+                down.append([np.ascontiguousarray(e[:, pl]) for e in edges(other, False)])
+                up.append([np.ascontiguousarray(e[:, pl]) for e in edges(other, True)])
+            return down, up
+        chk = SeamCheck(HostMemory, desc_l, zs, [a.ctypes.data for a in before[r]], desc_l.arr_nx * desc_l.arr_ny * desc_l.arr_nz,
+                        None, axis, swap)
+        chk.seed(o.iteration)
+        checks.append(chk)
+    o.run(2, save_last=False)
+    after = [_cut(o, desc_l, axis, r, n, copies) for r in (0, 1)]
+    for r, chk in enumerate(checks):
+        chk.advance(2, save_last=False)
+        chk.dist_addrs = [a.ctypes.data for a in after[r]]
+        res = chk.compare(fields=False)
+        assert res['dist_exact'], (r, res)
+        assert res['compared_values'] == 19 * len(zs) * size_l[0] * size_l[1]
+    # and a value spoilt on the seam is seen
+    cur = 0 if pattern == 'AA' else (o.iteration & 1)
+    idx = [5, zs[0], 3, 3]
+    idx[3 - axis] = 1                                        # first real layer along the split axis
+    after[0][cur][tuple(idx)] += np.float32(1e-6)
+    assert not checks[0].compare(fields=False)['dist_exact']
