@@ -252,7 +252,8 @@ def validate(sim, backend, mass0, distributed, axis, rank=0, world=1):
     out['mass_rel_drift'] = abs(tot[0] - mass0[0]) / mass0[0]
     out['momentum_drift_over_mass_u'] = max(abs(a - b) for a, b in zip(tot[1:], mass0[1:])) / (mass0[0] * 0.05)
     out['steps_before_check'] = sim.iteration - 2
-    out['ok'] = bool(out['mass_rel_drift'] < 1e-5 and out['momentum_drift_over_mass_u'] < 1e-4 and
+    # f32 round-off random-walks the totals: 8e-6 after 540 steps at 512^3, 1.6e-5 after 1500; a lost face layer is 2e-3
+    out['ok'] = bool(out['mass_rel_drift'] < 5e-5 and out['momentum_drift_over_mass_u'] < 2e-4 and
                      out.get('populations_bit_identical', True) and out.get('rho_rel_err', 0.0) < 1e-6)
     if distributed:                      # every rank checked its own planes: all of them must agree
         flags = [1.0 if out['ok'] else 0.0, 1.0 if out.get('populations_bit_identical', True) else 0.0]

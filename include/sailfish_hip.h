@@ -50,9 +50,9 @@ enum { SLF_SIM_LBM = 0, SLF_SIM_SHAN_CHEN_BINARY = 1, SLF_SIM_SHAN_CHEN_SINGLE =
  * uint32 table `nodes` maps a node's dense index to its slot or SLF_INVALID_NODE.  Node map and
  * macroscopic fields stay dense.  In an indirect module CollideAndPropagate, SetInitialConditions and
  * ComputeMacroFields -- and, for SLF_SIM_SHAN_CHEN_BINARY, ShanChenPrepareMacroFields and
- * ShanChenCollideAndPropagate0 / 1 (lb_binary.py:121-123, 457-465; the fused sweep is not offered) -- take that table
- * as an additional FIRST pointer argument (as the reference's _add_indirect_args, subdomain_runner.py:1153-1157);
- * periodic boundaries must be wrapped in-sweep.  SLF_SIM_SHAN_CHEN_SINGLE modules are direct only. */
+ * ShanChenCollideAndPropagate0 / 1 (lb_binary.py:121-123, 457-465; the fused sweep is not offered), for
+ * SLF_SIM_SHAN_CHEN_SINGLE PrepareMacroFields as well -- take that table as an additional FIRST pointer argument (as
+ * the reference's _add_indirect_args, subdomain_runner.py:1153-1157); periodic boundaries must be wrapped in-sweep. */
 enum { SLF_ADDR_DIRECT = 0, SLF_ADDR_INDIRECT = 1 };
 
 /* How a body-force / Shan-Chen acceleration a enters the BGK collision (relaxation_common.mako:56-99):
@@ -278,6 +278,22 @@ int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* st
  * populations in bit mask `dirs` of the node box base + c col_stride + r row_stride <-> dense buffer [k][r][c];
  * 'i' arguments, base < 2^32), plus "ComputeMacroFields"
  * (rho / v of the current state, arguments as CollideAndPropagate).
+ * The reference's own face kernels are served under their names AND argument lists as well (a host that binds the
+ * reference's _init_collect_kernels / _init_distrib_kernels, subdomain_runner.py:1160-1290, needs no special case):
+ * "CollectContinuousData" / "DistributeContinuousData" / "CollectContinuousDataWithSwap" /
+ * "DistributeContinuousDataWithSwap"(dist, face, base_gx, base_other, max_lx, max_other, buffer), format "PiiiiiP"
+ * [2-D: (dist, face, base_gx, max_lx, buffer), "PiiiP"] and "CollectContinuousMacroData" /
+ * "DistributeContinuousMacroData"(field, face, base_gx, base_other, max_lx, max_other, buffer) [2-D: (field, base_gx,
+ * max_lx, gy, buffer)] -- kernel_utils.mako:476-953: face = 2 Y_LOW, 3 Y_HIGH, 4 Z_LOW, 5 Z_HIGH; the populations are
+ * get_interblock_dists(grid, normal(face)) in ascending order (their OPPOSITE slots in the ...WithSwap kernels, which
+ * exist in AA modules only); the layer read / written is the reference's lat_linear (Collect: ghost layer of `face`),
+ * lat_linear_macro (CollectWithSwap, CollectMacro: first real layer), lat_linear_dist (Distribute: first real layer of
+ * the far side), lat_linear_with_swap (DistributeWithSwap: ghost layer of the far side), lat_linear (DistributeMacro),
+ * subdomain_runner.py:486-510; buffer [k][other][x], max_other = rows x populations.  Deviation: the reference strides
+ * the rows of the macro buffers by its launch grid's x size (kernel_utils.mako:886, 940); launch geometry is not part
+ * of this boundary, the rows are max_lx apart (dense).  The two forms of Collect / DistributeContinuousData are told
+ * apart by their argument formats.  x faces travel through index lists (or the x-face buffers below) as in the
+ * reference (subdomain_runner.py:1294-1306).
  * Binary Shan-Chen modules (simtype = SLF_SIM_SHAN_CHEN_BINARY) provide instead of CollideAndPropagate:
  * "ShanChenPrepareMacroFields"(map, dist1, dist2, rho, phi, vx, vy[, vz], options),
  * "ShanChenCollideAndPropagate0|1"(map, dist_in, dist_out, rho, phi, vx, vy[, vz], options),

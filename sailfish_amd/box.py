@@ -103,13 +103,14 @@ class BoxSim(object):
         # subdomain_runner.py:278-297)
         self.rho = np.full(self.shape, np.inf, dtype=self.dtype)
         self.v = [np.full(self.shape, np.inf, dtype=self.dtype) for _ in range(self.dim)]
-        self.gpu_rho = b.alloc_buf(like=self.rho)
-        self.gpu_v = [b.alloc_buf(like=a) for a in self.v]
+        foff = b.dist_align_offset(self.dtype().itemsize)      # x = 1 of every field row on a 128-byte line as well
+        self.gpu_rho = b.alloc_buf(like=self.rho, align_offset=foff)
+        self.gpu_v = [b.alloc_buf(like=a, align_offset=foff) for a in self.v]
         self.gpu_map = 0
         self.node_map = None
         if node_map is not None:
             self.node_map = np.ascontiguousarray(node_map, dtype=np.uint32).reshape(self.shape)
-            self.gpu_map = b.alloc_buf(like=self.node_map)
+            self.gpu_map = b.alloc_buf(like=self.node_map, align_offset=b.dist_align_offset(4))
         self.stream = b.make_stream()
         self.row_classes = None
         if self.gpu_map and b.supports_row_classes(desc) and os.environ.get('SLF_ROW_CLASSES', '1') != '0':

@@ -45,6 +45,10 @@ enum KernelKind {
   KK_DISTRIBUTE_SPARSE,
   KK_COLLECT_BOX,
   KK_DISTRIBUTE_BOX,
+  KK_COLLECT_FACE_SWAP,       // reference argument lists (kernel_utils.mako): ...ContinuousDataWithSwap
+  KK_DISTRIBUTE_FACE_SWAP,
+  KK_COLLECT_MACRO_FACE,      // ...ContinuousMacroData
+  KK_DISTRIBUTE_MACRO_FACE,
   KK_COMPUTE_MACRO,
   KK_SC_MACRO,
   KK_SC_SWEEP0,
@@ -616,9 +620,9 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   }
   if (d->node_addressing == SLF_ADDR_INDIRECT) {
     if (d->fluid_only) { delete m; return fail(SLF_ERR_INVALID, "indirect addressing needs the node map (fluid_only = 0)"); }
-    if (d->simtype != SLF_SIM_LBM && d->simtype != SLF_SIM_SHAN_CHEN_BINARY) {
+    if (d->simtype != SLF_SIM_LBM && d->simtype != SLF_SIM_SHAN_CHEN_BINARY && d->simtype != SLF_SIM_SHAN_CHEN_SINGLE) {
       delete m;
-      return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: single-fluid and binary Shan-Chen modules only");
+      return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: unknown simtype");
     }
   }
   m->access_pattern = d->access_pattern;
@@ -697,11 +701,13 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
     for (int i = 0; ok && i < d->n_types; i++) {
       const int k = d->type_kind[i];
       ok = k == SLF_NK_FLUID || k == SLF_NK_GHOST || k == SLF_NK_UNUSED || k == SLF_NK_PROPAGATION_ONLY ||
-           k == SLF_NK_FULL_BB || k == SLF_NK_HALF_BB;
+           k == SLF_NK_FULL_BB || k == SLF_NK_HALF_BB || k == SLF_NK_EQUILIBRIUM_DENSITY || k == SLF_NK_EQUILIBRIUM_VELOCITY;
     }
     if (!ok) {
       delete m;
-      return fail(SLF_ERR_UNSUPPORTED, "minimize_roundoff: BGK single-fluid modules with fluid and bounce-back nodes only");
+      return fail(SLF_ERR_UNSUPPORTED, "minimize_roundoff: BGK single-fluid modules with fluid, bounce-back and equilibrium "
+                                       "density / velocity nodes only (the reference's regularized and Zou-He expressions are "
+                                       "inconsistent under the option)");
     }
     g.variant = 0;       // no tuned / whole-row kernels: they implement the standard formulation
   } else if (d->incompressible != SLF_DENSITY_COMPRESSIBLE && d->incompressible != SLF_DENSITY_INCOMPRESSIBLE) {
@@ -903,6 +909,10 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   else if (!strcmp(name, "DistributeSparseData")) kk = KK_DISTRIBUTE_SPARSE;
   else if (!strcmp(name, "CollectContinuousData")) kk = KK_COLLECT_BOX;
   else if (!strcmp(name, "DistributeContinuousData")) kk = KK_DISTRIBUTE_BOX;
+  else if (!strcmp(name, "CollectContinuousDataWithSwap")) kk = KK_COLLECT_FACE_SWAP;
+  else if (!strcmp(name, "DistributeContinuousDataWithSwap")) kk = KK_DISTRIBUTE_FACE_SWAP;
+  else if (!strcmp(name, "CollectContinuousMacroData")) kk = KK_COLLECT_MACRO_FACE;
+  else if (!strcmp(name, "DistributeContinuousMacroData")) kk = KK_DISTRIBUTE_MACRO_FACE;
   else if (!strcmp(name, "ComputeMacroFields")) kk = KK_COMPUTE_MACRO;
   else return fail(SLF_ERR_NOT_FOUND, std::string("unknown kernel: ") + name);
   if (kk == KK_SCS_MACRO && m->sc.enabled != 2)
@@ -916,6 +926,12 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
                                      "(periodic_fused), there are no ghost-layer PBC kernels");
   if (kk == KK_PBC_SWAP && m->access_pattern != SLF_AA)
     return fail(SLF_ERR_NOT_FOUND, "ApplyPeriodicBoundaryConditionsWithSwap only exists for the AA access pattern");
+  if ((kk == KK_COLLECT_FACE_SWAP || kk == KK_DISTRIBUTE_FACE_SWAP) && m->access_pattern != SLF_AA)
+    return fail(SLF_ERR_NOT_FOUND, "Collect / DistributeContinuousDataWithSwap only exist for the AA access pattern "
+                                   "(reference kernel_utils.mako:536, 638, 700, 786)");
+  if ((kk == KK_COLLECT_FACE_SWAP || kk == KK_DISTRIBUTE_FACE_SWAP || kk == KK_COLLECT_MACRO_FACE ||
+       kk == KK_DISTRIBUTE_MACRO_FACE) && m->geo.indirect)
+    return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: halo through index lists (Collect / DistributeSparseData)");
   slf_kernel* k = new slf_kernel;
   k->mod = m;
   k->kind = kk;
@@ -958,6 +974,23 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_DISTRIBUTE_BOX:                                       // dist, buffer, dirs, base, col_stride, ncols, row_stride, nrows
       want_p = 2;                                                 // [, buffer stride between directions, between rows]
       want_i = (k->ints.size() == 8) ? 8 : 6;
+      // ... or the reference's own argument list (kernel_utils.mako:526-543, 629-645, 692-708, 777-793):
+      // 3-D (dist, face, base_gx, base_other, max_lx, max_other, buffer), 2-D (dist, face, base_gx, max_lx, buffer)
+      if (k->ints.size() == (dim == 3 ? 5u : 3u)) {
+        want_i = k->ints.size();
+        if (strcmp(fmt, dim == 3 ? "PiiiiiP" : "PiiiP")) return fail(SLF_ERR_INVALID, "reference form: the buffer is the last argument");
+        if (k->mod->geo.indirect) return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: halo through index lists");
+      }
+      break;
+    case KK_COLLECT_FACE_SWAP:
+    case KK_DISTRIBUTE_FACE_SWAP:                                 // as the reference form above
+      want_p = 2; want_i = dim == 3 ? 5 : 3;
+      if (strcmp(fmt, dim == 3 ? "PiiiiiP" : "PiiiP")) return fail(SLF_ERR_INVALID, "arguments: (dist, face, base_gx[, base_other], max_lx[, max_other], buffer)");
+      break;
+    case KK_COLLECT_MACRO_FACE:
+    case KK_DISTRIBUTE_MACRO_FACE:                                // 3-D (field, face, base_gx, base_other, max_lx, max_other, buffer)
+      want_p = 2; want_i = dim == 3 ? 5 : 3;                      // 2-D (field, base_gx, max_lx, gy, buffer)   kernel_utils.mako:839-953
+      if (strcmp(fmt, dim == 3 ? "PiiiiiP" : "PiiiP")) return fail(SLF_ERR_INVALID, "arguments: (field, [face,] base_gx, ..., buffer)");
       break;
     case KK_SC_MACRO:
     case KK_SC_SWEEP0:
@@ -971,7 +1004,8 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: the binary model runs its two per-lattice sweeps");
   if (k->mod->geo.indirect && (k->kind == KK_COLLIDE_AND_PROPAGATE || k->kind == KK_COMPUTE_MACRO ||
                                k->kind == KK_SET_INITIAL_CONDITIONS || k->kind == KK_SC_MACRO ||
-                               k->kind == KK_SC_SWEEP0 || k->kind == KK_SC_SWEEP1 || k->kind == KK_SC_INIT))
+                               k->kind == KK_SC_SWEEP0 || k->kind == KK_SC_SWEEP1 || k->kind == KK_SC_INIT ||
+                               k->kind == KK_SCS_MACRO || k->kind == KK_SCS_SWEEP))
     want_p += 1;   // leading `nodes` table (reference _add_indirect_args, subdomain_runner.py:1153-1157)
   if (k->ptrs.size() != want_p || k->ints.size() != want_i)
     return fail(SLF_ERR_INVALID, "argument list does not match the kernel's signature");
@@ -1110,23 +1144,25 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
     case KK_SCS_MACRO:
     case KK_SCS_SWEEP: {
       slf::SweepArgs a = {};
-      a.nodes = nullptr;
-      a.map = (const void*)k->ptrs[0];
-      a.dist_in = (void*)k->ptrs[1];
+      const int b0 = g.indirect ? 1 : 0;     // indirect: the `nodes` table leads the list (reference _add_indirect_args)
+      a.nodes = g.indirect ? (const void*)k->ptrs[0] : nullptr;
+      if (g.indirect && !a.nodes) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
+      a.map = (const void*)k->ptrs[b0 + 0];
+      a.dist_in = (void*)k->ptrs[b0 + 1];
       a.phi = nullptr;
       a.node_params = m->node_params;
       a.status = m->status;
       a.options = (uint32_t)k->ints[0];
       if (k->kind == KK_SCS_MACRO) {
         a.dist_out = nullptr;
-        a.rho = (void*)k->ptrs[2];
+        a.rho = (void*)k->ptrs[b0 + 2];
         a.v[0] = a.v[1] = a.v[2] = nullptr;
       } else {
-        a.dist_out = (void*)k->ptrs[2];
-        a.rho = (void*)k->ptrs[3];
-        a.v[0] = (void*)k->ptrs[4];
-        a.v[1] = (void*)k->ptrs[5];
-        a.v[2] = g.dim == 3 ? (void*)k->ptrs[6] : nullptr;
+        a.dist_out = (void*)k->ptrs[b0 + 2];
+        a.rho = (void*)k->ptrs[b0 + 3];
+        a.v[0] = (void*)k->ptrs[b0 + 4];
+        a.v[1] = (void*)k->ptrs[b0 + 5];
+        a.v[2] = g.dim == 3 ? (void*)k->ptrs[b0 + 6] : nullptr;
       }
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       slf::Prop prop = slf::PROP_AB;
@@ -1179,11 +1215,76 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       break;
     case KK_COLLECT_BOX:
     case KK_DISTRIBUTE_BOX:
-      e = slf::launch_box(m->sel, g, k->kind == KK_COLLECT_BOX, (void*)k->ptrs[0], (void*)k->ptrs[1],
-                          (unsigned int)k->ints[0], (unsigned long long)(uint32_t)k->ints[1], (long long)k->ints[2],
-                          (int)k->ints[3], (long long)k->ints[4], (int)k->ints[5],
-                          k->ints.size() == 8 ? (long long)k->ints[6] : 0, k->ints.size() == 8 ? (long long)k->ints[7] : 0, s);
+      if (k->ints.size() >= 6) {
+        int dirs[32], nd = 0;
+        for (int q = 0; q < 32; q++) if (((unsigned int)k->ints[0] >> q) & 1u) dirs[nd++] = q;    // ascending
+        e = slf::launch_box(m->sel, g, k->kind == KK_COLLECT_BOX, (void*)k->ptrs[0], (void*)k->ptrs[1], dirs, nd,
+                            (unsigned long long)(uint32_t)k->ints[1], (long long)k->ints[2], (int)k->ints[3],
+                            (long long)k->ints[4], (int)k->ints[5], k->ints.size() == 8 ? (long long)k->ints[6] : 0,
+                            k->ints.size() == 8 ? (long long)k->ints[7] : 0, false, s);
+        break;
+      }
+      [[fallthrough]];
+    case KK_COLLECT_FACE_SWAP:
+    case KK_DISTRIBUTE_FACE_SWAP:
+    case KK_COLLECT_MACRO_FACE:
+    case KK_DISTRIBUTE_MACRO_FACE: {
+      // The reference's face kernels (kernel_utils.mako:476-953), mapped onto the box kernel.  face: 2 Y_LOW, 3 Y_HIGH,
+      // 4 Z_LOW, 5 Z_HIGH (subdomain.py:30-36); the layer a kernel reads / writes is lat_linear / lat_linear_macro /
+      // lat_linear_dist / lat_linear_with_swap of subdomain_runner.py:486-510; the populations are
+      // get_interblock_dists(grid, normal(face)) in ascending order -- their opposite slots in the ...WithSwap kernels --
+      // buffer [k][other][x] (2-D: [k][x]).
+      const bool collect = k->kind == KK_COLLECT_BOX || k->kind == KK_COLLECT_FACE_SWAP || k->kind == KK_COLLECT_MACRO_FACE;
+      const bool swap = k->kind == KK_COLLECT_FACE_SWAP || k->kind == KK_DISTRIBUTE_FACE_SWAP;
+      const bool macro = k->kind == KK_COLLECT_MACRO_FACE || k->kind == KK_DISTRIBUTE_MACRO_FACE;
+      int face, base_gx, base_other = 0, max_lx, max_other = 1, layer = -1;
+      if (g.dim == 3) {
+        face = (int)k->ints[0]; base_gx = (int)k->ints[1]; base_other = (int)k->ints[2];
+        max_lx = (int)k->ints[3]; max_other = (int)k->ints[4];
+      } else if (macro) {
+        face = 2; base_gx = (int)k->ints[0]; max_lx = (int)k->ints[1]; layer = (int)k->ints[2];
+      } else {
+        face = (int)k->ints[0]; base_gx = (int)k->ints[1]; max_lx = (int)k->ints[2];
+      }
+      if (face < 2 || face >= 2 * g.dim) return fail(SLF_ERR_INVALID, "face must be a Y or Z face (X faces travel through index lists / x-face buffers)");
+      const int axis = face >> 1;
+      const bool low = (face & 1) == 0;
+      const int lat = axis == 1 ? g.lat_ny : g.lat_nz;
+      if (layer < 0) {
+        if (macro) layer = collect ? (low ? 1 : lat - 2) : (low ? 0 : lat - 1);             // lat_linear_macro / lat_linear
+        else if (collect) layer = swap ? (low ? 1 : lat - 2) : (low ? 0 : lat - 1);        // lat_linear_macro / lat_linear
+        else layer = swap ? (low ? lat - 1 : 0) : (low ? lat - 2 : 1);                     // lat_linear_with_swap / lat_linear_dist
+      }
+      int dirs[32], nd = 0;
+      if (macro) {
+        dirs[nd++] = 0;
+      } else {
+        const int sign = low ? -1 : 1;
+        for (int q = 1; q < (g.dim == 3 ? 19 : 9); q++) {
+          const int ea = g.dim == 3 ? slf::e_comp<slf::D3Q19>(q, axis) : slf::e_comp<slf::D2Q9>(q, axis);
+          if (ea == sign) dirs[nd++] = swap ? (g.dim == 3 ? slf::D3Q19::opp(q) : slf::D2Q9::opp(q)) : q;
+        }
+      }
+      int ncols, nrows;
+      if (g.dim == 3) {
+        if (max_other % nd) return fail(SLF_ERR_INVALID, "max_other must be a multiple of the number of populations that cross the face");
+        ncols = max_lx; nrows = max_other / nd;
+      } else {
+        if (!macro && max_lx % nd) return fail(SLF_ERR_INVALID, "max_lx must be a multiple of the number of populations that cross the face");
+        ncols = macro ? max_lx : max_lx / nd; nrows = 1;
+      }
+      const long long row_stride = axis == 1 ? (long long)g.arr_nxy : (long long)g.arr_nx;   // rows run along the other axis
+      const unsigned long long base = (unsigned long long)base_gx +
+          (axis == 1 ? (unsigned long long)g.arr_nx * layer + (unsigned long long)g.arr_nxy * base_other
+                     : (unsigned long long)g.arr_nx * base_other + (unsigned long long)g.arr_nxy * layer);
+      if (base_gx < 0 || base_gx + ncols > g.arr_nx || base_other < 0 || layer >= lat)
+        return fail(SLF_ERR_INVALID, "face box outside the subdomain");
+      slf::Geometry gm = g;
+      if (macro) gm.dist_size = 0;
+      e = slf::launch_box(m->sel, gm, collect, (void*)k->ptrs[0], (void*)k->ptrs[1], dirs, nd, base, 1, ncols, row_stride, nrows,
+                          0, 0, macro, s);
       break;
+    }
     case KK_COLLECT_SPARSE:
     case KK_DISTRIBUTE_SPARSE:
       e = slf::launch_sparse(m->sel, k->kind == KK_COLLECT_SPARSE, (const unsigned long long*)k->ptrs[0],

@@ -9,7 +9,7 @@
 //       (the even step touches only the node's own slots -> every access is aligned)
 //   8   x-streaming steps (odd AA, AB) use the whole-row kernel with aligned accesses
 // Populations are streamed exactly once per step: every access carries the non-temporal hint (NT).
-#include "slf_sweep.h"
+#include "slf_rowpush.h"
 
 namespace slf {
 
@@ -220,16 +220,16 @@ fast_row_kernel(const SweepParams<D3Q19, float> p) {
     static_for<0, NSEG>([&](auto S) {
       int kp = 0, km = 0;
       static_for<1, L::Q>([&](auto I) {
+        // one DPP wave shift per direction (slf_rowpush.h: lane_shift1); the lane without a source takes the word the
+        // neighbouring wave left in LDS (a wave-uniform slot: every lane reads the same address) -- the row's first
+        // node the wrap word; x = nx need not be lane 63 (nx % 64 != 0)
         if constexpr (L::ex(I) > 0) {
-          float t = __shfl_up(f[S][I], 1);
-          if (lane == 0 && vw[S] > 0) t = s_in_p[vw[S] - 1][kp];
-          if (x[S] == 1) t = s_inw_p[kp];
-          f[S][I] = t;
+          const float edge = (vw[S] == 0) ? s_inw_p[kp] : s_in_p[(vw[S] - 1) & (NW - 1)][kp];
+          f[S][I] = lane_shift1<float, true>(edge, f[S][I]);
           kp++;
         }
         if constexpr (L::ex(I) < 0) {
-          float t = __shfl_down(f[S][I], 1);
-          if (lane == 63) t = s_in_m[(vw[S] + 1) & (NW - 1)][km];
+          float t = lane_shift1<float, false>(s_in_m[(vw[S] + 1) & (NW - 1)][km], f[S][I]);
           if (x[S] == nx) t = s_inw_m[km];
           f[S][I] = t;
           km++;
@@ -285,13 +285,11 @@ fast_row_kernel(const SweepParams<D3Q19, float> p) {
       static_for<0, NSEG>([&](auto S) {
         float t = f[S][I];
         if constexpr (L::ex(I) > 0) {
-          t = __shfl_up(f[S][I], 1);
-          if (lane == 0 && vw[S] > 0) t = s_out_p[vw[S] - 1][kp];
-          if (x[S] == 1) t = s_wrap_p[kp];
+          const float edge = (vw[S] == 0) ? s_wrap_p[kp] : s_out_p[(vw[S] - 1) & (NW - 1)][kp];
+          t = lane_shift1<float, true>(edge, f[S][I]);
         }
         if constexpr (L::ex(I) < 0) {
-          t = __shfl_down(f[S][I], 1);
-          if (lane == 63) t = s_out_m[(vw[S] + 1) & (NW - 1)][km];
+          t = lane_shift1<float, false>(s_out_m[(vw[S] + 1) & (NW - 1)][km], f[S][I]);
           if (x[S] == nx) t = s_wrap_m[km];
         }
         if (live[S]) stg<NT>(at_byte(base, xb[S]), t);

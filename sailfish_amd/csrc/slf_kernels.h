@@ -116,8 +116,8 @@ hipError_t launch_sparse(const KernelSelector& sel, bool collect, const unsigned
                          int n, hipStream_t s);
 
 hipError_t launch_box(const KernelSelector& sel, const Geometry& g, bool collect, void* dist, void* buffer,
-                      unsigned int dirs, unsigned long long base, long long col_stride, int ncols, long long row_stride,
-                      int nrows, long long buf_k_stride, long long buf_row_stride, hipStream_t s);
+                      const int* dirs, int nd, unsigned long long base, long long col_stride, int ncols, long long row_stride,
+                      int nrows, long long buf_k_stride, long long buf_row_stride, bool deliver_all, hipStream_t s);
 
 hipError_t launch_macro(const KernelSelector& sel, Prop prop, const Geometry& g, const Physics& ph,
                         const SweepArgs& a, hipStream_t s);

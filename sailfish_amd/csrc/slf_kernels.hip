@@ -257,41 +257,43 @@ __global__ void __launch_bounds__(256) sparse_kernel(const unsigned long long* _
 // wave moves whole contiguous row segments; x faces (col_stride = arr_nx) are a strided gather / scatter, still
 // without the 8 bytes of index per 4 bytes of payload of the sparse kernels.
 template <class R, bool COLLECT>
-__global__ void __launch_bounds__(256) box_kernel(R* dist, R* buffer, size_t dq, unsigned int dirs, unsigned long long base,
+__global__ void __launch_bounds__(256) box_kernel(R* dist, R* buffer, size_t dq, unsigned long long dirlist, unsigned long long base,
                                                   long long col_stride, int ncols, long long row_stride, int nrows,
-                                                  long long buf_k_stride, long long buf_row_stride) {
+                                                  long long buf_k_stride, long long buf_row_stride, int deliver_all) {
   const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int r = (int)blockIdx.y;
   if (c >= ncols) return;
-  unsigned int m = dirs;
-  for (int i = 0; i < (int)blockIdx.z; i++) m &= m - 1u;      // the blockIdx.z-th set bit
-  const int q = __ffs(m) - 1;
+  const int q = (int)((dirlist >> (5u * blockIdx.z)) & 31ull);  // the blockIdx.z-th direction of the list (5 bits each)
   R* node = dist + dq * (size_t)q + base + (size_t)((long long)c * col_stride + (long long)r * row_stride);
   R* slot = buffer + (size_t)blockIdx.z * (size_t)buf_k_stride + (size_t)r * (size_t)buf_row_stride + (size_t)c;
   if constexpr (COLLECT) {
     *slot = *node;
   } else {
     const R val = *slot;
-    if (slf_isfinite(val)) *node = val;      // sentinels are not delivered (as sparse_kernel / the PBC kernels)
+    if (deliver_all || slf_isfinite(val)) *node = val;   // populations: sentinels are not delivered (as sparse_kernel / the PBC kernels)
   }
 }
 
+// dirs: the directions whose layers travel, in buffer order (at most 12, 5 bits each in the kernel argument).
 hipError_t launch_box(const KernelSelector& sel, const Geometry& g, bool collect, void* dist, void* buffer,
-                      unsigned int dirs, unsigned long long base, long long col_stride, int ncols, long long row_stride,
-                      int nrows, long long buf_k_stride, long long buf_row_stride, hipStream_t s) {
+                      const int* dirs, int nd, unsigned long long base, long long col_stride, int ncols, long long row_stride,
+                      int nrows, long long buf_k_stride, long long buf_row_stride, bool deliver_all, hipStream_t s) {
   if (buf_k_stride <= 0) buf_k_stride = (long long)nrows * ncols;     // dense [k][r][c]
   if (buf_row_stride <= 0) buf_row_stride = ncols;
-  const int nd = __builtin_popcount(dirs);
-  if (nd == 0 || ncols <= 0 || nrows <= 0) return hipSuccess;
+  if (nd <= 0 || ncols <= 0 || nrows <= 0) return hipSuccess;
+  if (nd > 12) return hipErrorInvalidValue;
+  unsigned long long dirlist = 0;
+  for (int i = 0; i < nd; i++) dirlist |= (unsigned long long)(dirs[i] & 31) << (5 * i);
   dim3 block(256, 1, 1);
   dim3 grid((ncols + 255) / 256, nrows, nd);
   const size_t dq = g.dist_size;
+  const int all = deliver_all ? 1 : 0;
   if (sel.precision == 4) {
-    if (collect) hipLaunchKernelGGL((box_kernel<float, true>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
-    else hipLaunchKernelGGL((box_kernel<float, false>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
+    if (collect) hipLaunchKernelGGL((box_kernel<float, true>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirlist, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride, all);
+    else hipLaunchKernelGGL((box_kernel<float, false>), grid, block, 0, s, (float*)dist, (float*)buffer, dq, dirlist, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride, all);
   } else {
-    if (collect) hipLaunchKernelGGL((box_kernel<double, true>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
-    else hipLaunchKernelGGL((box_kernel<double, false>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirs, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride);
+    if (collect) hipLaunchKernelGGL((box_kernel<double, true>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirlist, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride, all);
+    else hipLaunchKernelGGL((box_kernel<double, false>), grid, block, 0, s, (double*)dist, (double*)buffer, dq, dirlist, base, col_stride, ncols, row_stride, nrows, buf_k_stride, buf_row_stride, all);
   }
   return hipGetLastError();
 }

@@ -356,25 +356,31 @@ sc_fused_kernel(const ScParams<L, R> p) {
 
 // ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
 // PrepareMacroFields: density of every wet node
-template <class L, class R, int PROP, bool GENERAL>
+template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false>
 __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   bool live;
   const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live);
   if (!live) return;
+  uint32_t si = n.gi;
+  if constexpr (INDIRECT) {
+    si = p.nodes[n.gi];
+    if (si == INVALID_NODE) return;
+  }
   if constexpr (GENERAL) {
     const uint32_t code = p.map[n.gi];
     const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
     if (kind_is_excluded(kind)) return;
   }
   R f[L::Q];
-  sc_load<L, R, PROP>(f, p.d_in, g.dist_size, n);
+  sc_load<L, R, PROP, INDIRECT>(f, p.d_in, g.dist_size, n, p.nodes, si);
   p.rho0[n.gi] = density<L, R>(f);
 }
 
 // CollideAndPropagate with the self-interaction force F = -G psi(rho(x)) sum_i w_i e_i psi(rho(x + e_i))
-template <class L, class R, int PROP, bool GENERAL, bool ROW = false>
+template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool INDIRECT = false>
 __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p) {
+  static_assert(!(ROW && INDIRECT), "indirect addressing: per-node kernels only");
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
@@ -383,6 +389,11 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
     if (!live) return;
   }
   const uint32_t gi = n.gi;
+  uint32_t si = gi;
+  if constexpr (INDIRECT) {
+    si = p.nodes[gi];
+    if (si == INVALID_NODE) return;
+  }
   int kind = NK_FLUID;
   bool active = live;
   if constexpr (GENERAL) {
@@ -397,7 +408,7 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
   const bool wet = kind_is_wet(kind) && active;
   const size_t ds = g.dist_size;
   R f[L::Q];
-  sc_load<L, R, PROP>(f, p.d_in, ds, n);
+  sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
   R rho, v[3];
   macro_standard<L, R>(f, false, rho, v);
   R a[3] = {(R)0, (R)0, (R)0};
@@ -419,7 +430,7 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
     p.vy[gi] = v[1];
     if constexpr (L::dim == 3) p.vz[gi] = v[2];
   }
-  sc_store<L, R, PROP, GENERAL, ROW>(g, f, p.d_out, ds, n, nx, live, active);
+  sc_store<L, R, PROP, GENERAL, ROW, INDIRECT>(g, f, p.d_out, ds, n, nx, live, active, p.nodes, si);
 }
 
 // f1 = feq(rho, v), f2 = feq(phi, v) on every node (no type test)
@@ -627,11 +638,22 @@ static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometr
   p.G[0] = (R)sc.G[0];
   p.G[1] = (R)0;
   const int nx = g.lat_nx - 2;
-  const bool row = !macro && L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
+  const bool row = !macro && L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN && !g.indirect;
   if (row) block_x = row_block_x(nx);
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  if (g.indirect) {      // active-node slots: per-node kernels with translated neighbours (the node map is always read)
+    if (macro) {
+      if (prop == PROP_AA_ODD) hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AA_ODD, true, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AB, true, true>), grid, block, 0, s, p);
+    } else {
+      if (prop == PROP_AB) hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AB, true, false, true>), grid, block, 0, s, p);
+      else if (prop == PROP_AA_EVEN) hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_EVEN, true, false, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_ODD, true, false, true>), grid, block, 0, s, p);
+    }
+    return hipGetLastError();
+  }
   if constexpr (L::dim == 3) {
     if (row) {
       if (prop == PROP_AB) {

@@ -272,7 +272,45 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
   (void)ds;
   if constexpr (ROUNDOFF) {
     wet = GENERAL ? kind_is_wet(kind) : true;
-    macro_roundoff<L, R>(f, rho, v);
+    // equilibrium density / velocity nodes (boundary.mako:425-459, 492-504 with config.minimize_roundoff: the sum of the
+    // shifted populations is rho - 1; the imposed density enters as par_rho - 1; sym.py:573-682): the two boundary
+    // conditions whose reference expressions are consistent under the option (the regularized / Zou-He nodes are not:
+    // ex_eq_flux keeps multiplying by the density DELTA, DESIGN.md §9 -- refused at module creation)
+    bool bc = false;
+    if constexpr (GENERAL) {
+      const int orientation = (int)(code >> g.orient_shift);
+      if ((kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY) && orientation != 0) {
+        const int pidx = (int)((code >> g.param_shift) & g.param_mask);
+        bc = true;
+        with_orientation<L>(orientation, [&](auto O) {
+          fill_missing_with_opposite<L, R, O>(f);
+          const R rs = density<L, R>(f);
+          if (kind == NK_EQUILIBRIUM_DENSITY) {
+            const R par_rho = p.node_params[pidx];
+            const R t = ((rs + (R)1) - par_rho) / par_rho;
+            constexpr int n = L::dir2vecidx(O);
+            v[0] = v[1] = v[2] = (R)0;
+            static_for<0, L::dim>([&](auto D) {
+              constexpr int e = e_comp<L>(n, D);
+              if constexpr (e > 0) v[D] = (R)0 - t;
+              if constexpr (e < 0) v[D] = t;
+            });
+            rho = par_rho - (R)1;
+          } else {
+            v[0] = p.node_params[pidx];
+            v[1] = p.node_params[pidx + 1];
+            v[2] = (R)0;
+            if constexpr (L::dim == 3) v[2] = p.node_params[pidx + 2];
+            const R nv = ndotv<L, R, O>(v);
+            rho = (rs + nv) / ((R)1 - nv);
+          }
+        });
+      }
+    }
+    if (!bc) macro_roundoff<L, R>(f, rho, v);
+    if (GENERAL && (kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY)) {
+      set_equilibrium<L, R>(f, rho, rho + (R)1, v);          // boundary.mako:797-809 with rho0 = rho + 1
+    }
     if (GENERAL && kind == NK_FULL_BB) bounce_back<L, R>(f);
     if (wet && p.relaxation_enabled)
       bgk_relax_roundoff<L, R>(f, rho, v, p.cp.omega, p.cp.guo_pref, p.cp.has_force != 0, p.cp.accel, p.cp.force_edm != 0);

@@ -47,7 +47,8 @@ class LBFluidSim(LBSim):
         return hipabi.SLF_DENSITY_COMPRESSIBLE
 
     ROUNDOFF_KINDS = (hipabi.SLF_NK_FLUID, hipabi.SLF_NK_GHOST, hipabi.SLF_NK_UNUSED, hipabi.SLF_NK_PROPAGATION_ONLY,
-                      hipabi.SLF_NK_FULL_BB, hipabi.SLF_NK_HALF_BB)
+                      hipabi.SLF_NK_FULL_BB, hipabi.SLF_NK_HALF_BB, hipabi.SLF_NK_EQUILIBRIUM_DENSITY,
+                      hipabi.SLF_NK_EQUILIBRIUM_VELOCITY)
 
     @classmethod
     def check_module_desc(cls, kw):
@@ -56,8 +57,9 @@ class LBFluidSim(LBSim):
         if kw.get('incompressible') == hipabi.SLF_DENSITY_ROUNDOFF:
             bad = [k for k in kw.get('type_kind', []) if k not in cls.ROUNDOFF_KINDS]
             if bad:
-                raise NotImplementedError('--minimize_roundoff: fluid and bounce-back nodes only (node kinds %s are not '
-                                          'covered; the reference says "BGK-like models")' % sorted(set(bad)))
+                raise NotImplementedError('--minimize_roundoff: fluid, bounce-back and equilibrium density / velocity nodes '
+                                          'only (node kinds %s are not covered: the reference\'s own regularized / Zou-He '
+                                          'expressions are inconsistent under the option, DESIGN.md)' % sorted(set(bad)))
 
     def initial_conditions(self, runner):
         """f = feq(rho, v) on every copy of the distributions (reference lb_single.py:72-94)."""
@@ -164,7 +166,9 @@ class LBSingleFluidShanChen(LBFluidSim, LBForcedSim):
         gpu_map = runner.gpu_geo_map()
         options = np.uint32((1 if full_output else 0) | (2 if bulk else 0))
         ni = self.config.needs_iteration_num
-        macro_kernels = [runner.get_kernel('PrepareMacroFields', [gpu_map, runner.gpu_dist(0, c), gpu_rho, options],
-                                           'PPPi', needs_iteration=ni) for c in (0, 1)]
+        macro_kernels = []
+        for c in (0, 1):
+            args, sig = runner.add_indirect_args([gpu_map, runner.gpu_dist(0, c), gpu_rho, options], 'PPPi')
+            macro_kernels.append(runner.get_kernel('PrepareMacroFields', args, sig, needs_iteration=ni))
         sim_kernels = super(LBSingleFluidShanChen, self).get_compute_kernels(runner, full_output, bulk)
         return list(zip(macro_kernels, sim_kernels))

@@ -278,12 +278,17 @@ class SubdomainRunner(object):
     def _init_gpu_data(self):
         self._alloc_distributions()     # first: placed arrays want an allocator that has handed out nothing yet
         b = self.backend
+        # fields and node map: x = 1 of every row on a 128-byte line, like the distributions (the sweeps read / store them
+        # with the lane offsets of the populations: aligned accesses, 8-byte ones in the two-nodes-per-thread kernels)
+        def aligned(host):
+            kw = {'align_offset': b.dist_align_offset(host.dtype.itemsize)} if hasattr(b, 'dist_align_offset') else {}
+            return b.alloc_buf(like=host, **kw)
         for field in self._scalar_fields:
-            self._gpu_field_map[id(field)] = b.alloc_buf(like=self._host_base[id(field)])
+            self._gpu_field_map[id(field)] = aligned(self._host_base[id(field)])
         for vec in self._vector_fields:
             for comp in vec:
-                self._gpu_field_map[id(comp)] = b.alloc_buf(like=self._host_base[id(comp)])
-        self._gpu_geo_map = b.alloc_buf(like=self._host_base[id(self._subdomain._type_map_ghost)])
+                self._gpu_field_map[id(comp)] = aligned(self._host_base[id(comp)])
+        self._gpu_geo_map = aligned(self._host_base[id(self._subdomain._type_map_ghost)])
         self.row_classes = None
         if getattr(b, 'supports_row_classes', None) and b.supports_row_classes(self._desc) and \
                 getattr(self.config, 'hip_row_classes', True) and os.environ.get('SLF_ROW_CLASSES', '1') != '0':

@@ -108,3 +108,30 @@ def make_wall_sim(dim, seed=11, amplitude=1e-3, wall=4):
         subdomain = Walled
 
     return Sim, geo
+
+
+def make_single_wall_sim(dim, wall=4, **kw):
+    """Single-component vapour between two solid slabs with a solid block in the channel (as make_wall_sim)."""
+    from sailfish_amd.node_type import NTFullBBWall
+    base, geo = make_single_sim(dim, **kw)
+    sub = base.subdomain
+
+    class Walled(sub):
+        def _solid(self, *h):
+            hy, hx = h[1], h[0]
+            solid = (hy < wall) | (hy >= self.gy - wall)
+            block = (hx >= 5) & (hx < 9) & (hy >= wall + 2) & (hy < wall + 6)
+            if dim == 3:
+                block = block & (h[2] >= 1) & (h[2] < 5)
+            return solid | block
+
+        def boundary_conditions(self, *h):
+            self.set_node(self._solid(*h), NTFullBBWall)
+
+        def load_active_node_map(self, *h):
+            self.set_active_node_map_from_wall_map(self._solid(*h))
+
+    class Sim(base):
+        subdomain = Walled
+
+    return Sim, geo

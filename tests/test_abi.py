@@ -70,3 +70,24 @@ def test_single_hip_runtime(order):
              "print(len(set(re.findall(r'/\\S*libamdhip64[^\\s]*', m))), len(set(re.findall(r'/\\S*libhsa-runtime64[^\\s]*', m))))")
     out = subprocess.check_output([sys.executable, '-c', code], cwd=ROOT).split()
     assert [int(x) for x in out[-2:]] == [1, 1]
+
+
+# every in-scope `${kernel}` of sailfish/templates/, under the reference's own name
+REFERENCE_KERNELS = [
+    'CollideAndPropagate', 'SetInitialConditions', 'PrepareMacroFields', 'ApplyPeriodicBoundaryConditions',
+    'ApplyPeriodicBoundaryConditionsWithSwap', 'ApplyMacroPeriodicBoundaryConditions', 'CollectContinuousData',
+    'CollectContinuousDataWithSwap', 'DistributeContinuousData', 'DistributeContinuousDataWithSwap', 'CollectSparseData',
+    'DistributeSparseData', 'CollectContinuousMacroData', 'DistributeContinuousMacroData', 'ShanChenPrepareMacroFields',
+    'ShanChenCollideAndPropagate0', 'ShanChenCollideAndPropagate1']
+
+
+def test_every_in_scope_reference_kernel_name_is_served():
+    """slf_kernel_get() resolves names with a chain of string compares: every name of the table must be in it (the GPU
+    round trips of the face kernels are tests/test_gpu_face_kernels.py; the sweeps and PBC kernels run in every test)."""
+    src = open(os.path.join(ROOT, 'sailfish_amd', 'csrc', 'slf_api.hip')).read()
+    served = set(re.findall(r'!strcmp\(name, "([A-Za-z0-9]+)"\)', src))
+    missing = [n for n in REFERENCE_KERNELS if n not in served]
+    assert not missing, missing
+    header = open(HEADER).read()
+    for n in REFERENCE_KERNELS:
+        assert n.replace('0', '').replace('1', '') in header.replace('0|1', ''), 'include/sailfish_hip.h does not document %s' % n

@@ -202,6 +202,64 @@ def boundary_probe(backend, golden_dir, name, precision, kind, box_cls=None, rel
         s.release()
 
 
+RO_TYPE_KIND = [hipabi.SLF_NK_FLUID, hipabi.SLF_NK_GHOST, hipabi.SLF_NK_FULL_BB, hipabi.SLF_NK_EQUILIBRIUM_VELOCITY,
+                hipabi.SLF_NK_EQUILIBRIUM_DENSITY]
+RO_BC_CASES = {   # kind: (type id in RO_TYPE_KIND, parameter fixture, expected populations, expected density delta, expected v)
+    'equilibrium_velocity': (3, 'bc_v', 'eqvel_post', 'eqvel_drho', 'bc_v'),
+    'equilibrium_density': (4, 'bc_rho', 'eqdens_post', 'bc_drho', 'eqdens_v'),
+}
+
+
+@pytest.mark.parametrize('kind', sorted(RO_BC_CASES))
+@pytest.mark.parametrize('precision', ['double', 'single'])
+@pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
+def test_minimize_roundoff_boundary_nodes_against_reference_fixtures(backend, golden_dir, name, precision, kind):
+    roundoff_boundary_probe(backend, golden_dir, name, precision, kind)
+
+
+def roundoff_boundary_probe(backend, golden_dir, name, precision, kind, box_cls=None):
+    """Equilibrium velocity / density nodes under --minimize_roundoff (boundary.mako:420-506, 797-809 with
+    config.minimize_roundoff; fixtures tools/capture_goldens.py: roundoff_bc_goldens): single-node probes as
+    boundary_probe(), the arrays hold f_i - w_i, the stored density is the delta."""
+    from tests import _geometry as geo
+    grid, _ = GRIDS[name]
+    dim = grid.dim
+    G = np.load(os.path.join(golden_dir, 'arith_ro_bc_%s.npz' % name))
+    tid, pkey, fkey, rkey, vkey = RO_BC_CASES[kind]
+    tol = TOL[precision] * 2
+    norient = 2 * dim
+    size = (2 * norient + 3, 5) + ((5,) if dim == 3 else ())
+    for k in range(3):
+        params = [float(x) for x in np.atleast_1d(G[pkey][k])]
+        desc = make_box_desc(grid, size, precision=precision, access_pattern='AB', fluid_only=False, type_kind=RO_TYPE_KIND,
+                             nt_bits=geo.NT_BITS, node_params=params, relaxation_enabled=False, model='bgk',
+                             incompressible=hipabi.SLF_DENSITY_ROUNDOFF)
+        m = geo.empty_map(desc)
+        probes = []
+        for o in range(1, norient + 1):
+            pos = (3 if dim == 3 else 0, 3, 2 * o)
+            m[pos] = geo.encode(tid, orientation=o, param=0)
+            probes.append(pos)
+        s = (box_cls or BoxSim)(backend, desc, periodic=(False, False, False), node_map=m)
+        full = np.empty((s.Q,) + s.shape, dtype=s.dtype)
+        full[...] = np.asarray(G['f'][k], dtype=s.dtype).reshape((s.Q,) + (1,) * len(s.shape))
+        s.set_dist(full, 0)
+        s.set_dist(full, 1)
+        s.step(save_macro=True)
+        out = s.get_dist().astype(np.float64)
+        rho, v = s.fetch_fields()
+        for o, (z, y, x) in enumerate(probes):
+            got = np.array([out[i, z + (grid.basis[i][2] if dim == 3 else 0), y + grid.basis[i][1], x + grid.basis[i][0]]
+                            for i in range(grid.Q)])
+            err = float(np.max(np.abs(got - G[fkey][o, k])))
+            assert err < tol, (kind, o + 1, k, err)
+            want_rho = G[rkey][o, k] if G[rkey].ndim == 2 else G[rkey][k]
+            want_v = G[vkey][o, k] if G[vkey].ndim == 3 else G[vkey][k]
+            assert abs(float(rho[z, y, x]) - float(want_rho)) < max(tol, 1e-7)
+            assert max(abs(float(v[d][z, y, x]) - float(want_v[d])) for d in range(dim)) < max(tol, 1e-7)
+        s.release()
+
+
 @pytest.mark.parametrize('precision', ['double', 'single'])
 @pytest.mark.parametrize('name', ['D2Q9', 'D3Q19'])
 def test_initial_conditions_against_reference_fixtures(backend, golden_dir, name, precision):

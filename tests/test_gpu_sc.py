@@ -393,3 +393,42 @@ def test_sc_indirect_addressing(dim, size, nsub, axis, pattern):
         for grid_num, od in enumerate(o.current()):
             gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
             assert np.array_equal(gd[:, wet], o.real(o.dense(od))[:, wet]), 'subdomain %d lattice %d' % (r._spec.id, grid_num)
+
+
+@pytest.mark.parametrize('pattern,walls', [('AB', True), ('AA', False), ('AB', False)])
+@pytest.mark.parametrize('dim,size,nsub', [(2, (70, 26), 1), (3, (40, 22, 8), 1), (3, (40, 22, 8), 2)])
+def test_single_component_indirect_addressing(dim, size, nsub, pattern, walls):
+    """--node_addressing=indirect with the single-component Shan-Chen model (the reference's sparse address map serves
+    every runner, subdomain_runner.py:829-878; PrepareMacroFields and CollideAndPropagate take the `nodes` table as their
+    first argument): the distributions hold the active nodes only, the density field stays dense -- and every wet node
+    carries the same populations and density as in the dense run, bit for bit.  With solid walls only in the two-copy
+    pattern: PrepareMacroFields also computes a density for the WALL nodes next to the fluid (lb_single_fluid.mako:
+    143-146 skips excluded nodes only), and in the in-place pattern their odd step pulls from the wall's inner nodes,
+    which hold no slot in the sparse arrays -- the reference indexes `nodes[]` unguarded there (geo_helpers.mako:246-252);
+    here such a population counts as 0, so the pseudopotential of those wall nodes is a different (equally arbitrary)
+    number than in the dense run."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    steps = 11
+    sim_cls, _ = _sc.make_single_wall_sim(dim) if walls else _sc.make_single_sim(dim)
+    cfg = _sc.single_config(dim, size, pattern=pattern, G=-1.2, potential='linear')
+    cfg.update(periodic_y=not walls, subdomains=nsub, conn_axis='x')
+    geo_name = 'EqualSubdomainsGeometry%dD' % dim
+    runs = []
+    for addressing in ('indirect', 'direct'):
+        ctrl = LBSimulationController(sim_cls, getattr(geo_mod, geo_name),
+                                      default_config=dict(cfg, node_addressing=addressing, max_iters=steps, quiet=True,
+                                                          perf_stats_every=0))
+        ctrl.run(ignore_cmdline=True)
+        runs.append(ctrl)
+    sparse, dense = runs
+    assert len(sparse.runners) == nsub
+    for rs, rd in zip(sparse.runners, dense.runners):
+        assert rs._desc.node_addressing == 1
+        if walls:
+            assert rs._dist_stride < 0.85 * int(np.prod(rs._physical_size))
+        wet = rs._subdomain.fluid_map()
+        assert wet.any() and np.array_equal(wet, rd._subdomain.fluid_map())
+        assert np.array_equal(rs._sim.rho[wet], rd._sim.rho[wet])
+        sl = (slice(None),) + tuple(rs._spec._nonghost_slice)
+        assert np.array_equal(rs._debug_get_dist()[sl][:, wet], rd._debug_get_dist()[sl][:, wet])

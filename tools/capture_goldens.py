@@ -518,12 +518,82 @@ def shan_chen_goldens(grid, rng, n=24):
     return out
 
 
+def roundoff_bc_goldens(grid, rng, n=12):
+    """Boundary-condition nodes under --minimize_roundoff (config.minimize_roundoff = True; the populations are
+    f_i - w_i, the density variable is rho - 1), evaluated from the reference's expression objects in the order of
+    boundary.mako:420-506 (getMacro) and :797-809 (equilibrium nodes):
+      equilibrium VELOCITY node: fill the unknown populations with their opposites; rho = ex_rho(missing_dir,
+        minimize_roundoff) = (sum + n.v) / (1 - n.v); f := bgk_equilibrium(cfg)(rho, v_bc)
+      equilibrium DENSITY node: v from ex_velocity(missing_dir, par_rho) (= -n (sum + 1 - par_rho) / par_rho);
+        rho = par_rho - 1 (boundary.mako:492-504); f := equilibrium
+    and, as evidence for what is NOT offered, the reference's REGULARIZED velocity node under the option applied to a
+    node that is exactly at equilibrium: the standard formulation returns the equilibrium (the non-equilibrium flux
+    vanishes); with minimize_roundoff ex_flux adds c_s^2 (sym.py:684-695) while ex_eq_flux keeps multiplying by the
+    density DELTA (sym.py:697-703), so the "non-equilibrium" flux is off by O(1) and the node comes out wrong."""
+    dim, Q = grid.dim, grid.Q
+    cfg_ro, cfg = _Cfg(minimize_roundoff=True), _Cfg()
+    eq_ro = sym_equilibrium.bgk_equilibrium(grid, cfg_ro).expression
+    eq_std = sym_equilibrium.bgk_equilibrium(grid, cfg).expression
+    wts = np.array([float(w) for w in grid.weights])
+    rho = rng.uniform(0.9, 1.1, n)
+    f = wts[None, :] * rho[:, None] * (1.0 + rng.uniform(-0.05, 0.05, (n, Q)))
+    bc_v = rng.uniform(-0.08, 0.08, (n, dim))
+    bc_rho = rng.uniform(0.95, 1.05, n)
+    out = {'f': f - wts[None, :], 'bc_v': bc_v, 'bc_rho': bc_rho, 'bc_drho': bc_rho - 1.0}
+    eqv_rho = np.zeros((2 * dim, n))
+    eqv = np.zeros((2 * dim, n, Q))
+    eqd_v = np.zeros((2 * dim, n, dim))
+    eqd = np.zeros((2 * dim, n, Q))
+    reg_defect = np.zeros((2 * dim, 2))
+    reg = sym.reglb_flux_tensor(grid)
+    for o in range(1, 2 * dim + 1):
+        missing = sym.get_missing_dists(grid, o)
+        for k in range(n):
+            fi = out['f'][k].copy()
+            for i in missing:
+                fi[i] = fi[grid.idx_opposite[i]]
+            rs = _evalf(sym.ex_rho(grid, 'fi', False, minimize_roundoff=True), _fi_subs(grid, fi))
+            # equilibrium velocity node
+            subs = _macro_subs(grid, rs, bc_v[k])
+            r = _evalf(sym.ex_rho(grid, 'fi', False, missing_dir=o, minimize_roundoff=True), subs)
+            eqv_rho[o - 1, k] = r
+            subs = _macro_subs(grid, r, bc_v[k])
+            eqv[o - 1, k] = [_evalf(e, subs) for e in eq_ro]
+            # equilibrium density node
+            subs = {'g0m0': rs, 'rho': rs, 'par_rho': bc_rho[k]}
+            vv = [_evalf(sym.ex_velocity(grid, 'fi', d, cfg_ro, missing_dir=o, par_rho='par_rho'), subs) for d in range(dim)]
+            eqd_v[o - 1, k] = vv
+            subs = _macro_subs(grid, bc_rho[k] - 1.0, vv)
+            eqd[o - 1, k] = [_evalf(e, subs) for e in eq_ro]
+        # the regularized node on an equilibrium state, both formulations
+        r0, u0 = 1.03, [0.04, -0.02, 0.03][:dim]
+        for col, (c, eqx, shift) in enumerate(((cfg, eq_std, 0.0), (cfg_ro, eq_ro, 1.0))):
+            subs = _macro_subs(grid, r0 - shift, u0)
+            g = np.array([_evalf(e, subs) for e in eqx])            # f = feq exactly (shifted under the option)
+            subs.update(_fi_subs(grid, g))
+            fl = []
+            for a in range(dim):
+                for b in range(a, dim):
+                    fl.append(_evalf(sym.ex_flux(grid, 'fi', a, b, c), subs) - _evalf(sym.ex_eq_flux(grid, a, b), subs))
+            subs.update({'flux[%d]' % j: x for j, x in enumerate(fl)})
+            res = np.array([_evalf(eqx[i], subs) + _evalf(reg[i], subs) for i in range(Q)])
+            reg_defect[o - 1, col] = float(np.max(np.abs(res - g)))
+    out.update(eqvel_drho=eqv_rho, eqvel_post=eqv, eqdens_v=eqd_v, eqdens_post=eqd, regvel_defect_std_vs_roundoff=reg_defect)
+    return out
+
+
 def main():
     rng_sc = np.random.RandomState(777)
     for grid in (sym.D2Q9, sym.D3Q19):
         np.savez_compressed(os.path.join(OUT, 'shan_chen_%s.npz' % grid.__name__), **shan_chen_goldens(grid, rng_sc))
         print('wrote Shan-Chen goldens for', grid.__name__)
     if len(sys.argv) > 1 and sys.argv[1] == 'sc':
+        return
+    rng_ro = np.random.RandomState(4242)
+    for grid in (sym.D2Q9, sym.D3Q19):
+        np.savez_compressed(os.path.join(OUT, 'arith_ro_bc_%s.npz' % grid.__name__), **roundoff_bc_goldens(grid, rng_ro))
+        print('wrote --minimize_roundoff boundary-node goldens for', grid.__name__)
+    if len(sys.argv) > 1 and sys.argv[1] == 'ro_bc':
         return
     rng = np.random.RandomState(20260926)
     tables = {}
