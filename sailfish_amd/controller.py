@@ -61,68 +61,117 @@ def lb_single_fluid():
 
 
 class LocalGroup(object):
-    """Lock-step driver for runners that live in this process."""
+    """Lock-step driver for runners that live in this process.  One step of the whole group is ONE program
+    (stepqueue.py): the fronts of all runners (macro pass, sweep, pack), the device-to-device copies between their halo
+    buffers, the backs (unpack) -- replayed from a C-ABI step plan where every subdomain sits on the same GPU, performed
+    entry by entry otherwise (several GPUs in one process: peer copies) and on the steps that record timing events."""
 
     def __init__(self, runners):
         self.runners = runners
         self.by_id = dict((r._spec.id, r) for r in runners)
+        self._plans = {}
+        self._plan_ok = None
 
-    def exchange(self, kind='dist'):
-        """Copies every packed send buffer into the matching receive buffer of the neighbour
-        (kind: 'dist' populations, 'macro' fields of non-local models)."""
-        if kind == 'dist' and getattr(self.runners[0], '_xface', None) is not None:
-            return self._exchange_xface()
-        events, msgs = {}, {}
+    # ---------------------------------------------------------------- the group's step as a program
+    def _program(self, q, it, reqs):
+        rs = self.runners
+        for r in rs:
+            r._set_step_state(it)
+        if rs[0].has_macro_exchange:
+            for r in rs:
+                r._program_macro(q, it, group=self)
+            self._program_copies(q, it, 'macro')
+            for r in rs:
+                r._program_macro_back(q, it)
+        for r, (_, fields_req, _) in zip(rs, reqs):
+            r._program_front(q, it, fields_req, group=self)
+        self._program_copies(q, it, 'dist')
+        for r in rs:
+            r._program_back(q, it)
+
+    def _copy(self, q, dst_runner, src_runner, dst, src, nbytes):
+        b, sh = dst_runner.backend, dst_runner._data_stream
+        if src_runner.backend.gpu_id == b.gpu_id:
+            q.copy(dst, src, nbytes, sh)
+        else:       # another GPU of this process: a peer copy, which a step plan cannot hold
+            q.call(lambda: b.copy_peer_async(dst, b.gpu_id, src, src_runner.backend.gpu_id, nbytes, sh))
+
+    def _program_copies(self, q, it, kind):
+        """Every packed send buffer into the matching receive buffer of the neighbour, on the receiver's data stream
+        (kind: 'dist' populations, 'macro' fields of non-local models); event 'copied' after a runner's copies: its
+        neighbours' next pack into the same send buffers waits for it."""
+        par = it & 1
+        pre = '' if kind == 'dist' else 'macro_'
+        msgs = dict((r._spec.id, dict((m[0], m) for m in r.halo_messages(kind))) for r in self.runners)
         for r in self.runners:
-            msgs[r._spec.id] = dict((m[0], m) for m in r.halo_messages(kind))
-            if msgs[r._spec.id]:
-                events[r._spec.id] = r.backend.make_event(r._data_stream)
-        for r in self.runners:
-            for nid, (_, _, _, recv_buf, n_recv) in sorted(msgs[r._spec.id].items()):
+            if kind == 'dist' and r._xface is not None:
+                self._program_copies_xface(q, it, r)
+                continue
+            mine = msgs[r._spec.id]
+            if not mine:
+                continue
+            sh = r._data_stream
+            for nid, (_, _, _, recv_buf, n_recv) in sorted(mine.items()):
                 src = self.by_id[nid]
                 _, send_buf, n_send, _, _ = msgs[nid][r._spec.id]
                 assert n_send == n_recv, 'halo size mismatch between subdomains %d and %d' % (nid, r._spec.id)
                 if n_recv == 0:
                     continue
-                r._data_stream.wait_for_event(events[nid])
-                nbytes = n_recv * r.float().itemsize
-                if src.backend.gpu_id == r.backend.gpu_id:
-                    r.backend.copy_buf_async(recv_buf, send_buf, nbytes, r._data_stream)
-                else:
-                    r.backend.copy_peer_async(recv_buf, r.backend.gpu_id, send_buf, src.backend.gpu_id, nbytes,
-                                              r._data_stream)
-                # the owner of send_buf must not pack into it again before this copy has read it (its next pack
-                # is ordered only after its own unpack, i.e. after *its* neighbours' packs, not after our copy)
-                src.send_buffer_readers(kind).append(r.backend.make_event(r._data_stream))
+                q.wait(sh, src._pev[par][pre + 'packed'])
+                self._copy(q, r, src, recv_buf, send_buf, n_recv * r.float().itemsize)
+            q.record(r._pev[par][pre + 'copied'], sh)
 
-    def _exchange_xface(self):
-        """1-D x decompositions (sailfish_amd/xface.py): every runner has enqueued its sweep in z-chunks; batch i of a
-        runner's face-buffer planes is ready with its i-th chunk event.  The receiver copies it on its data stream and
-        records the event its next step's chunks wait for; the owner of the send set must not write it again (two
-        steps later) before the copy has read it."""
-        for r in self.runners:
-            events = []
-            for pos in range(len(r._xchunks.order)):
-                mine = r.xface_pieces(pos)
-                for nid in sorted(set(p[0] for p in mine)):
-                    src = self.by_id[nid]
-                    # pieces are listed in the order both sides post them: my k-th receive from this neighbour takes
-                    # its k-th send to me
-                    theirs = [p for p in src.xface_pieces(pos) if p[0] == r._spec.id]
-                    r._data_stream.wait_for_event(src._xface_ready[pos])
-                    for (_, _, recv_addr, n), (_, send_addr, _, n_s) in zip([p for p in mine if p[0] == nid], theirs):
-                        assert n == n_s, 'x-face piece mismatch between subdomains %d and %d' % (nid, r._spec.id)
-                        nbytes = n * r.float().itemsize
-                        if src.backend.gpu_id == r.backend.gpu_id:
-                            r.backend.copy_buf_async(recv_addr, send_addr, nbytes, r._data_stream)
-                        else:
-                            r.backend.copy_peer_async(recv_addr, r.backend.gpu_id, send_addr, src.backend.gpu_id,
-                                                      nbytes, r._data_stream)
-                ev = r.backend.make_event(r._data_stream)
-                events.append(ev)
-                for nid in set(p[0] for p in mine):
-                    self.by_id[nid].send_buffer_readers('dist%d' % r._xface_parity).append(ev)
-            r._xface_events = events
+    def _program_copies_xface(self, q, it, r):
+        """1-D x decompositions (sailfish_amd/xface.py): batch i of a runner's face-buffer planes is ready with its i-th
+        chunk event; the receiver copies it on its data stream and records the event its next step's chunks wait for."""
+        par = it & 1
+        sh = r._data_stream
+        for pos in range(len(r._xchunks.order)):
+            mine = r.xface_pieces(pos)
+            for nid in sorted(set(p[0] for p in mine)):
+                src = self.by_id[nid]
+                # pieces are listed in the order both sides post them: my k-th receive from this neighbour takes its
+                # k-th send to me
+                theirs = [p for p in src.xface_pieces(pos) if p[0] == r._spec.id]
+                q.wait(sh, src._ev_chunk[par][pos])
+                for (_, _, recv_addr, n), (_, send_addr, _, n_s) in zip([p for p in mine if p[0] == nid], theirs):
+                    assert n == n_s, 'x-face piece mismatch between subdomains %d and %d' % (nid, r._spec.id)
+                    self._copy(q, r, src, recv_addr, send_addr, n * r.float().itemsize)
+            q.record(r._ev_batch[par][pos], sh)
+        q.record(r._pev[par]['copied'], sh)
+
+    def step(self, reqs):
+        from sailfish_amd.stepqueue import DirectQueue, NotPlannable
+        rs = self.runners
+        b0 = rs[0].backend
+        it = rs[0]._sim.iteration
+        if self._plan_ok is None:
+            self._plan_ok = all(r._plan_ok for r in rs)
+        timed = any(r._profile.wants_gpu_events() for r in rs)
+        plan = None
+        if self._plan_ok and not timed:
+            key = (it & 1, tuple(bool(req[1]) for req in reqs))
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = b0.make_plan()
+                try:
+                    self._program(plan, it, reqs)
+                    self._plans[key] = plan
+                except NotPlannable:
+                    self._plan_ok, plan = False, None
+        if plan is not None:
+            for r in rs:
+                r._set_step_state(it)
+            plan.run(it)
+        else:
+            for r in rs:
+                r.backend.set_iteration(it)
+            self._program(DirectQueue(b0), it, reqs)
+        for r in rs:
+            if r._xface is not None:
+                r._xface._bound = None
+            r._sim.iteration += 1
+            r.backend.set_iteration(r._sim.iteration)
 
     def run(self):
         runners = self.runners
@@ -143,18 +192,7 @@ class LocalGroup(object):
             reqs = [r.pre_step() for r in runners]
             for r in runners:
                 r._profile.start_step()
-            if len(runners) > 1 and runners[0].has_macro_exchange:
-                for r in runners:
-                    r.step_macro()
-                self.exchange('macro')
-                for r in runners:
-                    r.step_macro_finish()
-            for r, (sync_req, fields_req, output_req) in zip(runners, reqs):
-                r.step_compute(fields_req)
-            if len(runners) > 1:
-                self.exchange()
-            for r in runners:
-                r.step_finish()
+            self.step(reqs)
             for r, (sync_req, fields_req, output_req) in zip(runners, reqs):
                 r.post_step(sync_req, output_req)
             for r in runners:

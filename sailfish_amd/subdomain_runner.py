@@ -425,19 +425,6 @@ class SubdomainRunner(object):
                     link.kernels[(mode, copy)] = (packs, unpacks, len(s_idx) * n_grids, len(r_idx) * n_grids)
             self._links[nid] = link
 
-    def send_buffer_readers(self, kind='dist'):
-        """Events after which the send buffers of `kind` have been read by the neighbours that copy them
-        (same-process groups, controller.LocalGroup); the next pack waits for them."""
-        return self.__dict__.setdefault('_send_readers', {}).setdefault(kind, [])
-
-    def _wait_send_buffers_free(self, kind='dist', stream=None):
-        """`stream` (default: the data stream, where the pack kernels run) waits until the neighbours have read the
-        send buffers of the previous step."""
-        evs = self.send_buffer_readers(kind)
-        for ev in evs:
-            (stream or self._data_stream).wait_for_event(ev)
-        del evs[:]
-
     # -- 1-D decompositions along x: dense face buffers written / read by the sweep itself (xface.py)
     _xface = None
 
@@ -503,7 +490,6 @@ class SubdomainRunner(object):
         # instead: one chunk (profiles/r03/xface_overlap_schemes.jsonl)
         self._xchunks = xface.ChunkPlan(lat[2] - 2, self._fused[2],
                                         None if getattr(self._connector, 'mid_step', False) else 1)
-        self._xface_events, self._xface_prev_kind = None, None
 
     def xface_pieces(self, pos):
         """[(neighbour id, send address, receive address, elements)] of batch `pos` of the step just enqueued: for every
@@ -532,8 +518,7 @@ class SubdomainRunner(object):
             self.backend.sync_stream(*self._all_streams())
             self._xface.reset(self._calc_stream)
             self.__dict__.pop('_halo_mode', None)
-            self._xface_events, self._xface_prev_kind = None, None
-
+    
     def _materialise_halo(self):
         """x-face buffers: the arrays are stale at the connected faces until the received values are written into
         them (before anything reads the arrays on the host)."""
@@ -611,109 +596,6 @@ class SubdomainRunner(object):
         return bnd, (by0, by1, bz0, bz1)
 
     # ------------------------------------------------------------------ stepping
-    def _run_sweep(self, kernels, regions_bulk):
-        b = self.backend
-        bnd, bulk = regions_bulk
-        if self._links and self._ev_halo is not None:
-            self._calc_stream.wait_for_event(self._ev_halo)
-        prof = self._profile
-        ev = None
-        if bnd:
-            prof.record_gpu_start(TimeProfile.BOUNDARY, self._calc_stream)
-            for reg in bnd:
-                for k in kernels:
-                    b.run_kernel(k, reg, self._calc_stream)
-            ev = prof.record_gpu_end(TimeProfile.BOUNDARY, self._calc_stream, need_event=True)
-        prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
-        for k in kernels:
-            b.run_kernel(k, bulk, self._calc_stream)
-        prof.record_gpu_end(TimeProfile.BULK, self._calc_stream)
-        return ev
-
-    def _run_sweep_xface(self, kernels, it):
-        """1-D x decomposition: the sweep in z-chunks; after each chunk the planes of the face buffers that are now
-        complete are handed to the transport (a connector that can be called in the middle of a step moves them at
-        once, on the data stream; a same-process group picks them up through xface_pieces() / the ready events), and
-        a chunk waits only for the transfers of the previous step it reads from."""
-        b, x, plan = self.backend, self._xface, self._xchunks
-        aa = self.config.access_pattern == 'AA'
-        kind = 'own' if (aa and (it & 1) == 0) else 'push'
-        # the send set of this parity was last read by the transfers of step it - 2
-        self._wait_send_buffers_free('dist%d' % (it & 1), self._calc_stream)
-        par = x.begin_step(it, self._calc_stream)
-        self._xface_parity, self._xface_kind = par, kind
-        prev = self._xface_events
-        need = plan.need[self._xface_prev_kind] if self._xface_prev_kind else None
-        ny = list(reversed(self._lat_size))[1] - 2
-        prof = self._profile
-        overlapped = getattr(self._connector, 'mid_step', False)
-        ready, events = [], []
-        prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
-        for pos, c in enumerate(plan.order):
-            if prev is not None and need[c] >= 0:
-                self._calc_stream.wait_for_event(prev[need[c]])
-            for k in kernels:
-                b.run_kernel(k, plan.region(c, ny), self._calc_stream)
-            ev = b.make_event(self._calc_stream)
-            ready.append(ev)
-            if overlapped:
-                self._data_stream.wait_for_event(ev)
-                self._connector.exchange_pieces(self, self.xface_pieces(pos))
-                events.append(b.make_event(self._data_stream))
-        prof.record_gpu_end(TimeProfile.BULK, self._calc_stream)
-        self._xface_ready = ready
-        self._xface_events = events if overlapped else None
-        self._xface_prev_kind = kind
-
-    def step_compute(self, sync_req=False):
-        """Sweep + local periodic boundaries + halo pack.  Returns the per-neighbour (send buffer, count)."""
-        b = self.backend
-        it = self._sim.iteration
-        kernels = self._kernels_full if sync_req else self._kernels_none
-        kernels = kernels.primary if (it & 1) == 0 else kernels.secondary
-        if self._xface is not None:
-            self._run_sweep_xface(kernels, it)
-            ev_bnd = None
-        else:
-            ev_bnd = self._run_sweep(kernels, self._regions)
-        base = 1 - (it & 1)
-        for axis in self._pbc_axes:
-            for k in self._pbc_kernels[base][axis]:
-                b.run_kernel(k, None, self._calc_stream)
-        self._pack_halo(it, ev_bnd)
-        self._sim.iteration += 1
-        b.set_iteration(self._sim.iteration)
-
-    def _pack_halo(self, it, ev_bnd=None):
-        """Packs the populations that leave the subdomain after the step of iteration `it` (on the data
-        stream, as soon as the boundary regions / the whole sweep are done)."""
-        b = self.backend
-        aa = self.config.access_pattern == 'AA'
-        self._halo_mode = 'pull' if (aa and (it & 1) == 0) else 'push'
-        self._halo_copy = 0 if aa else 1 - (it & 1)
-        if self._links and self._xface is None:
-            # unsplit subdomains: the whole sweep (and the local PBC) must be done first
-            ev = ev_bnd if (ev_bnd is not None and not self._pbc_axes) else b.make_event(self._calc_stream)
-            self._data_stream.wait_for_event(ev)
-            self._wait_send_buffers_free('dist')
-            self._profile.record_gpu_start(TimeProfile.COLLECTION, self._data_stream)
-            for nid, link in self._links.items():
-                for pack in link.kernels[(self._halo_mode, self._halo_copy)][0]:
-                    b.run_kernel(pack, None, self._data_stream)
-            self._profile.record_gpu_end(TimeProfile.COLLECTION, self._data_stream)
-
-    def step_finish(self):
-        """Unpack the received halos (the exchange has been enqueued on the data stream)."""
-        b = self.backend
-        if not self._links or self._xface is not None:
-            return
-        self._profile.record_gpu_start(TimeProfile.DISTRIB, self._data_stream)
-        for nid, link in self._links.items():
-            for unpack in link.kernels[(self._halo_mode, self._halo_copy)][1]:
-                b.run_kernel(unpack, None, self._data_stream)
-        self._profile.record_gpu_end(TimeProfile.DISTRIB, self._data_stream)
-        self._ev_halo = b.make_event(self._data_stream)
-
     has_macro_exchange = False
 
     def step(self, sync_req=False):
@@ -758,7 +640,7 @@ class SubdomainRunner(object):
         self._plans = {}
         self._plan_ok = bool(getattr(b, 'supports_step_plans', False)) and getattr(self.config, 'hip_step_plans', True) and \
             os.environ.get('SLF_STEP_PLAN', '1') != '0'
-        names = ('bnd', 'bulk', 'halo', 'macro', 'macro_halo')
+        names = ('bnd', 'bulk', 'halo', 'packed', 'copied', 'macro', 'macro_halo', 'macro_packed', 'macro_copied')
         self._pev = [dict((n, b.make_event(self._calc_stream)) for n in names) for _ in (0, 1)]
         # a second calc stream (SLF_CALC_STREAMS=1: off).  z / y decompositions sweep their face layers on it: the
         # interior depends on the neighbours only through the face layers of the step before, so its stream never waits
@@ -790,17 +672,36 @@ class SubdomainRunner(object):
         if self._xface is not None:
             self._xface_parity = it & 1
             self._xface_kind = 'own' if (aa and (it & 1) == 0) else 'push'
-            self._xface_prev_kind = self._xface_kind
 
     def _program(self, q, it, sync_req):
-        """Single-fluid step: [face layers -> event] -> interior -> ghost-layer PBC kernels; halo stream: pack ->
-        exchange -> unpack -> event (reference subdomain_runner.py:960-1058)."""
-        prof, timed = self._profile, not q.planned
+        """One step of a runner that owns its process (reference subdomain_runner.py:960-1058): macro pass of the
+        non-local models, sweep, halo -- the exchanges through the connector."""
         self._set_step_state(it)
+        self._program_macro(q, it)
+        self._program_front(q, it, sync_req)
+        self._program_back(q, it)
+
+    def _neighbour_events(self, group, name, parity):
+        """Events `name` of parity `parity` of the runners this one exchanges halos with (same-process groups)."""
+        ids = set(self._links) | set(getattr(self, '_macro_links', {}))
+        return [group.by_id[nid]._pev[parity][name] for nid in sorted(ids) if nid in group.by_id]
+
+    def _program_macro(self, q, it, group=None):
+        """Macroscopic-field pass of the non-local models (NNSubdomainRunner); nothing here."""
+
+    def _program_macro_back(self, q, it):
+        pass
+
+    def _program_front(self, q, it, sync_req, group=None):
+        """[face layers -> event] -> interior -> ghost-layer PBC kernels on the calc stream(s); pack on the data stream.
+        group: the controller.LocalGroup that steps this runner together with its neighbours in one process -- the group
+        moves the packed buffers itself, between the fronts and the backs of its runners; None: the connector does, right
+        here (x-face pieces: after every z-chunk)."""
+        prof, timed = self._profile, not q.planned
         ev, pev = self._pev[it & 1], self._pev[1 - (it & 1)]
         kernels = self._sweep_kernels(it, sync_req)
         if self._xface is not None:
-            return self._program_xface(q, it, kernels)
+            return self._program_xface(q, it, kernels, group)
         sk, sb = self._calc_stream, self._bnd_stream
         bnd, bulk = self._regions
         ready = None
@@ -822,6 +723,12 @@ class SubdomainRunner(object):
             ready = ev['bnd']
         elif self._links:
             q.wait(sk, pev['halo'])
+        self._program_sweep_rest(q, it, kernels, bulk, ready, group)
+
+    def _program_sweep_rest(self, q, it, kernels, bulk, ready, group):
+        prof, timed = self._profile, not q.planned
+        ev = self._pev[it & 1]
+        sk = self._calc_stream
         if timed:
             prof.record_gpu_start(TimeProfile.BULK, sk)
         for k in kernels:
@@ -830,44 +737,67 @@ class SubdomainRunner(object):
             prof.record_gpu_end(TimeProfile.BULK, sk)
         base = 1 - (it & 1)
         for axis in self._pbc_axes:
-            for k in self._pbc_kernels[base][axis]:
+            for k in self._dist_pbc_kernels()[base][axis]:
                 q.launch(k, None, sk)
         q.record(ev['bulk'], sk)
         if ready is None or self._pbc_axes:
             ready = ev['bulk']       # unsplit subdomains: the whole sweep (and the local PBC) must be done first
-        self._program_halo(q, ready, ev)
+        self._program_pack(q, it, ready, group)
 
-    def _program_halo(self, q, ready, ev):
-        """Halo stream: wait(`ready`) -> pack -> exchange -> unpack -> event 'halo'."""
-        if not self._links:
+    def _dist_pbc_kernels(self):
+        return self._pbc_kernels
+
+    def _program_pack(self, q, it, ready, group, kind='dist'):
+        """Data stream: wait(`ready`) -> pack -> event 'packed'; without a group the exchange follows at once."""
+        links = self._links if kind == 'dist' else self._macro_links
+        if not links:
             return
         prof, timed, sh = self._profile, not q.planned, self._data_stream
+        ev = self._pev[it & 1]
+        pre = '' if kind == 'dist' else 'macro_'
         q.wait(sh, ready)
-        key = (self._halo_mode, self._halo_copy)
+        if group is not None:
+            # a send buffer is not written again before the neighbours' copies of the previous step have read it
+            for e in self._neighbour_events(group, pre + 'copied', 1 - (it & 1)):
+                q.wait(sh, e)
+        tp = TimeProfile.COLLECTION if kind == 'dist' else TimeProfile.MACRO_COLLECTION
         if timed:
-            prof.record_gpu_start(TimeProfile.COLLECTION, sh)
-        for nid in sorted(self._links):
-            for pack in self._links[nid].kernels[key][0]:
+            prof.record_gpu_start(tp, sh)
+        for nid in sorted(links):
+            link = links[nid]
+            packs = link.kernels[(self._halo_mode, self._halo_copy)][0] if kind == 'dist' else link.packs
+            for pack in packs:
                 q.launch(pack, None, sh)
         if timed:
-            prof.record_gpu_end(TimeProfile.COLLECTION, sh)
-            prof.record_cpu_start(TimeProfile.RECV_DISTS)
-        self._connector.enqueue_exchange(q, self, 'dist')
+            prof.record_gpu_end(tp, sh)
+        q.record(ev[pre + 'packed'], sh)
+        if group is None:
+            if timed and kind == 'dist':
+                prof.record_cpu_start(TimeProfile.RECV_DISTS)
+            self._connector.enqueue_exchange(q, self, kind)
+            if timed and kind == 'dist':
+                prof.record_cpu_end(TimeProfile.RECV_DISTS)
+
+    def _program_back(self, q, it):
+        """Data stream: unpack what the exchange delivered -> event 'halo' (the next step's face layers wait for it)."""
+        if not self._links or self._xface is not None:
+            return
+        prof, timed, sh = self._profile, not q.planned, self._data_stream
         if timed:
-            prof.record_cpu_end(TimeProfile.RECV_DISTS)
             prof.record_gpu_start(TimeProfile.DISTRIB, sh)
         for nid in sorted(self._links):
-            for unpack in self._links[nid].kernels[key][1]:
+            for unpack in self._links[nid].kernels[(self._halo_mode, self._halo_copy)][1]:
                 q.launch(unpack, None, sh)
         if timed:
             prof.record_gpu_end(TimeProfile.DISTRIB, sh)
-        q.record(ev['halo'], sh)
+        q.record(self._pev[it & 1]['halo'], sh)
 
-    def _program_xface(self, q, it, kernels):
-        """1-D x decomposition: the sweep in z-chunks, alternating between the two calc streams; after each chunk the
-        planes of the face buffers that are now complete travel on the data stream.  A chunk waits for the transfers of
-        the previous step that carry the planes it reads and for the chunks of the previous step that touched its
-        planes or their neighbours and ran on the other stream (xface.ChunkPlan)."""
+    def _program_xface(self, q, it, kernels, group=None):
+        """1-D x decomposition: the sweep in z-chunks; after each chunk the planes of the face buffers that are now
+        complete travel on the data stream (own process: through the connector, right here; same-process group: the
+        group copies them after the fronts of all its runners).  A chunk waits for the transfers of the previous step
+        that carry the planes it reads (xface.ChunkPlan); with SLF_XFACE_STREAMS=2 the chunks alternate between the two
+        calc streams and also wait for the chunks of the previous step that touched their planes or their neighbours."""
         prof, timed = self._profile, not q.planned
         x, plan = self._xface, self._xchunks
         par = it & 1
@@ -876,6 +806,10 @@ class SubdomainRunner(object):
         ny = list(reversed(self._lat_size))[1] - 2
         streams = [self._calc_stream, self._bnd_stream]
         snd, rcv = x.send[par], x.recv[1 - par]
+        if group is not None:
+            # the send set of this parity was last read by the neighbours' copies of step it - 2
+            for e in self._neighbour_events(group, 'copied', par):
+                q.wait(streams[0], e)
         q.xface(self.module, snd[xface.LOW], snd[xface.HIGH], rcv[xface.LOW], rcv[xface.HIGH])
         if x.needs_clear:
             for a in snd:
@@ -898,9 +832,10 @@ class SubdomainRunner(object):
             for k in kernels:
                 q.launch(k, plan.region(c, ny), st)
             q.record(evc[pos], st)
-            q.wait(sh, evc[pos])
-            self._connector.enqueue_pieces(q, self, self.xface_pieces(pos))
-            q.record(evb[pos], sh)
+            if group is None:
+                q.wait(sh, evc[pos])
+                self._connector.enqueue_pieces(q, self, self.xface_pieces(pos))
+                q.record(evb[pos], sh)
         if timed:
             if streams[1] is not streams[0]:
                 streams[0].wait_for_event(evc[len(plan.order) - 1])
@@ -1289,48 +1224,6 @@ class NNSubdomainRunner(SubdomainRunner):
         self._regions = self._make_regions()
         self._kernels_prepared = True
 
-    def _run_macro(self):
-        """Macroscopic fields of every real node, then their local periodic images."""
-        b = self.backend
-        it = self._sim.iteration
-        macro_kernel = self._kernels_none[it & 1][0]
-        prof = self._profile
-        if self._links and self._ev_halo is not None:
-            self._calc_stream.wait_for_event(self._ev_halo)      # populations received after the last step
-        prof.record_gpu_start(TimeProfile.MACRO_BULK, self._calc_stream)
-        b.run_kernel(macro_kernel, None, self._calc_stream)
-        prof.record_gpu_end(TimeProfile.MACRO_BULK, self._calc_stream)
-        base = 1 - (it & 1)
-        for axis in self._pbc_axes:
-            for k in self._pbc_kernels.macro[base][axis]:
-                b.run_kernel(k, None, self._calc_stream)
-
-    def step_macro(self):
-        """First half of a step with neighbours: macro fields + pack of the boundary values."""
-        b = self.backend
-        self._run_macro()
-        self._macro_done = True
-        if self._macro_links:
-            self._data_stream.wait_for_event(b.make_event(self._calc_stream))
-            self._wait_send_buffers_free('macro')
-            self._profile.record_gpu_start(TimeProfile.MACRO_COLLECTION, self._data_stream)
-            for nid, link in self._macro_links.items():
-                for k in link.packs:
-                    b.run_kernel(k, None, self._data_stream)
-            self._profile.record_gpu_end(TimeProfile.MACRO_COLLECTION, self._data_stream)
-
-    def step_macro_finish(self):
-        """Unpack the neighbours' values into the ghost nodes; the sweep waits for it."""
-        b = self.backend
-        if not self._macro_links:
-            return
-        self._profile.record_gpu_start(TimeProfile.MACRO_DISTRIB, self._data_stream)
-        for nid, link in self._macro_links.items():
-            for k in link.unpacks:
-                b.run_kernel(k, None, self._data_stream)
-        self._profile.record_gpu_end(TimeProfile.MACRO_DISTRIB, self._data_stream)
-        self._calc_stream.wait_for_event(b.make_event(self._data_stream))
-
     def _enqueue_plain_step(self, it):
         b = self.backend
         macro_kernel, sim_kernels = self._kernels_none[it & 1]
@@ -1345,36 +1238,20 @@ class NNSubdomainRunner(SubdomainRunner):
             for k in self._pbc_kernels.distributions[base][axis]:
                 b.run_kernel(k, None, self._calc_stream)
 
-    def step_compute(self, sync_req=False):
-        b = self.backend
-        it = self._sim.iteration
-        if not getattr(self, '_macro_done', False):
-            self._run_macro()
-        self._macro_done = False
-        kernels = self._kernels_full if sync_req else self._kernels_none
-        sim_kernels = kernels[it & 1][1]
-        prof = self._profile
-        base = 1 - (it & 1)
-        prof.record_gpu_start(TimeProfile.BULK, self._calc_stream)
-        for k in sim_kernels:
-            b.run_kernel(k, None, self._calc_stream)
-        prof.record_gpu_end(TimeProfile.BULK, self._calc_stream)
-        for axis in self._pbc_axes:
-            for k in self._pbc_kernels.distributions[base][axis]:
-                b.run_kernel(k, None, self._calc_stream)
-        self._pack_halo(it)
-        self._sim.iteration += 1
-        b.set_iteration(self._sim.iteration)
+    def _dist_pbc_kernels(self):
+        return self._pbc_kernels.distributions
 
-    def _program(self, q, it, sync_req):
-        """Non-local models: macro pass -> [exchange of the macroscopic fields] -> sweeps of every lattice -> population
-        halo (reference NNSubdomainRunner.step, subdomain_runner.py:2102-2197), on one calc stream."""
+    def _sweep_kernels(self, it, sync_req):
+        return (self._kernels_full if sync_req else self._kernels_none)[it & 1][1]
+
+    def _program_macro(self, q, it, group=None):
+        """Macroscopic fields of every real node, their local periodic images, and the exchange of the values the
+        non-local force reads in the neighbours' territory (reference NNSubdomainRunner.step, subdomain_runner.py:
+        2102-2197): calc stream -> event -> data stream: pack -> [exchange] -> unpack -> event -> calc stream."""
         prof, timed = self._profile, not q.planned
-        self._set_step_state(it)
         ev, pev = self._pev[it & 1], self._pev[1 - (it & 1)]
-        sk, sh = self._calc_stream, self._data_stream
+        sk = self._calc_stream
         macro_kernel = self._kernels_none[it & 1][0]
-        sim_kernels = (self._kernels_full if sync_req else self._kernels_none)[it & 1][1]
         base = 1 - (it & 1)
         if self._links:
             q.wait(sk, pev['halo'])                          # populations received after the last step
@@ -1388,35 +1265,30 @@ class NNSubdomainRunner(SubdomainRunner):
                 q.launch(k, None, sk)
         if self._macro_links:
             q.record(ev['macro'], sk)
-            q.wait(sh, ev['macro'])
-            if timed:
-                prof.record_gpu_start(TimeProfile.MACRO_COLLECTION, sh)
-            for nid in sorted(self._macro_links):
-                for k in self._macro_links[nid].packs:
-                    q.launch(k, None, sh)
-            if timed:
-                prof.record_gpu_end(TimeProfile.MACRO_COLLECTION, sh)
-            self._connector.enqueue_exchange(q, self, 'macro')
-            if timed:
-                prof.record_gpu_start(TimeProfile.MACRO_DISTRIB, sh)
-            for nid in sorted(self._macro_links):
-                for k in self._macro_links[nid].unpacks:
-                    q.launch(k, None, sh)
-            if timed:
-                prof.record_gpu_end(TimeProfile.MACRO_DISTRIB, sh)
-            q.record(ev['macro_halo'], sh)
-            q.wait(sk, ev['macro_halo'])
+            self._program_pack(q, it, ev['macro'], group, kind='macro')
+            if group is None:
+                self._program_macro_back(q, it)
+
+    def _program_macro_back(self, q, it):
+        """Unpack the neighbours' values into the ghost nodes; the sweep waits for it."""
+        if not self._macro_links:
+            return
+        prof, timed = self._profile, not q.planned
+        ev, sh = self._pev[it & 1], self._data_stream
         if timed:
-            prof.record_gpu_start(TimeProfile.BULK, sk)
-        for k in sim_kernels:
-            q.launch(k, None, sk)
+            prof.record_gpu_start(TimeProfile.MACRO_DISTRIB, sh)
+        for nid in sorted(self._macro_links):
+            for k in self._macro_links[nid].unpacks:
+                q.launch(k, None, sh)
         if timed:
-            prof.record_gpu_end(TimeProfile.BULK, sk)
-        for axis in self._pbc_axes:
-            for k in self._pbc_kernels.distributions[base][axis]:
-                q.launch(k, None, sk)
-        q.record(ev['bulk'], sk)
-        self._program_halo(q, ev['bulk'], ev)
+            prof.record_gpu_end(TimeProfile.MACRO_DISTRIB, sh)
+        q.record(ev['macro_halo'], sh)
+        q.wait(self._calc_stream, ev['macro_halo'])
+
+    def _program_front(self, q, it, sync_req, group=None):
+        """The sweeps of every lattice over the whole subdomain (no face layers split off: the force reads the fields of
+        the step, which the macro pass has just written) -> ghost-layer PBC kernels -> pack."""
+        self._program_sweep_rest(q, it, self._sweep_kernels(it, sync_req), None, None, group)
 
     def _debug_get_dist(self, output=True, grid_num=0, copy=None):
         return SubdomainRunner._debug_get_dist(self, output, grid_num, copy)

@@ -86,3 +86,25 @@ def test_controller_starts_its_own_ranks(pattern, axis, tmp_path):
     assert set(got) == set(ref) and 'rho' in ref
     for name in ref:
         assert np.array_equal(got[name], ref[name], equal_nan=True), name
+
+
+@pytest.mark.parametrize('pattern,axis,nsub', [('AA', 'z', 2), ('AB', 'x', 3), ('AA', 'y', 2)])
+def test_same_process_group_steps_as_one_program(pattern, axis, nsub, tmp_path):
+    """controller.LocalGroup (several subdomains in THIS process, one --gpus entry) with the CPU test backend: the group's
+    step -- fronts of all runners, copies between their halo buffers, backs -- gives the undivided run bit for bit."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from utils.merge_subdomains import merge_subdomains
+    sim_cls = _host.load_sim_class('ldc_3d', 'LDCSim')
+    steps = 7
+    base = dict(lat_nx=18, lat_ny=12, lat_nz=10, visc=0.03, access_pattern=pattern, conn_axis=axis, max_iters=steps,
+                quiet=True, perf_stats_every=0, every=steps, backends='tests._oracle_backend', output_compress=False, gpus=[0])
+    for name, n in (('many', nsub), ('one', 1)):
+        ctrl = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D,
+                                      default_config=dict(base, subdomains=n, output=str(tmp_path / name)))
+        ctrl.run(ignore_cmdline=True)
+        assert len(ctrl.runners) == n
+    got = merge_subdomains(str(tmp_path / 'many'), 1, steps, save=False)
+    ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
+    for name in ref:
+        assert np.array_equal(got[name], ref[name], equal_nan=True), name
