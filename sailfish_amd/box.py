@@ -27,14 +27,13 @@ def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='A
     dim = grid.dim
     assert len(size) == dim
     lat = [s + 2 for s in size]
-    alignment = int(os.environ.get('SLF_MEM_ALIGNMENT', alignment))     # experiments
     kw = dict(lattice=grid.slf_id,
               model=hipabi.SLF_MRT if model == 'mrt' else hipabi.SLF_BGK,
               precision=4 if precision == 'single' else 8,
               access_pattern=hipabi.SLF_AA if access_pattern == 'AA' else hipabi.SLF_AB,
               lat_nx=lat[0], lat_ny=lat[1], lat_nz=lat[2] if dim == 3 else 1,
-              arr_nx=padded_nx(lat[0], alignment) + int(os.environ.get('SLF_ARR_NX_PAD', '0')),   # experiments
-              arr_ny=lat[1] + int(os.environ.get('SLF_ARR_NY_PAD', '0')), arr_nz=lat[2] if dim == 3 else 1,
+              arr_nx=padded_nx(lat[0], alignment),
+              arr_ny=lat[1], arr_nz=lat[2] if dim == 3 else 1,
               periodic_fused=list(periodic_fused), fluid_only=int(fluid_only),
               tau=sym.relaxation_time(visc), visc=visc, mrt_rates=sym.mrt_rates(grid, visc),
               incompressible=int(incompressible), relaxation_enabled=int(relaxation_enabled),
@@ -49,8 +48,6 @@ def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='A
     if nt_bits is not None:
         misc, param, scratch = nt_bits
         kw.update(nt_type_mask=(1 << misc) - 1, nt_misc_shift=misc, nt_param_shift=param, nt_scratch_shift=scratch)
-    if dist_pad is None:
-        dist_pad = int(os.environ.get('SLF_DIST_PAD', '0'))
     if dist_pad:
         kw['dist_stride'] = kw['arr_nx'] * kw['arr_ny'] * kw['arr_nz'] + int(dist_pad)
     return hipabi.make_desc(**kw)

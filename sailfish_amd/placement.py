@@ -38,11 +38,6 @@ class PlacedBuffer(object):
         need = int(nbytes) + 256
         self.parts = parts
         self.part_bytes = (need + parts * gran - 1) // (parts * gran) * gran
-        if os.environ.get('SLF_PLACEMENT_POW2') == '1':     # experiment: buddy-allocator friendly chunk sizes
-            p2 = gran
-            while p2 < self.part_bytes:
-                p2 *= 2
-            self.part_bytes = p2
         self.total = self.part_bytes * parts
         self.va = backend.vmm_reserve(self.total)
         self.addr = self.va + int(align_offset)

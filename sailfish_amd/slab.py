@@ -268,10 +268,12 @@ class SlabSim(BoxSim):
         pos_of = dict((c, pos) for pos, c in enumerate(plan.order))
         sh = self.halo_stream
         t0 = None
+        waited = {}
         for pos, c in enumerate(plan.order):
             st = streams[pos & 1]
-            if need[c] >= 0:
+            if need[c] > waited.get(id(st), -1):     # the streams are in order: a later transfer waited for covers the earlier ones
                 q.wait(st, pevb[need[c]])
+                waited[id(st)] = need[c]
             for c2 in plan.neighbours(c):
                 if streams[pos_of[c2] & 1] is not st:
                     q.wait(st, pevc[pos_of[c2]])

@@ -822,10 +822,12 @@ class SubdomainRunner(object):
         sh = self._data_stream
         if timed:
             prof.record_gpu_start(TimeProfile.BULK, streams[0])
+        waited = {}
         for pos, c in enumerate(plan.order):
             st = streams[pos & 1]
-            if need[c] >= 0:
+            if need[c] > waited.get(id(st), -1):     # the streams are in order: a later transfer waited for covers the earlier ones
                 q.wait(st, pevb[need[c]])
+                waited[id(st)] = need[c]
             for c2 in plan.neighbours(c):
                 if streams[pos_of[c2] & 1] is not st:
                     q.wait(st, pevc[pos_of[c2]])

@@ -508,7 +508,8 @@ def test_pressure_driven_channel_minimize_roundoff(pattern):
     assert np.array_equal(fg[m], fo[m])
     std = run_gpu('poiseuille', 'PoiseuilleSim', 2, dict(cfg, minimize_roundoff=False), steps)
     rho_ro, rho = merged_gpu(ro, 'rho'), merged_gpu(std, 'rho')
-    wet = np.isfinite(rho) & (rho != 0)
+    wet = ro.runners[0]._subdomain.fluid_map()          # nodes the sweep writes (the corner nodes of the inlet / outlet
+    assert wet.sum() > 0.8 * wet.size                   # columns have no fluid neighbour: unused, they keep the initial field)
     assert np.max(np.abs((rho_ro[wet] + 1.0) - rho[wet])) < 2e-6
     for d in range(2):
         assert np.max(np.abs(merged_gpu(ro, 'v%d' % d)[wet] - merged_gpu(std, 'v%d' % d)[wet])) < 2e-6
