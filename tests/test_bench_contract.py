@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'bench_final.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04', 'bench_driver_cmd_final.json')))    # the driver's command line
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -17,7 +17,9 @@ def test_committed_bench_line_has_every_contract_field():
     assert d['vs_baseline'] is None and d['dtype'] == 'f32' and 'workload' in d['config'] and 'model' not in d['config']
     assert 'D3Q19 BGK 512^3' in d['metric']
     c = d['config']
-    assert c['value_is'] == 'best of repeats' and len(c['runs_mlups']) == c['repeats']
+    # round 4: blocks of exactly K steps, repeated until at least half a second has been timed
+    assert c['value_is'].startswith('best block of exactly K steps') and c['timed_blocks'] >= c['repeats']
+    assert c['timed_seconds'] >= 0.5 and abs(c['timed_seconds'] / c['timed_blocks'] - d['ms_per_step'] * d['steps'] * 1e-3) < 0.2 * c['timed_seconds'] / c['timed_blocks']
     assert min(c['runs_mlups']) <= c['median_mlups'] <= max(c['runs_mlups']) and abs(max(c['runs_mlups']) - d['value']) < 1.0
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
