@@ -22,7 +22,6 @@ needs before it may count itself writes the L2 of its XCD back, 25 x slower -- p
 Replaces, for 1-D decompositions along x (the reference's default axis, geo.py:100-135), the reference's
 CollectContinuousData / DistributeContinuousData on x faces (kernel_utils.mako:526-543, 692-708).
 """
-import ctypes
 import os
 
 import numpy as np

@@ -135,3 +135,76 @@ def test_example_starts_its_own_ranks(pattern, axis, tmp_path):
     assert set(got) == set(ref) and 'rho' in ref and 'v' in ref
     for name in ref:
         assert np.array_equal(got[name], ref[name], equal_nan=True), name
+
+
+# ---- the same paths over RCCL: run by themselves on any box with at least two GPUs (an 8-GPU node exercises the real
+# ---- transport -- DirectRccl communicator of two ranks, step plans with RCCL batches to another device -- without anyone
+# ---- asking); skipped on the 1-GPU boxes of the build pool.
+def _gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+needs_two_gpus = pytest.mark.skipif(_gpus() < 2, reason='needs two GPUs (RCCL refuses two ranks per device)')
+
+
+def _rccl_env():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'SLF_DIST_BACKEND', 'SLF_FORCE_DEVICE'):
+        env.pop(k, None)
+    return env
+
+
+@needs_two_gpus
+@pytest.mark.parametrize('mode', [['--scaling', 'weak', '--size', '96'],
+                                  ['--scaling', 'strong', '--domain', '128x64x96', '--axis', 'z'],
+                                  ['--scaling', 'strong', '--domain', '256x48x40', '--axis', 'x']],
+                         ids=['weak_z', 'strong_z', 'strong_x'])
+def test_bench_with_two_rccl_ranks(mode):
+    """`python bench.py --gpus 2` on two GPUs: RCCL process group, halos through the C-ABI communicator inside the step
+    plans, seam layers validated on both ranks."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--prewarm_steps', '2',
+           '--repeats', '1', '--no_cpu_baseline', '--no_gpu_state', '--min_seconds', '0.05'] + mode
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=_rccl_env(), timeout=900)
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode == 0, out[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    c = json.loads(lines[0])['config']
+    assert c['rccl_ranks'] == 2 and c['dist_backend'] == 'nccl' and 'C ABI' in c['halo_transport']
+    assert sorted(r['device'] for r in c['per_rank']) == [0, 1] and all(r['step_plans'] for r in c['per_rank'])
+    assert c['validated'] is True and all(v['populations_bit_identical'] and v['ranks_checked'] == 2 for v in c['validation'].values())
+
+
+@needs_two_gpus
+@pytest.mark.parametrize('axis,pattern,model', [('z', 'AA', 'bgk'), ('x', 'AA', 'bgk'), ('x', 'AB', 'mrt'), ('y', 'AB', 'bgk')])
+def test_two_rccl_ranks_equal_one_box(axis, pattern, model):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', '_two_rank_worker.py'), axis, pattern, model]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=_rccl_env(), timeout=900)
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode == 0 and 'TWO_RANK_PARITY OK backend=nccl world=2' in out, out[-3000:]
+
+
+@needs_two_gpus
+@pytest.mark.parametrize('pattern,axis', [('AA', 'x'), ('AB', 'z')])
+def test_example_starts_its_own_rccl_ranks(pattern, axis, tmp_path):
+    """`python examples/ldc_3d.py --subdomains=2 --gpus 0 1`: the controller starts one process per GPU, the runners'
+    step plans carry the RCCL batches; merged output == the single-subdomain run."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from utils.merge_subdomains import merge_subdomains
+    steps = 9
+    common = ['--lat_nx=40', '--lat_ny=12', '--lat_nz=10', '--visc=0.03', '--max_iters=%d' % steps, '--every=%d' % steps,
+              '--access_pattern=' + pattern, '--conn_axis=' + axis, '--quiet', '--nooutput_compress', '--perf_stats_every=0']
+    for name, extra in (('two', ['--subdomains=2', '--gpus', '0', '1']), ('one', ['--subdomains=1', '--gpus', '0'])):
+        cmd = [sys.executable, os.path.join(ROOT, 'examples', 'ldc_3d.py'), '--output=' + str(tmp_path / name)] + common + extra
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=_rccl_env(), timeout=900)
+        assert res.returncode == 0, res.stdout.decode(errors='replace')[-3000:]
+    got = merge_subdomains(str(tmp_path / 'two'), 1, steps, save=False)
+    ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
+    for name in ref:
+        assert np.array_equal(got[name], ref[name], equal_nan=True), name
