@@ -52,3 +52,40 @@ def test_halo_index_lists_name_what_the_reference_connections_transfer(name):
     assert sorted(got) == sorted(want)
     for k in want:
         assert got[k] == want[k], (name, k, sorted(got[k] ^ want[k])[:6])
+
+
+@pytest.mark.parametrize('name', sorted(GOLD))
+def test_macro_field_links_fill_every_ghost_node_the_reference_fills(name):
+    """Non-local models (Shan-Chen): which ghost nodes take a neighbour's field value.  The reference's connection
+    objects name them through `dst_macro_slice` (subdomain_connection.py:262-290); build_macro_links() routes EVERY ghost
+    node that another subdomain owns.  Same sets for slabs and 2-D blocks; a superset where the reference leaves ghost
+    nodes to a later pass (ghost corners across periodic axes of a slab: its macro PBC kernel fills them afterwards) or
+    to nobody (corner ghosts owned by the body-diagonal block of a 2 x 2 x 2 layout, which no D3Q19 direction reaches)."""
+    case = GOLD[name]
+    dim = len(case['gsize'])
+    cls = SubdomainSpec2D if dim == 2 else SubdomainSpec3D
+    specs = [cls(tuple(loc), tuple(size)) for loc, size in case['boxes']]
+    for i, s in enumerate(specs):
+        s.id = i
+        s.set_actual_size(1)
+    subdomain_connection.connect_subdomains(specs, case['gsize'], case['periodic'])
+    got = {}
+    for recv in specs:
+        arr = [n + 2 for n in recv.size]
+        links = subdomain_connection.build_macro_links(recv, specs, case['gsize'], case['periodic'], arr, lambda s: [0] * dim)
+        for sender_id, link in links.items():
+            node = link.recv.astype(np.int64)
+            coords = []
+            for a in range(dim):
+                coords.append(node % arr[a])
+                node = node // arr[a]
+            got['%d->%d' % (sender_id, recv.id)] = set(zip(*[c.tolist() for c in coords]))
+            # the sender lists as many real nodes as the receiver lists ghost nodes
+            back = subdomain_connection.build_macro_links(specs[sender_id], specs, case['gsize'], case['periodic'],
+                                                          [n + 2 for n in specs[sender_id].size], lambda s: [0] * dim)
+            assert len(back[recv.id].send) == len(link.recv)
+    want = dict((k, set(tuple(t) for t in v)) for k, v in case['macro_ghosts'].items())
+    for k in want:
+        assert want[k] <= got.get(k, set()), (name, k, sorted(want[k] - got.get(k, set()))[:6])
+    if name not in ('3d_x8_periodic_xyz', '3d_blocks_2x2x2_periodic_z'):
+        assert dict((k, v) for k, v in got.items() if v) == want

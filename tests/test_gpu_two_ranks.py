@@ -208,3 +208,26 @@ def test_example_starts_its_own_rccl_ranks(pattern, axis, tmp_path):
     ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
     for name in ref:
         assert np.array_equal(got[name], ref[name], equal_nan=True), name
+
+
+@pytest.mark.parametrize('mode', [['--scaling', 'weak', '--size', '64'],
+                                  ['--scaling', 'strong', '--domain', '256x24x40', '--axis', 'x']], ids=['weak_z', 'strong_x'])
+def test_bench_with_four_ranks_on_one_gpu(mode):
+    """Four ranks (gloo, one GPU): a ring whose up and down neighbours are DIFFERENT ranks -- with two ranks they
+    coincide -- through the slab exchange, the seam validation (every rank's windows take layers of both neighbours)
+    and the gathered per-rank figures."""
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '4', '--warmup', '2', '--prewarm_steps', '2',
+           '--repeats', '1', '--no_cpu_baseline', '--no_gpu_state', '--min_seconds', '0.02', '--halo_timing_steps', '4'] + mode
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=900)
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode == 0, out[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 4 and c['rccl_ranks'] == 4 and sorted(r['rank'] for r in c['per_rank']) == [0, 1, 2, 3]
+    assert c['validated'] is True, c['validation']
+    assert all(v['populations_bit_identical'] and v['ranks_checked'] == 4 for v in c['validation'].values())

@@ -58,8 +58,8 @@ def test_config_travels_to_the_ranks_as_plain_values():
     pickle.dumps(d)
 
 
-@pytest.mark.parametrize('pattern,axis', [('AA', 'z'), ('AB', 'x')])
-def test_controller_starts_its_own_ranks(pattern, axis, tmp_path):
+@pytest.mark.parametrize('pattern,axis,nsub', [('AA', 'z', 2), ('AB', 'x', 2), ('AA', 'x', 3)])
+def test_controller_starts_its_own_ranks(pattern, axis, nsub, tmp_path):
     from sailfish_amd import geo as geo_mod
     from sailfish_amd.controller import LBSimulationController
     from utils.merge_subdomains import merge_subdomains
@@ -70,7 +70,7 @@ def test_controller_starts_its_own_ranks(pattern, axis, tmp_path):
     env = dict((k, os.environ.pop(k, None)) for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'))
     try:
         two = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D,
-                                     default_config=dict(base, subdomains=2, gpus=[0, 0], output=str(tmp_path / 'two')))
+                                     default_config=dict(base, subdomains=nsub, gpus=[0] * nsub, output=str(tmp_path / 'two')))
         two.run(ignore_cmdline=True)
         assert two.runners == []                      # the subdomains ran in their own processes
         one = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D,

@@ -117,9 +117,28 @@ def main():
                 for cpair in s.get_connections(face, nid):
                     items = expand(cpair.src, dim, conn_axis, face_high, dst.size)
                     pairs.setdefault('%d->%d' % (s.id, nid), set()).update(items)
+        # macroscopic fields (non-local models): ghost nodes of s that take the value of a real node of nid
+        # (LBConnection.dst_macro_slice of s's own connection object, in s's ghost-including coordinates; the ghost
+        # layer of `face`)
+        macro = {}
+        for s in specs:
+            for face, nid in s.connecting_subdomains():
+                conn_axis = s.face_to_axis(face)
+                slice_axes = [a for a in range(dim) if a != conn_axis]
+                layer = s.size[conn_axis] + 1 if face % 2 == 1 else 0
+                for cpair in s.get_connections(face, nid):
+                    ranges = [range(sl.start, sl.stop) for sl in cpair.src.dst_macro_slice]
+                    grids = np.meshgrid(*ranges, indexing='ij')
+                    for coords in zip(*[g.ravel() for g in grids]):
+                        p = [0] * dim
+                        p[conn_axis] = layer
+                        for a, c in zip(slice_axes, coords):
+                            p[a] = int(c)
+                        macro.setdefault('%d->%d' % (nid, s.id), set()).add(tuple(p))
         res[name] = {'gsize': list(case['gsize']), 'periodic': [int(p) for p in case['periodic']],
                      'boxes': [[list(l), list(sz)] for l, sz in case['boxes']],
-                     'pairs': dict((k, sorted(list(v))) for k, v in sorted(pairs.items()))}
+                     'pairs': dict((k, sorted(list(v))) for k, v in sorted(pairs.items())),
+                     'macro_ghosts': dict((k, sorted(list(v))) for k, v in sorted(macro.items()))}
         print(name, dict((k, len(v)) for k, v in sorted(pairs.items())))
     with open(OUT, 'w') as fh:
         json.dump(res, fh, separators=(',', ':'))
