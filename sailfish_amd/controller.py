@@ -127,6 +127,8 @@ class LocalGroup(object):
         par = it & 1
         sh = r._data_stream
         for pos in range(len(r._xchunks.order)):
+            if not r._xchunks.exchanges_at(pos):
+                continue
             mine = r.xface_pieces(pos)
             for nid in sorted(set(p[0] for p in mine)):
                 src = self.by_id[nid]

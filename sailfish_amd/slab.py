@@ -278,9 +278,11 @@ class SlabSim(BoxSim):
                 if streams[pos_of[c2] & 1] is not st:
                     q.wait(st, pevc[pos_of[c2]])
             q.launch(k, plan.region(c, ny), st)
+            if not plan.exchanges_at(pos) and streams[0] is streams[1]:
+                continue                 # nothing travels after this chunk and nobody waits for it
             q.record(evc[pos], st)
             q.wait(sh, evc[pos])
-            if self.time_halo and not q.planned and pos == 0:
+            if self.time_halo and not q.planned and t0 is None:
                 t0 = self.backend.make_event(sh, timing=True)
             runs = plan.batches[kind][pos]
             if runs:

@@ -833,6 +833,8 @@ class SubdomainRunner(object):
                     q.wait(st, pevc[pos_of[c2]])
             for k in kernels:
                 q.launch(k, plan.region(c, ny), st)
+            if not plan.exchanges_at(pos) and streams[0] is streams[1]:
+                continue                 # nothing travels after this chunk and nobody waits for it
             q.record(evc[pos], st)
             if group is None:
                 q.wait(sh, evc[pos])

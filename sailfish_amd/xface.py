@@ -94,6 +94,16 @@ class ChunkPlan(object):
         for pos, c in enumerate(self.order):
             for p in self.writes(kind, c):
                 done_at[p] = pos                   # the LAST writer decides
+        # SLF_XFACE_BATCHES=two: only two transfers per step -- everything that is complete before the last chunk starts
+        # travels while the last chunk is swept, the rest while the first chunk of the next step is swept (which, by the
+        # order above, reads none of it): two event records and two RCCL groups less per step.  Measured SLOWER with one
+        # rank sending to itself (0.935 against 0.913 ms per step, AB 1.02 against 0.98: the three-quarter-face transfer
+        # is a 200 us RCCL self-copy beside the last chunk, and the next step waits for it; profiles/NOTES.md), so one
+        # transfer after every chunk stays the default; over xGMI the balance may differ.
+        if os.environ.get('SLF_XFACE_BATCHES', 'all') == 'two':
+            first = max(0, len(self.order) - 2)
+            for p in done_at:
+                done_at[p] = max(done_at[p], first)
         batches = []
         for pos in range(len(self.order)):
             planes = sorted(p for p, d in done_at.items() if d == pos)
@@ -109,6 +119,11 @@ class ChunkPlan(object):
             js = [done_at[p] for p in self.reads_after(kind, c) if p in done_at]
             need.append(max(js) if js else -1)
         return batches, need
+
+    def exchanges_at(self, pos):
+        """Does a transfer (of either step kind) start after the chunk at position `pos`?  Positions without one need no
+        event either: nothing waits for them."""
+        return any(self.batches[kind][pos] for kind in self.batches)
 
     def region(self, c, ny):
         z0, z1 = self.chunks[c]

@@ -151,7 +151,8 @@ def test_step_plan_equals_direct_enqueue(pattern, axis):
     ref, ref_rho, planned = _ring_of_one(axis, pattern, n, 9)
     assert planned == [(0, 0), (0, 1), (1, 0)]           # both parities, the last step with field output
     for env in ({'SLF_STEP_PLAN': '0'}, {'SLF_STEP_PLAN': '0', 'SLF_CALC_STREAMS': '1'}, {'SLF_CALC_STREAMS': '1'},
-                {'SLF_XFACE_CHUNKS': '2'}, {'SLF_XFACE_CHUNKS': '1'}, {'SLF_XFACE_STREAMS': '2'}):
+                {'SLF_XFACE_CHUNKS': '2'}, {'SLF_XFACE_CHUNKS': '1'}, {'SLF_XFACE_STREAMS': '2'}, {'SLF_XFACE_BATCHES': 'two'},
+                {'SLF_XFACE_CHUNKS': '8'}):
         got, got_rho, planned = _ring_of_one(axis, pattern, n, 9, env)
         assert (planned == []) == (env.get('SLF_STEP_PLAN') == '0')
         assert np.array_equal(got, ref), env

@@ -25,7 +25,7 @@ def test_every_written_plane_travels_once_and_nothing_is_read_too_early(nz, wrap
         for c in range(len(p.chunks)):
             written.update(p.writes(kind, c))
         assert set(sent) == written
-        # a plane travels only after its last writer has been swept
+        # a plane travels as soon as its last writer has been swept
         done = {}
         for pos, c in enumerate(p.order):
             for pl in p.writes(kind, c):
@@ -53,3 +53,21 @@ def test_the_first_chunk_of_a_step_never_waits_for_the_last_transfer_of_the_prev
 def test_thin_subdomains_are_not_cut():
     p = ChunkPlan(6, True, 4)
     assert p.chunks == [(1, 7)] and p.order == [0] and p.need['push'] == [0]
+
+
+def test_two_transfers_per_step_on_request(monkeypatch):
+    """SLF_XFACE_BATCHES=two: what is complete before the last chunk starts travels in one piece, the rest after it; the
+    first chunk of the next step still does not wait for the last transfer."""
+    monkeypatch.setenv('SLF_XFACE_BATCHES', 'two')
+    for wrap in (True, False):
+        p = ChunkPlan(512, wrap, 4)
+        assert [p.exchanges_at(pos) for pos in range(4)] == [False, False, True, True]
+        for kind in ('push', 'own'):
+            sent = dict((pl, pos) for pos, runs in enumerate(p.batches[kind]) for p0, p1 in runs for pl in range(p0, p1))
+            done = {}
+            for pos, c in enumerate(p.order):
+                for pl in p.writes(kind, c):
+                    done[pl] = pos
+            assert all(sent[pl] == max(done[pl], 2) for pl in done)
+            assert p.need[kind][p.order[0]] == 2 and all(n == 3 for c, n in enumerate(p.need[kind]) if c != p.order[0] and
+                                                         (wrap or c != 1))
