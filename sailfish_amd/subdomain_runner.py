@@ -517,6 +517,13 @@ class SubdomainRunner(object):
         if self._xface is not None:
             self.backend.sync_stream(*self._all_streams())
             self._xface.reset(self._calc_stream)
+            it = self._sim.iteration
+            if self.config.access_pattern == 'AA' and (it & 1):
+                # the next step pulls, and the edge lanes of the fluid-only row kernel take what enters through a
+                # connected x face from the receive buffers alone (slf_row.hip: no pull out of the ghost column): prime
+                # them from the ghost columns of the state just written (a checkpoint taken at an odd iteration)
+                self._xface.prime_pull(self.gpu_dist(0, 0), self._calc_stream, parity=1 - (it & 1))
+            self.backend.sync_stream(self._calc_stream)
             self.__dict__.pop('_halo_mode', None)
     
     def _materialise_halo(self):
