@@ -856,10 +856,9 @@ int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]) {
   return SLF_OK;
 }
 
-int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high) {
+static int check_xface_buffers(const slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high) {
   if (!m) return fail(SLF_ERR_INVALID, "module is NULL");
-  const bool any = send_low || send_high || recv_low || recv_high;
-  if (any) {
+  if (send_low || send_high || recv_low || recv_high) {
     const slf::Geometry& g = m->geo;
     if (m->sel.lattice != 1 || g.indirect || m->sc.enabled || !(g.variant & 8))
       return fail(SLF_ERR_UNSUPPORTED, "x-face buffers: D3Q19 single-fluid modules with direct addressing (whole-row kernels) only");
@@ -868,6 +867,11 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
     if ((send_low == nullptr) != (recv_low == nullptr) || (send_high == nullptr) != (recv_high == nullptr))
       return fail(SLF_ERR_INVALID, "a connected face needs both its send and its receive buffer");
   }
+  return SLF_OK;
+}
+
+int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high) {
+  if (int e = check_xface_buffers(m, send_low, send_high, recv_low, recv_high)) return e;
   m->xsend[0] = send_low;
   m->xsend[1] = send_high;
   m->xrecv[0] = recv_low;
@@ -1420,9 +1424,7 @@ int slf_plan_add_copy(slf_plan* p, void* dst, const void* src, size_t bytes, slf
 int slf_plan_add_xface_buffers(slf_plan* p, slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high) {
   if (!p || !m) return fail(SLF_ERR_INVALID, "NULL argument");
   // validated now, with the module's rules, so that slf_plan_run cannot fail on it
-  void* keep[4] = {m->xsend[0], m->xsend[1], m->xrecv[0], m->xrecv[1]};
-  if (int e = slf_module_set_xface_buffers(m, send_low, send_high, recv_low, recv_high)) return e;
-  m->xsend[0] = keep[0]; m->xsend[1] = keep[1]; m->xrecv[0] = keep[2]; m->xrecv[1] = keep[3];
+  if (int e = check_xface_buffers(m, send_low, send_high, recv_low, recv_high)) return e;
   PlanOp o;
   o.kind = PL_XFACE;
   o.mod = m;

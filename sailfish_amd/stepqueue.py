@@ -23,8 +23,12 @@ class DirectQueue(object):
     def __init__(self, backend):
         self.backend = backend
 
+    def _of(self, stream):
+        """The backend a stream belongs to (a same-process group steps runners with a backend object each)."""
+        return getattr(stream, '_backend', None) or self.backend
+
     def launch(self, kernel, region, stream):
-        self.backend.run_kernel(kernel, region, stream)
+        self._of(stream).run_kernel(kernel, region, stream)
 
     def record(self, event, stream):
         event.record(stream)
@@ -37,10 +41,10 @@ class DirectQueue(object):
         rccl.run(batch, stream)
 
     def memset(self, addr, value, nbytes, stream):
-        self.backend.memset_buf(addr, value, nbytes, stream)
+        self._of(stream).memset_buf(addr, value, nbytes, stream)
 
     def copy(self, dst, src, nbytes, stream):
-        self.backend.copy_buf_async(dst, src, nbytes, stream)
+        self._of(stream).copy_buf_async(dst, src, nbytes, stream)
 
     def xface(self, module, send_low, send_high, recv_low, recv_high):
         self.backend.set_xface_buffers(module, send_low, send_high, recv_low, recv_high)
