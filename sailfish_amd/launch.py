@@ -187,16 +187,34 @@ def run_processes(lb_class, lb_geo, cfg, n_subdomains, gpus, log=None):
         p.start()
         procs.append(p)
     child.close()
-    summary = None
+    summary, got = None, False
     try:
-        if parent.poll(None):
-            try:
-                summary = parent.recv()
-            except EOFError:
-                summary = None
+        # wait for rank 0's summary, but keep an eye on the others: a rank that died leaves its neighbours waiting in an
+        # exchange for ever (the reference's master polls its subprocesses the same way, master.py:268-312)
+        while True:
+            if not got and parent.poll(0.2):
+                try:
+                    summary = parent.recv()
+                except EOFError:
+                    summary = None
+                got = True
+            failed = [p for p in procs if p.exitcode not in (None, 0)]
+            if failed:
+                for p in procs:
+                    if p.exitcode is None:
+                        p.terminate()
+                break
+            if all(p.exitcode is not None for p in procs):
+                break
+            if got:
+                for p in procs:
+                    p.join(0.2)
     finally:
         for p in procs:
-            p.join()
+            p.join(30)
+            if p.exitcode is None:
+                p.kill()
+                p.join()
     bad = [(p.name, p.exitcode) for p in procs if p.exitcode != 0]
     if bad:
         raise RuntimeError('subdomain processes failed: %s' % bad)

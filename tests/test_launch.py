@@ -108,3 +108,26 @@ def test_same_process_group_steps_as_one_program(pattern, axis, nsub, tmp_path):
     ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
     for name in ref:
         assert np.array_equal(got[name], ref[name], equal_nan=True), name
+
+
+def test_a_rank_that_dies_ends_the_run_instead_of_hanging_it(tmp_path):
+    """One subdomain process fails during set-up: the controller ends the others and raises (it does not wait for ever
+    for rank 0, which sits in an exchange with the dead rank)."""
+    import time
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from tests._failing_sim import FailingSim
+    env = dict((k, os.environ.pop(k, None)) for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'))
+    try:
+        ctrl = LBSimulationController(FailingSim, geo_mod.EqualSubdomainsGeometry3D,
+                                      default_config=dict(lat_nx=18, lat_ny=10, lat_nz=8, visc=0.03, access_pattern='AB',
+                                                          conn_axis='x', max_iters=50, quiet=True, perf_stats_every=0,
+                                                          backends='tests._oracle_backend', subdomains=2, gpus=[0, 0]))
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match='subdomain processes failed'):
+            ctrl.run(ignore_cmdline=True)
+        assert time.time() - t0 < 120
+    finally:
+        for k, v in env.items():
+            if v is not None:
+                os.environ[k] = v
