@@ -305,6 +305,22 @@ def main():
 
     backend = HIPBackend(Opt(), local_rank)
     distributed = world > 1 or args.force_distributed
+    pinned = None
+    if world > 1 and os.environ.get('SLF_PIN_RANKS', '1') != '0':
+        # every rank on cores of its GPU's NUMA node, the node's cores dealt out between the ranks that share it (what
+        # the controller does for the subdomain processes it starts: sailfish_amd/launch.py)
+        try:
+            from sailfish_amd import launch
+            per_node = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+            me = int(os.environ.get('LOCAL_RANK', '0')) % per_node
+            forced = os.environ.get('SLF_FORCE_DEVICE')
+            nodes = [launch.gpu_numa_node(HIPBackend.pci_bus_id(int(forced) if forced is not None else d))
+                     for d in range(per_node)]
+            sets = launch.cpu_sets(nodes, sorted(os.sched_getaffinity(0)), launch.numa_cpus)
+            os.sched_setaffinity(0, sets[me])
+            pinned = {'numa_node': nodes[me], 'cpus': len(sets[me])}
+        except Exception as e:  # noqa: BLE001 -- pinning is an optimisation, never a reason to fail
+            pinned = {'error': str(e)[:80]}
     if distributed:
         from sailfish_amd.connector import init_distributed
         init_distributed(force=True)
@@ -423,6 +439,7 @@ def main():
         mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms', 'host_ms', 'host_ms_median') if k in best)
         mine['rank'] = rank
         mine['step_plans'] = best.get('step_plans')
+        mine['pinned'] = pinned
         mine.update(device_report(local_rank))
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, mine)
