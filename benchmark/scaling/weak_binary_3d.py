@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Weak scaling, 3D binary Shan-Chen mixture in a closed box (counterpart of the reference's
 benchmark/scaling/weak_binary_3d.py): two lattices, two halo exchanges per step (macroscopic fields,
-then populations)."""
+then populations).  Started like weak_single_3d.py (--num_blocks N --gpus 0 .. N-1, or under torch.distributed.run)."""
 import os
 import sys
 
@@ -22,6 +22,11 @@ class ClosedBox(MixtureSubdomain):
         self.set_node(np.asarray(shell), NTFullBBWall)
 
 
+class ClosedBoxSim(SeparationSim):
+    # a class of its own (not an attribute patched onto SeparationSim): the ranks the controller starts import it by name
+    subdomain = ClosedBox
+
+
 def run_benchmark(num_blocks, edge=256):
     settings = {
         'max_iters': 700,
@@ -37,8 +42,7 @@ def run_benchmark(num_blocks, edge=256):
         'lat_ny': edge,
         'lat_nz': edge * num_blocks,
     }
-    SeparationSim.subdomain = ClosedBox
-    ctrl = LBSimulationController(SeparationSim, EqualSubdomainsGeometry3D, settings)
+    ctrl = LBSimulationController(ClosedBoxSim, EqualSubdomainsGeometry3D, settings)
     timing_infos, min_timings, max_timings, subdomains = ctrl.run()
     return util.save_result('weak_3d_binary', num_blocks, timing_infos, min_timings, max_timings, subdomains)
 

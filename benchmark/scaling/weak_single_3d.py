@@ -2,9 +2,11 @@
 """Weak scaling, 3D single-phase fluid: the lid-driven cavity, one edge^3 block per GPU, blocks stacked
 along z (counterpart of the reference's benchmark/scaling/weak_single_3d.py, sized for an MI355X).
 
-    python benchmark/scaling/weak_single_3d.py --num_blocks 1                    # all blocks in one process
+    python benchmark/scaling/weak_single_3d.py --num_blocks 1                    # one block, one process
+    python benchmark/scaling/weak_single_3d.py --num_blocks 8 --gpus 0 1 2 3 4 5 6 7
+                                        # the controller starts one process per GPU itself (sailfish_amd/launch.py)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        benchmark/scaling/weak_single_3d.py                                      # one block per rank / GPU
+        benchmark/scaling/weak_single_3d.py                                      # or: ranks started by torchrun
 """
 import os
 import sys

@@ -46,3 +46,22 @@ def test_weak_scaling_harness(tmp_path):
     assert res.returncode == 0, res.stdout.decode()[-2000:]
     assert b'weak_3d_single blocks=2' in res.stdout
     assert os.path.exists(os.path.join(str(tmp_path), 'weak_3d_single_mlups_2'))
+
+
+@pytest.mark.parametrize('script,tag,edge', [('weak_single_3d.py', 'weak_3d_single', 48), ('weak_binary_3d.py', 'weak_3d_binary', 32)])
+def test_weak_scaling_harness_starts_its_own_ranks(script, tag, edge, tmp_path):
+    """--gpus on the harness's command line reaches the controller, which starts one process per block (two ranks on the
+    one GPU here, gloo); the timing summary of all ranks comes back to the script."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'SLF_DIST_BACKEND', 'SLF_FORCE_DEVICE'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'benchmark', 'scaling', script), '--num_blocks', '2', '--edge', str(edge),
+           '--gpus', '0', '0']
+    res = subprocess.run(cmd, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=900)
+    assert res.returncode == 0, res.stdout.decode(errors='replace')[-3000:]
+    assert ('%s blocks=2' % tag).encode() in res.stdout
+    with open(os.path.join(str(tmp_path), '%s_mlups_2' % tag)) as f:
+        eff, comp = [float(x) for x in f.read().split()]
+    assert eff > 0 and comp > 0
+    with open(os.path.join(str(tmp_path), '%s_2' % tag)) as f:
+        assert f.read().count('TimingInfo') == 2                # one per block

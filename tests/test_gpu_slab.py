@@ -168,3 +168,46 @@ def test_x_slab_state_written_at_odd_iteration(restore_at):
     ref, _, _ = _ring_of_one('x', 'AA', n, 8)
     got, _, _ = _ring_of_one('x', 'AA', n, 8, restore_at=restore_at)
     assert np.array_equal(got, ref)
+
+
+def test_step_plan_c_abi_basics():
+    """slf_plan_*: entries are performed in order by one call; kernels that take the iteration get it from
+    slf_plan_run(); misuse is refused when the entry is added, not when the plan runs."""
+    import ctypes
+    from sailfish_amd.backend_hip import HIPBackend, HIPEvent, HIPKernel
+    from sailfish_amd.box import BoxSim, make_box_desc
+
+    class Opt(object):
+        pass
+    b = HIPBackend(Opt(), 0)
+    desc = make_box_desc(sym.D3Q19, (32, 8, 6), access_pattern='AA', visc=0.02, periodic_fused=[1, 1, 1])
+    ref = BoxSim(b, desc, periodic=(True, True, True))
+    sim = BoxSim(b, desc, periodic=(True, True, True))
+    rng = np.random.RandomState(0)
+    rho = 1.0 + 1e-3 * rng.rand(6, 8, 32)
+    v = [0.01 * rng.rand(6, 8, 32) for _ in range(3)]
+    for s in (ref, sim):
+        s.set_fields(rho, v)
+        s.initial_conditions()
+    for _ in range(4):
+        ref.step()
+    plan = b.make_plan()
+    ev = HIPEvent(b)
+    other = b.make_stream()
+    plan.launch(sim.k_sweep[0][0], None, sim.stream)          # the AA kernel: parity from the iteration given to run()
+    plan.record(ev, sim.stream)
+    plan.wait(other, ev)
+    plan.memset(sim.gpu_rho, 0, 16, other)
+    assert len(plan) == 4
+    for it in range(4):
+        plan.run(it)
+    sim.iteration = 4
+    sim.sync()
+    other.synchronize()
+    assert np.array_equal(sim.real_view(sim.get_dist()), ref.real_view(ref.get_dist()))
+    unbound = HIPKernel(b._lib, sim.module, 'CollideAndPropagate')
+    with pytest.raises(b.FatalError):
+        plan.launch(unbound, None, sim.stream)
+    assert b._lib.slf_plan_run(None, 0) != 0
+    assert b._lib.slf_plan_add_memset(plan.handle, ctypes.c_void_p(sim.gpu_rho), 0, 16, None) != 0      # a stream is needed
+    assert len(plan) == 4
