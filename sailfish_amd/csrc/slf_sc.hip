@@ -277,9 +277,6 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 #ifndef SLF_SC_FUSED_WAVES
 #define SLF_SC_FUSED_WAVES 5
 #endif
-#ifndef SLF_SC_FUSED_ORDER
-#define SLF_SC_FUSED_ORDER 0
-#endif
 template <class L, class R, int PROP, bool GENERAL, bool ROW = false>
 __global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? SLF_SC_FUSED_WAVES : 4)
 sc_fused_kernel(const ScParams<L, R> p) {
@@ -312,8 +309,7 @@ sc_fused_kernel(const ScParams<L, R> p) {
   if constexpr (L::dim == 3) vc[2] = p.vz[gi];
   // stencil sums of the fields some lattice is coupled to
   R S[2][3] = {{(R)0, (R)0, (R)0}, {(R)0, (R)0, (R)0}};
-  auto stencil = [&]() {
-    if (!wet) return;
+  if (wet) {
     const R* const fields[2] = {p.rho0, p.rho1};
     static_for<0, 2>([&](auto J) {
       if (p.G[J] != (R)0 || p.G2[J] != (R)0) {
@@ -327,11 +323,7 @@ sc_fused_kernel(const ScParams<L, R> p) {
         });
       }
     });
-  };
-#if SLF_SC_FUSED_ORDER == 0
-  stencil();
-#endif
-#if SLF_SC_FUSED_ORDER == 0
+  }
   static_for<0, 2>([&](auto K) {
     // one lattice at a time: without the fence the scheduler starts the loads of lattice 1 under the collision of
     // lattice 0, and two sets of populations in registers cost a resident wave
@@ -360,57 +352,6 @@ sc_fused_kernel(const ScParams<L, R> p) {
     if constexpr (ROW && PROP != PROP_AA_EVEN && K == 1) __syncthreads();     // row_push's LDS words are still being read
     sc_store<L, R, PROP, GENERAL, ROW>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n, nx, live, active);
   });
-#else
-  // Memory phases overlapped: the populations of lattice 0 are requested before the stencil sums are formed (order 1),
-  // and those of lattice 1 as soon as lattice 0 has collided, ahead of its stores / row push (order 2) -- the two sets
-  // of populations are in registers together only where the collision's temporaries are not.
-  auto accel_of = [&](auto K, R (&a)[3]) {
-    if (wet) {
-      const R psi_loc = sc_psi<R>(rho[K], p.potential);
-      static_for<0, 2>([&](auto J) {
-        const R cc = (K == 0) ? p.G[J] : p.G2[J];
-        if (cc != (R)0) {
-          static_for<0, L::dim>([&](auto D) { a[D] = a[D] + S[J][D] * (((R)0 - psi_loc) * cc); });
-        }
-      });
-      static_for<0, L::dim>([&](auto D) { a[D] = a[D] / rho[K]; });
-      if (K == 0 ? p.has_body_force : p.has_body_force2) {
-        static_for<0, L::dim>([&](auto D) { a[D] = a[D] + (K == 0 ? p.accel[D] : p.accel2[D]); });
-      }
-    }
-  };
-  auto collide = [&](auto K, R (&f)[L::Q]) {
-    R a[3] = {(R)0, (R)0, (R)0};
-    accel_of(K, a);
-    R v[3] = {vc[0], vc[1], vc[2]};
-    if constexpr (GENERAL) {
-      if (kind == NK_FULL_BB) bounce_back<L, R>(f);
-    }
-    if (wet) bgk_relax_accel<L, R>(f, rho[K], v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  R f0[L::Q], f1[L::Q];
-  sc_load<L, R, PROP>(f0, p.d_in, ds, n);
-  __builtin_amdgcn_sched_barrier(0);
-  stencil();
-  __builtin_amdgcn_sched_barrier(0);
-  collide(I0{}, f0);
-#if SLF_SC_FUSED_ORDER == 2
-  __builtin_amdgcn_sched_barrier(0);
-  sc_load<L, R, PROP>(f1, p.d_in2, ds, n);
-  __builtin_amdgcn_sched_barrier(0);
-  sc_store<L, R, PROP, GENERAL, ROW>(g, f0, p.d_out, ds, n, nx, live, active);
-  __builtin_amdgcn_sched_barrier(0);
-#else
-  sc_store<L, R, PROP, GENERAL, ROW>(g, f0, p.d_out, ds, n, nx, live, active);
-  __builtin_amdgcn_sched_barrier(0);
-  sc_load<L, R, PROP>(f1, p.d_in2, ds, n);
-#endif
-  collide(I1{}, f1);
-  if constexpr (ROW && PROP != PROP_AA_EVEN) __syncthreads();     // row_push's LDS words are still being read
-  sc_store<L, R, PROP, GENERAL, ROW>(g, f1, p.d_out2, ds, n, nx, live, active);
-#endif
 }
 
 // ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
