@@ -298,7 +298,12 @@ int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* st
  * "ShanChenPrepareMacroFields"(map, dist1, dist2, rho, phi, vx, vy[, vz], options),
  * "ShanChenCollideAndPropagate0|1"(map, dist_in, dist_out, rho, phi, vx, vy[, vz], options),
  * "ShanChenCollideAndPropagateFused"(map, dist0_in, dist0_out, dist1_in, dist1_out, rho, phi, vx, vy[, vz], options)
- * = both of them in one pass (the fields and the pseudopotential stencil are read once; same results) and the
+ * = both of them in one pass (the fields and the pseudopotential stencil are read once; same results),
+ * the pair "ShanChenPrepareDensities" (arguments of ShanChenPrepareMacroFields) + "ShanChenCollideAndPropagateFusedV"
+ * (arguments of ...Fused) = the same step with the node's own densities and the common velocity formed inside the
+ * sweep from the populations it loads anyway (same operation order, same bits): the pass in front stores rho and phi
+ * only, and vx, vy, vz only in launches whose options have bit 0 set (the reference's full_output kernels,
+ * lb_binary.py:434-440) -- between two such launches the velocity arrays keep the values of the last one; and the
  * two-lattice "SetInitialConditions"(map, dist1, dist2, vx, vy[, vz], rho, phi)
  * (reference templates/models/binary_shan_chen.mako:19-141, lb_binary_fluid.mako:87-127).
  * Single-component Shan-Chen modules (SLF_SIM_SHAN_CHEN_SINGLE) keep the single-fluid kernel names; their

@@ -257,6 +257,7 @@ class HIPBackend(placement.VmmMixin):
     supports_xface = True      # slf_module_set_xface_buffers (sailfish_amd/xface.py)
     supports_stream_priority = True
     supports_fused_shan_chen = True   # kernel "ShanChenCollideAndPropagateFused"
+    supports_fused_shan_chen_local_velocity = True   # "ShanChenPrepareDensities" + "ShanChenCollideAndPropagateFusedV"
     FatalError = HIPFatalError
 
     @classmethod

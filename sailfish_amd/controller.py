@@ -78,8 +78,8 @@ class LocalGroup(object):
         for r in rs:
             r._set_step_state(it)
         if rs[0].has_macro_exchange:
-            for r in rs:
-                r._program_macro(q, it, group=self)
+            for r, (_, fields_req, _) in zip(rs, reqs):
+                r._program_macro(q, it, group=self, sync_req=fields_req)
             self._program_copies(q, it, 'macro')
             for r in rs:
                 r._program_macro_back(q, it)

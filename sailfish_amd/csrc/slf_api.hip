@@ -99,6 +99,7 @@ struct slf_kernel {
   int needs_iteration;
   uint32_t iteration;
   bool bound;
+  bool sc_local_velocity;   // ShanChenPrepareDensities / ShanChenCollideAndPropagateFusedV
 };
 
 static hipStream_t native(slf_stream* s) { return s ? s->s : (hipStream_t)0; }
@@ -899,6 +900,7 @@ int slf_module_block_size(slf_module* m, int* threads) {
 int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   if (!m || !name || !out) return fail(SLF_ERR_INVALID, "NULL argument");
   KernelKind kk;
+  bool sc_local_velocity = false;
   if (!strcmp(name, "CollideAndPropagate")) kk = (m->sc.enabled == 2) ? KK_SCS_SWEEP : KK_COLLIDE_AND_PROPAGATE;
   else if (!strcmp(name, "PrepareMacroFields")) kk = KK_SCS_MACRO;
   else if (!strcmp(name, "SetInitialConditions")) kk = (m->sc.enabled == 1) ? KK_SC_INIT : KK_SET_INITIAL_CONDITIONS;
@@ -906,6 +908,8 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   else if (!strcmp(name, "ShanChenCollideAndPropagate0")) kk = KK_SC_SWEEP0;
   else if (!strcmp(name, "ShanChenCollideAndPropagate1")) kk = KK_SC_SWEEP1;
   else if (!strcmp(name, "ShanChenCollideAndPropagateFused")) kk = KK_SC_FUSED;
+  else if (!strcmp(name, "ShanChenPrepareDensities")) { kk = KK_SC_MACRO; sc_local_velocity = true; }
+  else if (!strcmp(name, "ShanChenCollideAndPropagateFusedV")) { kk = KK_SC_FUSED; sc_local_velocity = true; }
   else if (!strcmp(name, "ApplyPeriodicBoundaryConditions")) kk = KK_PBC;
   else if (!strcmp(name, "ApplyPeriodicBoundaryConditionsWithSwap")) kk = KK_PBC_SWAP;
   else if (!strcmp(name, "ApplyMacroPeriodicBoundaryConditions")) kk = KK_MACRO_PBC;
@@ -942,6 +946,7 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   k->needs_iteration = 0;
   k->iteration = 0;
   k->bound = false;
+  k->sc_local_velocity = sc_local_velocity;
   *out = k;
   return SLF_OK;
 }
@@ -1004,8 +1009,8 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_SCS_MACRO: want_p = 3; want_i = 1; break;             // map, dist, rho, options
     case KK_SCS_SWEEP: want_p = 4 + dim; want_i = 1; break;       // as CollideAndPropagate
   }
-  if (k->mod->geo.indirect && k->kind == KK_SC_FUSED)
-    return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: the binary model runs its two per-lattice sweeps");
+  if (k->mod->geo.indirect && (k->kind == KK_SC_FUSED || k->sc_local_velocity))
+    return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: the binary model runs the reference's pass and its two per-lattice sweeps");
   if (k->mod->geo.indirect && (k->kind == KK_COLLIDE_AND_PROPAGATE || k->kind == KK_COMPUTE_MACRO ||
                                k->kind == KK_SET_INITIAL_CONDITIONS || k->kind == KK_SC_MACRO ||
                                k->kind == KK_SC_SWEEP0 || k->kind == KK_SC_SWEEP1 || k->kind == KK_SC_INIT ||
@@ -1094,6 +1099,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.node_params = m->node_params;
       a.status = m->status;
       a.options = (uint32_t)k->ints[0];
+      a.sc_local_velocity = k->sc_local_velocity;
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       slf::Prop prop = slf::PROP_AB;
       if (m->access_pattern == SLF_AA) {
@@ -1128,6 +1134,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.node_params = m->node_params;
       a.status = m->status;
       a.options = (uint32_t)k->ints[0];
+      a.sc_local_velocity = k->sc_local_velocity;
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       slf::Prop prop = slf::PROP_AB;
       if (m->access_pattern == SLF_AA) {

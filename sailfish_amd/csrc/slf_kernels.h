@@ -71,6 +71,10 @@ struct SweepArgs {
   const void* node_params;
   void* status;        // device uint32[4]: invalid-value flag + position
   uint32_t options;
+  // binary Shan-Chen: the fused sweep forms densities and velocity of its own node itself (kernels
+  // ShanChenPrepareDensities / ShanChenCollideAndPropagateFusedV); the pass in front stores rho, phi and -- only when
+  // options bit 0 asks for output -- the velocity
+  bool sc_local_velocity;
   // x-face buffers (slf_module_set_xface_buffers): [0] low face (x = 1 side), [1] high face; NULL = not used
   void* xsend[2];
   const void* xrecv[2];

@@ -171,7 +171,10 @@ __device__ __forceinline__ void sc_store(const Geometry& g, R (&f)[L::Q], R* dou
   }
 }
 
-template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false>
+// VOUT = false ("ShanChenPrepareDensities", the partner of the fused sweep that forms the velocity itself): only the
+// two densities are stored -- three of the five written streams gone; the velocity arrays are brought up to date by
+// the launches whose options ask for output (bit 0), which run the VOUT = true instantiation.
+template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool VOUT = true>
 __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   bool live;
@@ -193,24 +196,27 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   // lattice 0
   sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
   const R rho0 = density<L, R>(f);
-  R v[3];
-  v[0] = p.omega[0] * momentum<L, R, 0>(f);
-  v[1] = p.omega[0] * momentum<L, R, 1>(f);
-  v[2] = (R)0;
-  if constexpr (L::dim == 3) v[2] = p.omega[0] * momentum<L, R, 2>(f);
+  R v[3] = {(R)0, (R)0, (R)0};
+  if constexpr (VOUT) {
+    v[0] = p.omega[0] * momentum<L, R, 0>(f);
+    v[1] = p.omega[0] * momentum<L, R, 1>(f);
+    if constexpr (L::dim == 3) v[2] = p.omega[0] * momentum<L, R, 2>(f);
+  }
   // lattice 1
   sc_load<L, R, PROP, INDIRECT>(f, (const R*)p.d_out, ds, n, p.nodes, si);
   const R rho1 = density<L, R>(f);
-  v[0] = v[0] + p.omega[1] * momentum<L, R, 0>(f);
-  v[1] = v[1] + p.omega[1] * momentum<L, R, 1>(f);
-  if constexpr (L::dim == 3) v[2] = v[2] + p.omega[1] * momentum<L, R, 2>(f);
-  // common velocity: sum_k j_k / tau_k over sum_k rho_k / tau_k (binary_shan_chen.mako:69-83)
-  const R total = p.omega[0] * rho0 + p.omega[1] * rho1;
   p.rho0[gi] = rho0;
   p.rho1[gi] = rho1;
-  p.vx[gi] = v[0] / total;
-  p.vy[gi] = v[1] / total;
-  if constexpr (L::dim == 3) p.vz[gi] = v[2] / total;
+  if constexpr (VOUT) {
+    v[0] = v[0] + p.omega[1] * momentum<L, R, 0>(f);
+    v[1] = v[1] + p.omega[1] * momentum<L, R, 1>(f);
+    if constexpr (L::dim == 3) v[2] = v[2] + p.omega[1] * momentum<L, R, 2>(f);
+    // common velocity: sum_k j_k / tau_k over sum_k rho_k / tau_k (binary_shan_chen.mako:69-83)
+    const R total = p.omega[0] * rho0 + p.omega[1] * rho1;
+    p.vx[gi] = v[0] / total;
+    p.vy[gi] = v[1] / total;
+    if constexpr (L::dim == 3) p.vz[gi] = v[2] / total;
+  }
 }
 
 // ROW: one workgroup = one whole row, streaming through row_push() (aligned stores, slf_rowpush.h); every
@@ -277,8 +283,18 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 #ifndef SLF_SC_FUSED_WAVES
 #define SLF_SC_FUSED_WAVES 5
 #endif
-template <class L, class R, int PROP, bool GENERAL, bool ROW = false>
-__global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? SLF_SC_FUSED_WAVES : 4)
+#ifndef SLF_SC_PARK
+#define SLF_SC_PARK 1
+#endif
+#ifndef SLF_SC_FUSEDV_WAVES
+#define SLF_SC_FUSEDV_WAVES (SLF_SC_PARK ? 5 : 4)   // two sets of populations in registers: five waves spill 50-100 bytes per lane
+#endif
+// OWNV ("ShanChenCollideAndPropagateFusedV"): the node's densities and the common velocity are formed here, from the
+// populations the sweep loads anyway, in the operation order of sc_macro_kernel -- the same bits; rho / phi are read for
+// the neighbours only, the velocity arrays not at all (the pass in front of it then stores two streams instead of five).
+// Both sets of populations are in registers from the start.
+template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool OWNV = false>
+__global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? (OWNV ? SLF_SC_FUSEDV_WAVES : SLF_SC_FUSED_WAVES) : 4)
 sc_fused_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
@@ -299,14 +315,24 @@ sc_fused_kernel(const ScParams<L, R> p) {
       active = live && !kind_is_excluded(kind);
     }
   }
-  const bool wet = kind_is_wet(kind) && active;
+  bool wet = kind_is_wet(kind) && active;
+  if constexpr (OWNV && !GENERAL) {
+    // fluid-only: keep `wet` a run-time value, so that the blocks it guards stay blocks -- with the guard folded away the
+    // scheduler pulls the collision's temporaries over the two sets of populations and spills (96 VGPRs + 20-24 bytes)
+    int one = 1;
+    asm volatile("" : "+s"(one));
+    wet = wet && (one != 0);
+  }
   const size_t ds = g.dist_size;
-  const R rho[2] = {p.rho0[gi], p.rho1[gi]};
-  R vc[3];
-  vc[0] = p.vx[gi];
-  vc[1] = p.vy[gi];
-  vc[2] = (R)0;
-  if constexpr (L::dim == 3) vc[2] = p.vz[gi];
+  R rho[2];
+  R vc[3] = {(R)0, (R)0, (R)0};
+  if constexpr (!OWNV) {
+    rho[0] = p.rho0[gi];
+    rho[1] = p.rho1[gi];
+    vc[0] = p.vx[gi];
+    vc[1] = p.vy[gi];
+    if constexpr (L::dim == 3) vc[2] = p.vz[gi];
+  }
   // stencil sums of the fields some lattice is coupled to
   R S[2][3] = {{(R)0, (R)0, (R)0}, {(R)0, (R)0, (R)0}};
   if (wet) {
@@ -324,12 +350,26 @@ sc_fused_kernel(const ScParams<L, R> p) {
       }
     });
   }
-  static_for<0, 2>([&](auto K) {
-    // one lattice at a time: without the fence the scheduler starts the loads of lattice 1 under the collision of
-    // lattice 0, and two sets of populations in registers cost a resident wave
+  R fa[OWNV ? L::Q : 1], fb[OWNV ? L::Q : 1];
+  if constexpr (OWNV) {
+    // after the stencil sums: their 36 neighbour values and the 38 populations are not in registers together
     __builtin_amdgcn_sched_barrier(0);
-    R f[L::Q];
-    sc_load<L, R, PROP>(f, K == 0 ? p.d_in : p.d_in2, ds, n);
+    sc_load<L, R, PROP>(fa, p.d_in, ds, n);
+    sc_load<L, R, PROP>(fb, p.d_in2, ds, n);
+    rho[0] = density<L, R>(fa);
+    vc[0] = p.omega[0] * momentum<L, R, 0>(fa);
+    vc[1] = p.omega[0] * momentum<L, R, 1>(fa);
+    if constexpr (L::dim == 3) vc[2] = p.omega[0] * momentum<L, R, 2>(fa);
+    rho[1] = density<L, R>(fb);
+    vc[0] = vc[0] + p.omega[1] * momentum<L, R, 0>(fb);
+    vc[1] = vc[1] + p.omega[1] * momentum<L, R, 1>(fb);
+    if constexpr (L::dim == 3) vc[2] = vc[2] + p.omega[1] * momentum<L, R, 2>(fb);
+    const R total = p.omega[0] * rho[0] + p.omega[1] * rho[1];
+    vc[0] = vc[0] / total;
+    vc[1] = vc[1] / total;
+    if constexpr (L::dim == 3) vc[2] = vc[2] / total;
+  }
+  auto finish = [&](auto K, R (&f)[L::Q]) {
     R a[3] = {(R)0, (R)0, (R)0};
     if (wet) {
       const R psi_loc = sc_psi<R>(rho[K], p.potential);
@@ -351,7 +391,41 @@ sc_fused_kernel(const ScParams<L, R> p) {
     if (wet) bgk_relax_accel<L, R>(f, rho[K], v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
     if constexpr (ROW && PROP != PROP_AA_EVEN && K == 1) __syncthreads();     // row_push's LDS words are still being read
     sc_store<L, R, PROP, GENERAL, ROW>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n, nx, live, active);
-  });
+  };
+  if constexpr (OWNV) {
+    // single precision D3Q19: lattice 1 waits in LDS while lattice 0 collides and streams -- registers as for one
+    // lattice, a resident wave more.  80 bytes per lane, lane after lane: ONE address register with immediate offsets,
+    // and 16 consecutive lanes' 16-byte accesses fall on 16 different groups of four banks (20 l mod 64)
+    constexpr bool PARK = SLF_SC_PARK && sizeof(R) == 4 && L::Q == 19;
+    if constexpr (PARK) {
+      extern __shared__ float4 sc_park[];
+      static_for<0, 5>([&](auto K4) {
+        constexpr int b = 4 * K4;
+        sc_park[5 * threadIdx.x + K4] = make_float4(fb[b], fb[b + 1], fb[b + 2], b + 3 < 19 ? fb[b + 3 < 19 ? b + 3 : 18] : 0.0f);
+      });
+      __builtin_amdgcn_sched_barrier(0);      // parked before the collision's temporaries come to life
+    }
+    finish(std::integral_constant<int, 0>{}, fa);
+    if constexpr (PARK) {
+      extern __shared__ float4 sc_park[];
+      static_for<0, 5>([&](auto K4) {
+        constexpr int b = 4 * K4;
+        const float4 t = sc_park[5 * threadIdx.x + K4];
+        fb[b] = t.x; fb[b + 1] = t.y; fb[b + 2] = t.z;
+        if constexpr (b + 3 < 19) fb[b + 3] = t.w;
+      });
+    }
+    finish(std::integral_constant<int, 1>{}, fb);
+  } else {
+    static_for<0, 2>([&](auto K) {
+      // one lattice at a time: without the fence the scheduler starts the loads of lattice 1 under the collision of
+      // lattice 0, and two sets of populations in registers cost a resident wave
+      __builtin_amdgcn_sched_barrier(0);
+      R f[L::Q];
+      sc_load<L, R, PROP>(f, K == 0 ? p.d_in : p.d_in2, ds, n);
+      finish(K, f);
+    });
+  }
 }
 
 // ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
@@ -515,11 +589,15 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
   dim3 block(bx, 1, 1);
   dim3 grid((nx + bx - 1) / bx, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  // the densities-only form: indirect addressing keeps the reference's pass
+  const bool vout = !a.sc_local_velocity || (a.options & 1u) || g.indirect;
 #define SLF_SCM(P)                                                                        \
   do {                                                                                    \
     if (g.indirect) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true, true>), grid, block, 0, s, p); \
-    else if (general) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((sc_macro_kernel<L, R, P, false>), grid, block, 0, s, p);        \
+    else if (general && vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true>), grid, block, 0, s, p); \
+    else if (general) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true, false, false>), grid, block, 0, s, p); \
+    else if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, false>), grid, block, 0, s, p);        \
+    else hipLaunchKernelGGL((sc_macro_kernel<L, R, P, false, false, false>), grid, block, 0, s, p);        \
   } while (0)
   if (prop == PROP_AA_ODD) SLF_SCM(PROP_AA_ODD);
   else SLF_SCM(PROP_AB);
@@ -608,10 +686,16 @@ static hipError_t sc_fused2(Prop prop, bool general, const Geometry& g, const Ph
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  const size_t park = (SLF_SC_PARK && sizeof(R) == 4 && L::Q == 19) ? (size_t)block_x * 5 * 16 : 0;   // lattice 1 parked in LDS
 #define SLF_SCF(P, ROW)                                                                            \
   do {                                                                                             \
-    if (general) hipLaunchKernelGGL((sc_fused_kernel<L, R, P, true, ROW>), grid, block, 0, s, p);   \
-    else hipLaunchKernelGGL((sc_fused_kernel<L, R, P, false, ROW>), grid, block, 0, s, p);          \
+    if (a.sc_local_velocity) {                                                                     \
+      if (general) hipLaunchKernelGGL((sc_fused_kernel<L, R, P, true, ROW, true>), grid, block, park, s, p);   \
+      else hipLaunchKernelGGL((sc_fused_kernel<L, R, P, false, ROW, true>), grid, block, park, s, p);          \
+    } else {                                                                                       \
+      if (general) hipLaunchKernelGGL((sc_fused_kernel<L, R, P, true, ROW>), grid, block, 0, s, p);   \
+      else hipLaunchKernelGGL((sc_fused_kernel<L, R, P, false, ROW>), grid, block, 0, s, p);          \
+    }                                                                                              \
   } while (0)
   if constexpr (L::dim == 3) {
     if (row && prop == PROP_AB) { SLF_SCF(PROP_AB, true); return hipGetLastError(); }

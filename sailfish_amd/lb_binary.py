@@ -118,21 +118,27 @@ class LBBinaryFluidShanChen(LBBinaryFluidBase, LBForcedSim):
             args, s = runner.add_indirect_args([gpu_map, a, b] + tail, sig)
             return runner.get_kernel(name, args, s, needs_iteration=ni)
 
-        # backends that have it sweep both lattices in ONE pass (rho, phi, u and the pseudopotential stencil are read
-        # once; C ABI kernel "ShanChenCollideAndPropagateFused"), otherwise the reference's two kernels
+        # backends that have it sweep both lattices in ONE pass (rho, phi and the pseudopotential stencil are read once;
+        # C ABI kernels "ShanChenCollideAndPropagateFused[V]"), otherwise the reference's two kernels.  SLF_SC_FUSED:
+        # 0 = the reference's kernels, 1 = fused sweep reading the velocity the pass in front stored, 2 (default) = fused
+        # sweep forming the node's densities and velocity itself + "ShanChenPrepareDensities" in front of it, which stores
+        # the velocity only in the full_output kernels (what the host reads after an output step)
+        mode = os.environ.get('SLF_SC_FUSED', '2')
         fused = getattr(runner.backend, 'supports_fused_shan_chen', False) and getattr(self.config, 'hip_sc_fused', True) and \
-            os.environ.get('SLF_SC_FUSED', '1') != '0' and not runner.indirect
+            mode != '0' and not runner.indirect
+        local_v = fused and mode != '1' and getattr(runner.backend, 'supports_fused_shan_chen_local_velocity', False)
+        sweep_name = 'ShanChenCollideAndPropagateFusedV' if local_v else 'ShanChenCollideAndPropagateFused'
+        macro_name = 'ShanChenPrepareDensities' if local_v else 'ShanChenPrepareMacroFields'
 
         def sweeps(in1, out1, in2, out2):
             if fused:
-                return [runner.get_kernel('ShanChenCollideAndPropagateFused', [gpu_map, in1, out1, in2, out2] + tail,
-                                          'PP' + sig, needs_iteration=ni)]
+                return [runner.get_kernel(sweep_name, [gpu_map, in1, out1, in2, out2] + tail, 'PP' + sig, needs_iteration=ni)]
             return [k('ShanChenCollideAndPropagate0', in1, out1), k('ShanChenCollideAndPropagate1', in2, out2)]
 
-        macro1 = k('ShanChenPrepareMacroFields', d1a, d2a)
+        macro1 = k(macro_name, d1a, d2a)
         primary = sweeps(d1a, d1b, d2a, d2b)
         if self.config.access_pattern == 'AB':
-            macro2 = k('ShanChenPrepareMacroFields', d1b, d2b)
+            macro2 = k(macro_name, d1b, d2b)
             secondary = sweeps(d1b, d1a, d2b, d2a)
         else:
             macro2, secondary = macro1, primary

@@ -684,7 +684,7 @@ class SubdomainRunner(object):
         """One step of a runner that owns its process (reference subdomain_runner.py:960-1058): macro pass of the
         non-local models, sweep, halo -- the exchanges through the connector."""
         self._set_step_state(it)
-        self._program_macro(q, it)
+        self._program_macro(q, it, sync_req=sync_req)
         self._program_front(q, it, sync_req)
         self._program_back(q, it)
 
@@ -693,7 +693,7 @@ class SubdomainRunner(object):
         ids = set(self._links) | set(getattr(self, '_macro_links', {}))
         return [group.by_id[nid]._pev[parity][name] for nid in sorted(ids) if nid in group.by_id]
 
-    def _program_macro(self, q, it, group=None):
+    def _program_macro(self, q, it, group=None, sync_req=False):
         """Macroscopic-field pass of the non-local models (NNSubdomainRunner); nothing here."""
 
     def _program_macro_back(self, q, it):
@@ -1255,14 +1255,16 @@ class NNSubdomainRunner(SubdomainRunner):
     def _sweep_kernels(self, it, sync_req):
         return (self._kernels_full if sync_req else self._kernels_none)[it & 1][1]
 
-    def _program_macro(self, q, it, group=None):
+    def _program_macro(self, q, it, group=None, sync_req=False):
         """Macroscopic fields of every real node, their local periodic images, and the exchange of the values the
         non-local force reads in the neighbours' territory (reference NNSubdomainRunner.step, subdomain_runner.py:
         2102-2197): calc stream -> event -> data stream: pack -> [exchange] -> unpack -> event -> calc stream."""
         prof, timed = self._profile, not q.planned
         ev, pev = self._pev[it & 1], self._pev[1 - (it & 1)]
         sk = self._calc_stream
-        macro_kernel = self._kernels_none[it & 1][0]
+        # the kernels of an output step store every field the host reads afterwards (binary Shan-Chen: the velocity,
+        # which the other steps' pass leaves to the sweep -- lb_binary.get_compute_kernels)
+        macro_kernel = (self._kernels_full if sync_req else self._kernels_none)[it & 1][0]
         base = 1 - (it & 1)
         if self._links:
             q.wait(sk, pev['halo'])                          # populations received after the last step

@@ -48,13 +48,16 @@ def test_sc_vs_oracle(dim, size, pattern, fused):
 
 @pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (130, 9, 8))])
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
-def test_fused_sweep_equals_the_two_kernels(dim, size, pattern):
-    """"ShanChenCollideAndPropagateFused" (both lattices in one pass, the stencil sums formed once) against the
-    reference's two kernels ShanChenCollideAndPropagate0 / 1: bit-identical populations, with self-coupling, the
-    classic (exponential) potential and a body force on one lattice."""
+def test_fused_sweep_equals_the_two_kernels(dim, size, pattern, monkeypatch):
+    """"ShanChenCollideAndPropagateFused" (both lattices in one pass, the stencil sums formed once) and the pair
+    "ShanChenPrepareDensities" + "ShanChenCollideAndPropagateFusedV" (the sweep forms its node's densities and velocity
+    itself; the default) against the reference's ShanChenPrepareMacroFields + ShanChenCollideAndPropagate0 / 1:
+    bit-identical populations and fields, with self-coupling, the classic (exponential) potential and a body force on one
+    lattice."""
     from sailfish_amd.controller import LBSimulationController
     out = []
-    for fused in (True, False):
+    for mode, fused in (('2', True), ('1', True), ('2', False)):
+        monkeypatch.setenv('SLF_SC_FUSED', mode)
         sim_cls, geo = _sc.make_forced_sim(dim, [1e-5, 0.0, 0.0][:dim], [0.0, -2e-5, 0.0][:dim])
         cfg = _sc.config(dim, size, pattern=pattern, fused=True, G12=0.9, G11=-0.3, G22=-0.2, potential='classic',
                          tau_phi=0.8)
@@ -62,9 +65,47 @@ def test_fused_sweep_equals_the_two_kernels(dim, size, pattern):
         ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
         ctrl.run(ignore_cmdline=True)
         r = ctrl.runners[0]
-        out.append([r._debug_get_dist(grid_num=g) for g in (0, 1)] + [r._sim.rho.copy(), r._sim.phi.copy()])
-    for a, b in zip(*out):
-        assert np.array_equal(a, b, equal_nan=True)
+        names = sorted(k.name for pair in r._kernels_none for k in [pair[0]] + list(pair[1]))
+        assert ('ShanChenCollideAndPropagateFusedV' in names) == (mode == '2' and fused), names
+        assert ('ShanChenPrepareDensities' in names) == (mode == '2' and fused), names
+        out.append([r._debug_get_dist(grid_num=g) for g in (0, 1)] + [r._sim.rho.copy(), r._sim.phi.copy()] +
+                   [c.copy() for c in r._sim.v])
+    for a, b, c in zip(*out):
+        assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
+
+
+def test_densities_pass_stores_the_velocity_on_output_steps_only():
+    """The C-ABI contract of "ShanChenPrepareDensities": rho and phi on every launch, vx / vy / vz only when bit 0 of
+    `options` is set (the full_output kernels); the fused sweep that follows does not read them."""
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls, geo = _sc.make_sim(3)
+    cfg = _sc.config(3, (70, 9, 8), pattern='AA')
+    cfg.update(max_iters=6, quiet=True, perf_stats_every=0)
+    ctrl = LBSimulationController(sim_cls, geo, default_config=cfg)
+    ctrl.run(ignore_cmdline=True)
+    r = ctrl.runners[0]
+    b = r.backend
+    v_after_run = [c.copy() for c in r._sim.v]
+    rho_after_run = r._sim.rho.copy()
+    assert any(np.abs(c).max() > 0 for c in v_after_run)
+    gpu_v = r.gpu_field(r._sim.v)
+    marker = np.float32(7.25)
+    for plain in (True, False):
+        for c, addr in zip(r._sim.v, gpu_v):
+            c[:] = marker
+            b.to_buf(addr)
+        r._sim.rho[:] = marker
+        b.to_buf(r.gpu_field(r._sim.rho))
+        it = r._sim.iteration
+        b.set_iteration(it)
+        kernels = r._kernels_none if plain else r._kernels_full
+        b.run_kernel(kernels[it & 1][0], None, r._calc_stream)
+        b.sync_stream(r._calc_stream)
+        for addr in gpu_v + [r.gpu_field(r._sim.rho)]:
+            b.from_buf(addr)
+        assert not np.any(r._sim.rho == marker)                                   # the densities: always
+        stored = [not np.any(c == marker) for c in r._sim.v]
+        assert stored == [not plain] * 3, (plain, stored)
 
 
 def test_sc_classic_potential_and_self_coupling():
