@@ -65,6 +65,8 @@ EXAMPLE_MAP = {
     ('poiseuille', 'PoiseuilleSim'): ('examples.poiseuille', 'ChannelSim'),
     ('poiseuille_3d', 'PoiseuilleSim'): ('examples.poiseuille_3d', 'PipeSim'),
     ('external_geometry', 'ExternalSimulation'): ('examples.external_geometry', 'GeometrySim'),
+    ('cylinder', 'CylinderSimulation'): ('examples.cylinder', 'CylinderSim'),
+    ('sphere_3d', 'SphereSimulation'): ('examples.sphere_3d', 'SphereSim'),
 }
 
 

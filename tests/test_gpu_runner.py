@@ -556,3 +556,44 @@ def test_x_split_box_restored_at_odd_iteration(stop_at, tmp_path):
     assert all(r._sim.iteration == total for r in restored.runners)
     assert np.array_equal(merged_gpu(restored, 'dist'), merged_gpu(straight, 'dist'))
     assert np.array_equal(merged_gpu(restored, 'rho'), merged_gpu(straight, 'rho'))
+
+
+def _masked_equal(a, b):
+    m = np.isfinite(a)
+    return np.array_equal(m, np.isfinite(b)) and np.array_equal(a[m], b[m])
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('addressing', ['direct', 'indirect'])
+@pytest.mark.parametrize('nsub,vertical', [(2, False), (3, False), (2, True), (3, True)])
+def test_cylinder_subdomains(pattern, addressing, nsub, vertical):
+    """The reference's regtest/subdomains/2d_cylinder.py (flow past a cylinder, examples/cylinder.py, cut into 2 or 3
+    subdomains along the flow, lying and standing, both access patterns, both addressing modes): the run equals the
+    single-subdomain run -- here bit for bit, fields and populations -- and the oracle twin of the same decomposition."""
+    size = dict(lat_nx=36, lat_ny=60) if vertical else dict(lat_nx=60, lat_ny=36)
+    cfg = dict(size, visc=0.1, vertical=vertical, access_pattern=pattern, node_addressing=addressing,
+               force_implementation='guo')
+    split = dict(cfg, subdomains=nsub, conn_axis='y' if vertical else 'x')
+    ctrl, exact = check_against_oracle('cylinder', 'CylinderSimulation', 2, split, 40, 1e-4)
+    assert exact
+    one = run_gpu('cylinder', 'CylinderSimulation', 2, dict(cfg, subdomains=1), 40)
+    for what in ('rho', 'v0', 'v1', 'dist'):
+        assert _masked_equal(merged_gpu(ctrl, what), merged_gpu(one, what)), what
+    assert np.nanmax(np.abs(merged_gpu(one, 'v1' if vertical else 'v0'))) > 1e-5       # the force drives a flow
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('addressing', ['direct', 'indirect'])
+@pytest.mark.parametrize('nsub,axis', [(2, 'x'), (2, 'z')])
+def test_sphere_subdomains(pattern, addressing, nsub, axis):
+    """regtest/subdomains/3d_sphere.py: flow past a sphere in a duct (examples/sphere_3d.py), two subdomains against one
+    (the reference cuts along x; here across the flow as well)."""
+    cfg = dict(lat_nx=40, lat_ny=21, lat_nz=24, visc=0.01, access_pattern=pattern, node_addressing=addressing,
+               force_implementation='guo')
+    split = dict(cfg, subdomains=nsub, conn_axis=axis)
+    ctrl, exact = check_against_oracle('sphere_3d', 'SphereSimulation', 3, split, 30, 1e-4)
+    assert exact
+    one = run_gpu('sphere_3d', 'SphereSimulation', 3, dict(cfg, subdomains=1), 30)
+    for what in ('rho', 'v0', 'v1', 'v2', 'dist'):
+        assert _masked_equal(merged_gpu(ctrl, what), merged_gpu(one, what)), what
+    assert np.nanmax(np.abs(merged_gpu(one, 'v0'))) > 1e-5

@@ -129,3 +129,31 @@ def test_block_decompositions_of_a_periodic_box(pattern, dim, cuts, size):
     one.run(9, save_last=True)
     many.run(9, save_last=True)
     _compare(one, many)
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('addressing', ['direct', 'indirect'])
+@pytest.mark.parametrize('nsub,vertical', [(2, False), (3, False), (2, True), (3, True)])
+def test_cylinder_subdomains(pattern, addressing, nsub, vertical):
+    """regtest/subdomains/2d_cylinder.py: an obstacle inside the flow, the channel periodic along the cut axis (the
+    subdomains' periodic images are each other), lying and standing, dense and active-node storage."""
+    size = dict(lat_nx=30, lat_ny=48) if vertical else dict(lat_nx=48, lat_ny=30)
+    cfg = dict(size, visc=0.1, vertical=vertical, access_pattern=pattern, node_addressing=addressing,
+               force_implementation='guo')
+    one = _run('cylinder', 'CylinderSimulation', 2, 'EqualSubdomainsGeometry2D', cfg, steps=20)
+    many = _run('cylinder', 'CylinderSimulation', 2, 'EqualSubdomainsGeometry2D',
+                dict(cfg, subdomains=nsub, conn_axis='y' if vertical else 'x'), steps=20)
+    _compare(one, many)
+    v = one.merged('v1' if vertical else 'v0')
+    assert np.nanmax(np.abs(v)) > 1e-5
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('nsub,axis', [(2, 'x'), (2, 'y')])
+def test_sphere_subdomains(pattern, nsub, axis):
+    """regtest/subdomains/3d_sphere.py."""
+    cfg = dict(lat_nx=30, lat_ny=15, lat_nz=18, visc=0.01, access_pattern=pattern, force_implementation='guo')
+    one = _run('sphere_3d', 'SphereSimulation', 3, 'EqualSubdomainsGeometry3D', cfg, steps=10)
+    many = _run('sphere_3d', 'SphereSimulation', 3, 'EqualSubdomainsGeometry3D',
+                dict(cfg, subdomains=nsub, conn_axis=axis), steps=10)
+    _compare(one, many)
