@@ -118,6 +118,65 @@ __device__ __forceinline__ void sc_load(R (&f)[L::Q], const R* din, size_t ds, c
   });
 }
 
+// Aligned pull of the populations of BOTH lattices for one (y, z) row in the odd in-place step -- the mirror image of
+// row_push(): node x needs slot opp(i) of node x - e_i; the lane that owns x' loads that slot of (y, z) - e_i(yz) at
+// ITS OWN x' (whole 128-byte lines, every line fetched by exactly one wave) and the value travels one lane along x: a
+// DPP wave shift, one LDS word per direction and lattice between neighbouring waves, the periodic wrap as the cyclic
+// continuation.  For rows that are wrapped along x inside the kernel and owned by one workgroup (nx <= 1024); every
+// thread of the workgroup must call it (one barrier).  Pure data movement: the same values as sc_load<PROP_AA_ODD>.
+template <class L, class R>
+__device__ __forceinline__ void sc_pull_rows(R (&fa)[L::Q], R (&fb)[L::Q], const R* da, const R* db, size_t ds,
+                                             const ScNode& n, int nx) {
+  constexpr int NW = 16;
+  constexpr int NXD = count_x_dirs<L>();
+  __shared__ R s_p[2][NW + 1][NXD], s_m[2][NW + 1][NXD];     // [lattice][wave | NW = the wrap][direction]
+  const int lane = (int)threadIdx.x & 63;
+  const int w = sgpr((int)threadIdx.x >> 6);
+  const bool is_xe = n.gx == nx;
+  const AxisOff ox0 = {0, 0};
+  static_for<0, L::Q>([&](auto I) {
+    const int off = dir_offset<L, I>(ox0, n.oy, n.oz, false);        // y, z part of x - e_i: the same for the whole row
+    const uint32_t lo = n.xi * (uint32_t)sizeof(R);
+    fa[I] = ldg<sc_nt<L>()>(at_byte(uniform_base(da + ds * (size_t)L::opp(I) + (uint32_t)((int)n.row + off)), lo));
+    fb[I] = ldg<sc_nt<L>()>(at_byte(uniform_base(db + ds * (size_t)L::opp(I) + (uint32_t)((int)n.row + off)), lo));
+  });
+  // what leaves a wave through its last / first lane
+  if (lane == 63 || is_xe) {
+    const int slot = is_xe ? NW : w;
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) > 0) {
+        constexpr int k = x_dir_rank<L, I>();
+        s_p[0][slot][k] = fa[I];
+        s_p[1][slot][k] = fb[I];
+        if (is_xe && lane == 63) { s_p[0][w][k] = fa[I]; s_p[1][w][k] = fb[I]; }
+      }
+    });
+  }
+  if (lane == 0) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) < 0) {
+        constexpr int k = x_dir_rank<L, I>();
+        s_m[0][w][k] = fa[I];
+        s_m[1][w][k] = fb[I];
+      }
+    });
+  }
+  __syncthreads();
+  const int from_p = (w == 0) ? NW : w - 1;
+  static_for<1, L::Q>([&](auto I) {
+    constexpr int k = x_dir_rank<L, I>();
+    if constexpr (L::ex(I) > 0) {                      // from x - 1
+      fa[I] = lane_shift1<R, true>(s_p[0][from_p][k], fa[I]);
+      fb[I] = lane_shift1<R, true>(s_p[1][from_p][k], fb[I]);
+    } else if constexpr (L::ex(I) < 0) {               // from x + 1; x = nx (need not be lane 63) takes x = 1
+      const R ta = lane_shift1<R, false>(s_m[0][w + 1][k], fa[I]);
+      const R tb = lane_shift1<R, false>(s_m[1][w + 1][k], fb[I]);
+      fa[I] = is_xe ? s_m[0][0][k] : ta;
+      fb[I] = is_xe ? s_m[1][0][k] : tb;
+    }
+  });
+}
+
 // Shan-Chen acceleration of one lattice (sc_calculate_force, shan_chen.mako:9-27): the 18 neighbour values of each
 // coupled field come through the caches (every value is used by 18 nodes).
 template <class L, class R, int NFIELDS>
@@ -219,6 +278,21 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   }
 }
 
+// "ShanChenPrepareDensities" of the odd in-place step for fluid-only rows wrapped along x inside the kernel: the
+// populations through sc_pull_rows() (aligned loads), everything else as sc_macro_kernel<..., VOUT = false>.
+template <class L, class R>
+__global__ void __launch_bounds__(1024) sc_density_pull_kernel(const ScParams<L, R> p) {
+  const Geometry& g = p.g;
+  const int nx = g.lat_nx - 2;
+  bool live;
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
+  R fa[L::Q], fb[L::Q];
+  sc_pull_rows<L, R>(fa, fb, p.d_in, (const R*)p.d_out, g.dist_size, n, nx);
+  if (!live) return;
+  p.rho0[n.gi] = density<L, R>(fa);
+  p.rho1[n.gi] = density<L, R>(fb);
+}
+
 // ROW: one workgroup = one whole row, streaming through row_push() (aligned stores, slf_rowpush.h); every
 // thread stays until the end (barrier inside), excluded nodes and idle lanes are merely inactive.
 template <class L, class R, int K, int PROP, bool GENERAL, bool ROW = false, bool INDIRECT = false>
@@ -283,6 +357,9 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 #ifndef SLF_SC_FUSED_WAVES
 #define SLF_SC_FUSED_WAVES 5
 #endif
+#ifndef SLF_SC_ROW_PULL
+#define SLF_SC_ROW_PULL 1
+#endif
 #ifndef SLF_SC_PARK
 #define SLF_SC_PARK 1
 #endif
@@ -293,7 +370,8 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 // populations the sweep loads anyway, in the operation order of sc_macro_kernel -- the same bits; rho / phi are read for
 // the neighbours only, the velocity arrays not at all (the pass in front of it then stores two streams instead of five).
 // Both sets of populations are in registers from the start.
-template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool OWNV = false>
+// PULL (with OWNV, ROW, the odd in-place step): the populations come through sc_pull_rows() -- aligned loads.
+template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool OWNV = false, bool PULL = false>
 __global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? (OWNV ? SLF_SC_FUSEDV_WAVES : SLF_SC_FUSED_WAVES) : 4)
 sc_fused_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
@@ -354,8 +432,13 @@ sc_fused_kernel(const ScParams<L, R> p) {
   if constexpr (OWNV) {
     // after the stencil sums: their 36 neighbour values and the 38 populations are not in registers together
     __builtin_amdgcn_sched_barrier(0);
-    sc_load<L, R, PROP>(fa, p.d_in, ds, n);
-    sc_load<L, R, PROP>(fb, p.d_in2, ds, n);
+    if constexpr (PULL) {
+      static_assert(OWNV && ROW && PROP == PROP_AA_ODD, "the aligned pull serves the whole-row odd step");
+      sc_pull_rows<L, R>(fa, fb, p.d_in, p.d_in2, ds, n, nx);
+    } else {
+      sc_load<L, R, PROP>(fa, p.d_in, ds, n);
+      sc_load<L, R, PROP>(fb, p.d_in2, ds, n);
+    }
     rho[0] = density<L, R>(fa);
     vc[0] = p.omega[0] * momentum<L, R, 0>(fa);
     vc[1] = p.omega[0] * momentum<L, R, 1>(fa);
@@ -579,6 +662,11 @@ static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanCh
   return p;
 }
 
+// rows sc_pull_rows() serves: wrapped along x inside the kernel, the whole row in one workgroup, whole-row kernels on
+static inline bool sc_row_pull_ok(const Geometry& g) {
+  return SLF_SC_ROW_PULL && g.wrap[0] && g.lat_nx - 2 <= 1024 && (g.variant & 8) && !g.indirect;
+}
+
 template <class L, class R>
 static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Physics& ph, const ShanChen& sc,
                             const SweepArgs& a, int y0, int y1, int z0, int z1, hipStream_t s) {
@@ -591,6 +679,12 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
   // the densities-only form: indirect addressing keeps the reference's pass
   const bool vout = !a.sc_local_velocity || (a.options & 1u) || g.indirect;
+  if constexpr (L::dim == 3) {
+    if (!vout && !general && prop == PROP_AA_ODD && sc_row_pull_ok(g)) {
+      hipLaunchKernelGGL((sc_density_pull_kernel<L, R>), grid, block, 0, s, p);
+      return hipGetLastError();
+    }
+  }
 #define SLF_SCM(P)                                                                        \
   do {                                                                                    \
     if (g.indirect) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, true, true>), grid, block, 0, s, p); \
@@ -699,6 +793,11 @@ static hipError_t sc_fused2(Prop prop, bool general, const Geometry& g, const Ph
   } while (0)
   if constexpr (L::dim == 3) {
     if (row && prop == PROP_AB) { SLF_SCF(PROP_AB, true); return hipGetLastError(); }
+    if (row && prop == PROP_AA_ODD && a.sc_local_velocity && sc_row_pull_ok(g) && grid.x == 1) {
+      if (general) hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AA_ODD, true, true, true, true>), grid, block, park, s, p);
+      else hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AA_ODD, false, true, true, true>), grid, block, park, s, p);
+      return hipGetLastError();
+    }
     if (row && prop == PROP_AA_ODD) { SLF_SCF(PROP_AA_ODD, true); return hipGetLastError(); }
   }
   if (prop == PROP_AB) SLF_SCF(PROP_AB, false);
