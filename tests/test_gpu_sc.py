@@ -283,7 +283,7 @@ def test_sc_edm(dim, size):
     assert not np.array_equal(g.real(g.current()[0]), o.real(o.current()[0]))
 
 
-@pytest.mark.parametrize('nx', [64, 128, 256, 512, 1024, 1100])    # 1100: three segments (slf_rowpush.h: row_block_x)
+@pytest.mark.parametrize('nx', [40, 64, 128, 200, 256, 512, 1024, 1100])    # 1100: three segments (slf_rowpush.h: row_block_x); 40, 200: a partial last wave
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
 @pytest.mark.parametrize('single', [False, True])
 def test_sc_full_wave_rows(nx, pattern, single):

@@ -152,7 +152,6 @@ def main():
                     print('   trace %s:' % mode, ' '.join('%.2f' % (evs[j + 1].time_since(evs[j]) / args.trace)
                                                            for j in range(len(evs) - 1)))
                 res.append('%s %.3f ms %.0f GB/s' % (mode, ms, bytes_step / ms / 1e6))
-                b._iteration_kernels.clear()
             print('variant %2d pad %6d block %4d | %s' % (variant, pad, bx, ' | '.join(res)), flush=True)
 
 

@@ -67,7 +67,6 @@ def main():
                 e1.synchronize()
                 res.append(e1.time_since(e0) / args.reps)
             line.append(res)
-            b._iteration_kernels.clear()
         print('step %d MiB:' % step)
         for k, res in enumerate(line):
             print('  off %6d MiB  %s  %s' % (k * step, ' '.join('%.3f' % t for t in res), 'SLOW' if res[0] > 3.6 * bytes_step / 20401094656.0 else ''))

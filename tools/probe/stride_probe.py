@@ -84,7 +84,6 @@ def main():
             e1 = b.make_event(stream, timing=True)
             e1.synchronize()
             row.append(e1.time_since(e0) / args.reps)
-            b._iteration_kernels.clear()
         print('%10d ' % pad + ' '.join('%8.3f' % t for t in row), flush=True)
 
 
