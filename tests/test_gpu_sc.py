@@ -436,6 +436,41 @@ def test_sc_indirect_addressing(dim, size, nsub, axis, pattern):
             assert np.array_equal(gd[:, wet], o.real(o.dense(od))[:, wet]), 'subdomain %d lattice %d' % (r._spec.id, grid_num)
 
 
+@pytest.mark.parametrize('mode', ['2', '1'])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('dim,size,nsub,axis', [(2, (70, 26), 1, 'x'), (3, (70, 22, 8), 1, 'x'), (3, (140, 22, 8), 1, 'x'),
+                                                (3, (40, 22, 8), 2, 'x'), (3, (40, 22, 12), 2, 'z')])
+def test_sc_walls_dense_addressing(dim, size, nsub, axis, pattern, mode, monkeypatch):
+    """The binary mixture between solid slabs with a solid block in the channel, dense arrays: the node-map instantiations
+    of the fused sweeps (rows wrapped along x: the aligned pull of the odd step with bounce-back and dry nodes in the
+    row; x-split: the x-shifted loads) against the oracle group, every wet node bit for bit."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from tests._oracle_group import OracleNNGroup
+    monkeypatch.setenv('SLF_SC_FUSED', mode)
+    steps = 11
+    sim_cls, _ = _sc.make_wall_sim(dim)
+    cfg = _sc.config(dim, size, pattern=pattern)
+    cfg.update(periodic_y=False, subdomains=nsub, conn_axis=axis)
+    geo_name = 'EqualSubdomainsGeometry%dD' % dim
+    og = OracleNNGroup(sim_cls, dim, geo_name, dict(cfg))
+    og.run(steps)
+    ctrl = LBSimulationController(sim_cls, getattr(geo_mod, geo_name),
+                                  default_config=dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0))
+    ctrl.run(ignore_cmdline=True)
+    assert len(ctrl.runners) == nsub
+    for r, o in zip(ctrl.runners, og.subs):
+        wet = r._subdomain.fluid_map()
+        assert wet.any() and not wet.all()
+        assert np.array_equal(r._sim.rho[wet], o.real(o.rho)[wet])
+        assert np.array_equal(r._sim.phi[wet], o.real(o.phi)[wet])
+        for d in range(dim):
+            assert np.max(np.abs(r._sim.v[d][wet] - o.real(o.v[d])[wet])) < 1e-9
+        for grid_num, od in enumerate(o.current()):
+            gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+            assert np.array_equal(gd[:, wet], o.real(o.dense(od))[:, wet]), 'subdomain %d lattice %d' % (r._spec.id, grid_num)
+
+
 @pytest.mark.parametrize('pattern,walls', [('AB', True), ('AA', False), ('AB', False)])
 @pytest.mark.parametrize('dim,size,nsub', [(2, (70, 26), 1), (3, (40, 22, 8), 1), (3, (40, 22, 8), 2)])
 def test_single_component_indirect_addressing(dim, size, nsub, pattern, walls):
