@@ -97,7 +97,7 @@ template <int MODEL, int VEC, bool FORCE, bool XFACE>
 // two more than six resident waves allow.)
 __global__ void __launch_bounds__(512, (VEC == 2 && MODEL == 0 && !FORCE) ? 6 : 2) fast_even_kernel(const SweepParams<D3Q19, float> p) {
   const Geometry& g = p.g;
-  const int gy = sgpr(p.y0 + (int)blockIdx.y);
+  const int gy = sgpr(p.y0 + (XFACE ? xcd_row((int)blockIdx.y, p.row_mode >> 4) : (int)blockIdx.y));
   const int gz = sgpr(p.z0 + (int)blockIdx.z);
   const uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;   // index of this thread's VEC-node group in the row
   const int gx0 = 1 + (int)vi * VEC;
@@ -315,8 +315,13 @@ static bool launch_fast_model(Prop prop, const Geometry& g, const SweepParams<D3
     if (bx > 512) bx = 512;
     dim3 block(bx, 1, 1);
     dim3 grid((threads_needed + bx - 1) / bx, ny, nz);
-    if (p.xsend[0] || p.xsend[1]) hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, FORCE, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, FORCE, false>), grid, block, 0, s, p);
+    if (p.xsend[0] || p.xsend[1]) {
+      SweepParams<D3Q19, float> q = p;
+      q.row_mode = xcd_shift_for((unsigned)ny, grid.x) << 4;      // rows that share face-buffer lines: one XCD
+      hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, FORCE, true>), grid, block, 0, s, q);
+    } else {
+      hipLaunchKernelGGL((fast_even_kernel<MODEL, 2, FORCE, false>), grid, block, 0, s, p);
+    }
     return true;
   }
   if (!g.wrap[0]) return false;                  // everything below wraps x in-sweep

@@ -246,6 +246,9 @@ static void launch_row5(Prop prop, SweepParams<L, R> p, int nx, int ny, int nz, 
   dim3 grid((nx + bx - 1) / bx, ny, nz);
   p.y1 = p.y0 + ny;
   p.z1 = p.z0 + nz;
+  // connected x faces: the rows that share the lines of the face buffers go to one XCD (xcd_row(), slf_sweep.h)
+  const int xs = (p.xsend[0] || p.xsend[1] || p.xrecv[0] || p.xrecv[1]) ? xcd_shift_for((unsigned)ny, grid.x) : 0;
+  p.row_mode = xs << 4;
   // node-map kernels: one instantiation per Geometry::bc_level (slf_kernels.h).  (Double precision too: the 64 bytes
   // of scratch per lane of its two-copy kernels are the outflow-node code of level 2, not the 128-VGPR cap of a
   // 1024-thread workgroup -- they stay with 512-thread workgroups: profiles/r03/f64_row_kernels_resources.txt)
@@ -258,7 +261,7 @@ static void launch_row5(Prop prop, SweepParams<L, R> p, int nx, int ny, int nz, 
     if (rc && p.seg_class) {
       // rows without boundary-condition nodes: level 0; the others (listed): the module's level
       if (rc->n_bc_rows < rc->n_rows) {
-        p.row_mode = rc->n_bc_rows ? 1 : 0;
+        p.row_mode = (rc->n_bc_rows ? 1 : 0) | (xs << 4);
         launch_level<L, R, MODEL, GENERAL, FORCE, 0>(prop, p, grid, block, s);
       }
       if (rc->n_bc_rows) {

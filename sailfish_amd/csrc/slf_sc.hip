@@ -42,6 +42,7 @@ struct ScParams {
   int has_body_force2;
   int potential;
   int force_edm;
+  int xcd_shift;     // xcd_row(): rows per XCD and block of rows = 1 << this
 };
 
 template <class R>
@@ -65,9 +66,11 @@ struct ScNode {
   AxisOff ox, oy, oz;
 };
 template <class L>
-__device__ __forceinline__ ScNode sc_node(const Geometry& g, int y0, int z0, int nx, bool& live) {
+__device__ __forceinline__ ScNode sc_node(const Geometry& g, int y0, int z0, int nx, bool& live, int xcd_shift = 0) {
   ScNode n;
-  n.gy = sgpr(y0 + (int)blockIdx.y);
+  // rows that share rho / phi rows through the L2 go to one XCD (xcd_row(), slf_sweep.h)
+  const int by = xcd_row((int)blockIdx.y, xcd_shift);
+  n.gy = sgpr(y0 + by);
   n.gz = (L::dim == 3) ? sgpr(z0 + (int)blockIdx.z) : 0;
   n.gx = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   live = n.gx <= nx;
@@ -237,7 +240,7 @@ template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool 
 __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   bool live;
-  const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live);
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live, p.xcd_shift);
   if (!live) return;
   const uint32_t gi = n.gi;
   uint32_t si = gi;
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(1024) sc_density_pull_kernel(const ScParams<L,
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
-  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live, p.xcd_shift);
   R fa[L::Q], fb[L::Q];
   sc_pull_rows<L, R>(fa, fb, p.d_in, (const R*)p.d_out, g.dist_size, n, nx);
   if (!live) return;
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
-  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live, p.xcd_shift);
   if constexpr (!ROW) {
     if (!live) return;
   }
@@ -377,7 +380,7 @@ sc_fused_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
-  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live, p.xcd_shift);
   if constexpr (!ROW) {
     if (!live) return;
   }
@@ -517,7 +520,7 @@ template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false>
 __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p) {
   const Geometry& g = p.g;
   bool live;
-  const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live);
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live, p.xcd_shift);
   if (!live) return;
   uint32_t si = n.gi;
   if constexpr (INDIRECT) {
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
-  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live);
+  const ScNode n = sc_node<L>(g, p.y0, p.z0, nx, live, p.xcd_shift);
   if constexpr (!ROW) {
     if (!live) return;
   }
@@ -654,6 +657,7 @@ static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanCh
   p.d_out2 = (R*)a.dist_out2;
   p.G2[0] = (R)sc.G[2];
   p.G2[1] = (R)sc.G[3];
+  p.xcd_shift = 0;
   p.has_body_force2 = 0;
   for (int d = 0; d < 3; d++) {
     p.accel2[d] = (R)sc.accel1[d];
@@ -670,7 +674,7 @@ static inline bool sc_row_pull_ok(const Geometry& g) {
 template <class L, class R>
 static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Physics& ph, const ShanChen& sc,
                             const SweepArgs& a, int y0, int y1, int z0, int z1, hipStream_t s) {
-  const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
+  ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
   const int nx = g.lat_nx - 2;
   int bx = ((nx + 63) / 64) * 64;
   if (bx > 1024) bx = 256;
@@ -734,7 +738,7 @@ template <class L, class R>
 static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometry& g, const Physics& ph,
                             const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                             hipStream_t s) {
-  const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, grid_idx, y0, z0);
+  ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, grid_idx, y0, z0);
   const int nx = g.lat_nx - 2;
   // whole-row workgroups + aligned stores for the x-streaming steps in 3-D (as slf_row.hip)
   const bool row = L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN && !g.indirect;
@@ -742,6 +746,7 @@ static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometr
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  p.xcd_shift = xcd_shift_for(grid.y, grid.x);      // the force stencil's rho / phi rows: neighbouring rows on one XCD
   if (grid_idx == 0) return sc_sweep3<L, R, 0>(prop, general, row, p, grid, block, s);
   return sc_sweep3<L, R, 1>(prop, general, row, p, grid, block, s);
 }
@@ -773,13 +778,14 @@ hipError_t launch_sc_sweep(const KernelSelector& sel, int grid_idx, Prop prop, c
 template <class L, class R>
 static hipError_t sc_fused2(Prop prop, bool general, const Geometry& g, const Physics& ph, const ShanChen& sc,
                             const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x, hipStream_t s) {
-  const ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
+  ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
   const int nx = g.lat_nx - 2;
   const bool row = L::dim == 3 && (g.variant & 8) && prop != PROP_AA_EVEN;
   if (row) block_x = row_block_x(nx);
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  p.xcd_shift = xcd_shift_for(grid.y, grid.x);      // the force stencil's rho / phi rows: neighbouring rows on one XCD
   const size_t park = (SLF_SC_PARK && sizeof(R) == 4 && L::Q == 19) ? (size_t)block_x * 5 * 16 : 0;   // lattice 1 parked in LDS
 #define SLF_SCF(P, ROW)                                                                            \
   do {                                                                                             \
@@ -826,6 +832,7 @@ static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometr
   dim3 block(block_x, 1, 1);
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
+  p.xcd_shift = xcd_shift_for(grid.y, grid.x);      // the force stencil's rho / phi rows: neighbouring rows on one XCD
   if (g.indirect) {      // active-node slots: per-node kernels with translated neighbours (the node map is always read)
     if (macro) {
       if (prop == PROP_AA_ODD) hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AA_ODD, true, true>), grid, block, 0, s, p);

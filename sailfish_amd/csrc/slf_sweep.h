@@ -41,18 +41,44 @@ struct SweepParams {
   int nseg, row_mode, y1, z1;
 };
 
+// Which rows an XCD gets.  Workgroups are dealt out to the eight XCDs round-robin by their flat index; with one
+// workgroup per row every XCD sweeps every eighth row of a plane.  Where neighbouring rows share data through the L2 --
+// the rho / phi rows a Shan-Chen force stencil reads (three rows per row, each last touched by another XCD), the words
+// of a line of an x-face buffer (32 consecutive rows write one line, every L2 holds a piece of it) -- the rows of a block
+// of 8 << s consecutive rows are handed out so that every XCD gets (1 << s) CONSECUTIVE ones.  All XCDs stay inside the
+// same block of rows, and rows with the same y in neighbouring planes stay on the same XCD (launches whose row count is
+// a multiple of the block; the hosts' xcd_shift_for() picks s accordingly, 0 = rows as they come).
+__device__ __forceinline__ int xcd_row(int by, int s) {
+  if (s == 0) return by;
+  const int r = by & ((8 << s) - 1);
+  return by - r + ((r & 7) << s) + (r >> 3);
+}
+static inline int xcd_shift_for(unsigned rows, unsigned grid_x) {
+  static const int max_shift = [] {
+    const char* e = getenv("SLF_XCD_ROWS_LOG2");      // rows per XCD and block = 1 << this; 0: off
+    const int v = e ? atoi(e) : 5;
+    return v < 0 ? 0 : (v > 8 ? 8 : v);
+  }();
+  if (grid_x != 1) return 0;
+  int s = max_shift;
+  while (s > 0 && (rows % (8u << s)) != 0) s--;
+  return s;
+}
+
 // The (y, z) row a workgroup of a whole-row launch works on; false: nothing to do here (wave-uniform).
+// row_mode: bits 0-3 the mode (below), bits 4+ the XCD row shift of xcd_row().
 template <class L, class R>
 __device__ __forceinline__ bool launch_row(const SweepParams<L, R>& p, int& gy, int& gz) {
-  if (p.row_mode == 2) {
+  const int mode = p.row_mode & 15;
+  if (mode == 2) {
     const uint32_t yz = p.bc_rows[blockIdx.y];
     gy = (int)(yz & 0xffffu);
     gz = (int)(yz >> 16);
     if (gy < p.y0 || gy >= p.y1 || (L::dim == 3 && (gz < p.z0 || gz >= p.z1))) return false;
   } else {
-    gy = p.y0 + (int)blockIdx.y;
+    gy = p.y0 + xcd_row((int)blockIdx.y, p.row_mode >> 4);
     gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
-    if (p.row_mode == 1 && p.row_class[gy + p.g.arr_ny * gz] >= 2) return false;
+    if (mode == 1 && p.row_class[gy + p.g.arr_ny * gz] >= 2) return false;
   }
   return true;
 }

@@ -424,7 +424,7 @@ def test_block_decomposition_on_gpu(pattern, dim, cuts, size):
 
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
 @pytest.mark.parametrize('steps', [7, 8])
-@pytest.mark.parametrize('case', ['cavity_3x', 'pipe_2x', 'cavity_mrt_2x'])
+@pytest.mark.parametrize('case', ['cavity_3x', 'pipe_2x', 'cavity_mrt_2x', 'cavity_64_rows'])
 def test_x_slabs_through_face_buffers(pattern, steps, case):
     """1-D decompositions along x (the reference's default axis): the sweep's edge lanes write / read dense x-face
     buffers (sailfish_amd/xface.py, slf_module_set_xface_buffers) instead of ghost columns + pack / unpack kernels.
@@ -433,6 +433,10 @@ def test_x_slabs_through_face_buffers(pattern, steps, case):
     if case == 'cavity_3x':
         args = ('ldc_3d', 'LDCSim', 3, dict(lat_nx=30, lat_ny=12, lat_nz=10, visc=0.03, model='bgk', access_pattern=pattern,
                                             subdomains=3, conn_axis='x'))
+        u = 0.05
+    elif case == 'cavity_64_rows':      # 64 rows per plane: the rows of a launch are regrouped for the XCDs (xcd_row, slf_sweep.h)
+        args = ('ldc_3d', 'LDCSim', 3, dict(lat_nx=24, lat_ny=64, lat_nz=6, visc=0.03, model='bgk', access_pattern=pattern,
+                                            subdomains=2, conn_axis='x'))
         u = 0.05
     elif case == 'cavity_mrt_2x':
         args = ('ldc_3d', 'LDCSim', 3, dict(lat_nx=140, lat_ny=8, lat_nz=7, visc=0.03, model='mrt', access_pattern=pattern,

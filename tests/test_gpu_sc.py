@@ -29,7 +29,7 @@ def run_oracle(dim, size, steps, **kw):
     return s
 
 
-@pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (70, 9, 8))])
+@pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (70, 9, 8)), (3, (70, 64, 4))])     # 64 rows: regrouped for the XCDs
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
 @pytest.mark.parametrize('fused', [True, False])
 def test_sc_vs_oracle(dim, size, pattern, fused):
