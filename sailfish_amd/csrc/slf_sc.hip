@@ -3,7 +3,10 @@
 //   sc_macro_kernel     ShanChenPrepareMacroFields      (reference templates/models/binary_shan_chen.mako:19-87)
 //   sc_sweep_kernel<K>  ShanChenCollideAndPropagate{0,1} (binary_shan_chen.mako:89-141, shan_chen.mako:9-84)
 //   sc_fused_kernel     both of them in one pass ("ShanChenCollideAndPropagateFused"): rho, phi, u and the 18-point
-//                       pseudopotential stencil of each field are read once for the two lattices
+//                       pseudopotential stencil of each field are read once for the two lattices;
+//                       <OWNV> ("...FusedV"): densities and velocity of the node formed in the sweep, lattice 1 parked in LDS
+//   sc_macro_kernel<VOUT = false>, sc_density_pull_kernel   "ShanChenPrepareDensities": rho and phi only (+ u on output steps)
+//   sc_pull_rows        the odd in-place step's populations through aligned loads and a one-lane shift
 //   sc_init_kernel      SetInitialConditions (binary)    (templates/models/lb_binary_fluid.mako:87-127)
 //
 // Same layout, streaming modes and launch shape as the single-fluid sweep (slf_kernels.hip).  The force
