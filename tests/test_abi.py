@@ -91,3 +91,19 @@ def test_every_in_scope_reference_kernel_name_is_served():
     header = open(HEADER).read()
     for n in REFERENCE_KERNELS:
         assert n.replace('0', '').replace('1', '') in header.replace('0|1', ''), 'include/sailfish_hip.h does not document %s' % n
+
+
+# kernels this library adds to the reference's set (documented in include/sailfish_hip.h next to the ones they stand in for)
+ADDED_KERNELS = ['ShanChenCollideAndPropagateFused', 'ShanChenCollideAndPropagateFusedV', 'ShanChenPrepareDensities',
+                 'ComputeMacroFields']
+
+
+def test_added_kernel_names_are_served_and_documented():
+    src = open(os.path.join(ROOT, 'sailfish_amd', 'csrc', 'slf_api.hip')).read()
+    served = set(re.findall(r'!strcmp\(name, "([A-Za-z0-9]+)"\)', src))
+    header = open(HEADER).read()
+    for n in ADDED_KERNELS:
+        assert n in served, n
+        assert n in header, 'include/sailfish_hip.h does not document %s' % n
+    # and nothing is served that neither list knows
+    assert served == set(REFERENCE_KERNELS) | set(ADDED_KERNELS), served ^ (set(REFERENCE_KERNELS) | set(ADDED_KERNELS))
