@@ -11,8 +11,10 @@ N > 1: launched by torch.distributed.run, one rank per GPU; face layers are exch
 every step on a halo stream that overlaps the interior sweep (sailfish_amd/slab.py).  --force_distributed takes the
 same path with a single rank (the slab is its own ring neighbour; RCCL send / recv to self).
 
-Prints ONE JSON line on rank 0 (field list: DESIGN.md §6).  `value` is the best of --repeats timed runs of exactly
-K steps (each bracketed by barrier + synchronize, max over ranks); the median and every run are in `config`.
+Prints ONE JSON line on rank 0 (field list: DESIGN.md §6).  `value` is the MEDIAN of the timed blocks of exactly K
+steps (each bracketed by barrier + synchronize, max over ranks; blocks are repeated until --min_seconds are timed, for
+--repeats fresh placements); `best_value` is the fastest block (what rounds 3-4 reported as `value`: not directly
+comparable), every block is in `config`.
 """
 import argparse
 import json
@@ -63,7 +65,7 @@ def parse_args():
                     help='skip the leg through LBSimulationController / SubdomainRunner.step() (N = 1 only)')
     ap.add_argument('--min_seconds', type=float, default=0.5,
                     help='the block of exactly K timed steps is repeated until at least this much time has been timed '
-                         '(every block bracketed by barrier + synchronize; best block = value, the median is reported too)')
+                         '(every block bracketed by barrier + synchronize; median block = value, the best one is reported too)')
     ap.add_argument('--halo_timing_steps', type=int, default=20,
                     help='N > 1: steps of the separate leg that brackets the halo stream with timing events')
     ap.add_argument('--no_validate', action='store_true',
@@ -100,15 +102,38 @@ def cpu_baseline(args):
     return cpu_twin.baseline(args.model, args.precision, args.visc, budget_s=args.cpu_seconds)
 
 
-def load_traffic(workload_key):
-    """HBM bytes per sweep launch from the committed rocprofv3 PMC runs (profiles/traffic.json),
-    if one exists for this exact workload."""
-    p = os.path.join(ROOT, 'profiles', 'traffic.json')
+def load_traffic(workload_key, path=None):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC runs (profiles/traffic.json), if one exists for this
+    exact workload AND for these kernels: the file carries the sha256 of sailfish_amd/csrc/* it was measured with
+    (sailfish_amd/build.py source_hash(); tools/traffic_update.py writes both) -- after any change of the kernel sources
+    the line says `traffic: null` until the PMC passes have been repeated."""
+    from sailfish_amd import build as slf_build
+    p = path or os.path.join(ROOT, 'profiles', 'traffic.json')
     try:
         with open(p) as fh:
-            return json.load(fh).get(workload_key)
+            data = json.load(fh)
     except Exception:  # noqa: BLE001
         return None
+    if data.get('_csrc_sha256') != slf_build.source_hash():
+        return None
+    return data.get(workload_key)
+
+
+def median_block(blocks):
+    """Index of the median timed block (the lower of the two middle ones for an even count: always a block that ran)."""
+    order = np.argsort(np.asarray(blocks, dtype=np.float64), kind='stable')
+    return int(order[(len(order) - 1) // 2])
+
+
+def rccl_ranks_of(exchanger, dist_backend, world):
+    """How many ranks RCCL itself reports for the communicator the halos travel over (C ABI slf_comm_count ->
+    ncclCommCount); 0 when they do not travel over RCCL (gloo / host staging, plain copies).  With
+    SLF_HALO_TRANSPORT=torch on an RCCL process group the communicator is torch's: its world size."""
+    if exchanger is not None and getattr(exchanger, 'direct', False):
+        return int(exchanger.rccl.count()[0])
+    if dist_backend == 'nccl':
+        return int(world)
+    return 0
 
 
 def self_launch(n):
@@ -232,6 +257,18 @@ def validate(sim, backend, mass0, distributed, axis, rank=0, world=1):
         out['seam_layers_checked'] = ({'z': 'planes z = 1 and z = nz', 'y': 'rows y = 1 and y = ny',
                                        'x': 'columns x = 1 and x = nx'}[axis] + ' of every sampled plane (windows reach 3 layers '
                                       'into the ring neighbours)')
+    glob = None
+    if sim.halo and world > 1:
+        # whole planes of the UNDIVIDED box across every seam and the wrap (window.GlobalCheck): each rank hands in its
+        # share of the windows, rank 0 merges and advances them with no notion of slabs
+        def gather(obj):
+            got = [None] * world if rank == 0 else None
+            torch.distributed.gather_object(obj, got, dst=0)
+            return got
+        gz = nz * world if axis == 'z' else nz
+        glob = window.GlobalCheck(backend, sim.desc, sorted(set([1, gz // 2 + 1])), sim.gpu_dist, sim.stride, AXES[axis],
+                                  rank, world, gather)
+        glob.seed(sim.iteration)
     chk.seed(sim.iteration)
     sim.step()
     sim.step(save_macro=True)
@@ -240,6 +277,15 @@ def validate(sim, backend, mass0, distributed, axis, rank=0, world=1):
         sim.materialise_faces()
     chk.advance(2, save_last=True)
     r = chk.compare()
+    if glob is not None:
+        glob.advance(2)
+        g = glob.compare()
+        if rank == 0:
+            out['undivided_box'] = {'box': g['box'], 'slabs': g['slabs'], 'planes': g['planes'],
+                                    'populations_compared': g['compared_values'],
+                                    'populations_bit_identical': g['dist_exact'], 'max_abs_err': g['dist_err'],
+                                    'what': 'whole planes of the merged slabs against oracle windows of the undivided '
+                                            'periodic box (window.GlobalCheck)'}
     out.update(planes=r['planes'], populations_compared=r['compared_values'], populations_bit_identical=r['dist_exact'],
                max_abs_err=r['dist_err'], rho_rel_err=r['rho_err'], u_abs_err=r['v_abs_err'])
     rho, v = sim.fetch_fields()
@@ -254,7 +300,8 @@ def validate(sim, backend, mass0, distributed, axis, rank=0, world=1):
     out['steps_before_check'] = sim.iteration - 2
     # f32 round-off random-walks the totals: 8e-6 after 540 steps at 512^3, 1.6e-5 after 1500; a lost face layer is 2e-3
     out['ok'] = bool(out['mass_rel_drift'] < 5e-5 and out['momentum_drift_over_mass_u'] < 2e-4 and
-                     out.get('populations_bit_identical', True) and out.get('rho_rel_err', 0.0) < 1e-6)
+                     out.get('populations_bit_identical', True) and out.get('rho_rel_err', 0.0) < 1e-6 and
+                     out.get('undivided_box', {}).get('populations_bit_identical', True))
     if distributed:                      # every rank checked its own planes: all of them must agree
         flags = [1.0 if out['ok'] else 0.0, 1.0 if out.get('populations_bit_identical', True) else 0.0]
         t = torch.tensor(flags, dtype=torch.float64, device='cuda')
@@ -398,10 +445,10 @@ def main():
             total += elapsed
             if total >= args.min_seconds or len(blocks) >= 200:
                 break
-        best = int(np.argmin(blocks))
-        res['elapsed'] = blocks[best]
+        res['elapsed'] = blocks[median_block(blocks)]    # the median block; the best one is reported beside it
         res['blocks'] = blocks
-        res['kernel_ms'] = kernel[best]
+        res['kernels'] = kernel
+        res['kernel_ms'] = float(np.median(kernel))
         # enqueueing time per step.  mean: includes the stretches in which the runtime / RCCL made the host wait because
         # their queues were full (the host runs far ahead of the GPU: that wait is harmless); median: what a step costs
         # the host when nothing holds it back
@@ -416,6 +463,8 @@ def main():
                 sim.step()
             res['halo_ms'] = sim.stop_halo_timing()
             res['step_plans'] = sorted(str(k) for k in getattr(sim, '_plans', {}))
+            res['rccl_ranks'] = rccl_ranks_of(getattr(sim, 'exchanger', None),
+                                              torch.distributed.get_backend() if torch.distributed.is_initialized() else None, world)
         if check:
             res['validation'] = validate(sim, backend, mass0[0], distributed, args.axis, rank, world)
         sim.release()
@@ -430,10 +479,13 @@ def main():
         for pat in patterns:
             runs[pat].append(measure(pat, check=(i == reps - 1 and not args.no_validate)))
     st_after = None if (args.no_gpu_state or rank) else gpu_state()
-    best_of = dict((p, min(rs, key=lambda r: r['elapsed'])) for p, rs in runs.items())
-    best = min(best_of.values(), key=lambda r: r['elapsed'])
-    elapsed, kernel_ms = best['elapsed'], best['kernel_ms']
-    args.access_pattern = best['pattern']
+    # per access pattern: every timed block of every repeat; the pattern with the better MEDIAN block is reported
+    pooled = dict((p, [b for r in rs for b in r['blocks']]) for p, rs in runs.items())
+    med_of = dict((p, bl[median_block(bl)]) for p, bl in pooled.items())
+    args.access_pattern = min(med_of, key=med_of.get)
+    elapsed = med_of[args.access_pattern]
+    kernel_ms = float(np.median([k for r in runs[args.access_pattern] for k in r['kernels']]))
+    best = min(runs[args.access_pattern], key=lambda r: r['elapsed'])
     per_rank = None
     if distributed:
         mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms', 'host_ms', 'host_ms_median') if k in best)
@@ -466,11 +518,12 @@ def main():
                'periodic': 'in-sweep wrap' if not args.no_fused_periodic else 'ghost-layer PBC kernels',
                'decomposition': ('%s-slabs x%d, RCCL halo' % (args.axis, world)) if distributed else 'single subdomain',
                'visc': args.visc, 'block_x': best['block'], 'repeats': max(1, args.repeats),
-               'value_is': 'best block of exactly K steps (blocks repeated until --min_seconds are timed, per repeat)',
+               'value_is': 'median block of exactly K steps (blocks repeated until --min_seconds are timed, per repeat); '
+                           'best_value = the fastest block',
                'timed_blocks': len(all_mlups), 'timed_seconds': round(sum(b for r in runs[args.access_pattern] for b in r['blocks']), 3),
-               'median_mlups': round(float(np.median(all_mlups)), 1),
+               'median_mlups': round(to_mlups(elapsed), 1),
                'runs_mlups': [round(v, 1) for v in (all_mlups if len(all_mlups) <= 12 else all_mlups[:4] + all_mlups[-8:])],
-               'candidates_mlups': dict((p, round(to_mlups(r['elapsed']), 1)) for p, r in best_of.items()),
+               'candidates_mlups': dict((p, round(to_mlups(t), 1)) for p, t in med_of.items()),
                'placement': best['placement']}
         checks = dict((p, rs[-1]['validation']) for p, rs in runs.items() if 'validation' in rs[-1])
         if checks:
@@ -481,7 +534,10 @@ def main():
             so = max(r.get('sweep_only_ms', 0.0) for r in per_rank)
             step_ms = elapsed / args.steps * 1e3
             exposed = max(0.0, step_ms - so)
-            cfg.update({'rccl_ranks': torch.distributed.get_world_size(),
+            cfg.update({'rccl_ranks': best.get('rccl_ranks', 0),
+                        'rccl_ranks_is': 'ncclCommCount of the communicator the halos travel over (C ABI slf_comm_count); '
+                                         '0 = not over RCCL',
+                        'world_size': torch.distributed.get_world_size(),
                         'dist_backend': torch.distributed.get_backend(),
                         'halo_transport': 'RCCL through the C ABI (slf_comm_exchange inside the step plan)'
                         if best.get('step_plans') else 'torch.distributed',
@@ -493,7 +549,8 @@ def main():
             cfg['gpu_state'] = {'before': st_before, 'after': st_after}
         out = {
             'metric': 'MLUPS (million lattice updates/s), %s' % what,
-            'value': round(to_mlups(elapsed), 1), 'median_value': round(float(np.median(all_mlups)), 1),
+            'value': round(to_mlups(elapsed), 1), 'best_value': round(max(all_mlups), 1),
+            'median_value': round(to_mlups(elapsed), 1),
             'unit': 'MLUPS', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,

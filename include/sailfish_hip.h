@@ -206,6 +206,9 @@ typedef struct slf_comm slf_comm;
 int slf_comm_unique_id(void* id128);
 int slf_comm_init(slf_ctx* ctx, int nranks, int rank, const void* unique_id, slf_comm** out);
 int slf_comm_destroy(slf_comm* comm);
+/* Size of the communicator and this process's rank in it as RCCL reports them (ncclCommCount, ncclCommUserRank);
+ * either pointer may be NULL.  bench.py's `rccl_ranks` is this number (0 when the halos do not travel over RCCL). */
+int slf_comm_count(slf_comm* comm, int* nranks, int* rank);
 int slf_comm_group_begin(void);
 int slf_comm_group_end(void);
 int slf_comm_sendrecv(slf_comm* comm, int peer, const void* send_dptr, size_t n_send, void* recv_dptr, size_t n_recv,
@@ -276,7 +279,8 @@ int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* st
  * [, buffer stride between directions, buffer stride between rows])
  * (reference kernel_utils.mako:526-543, 629-645, 692-708, 777-793: face planes without index lists -- the
  * populations in bit mask `dirs` of the node box base + c col_stride + r row_stride <-> dense buffer [k][r][c];
- * 'i' arguments, base < 2^32), plus "ComputeMacroFields"
+ * 'i' arguments, base < 2^32; at most 12 directions per launch -- the mask travels to the kernel as an ordered list
+ * of 5-bit entries; a face of D3Q19 carries 5, more is SLF_ERR_INVALID), plus "ComputeMacroFields"
  * (rho / v of the current state, arguments as CollideAndPropagate).
  * The reference's own face kernels are served under their names AND argument lists as well (a host that binds the
  * reference's _init_collect_kernels / _init_distrib_kernels, subdomain_runner.py:1160-1290, needs no special case):
@@ -289,7 +293,8 @@ int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* st
  * exist in AA modules only); the layer read / written is the reference's lat_linear (Collect: ghost layer of `face`),
  * lat_linear_macro (CollectWithSwap, CollectMacro: first real layer), lat_linear_dist (Distribute: first real layer of
  * the far side), lat_linear_with_swap (DistributeWithSwap: ghost layer of the far side), lat_linear (DistributeMacro),
- * subdomain_runner.py:486-510; buffer [k][other][x], max_other = rows x populations.  Deviation: the reference strides
+ * subdomain_runner.py:486-510; buffer [k][other][x], max_other = rows x populations; a box that leaves the arrays
+ * (base_gx + max_lx beyond the padded row, base_other + rows beyond the other axis) is SLF_ERR_INVALID.  Deviation: the reference strides
  * the rows of the macro buffers by its launch grid's x size (kernel_utils.mako:886, 940); launch geometry is not part
  * of this boundary, the rows are max_lx apart (dense).  The two forms of Collect / DistributeContinuousData are told
  * apart by their argument formats.  x faces travel through index lists (or the x-face buffers below) as in the

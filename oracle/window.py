@@ -277,3 +277,108 @@ def chunk_boundary_planes(placed, desc, stride, limit=4):
                 out.append(z)
             k += max(1, (pb.total // pb.part_bytes) // limit)
     return out
+
+
+class GlobalCheck(object):
+    """Plane windows of the UNDIVIDED box of a run that is cut into `world` slabs along `axis`, one slab per rank:
+    every rank hands in its share of the seven planes around each sampled GLOBAL plane (gather(obj) -> list of every
+    rank's obj on rank 0, None elsewhere -- bench.py passes torch.distributed.gather_object), rank 0 merges them into a
+    window of the undivided periodic box (full x / y extent of the GLOBAL box, every axis wrapped in-sweep: the oracle
+    has no notion of slabs, ranks or halos), advances it two steps and compares the sampled plane with the merged
+    plane of the slabs' arrays after their two steps -- every population of every real node, bit for bit.  Where
+    SeamCheck looks at one slab and three layers of its neighbours, this looks at whole planes across ALL the seams at
+    once (config 4: eight subdomains, seven inner seams and the wrap 7 -> 0).  The slabs are fluid-only periodic boxes
+    (bench.py's); seed with the devices idle and the x-face buffers materialised."""
+
+    def __init__(self, backend, desc, zs, dist_addrs, stride, axis, rank, world, gather):
+        self.pc = PlaneCheck(backend, desc, None, [], dist_addrs, stride, None)
+        self.desc, self.axis, self.rank, self.world, self.gather = desc, int(axis), int(rank), int(world), gather
+        self.n = [desc.lat_nx - 2, desc.lat_ny - 2, desc.lat_nz - 2]
+        g = list(self.n)
+        g[self.axis] *= self.world
+        self.g = g
+        gd = _clone_desc(desc, lat_nx=g[0] + 2, lat_ny=g[1] + 2, lat_nz=g[2] + 2, arr_nx=(g[0] + 2 + 31) // 32 * 32,
+                         arr_ny=g[1] + 2, arr_nz=g[2] + 2, dist_stride=0)
+        for a in range(3):
+            gd.periodic_fused[a] = gd.periodic_local[a] = 1
+        self.gdesc = gd
+        self.windows = [PlaneWindow(gd, None, z) for z in zs]       # planes: GLOBAL indices 1 .. g[2], wrapped
+        self.dtype = self.pc.dtype
+        self.iteration = None
+        self.aa = desc.access_pattern == hipabi.SLF_AA
+
+    # -- this rank's share of a list of global planes --------------------------------------------------------------
+    def _share(self, planes, addr):
+        """[19, len(planes), ny, nx] real nodes of the planes this rank holds (z split: None for the planes of other
+        ranks), as a dict {position in `planes`: [19, ny, nx]}."""
+        pc, n = self.pc, self.n
+        out = {}
+        for k, p in enumerate(planes):
+            if self.axis == 2:
+                if (p - 1) // n[2] != self.rank:
+                    continue
+                lp = (p - 1) % n[2] + 1
+            else:
+                lp = p
+            blk = np.empty((19, n[1], n[0]), dtype=self.dtype)
+            for q in range(19):
+                blk[q] = pc._fetch_planes(addr + q * pc.stride * pc.isz, lp, 1)[0][1:n[1] + 1, 1:n[0] + 1]
+            out[k] = blk
+        return out
+
+    def _merge(self, shares, count):
+        """Rank 0: the shares of every rank -> [19, count, g_ny + 2, g_arr_nx] (ghost rows / columns never read: zero)."""
+        gd, n = self.gdesc, self.n
+        blk = np.zeros((19, count, gd.arr_ny, gd.arr_nx), dtype=self.dtype)
+        filled = np.zeros(count, dtype=np.int64)
+        for r, sh in enumerate(shares):
+            oy = 1 + (r * n[1] if self.axis == 1 else 0)
+            ox = 1 + (r * n[0] if self.axis == 0 else 0)
+            for k, part in sh.items():
+                blk[:, k, oy:oy + n[1], ox:ox + n[0]] = part
+                filled[k] += 1
+        want = 1 if self.axis == 2 else self.world
+        if not np.all(filled == want):
+            raise RuntimeError('global window: planes covered %s times, expected %d' % (filled.tolist(), want))
+        return blk
+
+    def _current(self, iteration):
+        return 0 if len(self.pc.dist_addrs) == 1 else (iteration & 1)
+
+    def seed(self, iteration):
+        self.iteration = int(iteration)
+        cur = self._current(self.iteration)
+        for w in self.windows:
+            shares = self.gather(self._share(w.planes, self.pc.dist_addrs[cur]))
+            if self.rank == 0:
+                blk = self._merge(shares, W)
+                w.dist = [blk] if len(self.pc.dist_addrs) == 1 else [None, None]
+                if len(w.dist) == 2:
+                    w.dist[cur], w.dist[1 - cur] = blk, np.zeros_like(blk)
+                w.rho = np.full(w.o.shape, np.inf, dtype=self.dtype)
+                w.v = [np.full(w.o.shape, np.inf, dtype=self.dtype) for _ in range(3)]
+
+    def advance(self, steps=2):
+        if self.rank == 0:
+            self.pc.windows, self.pc.iteration = self.windows, self.iteration
+            self.pc.advance(steps, save_last=False)
+            self.pc.windows = []
+        self.iteration += steps
+
+    def compare(self):
+        """Rank 0: {'planes', 'compared_values', 'dist_exact', 'dist_err'}; other ranks: None (they only hand in)."""
+        cur = self._current(self.iteration)
+        res = {'planes': [w.z for w in self.windows], 'compared_values': 0, 'dist_exact': True, 'dist_err': 0.0,
+               'box': 'x'.join(str(v) for v in self.g), 'slabs': self.world}
+        for w in self.windows:
+            shares = self.gather(self._share([w.z], self.pc.dist_addrs[cur]))
+            if self.rank != 0:
+                continue
+            dev = self._merge(shares, 1)[:, 0, 1:self.g[1] + 1, 1:self.g[0] + 1]
+            ref = w.dist[cur][:, w.t, 1:self.g[1] + 1, 1:self.g[0] + 1]
+            res['compared_values'] += int(ref.size)
+            if not np.array_equal(dev, ref):
+                res['dist_exact'] = False
+                with np.errstate(invalid='ignore'):
+                    res['dist_err'] = max(res['dist_err'], float(np.nanmax(np.abs(dev - ref))))
+        return res if self.rank == 0 else None

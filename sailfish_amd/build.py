@@ -28,6 +28,22 @@ def _hipcc():
     return 'hipcc'
 
 
+def source_hash():
+    """sha256 over every file under csrc/ (names and contents, sorted): what the kernels of a build were compiled from.
+    Measurements that belong to one state of the kernels (profiles/traffic.json: PMC bytes per launch) carry it, and
+    bench.py reports them only while it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        path = os.path.join(CSRC, name)
+        if os.path.isfile(path) and name.endswith(('.hip', '.h')):
+            h.update(name.encode() + b'\0')
+            with open(path, 'rb') as fh:
+                h.update(fh.read())
+            h.update(b'\0')
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(LIBPATH):
         return True

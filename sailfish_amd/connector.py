@@ -137,6 +137,12 @@ class DirectRccl(object):
     def group(self, ops, stream):
         self.run(self.prepare(ops), stream)
 
+    def count(self):
+        """(ranks, my rank) as RCCL reports them for this communicator (ncclCommCount / ncclCommUserRank)."""
+        n, r = self._ctypes.c_int(), self._ctypes.c_int()
+        self._check(self.lib, self.lib.slf_comm_count(self.comm, self._ctypes.byref(n), self._ctypes.byref(r)), 'slf_comm_count')
+        return int(n.value), int(r.value)
+
     def close(self):
         if self.comm:
             self.lib.slf_comm_destroy(self.comm)

@@ -272,6 +272,8 @@ struct RcclApi {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
@@ -307,6 +309,8 @@ int rccl_load() {
   SLF_SYM(GetUniqueId, "ncclGetUniqueId")
   SLF_SYM(CommInitRank, "ncclCommInitRank")
   SLF_SYM(CommDestroy, "ncclCommDestroy")
+  SLF_SYM(CommCount, "ncclCommCount")
+  SLF_SYM(CommUserRank, "ncclCommUserRank")
   SLF_SYM(Send, "ncclSend")
   SLF_SYM(Recv, "ncclRecv")
   SLF_SYM(GroupStart, "ncclGroupStart")
@@ -353,6 +357,20 @@ int slf_comm_destroy(slf_comm* c) {
   int rc = g_rccl.CommDestroy(c->comm);
   delete c;
   return rc ? rccl_fail(rc, "ncclCommDestroy") : SLF_OK;
+}
+
+// What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank), not what the caller passed to
+// slf_comm_init(): the evidence a benchmark line carries that RCCL saw N ranks.
+int slf_comm_count(slf_comm* c, int* nranks, int* rank) {
+  if (!c) return fail(SLF_ERR_INVALID, "comm is NULL");
+  int n = 0, r = 0;
+  int rc = g_rccl.CommCount(c->comm, &n);
+  if (rc) return rccl_fail(rc, "ncclCommCount");
+  rc = g_rccl.CommUserRank(c->comm, &r);
+  if (rc) return rccl_fail(rc, "ncclCommUserRank");
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  return SLF_OK;
 }
 
 int slf_comm_group_begin(void) {
@@ -1229,6 +1247,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       if (k->ints.size() >= 6) {
         int dirs[32], nd = 0;
         for (int q = 0; q < 32; q++) if (((unsigned int)k->ints[0] >> q) & 1u) dirs[nd++] = q;    // ascending
+        if (nd > 12) return fail(SLF_ERR_INVALID, "Collect/DistributeContinuousData: at most 12 directions per launch (a face of D3Q19 carries 5)");
         e = slf::launch_box(m->sel, g, k->kind == KK_COLLECT_BOX, (void*)k->ptrs[0], (void*)k->ptrs[1], dirs, nd,
                             (unsigned long long)(uint32_t)k->ints[1], (long long)k->ints[2], (int)k->ints[3],
                             (long long)k->ints[4], (int)k->ints[5], k->ints.size() == 8 ? (long long)k->ints[6] : 0,
@@ -1288,8 +1307,9 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       const unsigned long long base = (unsigned long long)base_gx +
           (axis == 1 ? (unsigned long long)g.arr_nx * layer + (unsigned long long)g.arr_nxy * base_other
                      : (unsigned long long)g.arr_nx * base_other + (unsigned long long)g.arr_nxy * layer);
-      if (base_gx < 0 || base_gx + ncols > g.arr_nx || base_other < 0 || layer >= lat)
-        return fail(SLF_ERR_INVALID, "face box outside the subdomain");
+      const int lat_other = g.dim == 3 ? (axis == 1 ? g.lat_nz : g.lat_ny) : 1;       // extent along the rows' axis
+      if (base_gx < 0 || base_gx + ncols > g.arr_nx || base_other < 0 || base_other + nrows > lat_other || layer < 0 || layer >= lat)
+        return fail(SLF_ERR_INVALID, "face box outside the subdomain (base_gx + max_lx, base_other + rows or the layer exceed the arrays)");
       slf::Geometry gm = g;
       if (macro) gm.dist_size = 0;
       e = slf::launch_box(m->sel, gm, collect, (void*)k->ptrs[0], (void*)k->ptrs[1], dirs, nd, base, 1, ncols, row_stride, nrows,

@@ -96,6 +96,7 @@ SIGNATURES = {
     'slf_comm_unique_id': (c_int, [c_void_p]),
     'slf_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     'slf_comm_destroy': (c_int, [c_void_p]),
+    'slf_comm_count': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     'slf_comm_group_begin': (c_int, []),
     'slf_comm_group_end': (c_int, []),
     'slf_comm_sendrecv': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]),

@@ -28,6 +28,20 @@ def enabled():
     return os.environ.get('SLF_PLACEMENT', '1') not in ('0', 'off', 'no')
 
 
+def sharers():
+    """How many processes place arrays on THIS device at the same time: 1 in production (one process per GPU); the
+    world size when SLF_FORCE_DEVICE puts every rank of a functional run on one GPU (tests/test_gpu_two_ranks.py,
+    config 4's eight subdomains on a 1-GPU box), or whatever SLF_DEVICE_SHARERS says.  Each then takes its share of the
+    span and of the free memory, so that the spacers of all of them fit side by side."""
+    n = os.environ.get('SLF_DEVICE_SHARERS')
+    if n is None and os.environ.get('SLF_FORCE_DEVICE') is not None:
+        n = os.environ.get('WORLD_SIZE')
+    try:
+        return max(1, int(n or 1))
+    except ValueError:
+        return 1
+
+
 class PlacedBuffer(object):
     """A device buffer at a fixed virtual address made of `parts` equally sized physical chunks."""
 
@@ -107,8 +121,9 @@ def place(backend, buffers, span=None):
     payload = sum(b.total for b in buffers)
     if span is None:
         span = int(os.environ.get('SLF_PLACEMENT_SPAN_GIB', SPAN >> 30)) << 30
-    free = backend.free_memory() - payload          # what the device has left, whoever holds the rest
-    span = max(payload, min(span, payload + int(0.8 * max(0, free))))
+    n = sharers()
+    free = backend.free_memory() // n - payload     # what the device has left (this process's share of it), whoever holds the rest
+    span = max(payload, min(span // n, payload + int((0.8 if n == 1 else 0.5) * max(0, free))))
     spacer = max(0, (span - payload) // parts) // gran * gran
     spacers = []
     try:
@@ -149,14 +164,16 @@ def choose(make_set, measure, release, attempts=3, agree=0.02, log=None, room=No
             break
         try:
             bufs = make_set()
-        except Exception as e:  # noqa: BLE001 -- a further set that does not fit must not end a run that fitted before
+        except (RuntimeError, MemoryError, OSError) as e:   # the backend's errors (HIPFatalError is a RuntimeError): a
+            # further set that does not fit must not end a run that fitted before.  make_set() is all-or-nothing --
+            # alloc_placed() gives back what it had placed before it re-raises or falls back -- so nothing is held here
             if n == 0:
                 raise
             note = 'placing set %d failed: %s' % (n, str(e)[:100])
             break
         try:
             t = measure(bufs)
-        except Exception as e:  # noqa: BLE001
+        except (RuntimeError, MemoryError, OSError) as e:
             release(bufs)
             if n == 0:
                 raise
@@ -220,7 +237,7 @@ def probe_sweep(backend, desc, dim, src, dst, nbytes, stream, steps=12):
 def room_for(backend, nbytes, slack=1.15):
     """True when another set of `nbytes` of distribution arrays fits into the device memory that is free right now."""
     try:
-        return backend.free_memory() >= int(nbytes * slack)
+        return backend.free_memory() // sharers() >= int(nbytes * slack)
     except Exception:  # noqa: BLE001
         return False
 

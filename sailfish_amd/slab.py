@@ -376,12 +376,14 @@ class SlabSim(BoxSim):
                     self.t_bufs = self.t_sets[it & 1]
                 plan.run(it)
                 self.iteration += 1
+                b.set_iteration(self.iteration)     # kernels launched through run_kernel() next see the new parity
                 if self.xface is not None:
                     self.xface._bound = None        # the plan set the module's face buffers itself
                 return
         b.set_iteration(it)
         self._program(DirectQueue(b), it, save_macro)
         self.iteration += 1
+        b.set_iteration(self.iteration)
         if self.xface is not None:
             self.xface._bound = None
 
@@ -401,6 +403,7 @@ class SlabSim(BoxSim):
                 b.run_kernel(k, reg, self.calc_stream)
             b.run_kernel(k, getattr(self, 'reg_bulk', None), self.calc_stream)
         self.iteration += 1
+        b.set_iteration(self.iteration)
 
     def start_halo_timing(self):
         self.time_halo, self._halo_events = True, []

@@ -731,6 +731,10 @@ class SubdomainRunner(object):
         elif self._links:
             q.wait(sk, pev['halo'])
         self._program_sweep_rest(q, it, kernels, bulk, ready, group)
+        if bnd and sb is not sk and sync_req:
+            # the host is about to look at this step's results (fields to the host, the invalid-value poll, kernels a
+            # simulation enqueues from after_step() -- all on the calc stream): they come after the face layers too
+            q.wait(sk, ev['bnd'])
 
     def _program_sweep_rest(self, q, it, kernels, bulk, ready, group):
         prof, timed = self._profile, not q.planned

@@ -58,3 +58,62 @@ def test_bench_launches_its_own_ranks_and_refuses_to_run_without_a_gpu():
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=900)
     assert res.returncode != 0 and b'bench.py needs a GPU' in res.stdout and b'torch.distributed' in res.stdout, res.stdout[-2000:]
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_value_is_the_median_block_not_the_best():
+    """VERDICT r4 / ADVICE r4: the headline is the median timed block; the fastest one is an extra key."""
+    bench = _bench_module()
+    blocks = [0.0660, 0.0644, 0.0651, 0.0649, 0.0700]
+    assert blocks[bench.median_block(blocks)] == 0.0651
+    assert blocks[bench.median_block(blocks[:4])] == 0.0649          # even count: the lower middle one, a block that ran
+    assert bench.median_block([0.07]) == 0
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert "'best_value'" in src and "'value': round(to_mlups(elapsed), 1)" in src and 'np.argmin(blocks)' not in src
+
+
+def test_traffic_is_reported_only_for_the_sources_it_was_measured_with(tmp_path):
+    """profiles/traffic.json carries the sha256 of sailfish_amd/csrc/*; any other state of the sources -> null."""
+    from sailfish_amd import build as slf_build
+    bench = _bench_module()
+    good = tmp_path / 'good.json'
+    good.write_text(json.dumps({'_csrc_sha256': slf_build.source_hash(), 'K': 123}))
+    stale = tmp_path / 'stale.json'
+    stale.write_text(json.dumps({'_csrc_sha256': '0' * 64, 'K': 123}))
+    unstamped = tmp_path / 'unstamped.json'
+    unstamped.write_text(json.dumps({'K': 123}))
+    assert bench.load_traffic('K', str(good)) == 123 and bench.load_traffic('other', str(good)) is None
+    assert bench.load_traffic('K', str(stale)) is None and bench.load_traffic('K', str(unstamped)) is None
+    assert bench.load_traffic('K', str(tmp_path / 'missing.json')) is None
+    h = slf_build.source_hash()
+    assert len(h) == 64 and h == slf_build.source_hash()
+
+
+def test_rccl_ranks_come_from_the_communicator_not_from_the_process_group():
+    """`rccl_ranks` = ncclCommCount of the communicator the halos travel over (C ABI slf_comm_count); a gloo group
+    (several ranks on one GPU, host staging) reports 0 whatever its world size."""
+    bench = _bench_module()
+
+    class Rccl(object):
+        def count(self):
+            return (8, 3)
+
+    class Direct(object):
+        direct = True
+        rccl = Rccl()
+
+    class Staged(object):
+        pass
+
+    assert bench.rccl_ranks_of(Direct(), 'nccl', 8) == 8
+    assert bench.rccl_ranks_of(Staged(), 'gloo', 4) == 0 and bench.rccl_ranks_of(None, None, 1) == 0
+    assert bench.rccl_ranks_of(Staged(), 'nccl', 2) == 2            # SLF_HALO_TRANSPORT=torch: torch's own communicator
+    hdr = open(os.path.join(ROOT, 'include', 'sailfish_hip.h')).read()
+    assert 'int slf_comm_count(slf_comm* comm, int* nranks, int* rank);' in hdr

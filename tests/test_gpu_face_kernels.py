@@ -169,3 +169,24 @@ def test_swap_kernels_exist_for_the_in_place_pattern_only():
     with pytest.raises(b.FatalError):
         b.get_kernel(sim.module, 'CollectContinuousDataWithSwap', (64,), [sim.gpu_dist[0], 2, 1, 1, 4, 5, sim.gpu_rho], 'PiiiiiP')
     sim.release()
+
+
+def test_face_box_that_leaves_the_arrays_is_refused():
+    """base_other + rows (and the 12-direction limit of the box form) are checked before anything is
+    written; a bad max_other used to write out of bounds from DistributeContinuousData."""
+    from sailfish_amd.backend_hip import HIPFatalError
+    b = _backend()
+    desc = make_box_desc(sym.D3Q19, (20, 9, 7), precision='single', access_pattern='AA', visc=0.02)
+    sim = BoxSim(b, desc)
+    dbuf = b.alloc_buf(size=1 << 20)
+    rows_y, rows_z = desc.lat_ny, desc.lat_nz
+    for face, rows in ((Z_LOW, rows_y), (Y_HIGH, rows_z)):
+        ok = b.get_kernel(sim.module, 'DistributeContinuousData', (64,), [sim.gpu_dist[0], face, 1, 1, 10, (rows - 1) * 5, dbuf], 'PiiiiiP')
+        b.run_kernel(ok, None, sim.stream)
+        sim.sync()
+        bad = b.get_kernel(sim.module, 'DistributeContinuousData', (64,), [sim.gpu_dist[0], face, 1, 1, 10, rows * 5, dbuf], 'PiiiiiP')
+        with pytest.raises(HIPFatalError, match='outside the subdomain'):
+            b.run_kernel(bad, None, sim.stream)
+    many = b.get_kernel(sim.module, 'CollectContinuousData', (64,), [sim.gpu_dist[0], dbuf, (1 << 13) - 1, 0, 1, 4, desc.arr_nx, 2], 'PPiiiiii')
+    with pytest.raises(HIPFatalError, match='at most 12 directions'):
+        b.run_kernel(many, None, sim.stream)

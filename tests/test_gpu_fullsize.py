@@ -11,6 +11,8 @@ and regtest/subdomains/3d_ldc.py:79-95 at real sizes.
             (y = ny of every plane) and chunk-boundary planes;
   config 4  one 128 x 512 x 512 x-slab pair (2 of the 8 subdomains of 1024 x 512 x 512) through the x-face buffers
             against the undivided 256 x 512 x 512 box, which is checked against the oracle windows itself;
+  config 4  as stated: all EIGHT subdomains of 1024 x 512 x 512 (x-slabs 128 x 512 x 512, z-slabs 1024 x 512 x 64), one
+            process each on the one GPU, seam windows on every rank + whole planes against the undivided box;
   config 5  binary Shan-Chen 256^3 through the host stack, 2 steps, full field against the oracle twin.
 
 Populations must be bit-identical (same IEEE operation order, FMA contraction off); rho / u within the north-star
@@ -187,6 +189,46 @@ def test_config4_x_slab_pair_full_size(pattern):
     for s in sims + [one]:
         s.release()
     assert res['dist_exact'], res
+
+
+@pytest.mark.parametrize('axis', ['x', 'z'])
+def test_config4_eight_subdomains_full_extent(axis):
+    """BASELINE config 4 as stated: D3Q19 BGK 1024 x 512 x 512 cut into EIGHT subdomains (reference geo.py:100-135
+    EqualSubdomainsGeometry3D; x = its default axis: 128 x 512 x 512 each, z: 1024 x 512 x 64), one process per subdomain
+    -- a ring whose neighbours are all different ranks, with the wrap 7 -> 0 -- at full size.  The box of the build pool
+    has ONE GPU, so the eight ranks share it (gloo group, halo buffers staged through the host: `rccl_ranks` 0); on an
+    8-GPU node the same command line without the two environment variables is the RCCL run.  After the timed steps every
+    rank checks its seam layers through windows that reach into both neighbours (window.SeamCheck) and rank 0 checks
+    whole planes of the merged slabs against oracle windows of the UNDIVIDED 1024 x 512 x 512 box (window.GlobalCheck),
+    populations bit for bit, both access patterns."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--scaling', 'strong', '--domain', '1024x512x512',
+           '--axis', axis, '--steps', '4', '--warmup', '2', '--prewarm_steps', '4', '--repeats', '1', '--no_cpu_baseline',
+           '--no_gpu_state', '--min_seconds', '0.05', '--halo_timing_steps', '4']
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=1500)
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode == 0, out[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and c['world_size'] == 8 and c['rccl_ranks'] == 0
+    assert '1024x512x512' in c['workload'] and ('128x512x512' if axis == 'x' else '1024x512x64') in c['workload']
+    assert sorted(r['rank'] for r in c['per_rank']) == list(range(8))
+    assert c['validated'] is True, c['validation']
+    assert set(c['validation']) == {'AA', 'AB'}
+    for v in c['validation'].values():
+        assert v['populations_bit_identical'] and v['ranks_checked'] == 8 and v['rho_rel_err'] < RTOL
+        u = v['undivided_box']
+        assert u['box'] == '1024x512x512' and u['slabs'] == 8 and u['populations_bit_identical']
+        assert u['populations_compared'] == 19 * 2 * 1024 * 512
+    print('config 4, 8 ranks on one GPU, %s-slabs: %.0f MLUPS (functional: gloo, host staging)' % (axis, d['value']))
 
 
 def _plane(backend, sim, q, z):

@@ -40,7 +40,7 @@ def test_bench_with_two_ranks_on_one_gpu(mode):
     d = json.loads(lines[0])
     c = d['config']
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['scaling'] == mode[1]
-    assert c['rccl_ranks'] == 2 and c['dist_backend'] == 'gloo'
+    assert c['rccl_ranks'] == 0 and c['world_size'] == 2 and c['dist_backend'] == 'gloo'      # gloo: nothing went over RCCL
     assert sorted(r['rank'] for r in c['per_rank']) == [0, 1]
     assert all(r['kernel_ms'] > 0 and r['halo_ms'] > 0 for r in c['per_rank'])
     assert set(c['candidates_mlups']) == {'AA', 'AB'}
@@ -61,9 +61,10 @@ def test_bench_launches_two_ranks_itself():
     assert len(lines) == 1, out[-3000:]
     d = json.loads(lines[0])
     c = d['config']
-    assert d['n_gpus'] == 2 and c['rccl_ranks'] == 2 and sorted(r['rank'] for r in c['per_rank']) == [0, 1]
+    assert d['n_gpus'] == 2 and c['rccl_ranks'] == 0 and c['world_size'] == 2 and sorted(r['rank'] for r in c['per_rank']) == [0, 1]
     assert c['validated'] is True, c['validation']
     assert all(v['populations_bit_identical'] for v in c['validation'].values())
+    assert all(v['undivided_box']['populations_bit_identical'] and v['undivided_box']['slabs'] == 2 for v in c['validation'].values())
 
 
 @pytest.mark.parametrize('axis,pattern,model', [('z', 'AA', 'bgk'), ('z', 'AB', 'mrt'), ('x', 'AA', 'bgk'), ('x', 'AB', 'bgk'),
@@ -177,6 +178,7 @@ def test_bench_with_two_rccl_ranks(mode):
     assert c['rccl_ranks'] == 2 and c['dist_backend'] == 'nccl' and 'C ABI' in c['halo_transport']
     assert sorted(r['device'] for r in c['per_rank']) == [0, 1] and all(r['step_plans'] for r in c['per_rank'])
     assert c['validated'] is True and all(v['populations_bit_identical'] and v['ranks_checked'] == 2 for v in c['validation'].values())
+    assert all(v['undivided_box']['populations_bit_identical'] for v in c['validation'].values())
 
 
 @needs_two_gpus
@@ -228,6 +230,7 @@ def test_bench_with_four_ranks_on_one_gpu(mode):
     assert len(lines) == 1, out[-3000:]
     d = json.loads(lines[0])
     c = d['config']
-    assert d['n_gpus'] == 4 and c['rccl_ranks'] == 4 and sorted(r['rank'] for r in c['per_rank']) == [0, 1, 2, 3]
+    assert d['n_gpus'] == 4 and c['rccl_ranks'] == 0 and c['world_size'] == 4 and sorted(r['rank'] for r in c['per_rank']) == [0, 1, 2, 3]
     assert c['validated'] is True, c['validation']
     assert all(v['populations_bit_identical'] and v['ranks_checked'] == 4 for v in c['validation'].values())
+    assert all(v['undivided_box']['populations_bit_identical'] and v['undivided_box']['slabs'] == 4 for v in c['validation'].values())

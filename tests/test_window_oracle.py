@@ -152,3 +152,69 @@ def test_seam_windows_reach_into_the_neighbouring_slabs(axis, pattern, start):
     idx[3 - axis] = 1                                        # first real layer along the split axis
     after[0][cur][tuple(idx)] += np.float32(1e-6)
     assert not checks[0].compare(fields=False)['dist_exact']
+
+
+@pytest.mark.parametrize('axis', [0, 1, 2])
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+@pytest.mark.parametrize('start', [4, 5])
+def test_global_windows_merge_the_slabs_of_every_rank(axis, pattern, start):
+    """window.GlobalCheck (bench.py's second validation of N > 1 runs; BASELINE config 4: eight subdomains): a periodic
+    box cut into three slabs; the shares the ranks hand in are merged into windows of the UNDIVIDED box, which reproduce
+    the undivided oracle run on whole planes across every seam and the wrap; a value spoilt anywhere on a sampled plane
+    -- in any slab -- is seen."""
+    from oracle.window import GlobalCheck
+    world = 3
+    size_l = [12, 10, 8]
+    size_g = list(size_l)
+    size_g[axis] *= world
+    kw = dict(model='bgk', precision='single', access_pattern=pattern, visc=0.02)
+    desc_g = make_box_desc(sym.D3Q19, tuple(size_g), periodic_fused=[1, 1, 1], **kw)
+    fused_l = [1, 1, 1]
+    fused_l[axis] = 0
+    desc_l = make_box_desc(sym.D3Q19, tuple(size_l), periodic_fused=fused_l, **kw)
+    o = OracleBox(desc_g, periodic=(True, True, True))
+    rho, v = synthetic_fields(tuple(size_g), 3)
+    o.set_fields(rho, v)
+    o.initial_conditions()
+    o.run(start, save_last=False)
+    copies = range(len(o.dist))
+    n = size_l[axis]
+    before = [_cut(o, desc_l, axis, r, n, copies) for r in range(world)]
+    calls = {}
+
+    def gather_for(rank):          # ranks 1 .. world-1 hand in first, rank 0 last: it gets the list
+        count = [0]
+
+        def gather(obj):
+            slot = calls.setdefault(count[0], {})
+            slot[rank] = obj
+            count[0] += 1
+            return [slot[r] for r in range(world)] if rank == 0 else None
+        return gather
+
+    zs = [1, size_g[2] // 2, size_g[2]]
+    stride = desc_l.arr_nx * desc_l.arr_ny * desc_l.arr_nz
+    checks = [GlobalCheck(HostMemory, desc_l, zs, [a.ctypes.data for a in before[r]], stride, axis, r, world, gather_for(r))
+              for r in range(world)]
+    for r in (1, 2, 0):
+        checks[r].seed(o.iteration)
+    o.run(2, save_last=False)
+    after = [_cut(o, desc_l, axis, r, n, copies) for r in range(world)]
+    cur = 0 if pattern == 'AA' else (o.iteration & 1)
+    for spoil in (False, True):
+        if spoil:
+            idx = [7, 1, 2, 2]          # population 7, plane / row / column 1 or 2 of the LAST slab
+            if axis == 2:
+                idx[1] = size_l[2]      # global plane size_g[2] is its last local plane
+            after[world - 1][cur][tuple(idx)] += np.float32(1e-6)
+        res = None
+        for r in (1, 2, 0):
+            chk = checks[r]
+            if not spoil:
+                chk.advance(2)
+            chk.pc.dist_addrs = [a.ctypes.data for a in after[r]]
+            out = chk.compare()
+            assert (out is None) == (r != 0)
+            res = out if r == 0 else res
+        assert res['dist_exact'] == (not spoil), res
+        assert res['compared_values'] == 19 * len(zs) * size_g[0] * size_g[1]
