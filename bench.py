@@ -447,8 +447,8 @@ def main():
                 break
         res['elapsed'] = blocks[median_block(blocks)]    # the median block; the best one is reported beside it
         res['blocks'] = blocks
-        res['kernels'] = kernel
-        res['kernel_ms'] = float(np.median(kernel))
+        res['kernels'] = kernel                          # per block: HIP events on the sweep's own stream / K
+        res['kernel_ms'] = kernel[median_block(blocks)]
         # enqueueing time per step.  mean: includes the stretches in which the runtime / RCCL made the host wait because
         # their queues were full (the host runs far ahead of the GPU: that wait is harmless); median: what a step costs
         # the host when nothing holds it back
@@ -484,7 +484,8 @@ def main():
     med_of = dict((p, bl[median_block(bl)]) for p, bl in pooled.items())
     args.access_pattern = min(med_of, key=med_of.get)
     elapsed = med_of[args.access_pattern]
-    kernel_ms = float(np.median([k for r in runs[args.access_pattern] for k in r['kernels']]))
+    # the sweep time of that very block
+    kernel_ms = [k for r in runs[args.access_pattern] for k in r['kernels']][median_block(pooled[args.access_pattern])]
     best = min(runs[args.access_pattern], key=lambda r: r['elapsed'])
     per_rank = None
     if distributed:

@@ -126,7 +126,7 @@ PIPE_TOL = 2e-3
 def test_phase_separation_matches_reference_record_double(row, golden_dir):
     """regtest/sc_phase_sep.py --precision=double: 256^2, seed 2348, 50 000 steps, G = -linspace(3, 5.5, 79)[row];
     recorded (G, min rho, max rho, order parameter).  Homogeneous below the spinodal point, coexisting liquid / vapour
-    densities above it (same criteria as the single-precision test in test_gpu_sc.py)."""
+    densities above it."""
     from tests.test_gpu_sc import run_gpu_single
     data = np.loadtxt(os.path.join(golden_dir, 'sc_phase_separation_double.dat'))
     assert data.shape == (79, 4)
@@ -142,7 +142,10 @@ def test_phase_separation_matches_reference_record_double(row, golden_dir):
           % (G, lo, hi, order, lo_ref, hi_ref, order_ref))
     if hi_ref - lo_ref < 1e-3:            # homogeneous: the initial noise (amplitude 0.01) has decayed
         assert hi - lo < 1e-3 and abs(0.5 * (lo + hi) - 0.5 * (lo_ref + hi_ref)) < 2e-3
-    else:                                 # coexistence densities (droplet curvature / coarsening stage: a few per cent)
-        assert abs(hi - hi_ref) / hi_ref < 0.03, (lo, hi, data[row])
-        assert abs(lo - lo_ref) < 0.02, (lo, hi, data[row])
-        assert abs(order - order_ref) / order_ref < 0.15, (order, order_ref)
+    else:
+        # coexistence densities.  In double precision the run reproduces the reference's recorded GPU figures to 1e-5 ..
+        # 5e-5 (profiles/r05/pytest_physics3d_v1.log: G = 4.218: 0.357089 / 1.169276 against 0.357089 / 1.169280); the
+        # order parameter depends on the droplet pattern the random initial state leads to (0.01 % .. 0.1 % apart)
+        assert abs(hi - hi_ref) / hi_ref < 1e-3, (lo, hi, data[row])
+        assert abs(lo - lo_ref) < 1e-3, (lo, hi, data[row])
+        assert abs(order - order_ref) / order_ref < 0.01, (order, order_ref)
