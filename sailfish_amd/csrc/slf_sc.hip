@@ -48,12 +48,23 @@ struct ScParams {
   int xcd_shift;     // xcd_row(): rows per XCD and block of rows = 1 << this
 };
 
-template <class R>
-__device__ __forceinline__ R sc_psi(R rho, int potential) {
+template <class R, int POT>
+__device__ __forceinline__ R sc_psi(R rho) {
   // sym.py:896-908: linear psi = rho; classic psi = 1 - exp(-rho)
-  if (potential == 0) return rho;
-  if constexpr (sizeof(R) == 4) return 1.0f - expf(0.0f - rho);      // the reference's exp() on a float argument
+  if constexpr (POT == 0) return rho;
+  else if constexpr (sizeof(R) == 4) return 1.0f - expf(0.0f - rho);      // the reference's exp() on a float argument
   else return (R)1 - exp((R)0 - rho);
+}
+
+// The module's potential (a run-time constant of the launch) as a compile-time constant of `body`: ONE wave-uniform
+// branch around a whole block of psi evaluations.  With the choice inside sc_psi() the compiler turned it into a select:
+// every one of the 38 psi values of a node went through the 15-instruction expf sequence and was thrown away again when
+// the potential is linear -- a third of the fused sweep's vector instructions (1577 per wave, the vector ALUs ~80 % busy:
+// profiles/r05/sq_summary_shan_chen_before.txt).
+template <class F>
+__device__ __forceinline__ void sc_with_potential(int potential, F&& body) {
+  if (potential == 0) body(std::integral_constant<int, 0>{});
+  else body(std::integral_constant<int, 1>{});
 }
 
 // Cache hints for the populations: streamed once per kernel in 3-D (non-temporal); 2-D lattices live in the caches.
@@ -188,24 +199,26 @@ __device__ __forceinline__ void sc_pull_rows(R (&fa)[L::Q], R (&fb)[L::Q], const
 template <class L, class R, int NFIELDS>
 __device__ __forceinline__ void sc_accel(const R* const (&fields)[2], const R (&G)[2], R rho, int potential, const ScNode& n,
                                          R (&a)[3]) {
-  static_for<0, NFIELDS>([&](auto J) {
-    const R cc = G[J];
-    if (cc != (R)0) {
-      R force[3] = {(R)0, (R)0, (R)0};
-      static_for<1, L::Q>([&](auto I) {
-        const R psi = sc_psi<R>(*sc_neighbour<L, I>(fields[J], n, true), potential);
-        static_for<0, L::dim>([&](auto D) {
-          constexpr int e = e_comp<L>(I, D);
-          if constexpr (e > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
-          if constexpr (e < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
+  sc_with_potential(potential, [&](auto POT) {
+    static_for<0, NFIELDS>([&](auto J) {
+      const R cc = G[J];
+      if (cc != (R)0) {
+        R force[3] = {(R)0, (R)0, (R)0};
+        static_for<1, L::Q>([&](auto I) {
+          const R psi = sc_psi<R, POT>(*sc_neighbour<L, I>(fields[J], n, true));
+          static_for<0, L::dim>([&](auto D) {
+            constexpr int e = e_comp<L>(I, D);
+            if constexpr (e > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
+            if constexpr (e < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
+          });
         });
-      });
-      const R psi_loc = sc_psi<R>(rho, potential);
-      static_for<0, L::dim>([&](auto D) {
-        force[D] = force[D] * (((R)0 - psi_loc) * cc);
-        a[D] = a[D] + force[D];
-      });
-    }
+        const R psi_loc = sc_psi<R, POT>(rho);
+        static_for<0, L::dim>([&](auto D) {
+          force[D] = force[D] * (((R)0 - psi_loc) * cc);
+          a[D] = a[D] + force[D];
+        });
+      }
+    });
   });
 }
 
@@ -421,17 +434,19 @@ sc_fused_kernel(const ScParams<L, R> p) {
   R S[2][3] = {{(R)0, (R)0, (R)0}, {(R)0, (R)0, (R)0}};
   if (wet) {
     const R* const fields[2] = {p.rho0, p.rho1};
-    static_for<0, 2>([&](auto J) {
-      if (p.G[J] != (R)0 || p.G2[J] != (R)0) {
-        static_for<1, L::Q>([&](auto I) {
-          const R psi = sc_psi<R>(*sc_neighbour<L, I>(fields[J], n, true), p.potential);
-          static_for<0, L::dim>([&](auto D) {
-            constexpr int e = e_comp<L>(I, D);
-            if constexpr (e > 0) S[J][D] = S[J][D] + psi * Weights<L, R>::w(I);
-            if constexpr (e < 0) S[J][D] = S[J][D] + psi * ((R)0 - Weights<L, R>::w(I));
+    sc_with_potential(p.potential, [&](auto POT) {
+      static_for<0, 2>([&](auto J) {
+        if (p.G[J] != (R)0 || p.G2[J] != (R)0) {
+          static_for<1, L::Q>([&](auto I) {
+            const R psi = sc_psi<R, POT>(*sc_neighbour<L, I>(fields[J], n, true));
+            static_for<0, L::dim>([&](auto D) {
+              constexpr int e = e_comp<L>(I, D);
+              if constexpr (e > 0) S[J][D] = S[J][D] + psi * Weights<L, R>::w(I);
+              if constexpr (e < 0) S[J][D] = S[J][D] + psi * ((R)0 - Weights<L, R>::w(I));
+            });
           });
-        });
-      }
+        }
+      });
     });
   }
   R fa[OWNV ? L::Q : 1], fb[OWNV ? L::Q : 1];
@@ -458,10 +473,15 @@ sc_fused_kernel(const ScParams<L, R> p) {
     vc[1] = vc[1] / total;
     if constexpr (L::dim == 3) vc[2] = vc[2] / total;
   }
+  R psi_own[2] = {rho[0], rho[1]};
+  if (p.potential != 0) {
+    psi_own[0] = sc_psi<R, 1>(rho[0]);
+    psi_own[1] = sc_psi<R, 1>(rho[1]);
+  }
   auto finish = [&](auto K, R (&f)[L::Q]) {
     R a[3] = {(R)0, (R)0, (R)0};
     if (wet) {
-      const R psi_loc = sc_psi<R>(rho[K], p.potential);
+      const R psi_loc = psi_own[K];
       static_for<0, 2>([&](auto J) {
         const R cc = (K == 0) ? p.G[J] : p.G2[J];
         if (cc != (R)0) {

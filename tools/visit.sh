@@ -12,5 +12,26 @@ case $NAME in
     ( time timeout 1200 python -m pytest tests/test_gpu_two_ranks.py tests/test_gpu_face_kernels.py -m gpu -q -x --durations=6 ) > $O/pytest_ranks.log 2>&1; tail -15 $O/pytest_ranks.log
     timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd.json; cut -c1-700 $O/bench_driver_cmd.json
     ;;
+  r5v2)   # what bounds the Shan-Chen kernels (SQ counters, kernel trace) + the x-slab step against RCCL's channel count
+    TRACE_CONFIGS="4" bash tools/gpu.sh tracecfg sqcfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/
+    X="--force_distributed --scaling strong --domain 128x512x512 --axis x --no_cpu_baseline --no_gpu_state --access_pattern AA --repeats 1"
+    for ch in default 1 2 4; do
+      if [ $ch = default ]; then unset NCCL_MAX_NCHANNELS; else export NCCL_MAX_NCHANNELS=$ch; fi
+      timeout 300 python bench.py $X 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; r=c['per_rank'][0]; print('nchannels $ch', d['value'], d['best_value'], d['ms_per_step'], 'kernel', r['kernel_ms'], 'sweep_only', r['sweep_only_ms'], 'halo', r['halo_ms'], 'exposed', c['halo_exposed_ms'], c['validated'])" | tee -a $O/xslab_nchannels.txt
+    done
+    unset NCCL_MAX_NCHANNELS
+    ;;
+  r5v3)   # Shan-Chen after the potential became a compile-time constant of the psi blocks: parity, trace, SQ, PMC; x-slab vs RCCL channels
+    ( time timeout 900 python -m pytest tests/test_gpu_sc.py tests/test_gpu_fullsize.py -m gpu -q -x -k "not eight_subdomains" --durations=5 ) > $O/pytest_sc.log 2>&1; tail -12 $O/pytest_sc.log
+    TRACE_CONFIGS="4" bash tools/gpu.sh tracecfg sqcfg pmccfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/ $O/pmc_cfg*/
+    timeout 600 python tools/bench_configs.py --only 4 2>/dev/null | grep '^{' | tee $O/configs_sc.jsonl | cut -c1-200
+    X="--gpus 1 --force_distributed --scaling strong --domain 128x512x512 --axis x --no_cpu_baseline --no_gpu_state --access_pattern AA --repeats 1"
+    for ch in default 1 2 4; do
+      if [ $ch = default ]; then unset NCCL_MAX_NCHANNELS; else export NCCL_MAX_NCHANNELS=$ch; fi
+      timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py $X 2>&1 | tail -1 > $O/xslab_$ch.json
+      python -c "import sys,json; d=json.load(open('$O/xslab_$ch.json')); c=d['config']; r=c['per_rank'][0]; print('nchannels $ch', d['value'], d['best_value'], d['ms_per_step'], 'kernel', r['kernel_ms'], 'sweep_only', r['sweep_only_ms'], 'halo', r['halo_ms'], 'exposed', c['halo_exposed_ms'], c['validated'], c['rccl_ranks'])" 2>&1 | tail -1 | tee -a $O/xslab_nchannels.txt
+    done
+    unset NCCL_MAX_NCHANNELS
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
