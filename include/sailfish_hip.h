@@ -313,7 +313,19 @@ int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* st
  * (reference templates/models/binary_shan_chen.mako:19-141, lb_binary_fluid.mako:87-127).
  * Single-component Shan-Chen modules (SLF_SIM_SHAN_CHEN_SINGLE) keep the single-fluid kernel names; their
  * "CollideAndPropagate" adds the pseudopotential force, and "PrepareMacroFields"(map, dist, rho, options)
- * computes the density field it reads (reference templates/models/lb_single_fluid.mako:129-229). */
+ * computes the density field it reads (reference templates/models/lb_single_fluid.mako:129-229).
+ * Launch-bound 2-D subdomains (no counterpart in the reference, which launches CollideAndPropagate once per step,
+ * subdomain_runner.py:960-974): "CollideAndPropagateResident"(map, src_a, src_b, dst_a, dst_b, options, steps, tile_x,
+ * tile_y, halo), format "PPPPPiiiii", needs_iteration = 1 (the iteration of its FIRST step) performs `steps` time
+ * steps in one launch: every workgroup keeps a window (tile + halo) of the RAW distribution arrays in LDS, steps it
+ * exactly as CollideAndPropagate steps memory (same node code, same slots; even / odd in-place iterations resp. the two
+ * copies alternating) and writes its tile back -- every slot of every node, ghost layer included.  src_a / dst_a: the
+ * array of the in-place pattern resp. copy A of the two-copy pattern, src_b / dst_b: copy B (NULL in place); source and
+ * destination must be different buffers that agree outside the lattice box (padding, ghost columns of an axis wrapped
+ * in-sweep).  halo >= steps + 1 (two-copy) resp. 2 ceil(steps / 2) (in place); (tile + 2 halo)^2 <= 2048 nodes and
+ * 160 KiB of LDS.  SLF_ERR_UNSUPPORTED for 3-D, Shan-Chen, indirect-addressing and --minimize_roundoff modules, axes
+ * periodic through the ghost-layer kernels, and type tables with half-way bounce-back or outflow nodes (their node code
+ * reads / writes memory itself); options bit 0 (field output) is ignored. */
 int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out);
 int slf_kernel_destroy(slf_kernel* k);
 /* fmt: one char per argument, 'P' = device pointer (8 bytes), 'i' = int32,

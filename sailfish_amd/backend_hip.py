@@ -282,6 +282,9 @@ class HIPBackend(placement.VmmMixin):
                            help='print the workgroup shape chosen for the sweep kernels')
         group.add_argument('--nohip_graphs', dest='hip_graphs', action='store_false', default=True,
                            help='do not replay stretches of steps without host interaction as HIP graphs')
+        group.add_argument('--nohip_resident', dest='hip_resident', action='store_false', default=True,
+                           help='small 2-D subdomains: one launch per step instead of launches that perform several steps '
+                                'on LDS-resident windows (CollideAndPropagateResident)')
         group.add_argument('--nohip_step_plans', dest='hip_step_plans', action='store_false', default=True,
                            help='enqueue every kernel, event and halo exchange of a step from Python instead of replaying '
                                 'the step from a C-ABI step plan (one runtime call per step)')

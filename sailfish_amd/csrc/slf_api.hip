@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,7 @@ enum KernelKind {
   KK_SC_INIT,
   KK_SCS_MACRO,
   KK_SCS_SWEEP,
+  KK_RESIDENT,                // several steps inside one launch (slf_resident.hip)
 };
 
 }  // namespace
@@ -940,7 +942,24 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
   else if (!strcmp(name, "CollectContinuousMacroData")) kk = KK_COLLECT_MACRO_FACE;
   else if (!strcmp(name, "DistributeContinuousMacroData")) kk = KK_DISTRIBUTE_MACRO_FACE;
   else if (!strcmp(name, "ComputeMacroFields")) kk = KK_COMPUTE_MACRO;
+  else if (!strcmp(name, "CollideAndPropagateResident")) kk = KK_RESIDENT;
   else return fail(SLF_ERR_NOT_FOUND, std::string("unknown kernel: ") + name);
+  if (kk == KK_RESIDENT) {
+    // what the resident kernel serves (slf_resident.hip): 2-D single-fluid modules, direct addressing, the standard
+    // density formulation, node kinds whose code touches nothing but the node's own populations
+    const slf::Geometry& g = m->geo;
+    if (g.dim != 2 || m->sc.enabled || g.indirect || m->phys.incompressible == SLF_DENSITY_ROUNDOFF)
+      return fail(SLF_ERR_UNSUPPORTED, "CollideAndPropagateResident: 2-D single-fluid modules with direct addressing and the "
+                                       "standard density formulation only");
+    if (g.axis_mode[0] == 1 || g.axis_mode[1] == 1)
+      return fail(SLF_ERR_UNSUPPORTED, "CollideAndPropagateResident: periodic axes must be wrapped in-sweep (periodic_fused)");
+    for (int t = 0; t < 16; t++) {
+      const int kind = (int)((g.type_lut >> (4u * t)) & 0xFull);
+      if (kind == slf::NK_HALF_BB || kind == slf::NK_COPY || kind == slf::NK_YU_OUTFLOW)
+        return fail(SLF_ERR_UNSUPPORTED, "CollideAndPropagateResident: half-way bounce-back and outflow nodes read / write "
+                                         "memory from their node code");
+    }
+  }
   if (kk == KK_SCS_MACRO && m->sc.enabled != 2)
     return fail(SLF_ERR_NOT_FOUND, "PrepareMacroFields only exists in single-component Shan-Chen modules");
   if ((kk == KK_SC_MACRO || kk == KK_SC_SWEEP0 || kk == KK_SC_SWEEP1 || kk == KK_SC_FUSED) && m->sc.enabled != 1)
@@ -1026,6 +1045,25 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     case KK_SC_INIT: want_p = 5 + dim; want_i = 0; break;         // map, dist1, dist2, v.., rho, phi
     case KK_SCS_MACRO: want_p = 3; want_i = 1; break;             // map, dist, rho, options
     case KK_SCS_SWEEP: want_p = 4 + dim; want_i = 1; break;       // as CollideAndPropagate
+    case KK_RESIDENT: want_p = 5; want_i = 5; break;              // map, src a, src b, dst a, dst b, options, steps, tile x, tile y, halo
+  }
+  if (k->kind == KK_RESIDENT && k->ptrs.size() == 5 && k->ints.size() == 5) {
+    const bool aa = k->mod->access_pattern == SLF_AA;
+    const int steps = (int)k->ints[1], tx = (int)k->ints[2], ty = (int)k->ints[3], halo = (int)k->ints[4];
+    if (!needs_iteration) return fail(SLF_ERR_INVALID, "CollideAndPropagateResident needs the iteration argument (its first step)");
+    if (steps < 1 || tx < 1 || ty < 1 || halo < 1) return fail(SLF_ERR_INVALID, "steps, tile and halo must be positive");
+    if (!k->ptrs[1] || !k->ptrs[3] || (!aa && (!k->ptrs[2] || !k->ptrs[4])))
+      return fail(SLF_ERR_INVALID, "CollideAndPropagateResident: source and destination arrays (both copies of the two-copy pattern)");
+    if (k->ptrs[1] == k->ptrs[3] || (!aa && k->ptrs[2] == k->ptrs[4]))
+      return fail(SLF_ERR_INVALID, "CollideAndPropagateResident: source and destination must be different buffers");
+    // the halo that `steps` steps need depends on the parity of the first one: the worse of the two must fit
+    const int need = std::max(slf::resident_halo(aa, 0, steps), slf::resident_halo(aa, 1, steps));
+    if (halo < need) return fail(SLF_ERR_INVALID, "CollideAndPropagateResident: halo too small for this many steps");
+    const long long nw = (long long)(tx + 2 * halo) * (long long)(ty + 2 * halo);
+    if (nw > 2 * 1024) return fail(SLF_ERR_INVALID, "CollideAndPropagateResident: window larger than 2048 nodes");
+    const int q = 9;
+    if (slf::resident_lds_bytes(q, k->mod->sel.precision, aa, tx + 2 * halo, ty + 2 * halo) > 160 * 1024)
+      return fail(SLF_ERR_INVALID, "CollideAndPropagateResident: window does not fit the 160 KiB of LDS");
   }
   if (k->mod->geo.indirect && (k->kind == KK_SC_FUSED || k->sc_local_velocity))
     return fail(SLF_ERR_UNSUPPORTED, "indirect addressing: the binary model runs the reference's pass and its two per-lattice sweeps");
@@ -1168,6 +1206,19 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
           return fail(SLF_ERR_INVALID, "region outside the real nodes of the subdomain");
       }
       e = slf::launch_sc_fused(m->sel, prop, g, m->phys, m->sc, a, y0, y1, z0, z1, m->block_x, s);
+      break;
+    }
+    case KK_RESIDENT: {
+      slf::SweepArgs a = {};
+      a.map = (const void*)k->ptrs[0];
+      a.node_params = m->node_params;
+      a.status = m->status;
+      a.options = (uint32_t)k->ints[0] & ~1u;       // no field output from inside a stretch of resident steps
+      if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
+      const void* src[2] = {(const void*)k->ptrs[1], (const void*)k->ptrs[2]};
+      void* dst[2] = {(void*)k->ptrs[3], (void*)k->ptrs[4]};
+      e = slf::launch_resident(m->sel, m->access_pattern == SLF_AA, g, m->phys, a, src, dst, (int)k->iteration, (int)k->ints[1],
+                               (int)k->ints[2], (int)k->ints[3], (int)k->ints[4], s);
       break;
     }
     case KK_SCS_MACRO:

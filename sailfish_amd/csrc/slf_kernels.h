@@ -151,4 +151,13 @@ hipError_t launch_scs_sweep(const KernelSelector& sel, Prop prop, const Geometry
 hipError_t launch_sc_init(const KernelSelector& sel, const Geometry& g, const Physics& ph, void* dist1, void* dist2,
                           const void* rho, const void* phi, const void* const v[3], const void* nodes, hipStream_t s);
 
+// ---- several steps inside one launch (slf_resident.hip): 2-D lattices ----
+// src / dst: the raw distribution arrays ([0] = the array of the in-place pattern / copy A of the two-copy pattern, [1] =
+// copy B) and where the tiles go after `steps` steps from iteration it0; tiles of tile_x x tile_y nodes, halo of `halo`
+hipError_t launch_resident(const KernelSelector& sel, bool aa, const Geometry& g, const Physics& ph, const SweepArgs& a,
+                           const void* const src[2], void* const dst[2], int it0, int steps, int tile_x, int tile_y, int halo,
+                           hipStream_t s);
+int resident_halo(bool aa, int it0, int steps);
+size_t resident_lds_bytes(int q, int precision, bool aa, int win_x, int win_y);
+
 }  // namespace slf

@@ -105,6 +105,24 @@ class LBFluidSim(LBSim):
             return KernelPair([cnp_primary], [cnp_secondary])
         return KernelPair([cnp_primary], [cnp_primary])
 
+    def get_resident_kernels(self, runner, scratch, steps, tile, halo):
+        """(forward, backward): `steps` time steps inside ONE launch for launch-bound 2-D subdomains (library kernel
+        CollideAndPropagateResident, csrc/slf_resident.hip; no counterpart in the reference, which launches
+        CollideAndPropagate once per step: subdomain_runner.py:960-974).  `forward` reads the distribution arrays and
+        writes the scratch copies `scratch` = [copy A, copy B or 0], `backward` the other way round; the step the launch
+        starts with is the kernel's iteration argument."""
+        gpu_map = runner.gpu_geo_map()
+        ab = self.config.access_pattern == 'AB'
+        a, b = runner.gpu_dist(0, 0), (runner.gpu_dist(0, 1) if ab else 0)
+        options = 4 if getattr(self.config, 'check_invalid_results_gpu', False) else 0
+        ints = [np.uint32(options), np.uint32(steps), np.uint32(tile[0]), np.uint32(tile[1]), np.uint32(halo)]
+        sig = 'PPPPPiiiii'
+        fwd = runner.get_kernel('CollideAndPropagateResident', [gpu_map, a, b, scratch[0], scratch[1]] + ints, sig,
+                                needs_iteration=True)
+        bwd = runner.get_kernel('CollideAndPropagateResident', [gpu_map, scratch[0], scratch[1], a, b] + ints, sig,
+                                needs_iteration=True)
+        return fwd, bwd
+
     def get_pbc_kernels(self, runner):
         """grid copy (0 primary, 1 secondary) -> axis -> kernels (reference lb_single.py:153-185)."""
         if runner.indirect:      # periodic axes are wrapped inside the sweep; no ghost-layer kernels exist

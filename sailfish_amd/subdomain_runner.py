@@ -1082,9 +1082,107 @@ class SubdomainRunner(object):
             lim.append(prof._sample_from - it)             # sampling starts exactly there
         return max(0, min(lim))
 
+    # ------------------------------------------------------------------ several steps per launch (small 2-D subdomains)
+    RESIDENT_STEPS = {'AA': 8, 'AB': 7}       # steps per launch: a halo of 8 nodes either way (csrc/slf_resident.hip)
+    RESIDENT_LAUNCHES = (16, 2)               # launches per graph replay, largest first; even: the result is back in the arrays
+    RESIDENT_MAX_NODES = 300000               # beyond this a sweep is no longer launch-bound
+    _resident = None
+
+    @staticmethod
+    def resident_halo(aa, steps):
+        """Halo the tiles of a launch of `steps` steps need, whatever the parity of its first step (the library checks)."""
+        return 2 * ((steps + 1) // 2) if aa else steps + 1
+
+    def _resident_setup(self):
+        """Kernels, scratch copies and tile shape of the several-steps-per-launch path, or None where it does not apply:
+        2-D single-fluid subdomains without neighbours, small enough to be launch-bound, periodic axes wrapped in-sweep,
+        node kinds the library's resident kernel serves (it refuses the others)."""
+        if self._resident is not None:
+            return self._resident or None
+        self._resident = False
+        cfg, sim, b = self.config, self._sim, self.backend
+        if self.dim != 2 or not getattr(cfg, 'hip_resident', True) or os.environ.get('SLF_RESIDENT', '1') == '0' or \
+                not hasattr(sim, 'get_resident_kernels') or self._pbc_axes or self.indirect or len(sim.grids) != 1 or \
+                self._links or self.has_macro_exchange:
+            return None
+        d = self._desc
+        ext = [(d.lat_nx - 2) if d.periodic_fused[0] else d.lat_nx, (d.lat_ny - 2) if d.periodic_fused[1] else d.lat_ny]
+        if ext[0] * ext[1] > int(os.environ.get('SLF_RESIDENT_MAX_NODES', self.RESIDENT_MAX_NODES)):
+            return None
+        aa = cfg.access_pattern == 'AA'
+        steps = int(os.environ.get('SLF_RESIDENT_STEPS', self.RESIDENT_STEPS[cfg.access_pattern]))
+        halo = self.resident_halo(aa, steps)
+        isz = self.float().itemsize
+        # tiles: at most 16 x 16 of them (one workgroup per CU on 256 CUs), windows of at most 2048 nodes in 160 KiB of LDS
+        tile = [max(1, -(-e // 16)) for e in ext]
+        while (tile[0] + 2 * halo) * (tile[1] + 2 * halo) > 2048 or \
+                (tile[0] + 2 * halo) * (tile[1] + 2 * halo) * (9 * isz * 2 + 8) > 160 * 1024:
+            a = 0 if tile[0] >= tile[1] else 1
+            if tile[a] == 1:
+                return None
+            tile[a] -= 1
+        nbytes = sim.grid.Q * self._dist_stride * isz
+        off = b.dist_align_offset(isz)
+        scratch = [b.alloc_buf(size=nbytes, align_offset=off), 0 if aa else b.alloc_buf(size=nbytes, align_offset=off)]
+        try:
+            fwd, bwd = sim.get_resident_kernels(self, scratch, steps, tile, halo)
+        except b.FatalError as e:       # node kinds / formulations the resident kernel does not serve
+            cfg.logger.debug('several steps per launch not available: %s' % e)
+            for addr in scratch:
+                if addr:
+                    b.free_buf(addr)
+            return None
+        pairs = [(self.gpu_dist(0, 0), scratch[0])] + ([] if aa else [(self.gpu_dist(0, 1), scratch[1])])
+        self._resident = dict(steps=steps, halo=halo, tile=tile, fwd=fwd, bwd=bwd, pairs=pairs, nbytes=nbytes, graphs={})
+        cfg.logger.debug('several steps per launch: %d steps, tiles %s, halo %d' % (steps, tile, halo))
+        return self._resident
+
+    def _fast_forward_resident(self, n):
+        """As many of the coming n host-free steps as whole graphs of resident launches cover.  Returns the steps done."""
+        r = self._resident_setup()
+        if r is None or n < 2 * r['steps']:
+            return 0
+        b, prof, stream = self.backend, self._profile, self._calc_stream
+        it = self._sim.iteration
+        done = 0
+        first = True
+        for count in self.RESIDENT_LAUNCHES:
+            size = count * r['steps']
+            while n - done >= size:
+                key = (count, (it + done) & 1)
+                if key not in r['graphs']:
+                    start = it + done
+
+                    def enqueue():
+                        for j in range(count):
+                            b.set_iteration(start + j * r['steps'])
+                            b.run_kernel(r['fwd'] if (j & 1) == 0 else r['bwd'], None, stream)
+                    try:
+                        r['graphs'][key] = b.capture_graph(stream, enqueue)
+                    except b.FatalError as e:
+                        self.config.logger.warning('HIP graph capture of the resident launches failed (%s)' % e)
+                        self._resident = False
+                        b.set_iteration(self._sim.iteration)
+                        return done
+                if first:
+                    # what no tile covers (padding, the ghost columns of an axis wrapped in-sweep) is the same in both buffers
+                    for dist, scratch in r['pairs']:
+                        b.copy_buf_async(scratch, dist, r['nbytes'], stream)
+                    first = False
+                prof.start_step()
+                prof.record_gpu_start(TimeProfile.BULK, stream)
+                r['graphs'][key].launch(stream)
+                prof.record_gpu_end(TimeProfile.BULK, stream, steps=size)
+                done += size
+                self._sim.iteration = it + done
+                prof.end_step(size)
+        b.set_iteration(self._sim.iteration)
+        return done
+
     def fast_forward(self):
         """Replays as many of the coming steps as possible as HIP graphs (launch-bound small
-        subdomains: one runtime call per 2 / 16 steps instead of a Python-level launch per kernel).
+        subdomains: one runtime call per 2 / 16 steps instead of a Python-level launch per kernel); small 2-D subdomains
+        go through launches that perform several steps each (_fast_forward_resident) first.
         Returns the number of steps done (0: take a normal step)."""
         if not getattr(self.config, 'hip_graphs', True) or self._links or self._quit_requested():
             return 0
@@ -1092,9 +1190,9 @@ class SubdomainRunner(object):
         if n < 2:
             return 0
         b = self.backend
-        it = self._sim.iteration
+        done = self._fast_forward_resident(n)
+        it = self._sim.iteration - done
         graphs = self.__dict__.setdefault('_graphs', {})
-        done = 0
         prof = self._profile
         for size in self.GRAPH_STEPS:
             while n - done >= size:

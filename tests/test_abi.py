@@ -95,7 +95,7 @@ def test_every_in_scope_reference_kernel_name_is_served():
 
 # kernels this library adds to the reference's set (documented in include/sailfish_hip.h next to the ones they stand in for)
 ADDED_KERNELS = ['ShanChenCollideAndPropagateFused', 'ShanChenCollideAndPropagateFusedV', 'ShanChenPrepareDensities',
-                 'ComputeMacroFields']
+                 'ComputeMacroFields', 'CollideAndPropagateResident']
 
 
 def test_added_kernel_names_are_served_and_documented():

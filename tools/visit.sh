@@ -33,5 +33,30 @@ case $NAME in
     done
     unset NCCL_MAX_NCHANNELS
     ;;
+  r5v4)   # where the x-face buffers cost the slab's sweep (probe bits), and the x-slab step against MORE RCCL channels
+    for pat in AA AB; do timeout 300 python tools/probe/xface_cost_probe.py $pat 40 7 2>&1 | grep -v amdgpu.ids | tee -a $O/xface_cost_probe.txt; done
+    X="--gpus 1 --force_distributed --scaling strong --domain 128x512x512 --axis x --no_cpu_baseline --no_gpu_state --access_pattern AA --repeats 1"
+    for ch in 8 16 32; do
+      export NCCL_MIN_NCHANNELS=$ch
+      timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py $X 2>&1 | tail -1 > $O/xslab_min$ch.json
+      python -c "import sys,json; d=json.load(open('$O/xslab_min$ch.json')); c=d['config']; r=c['per_rank'][0]; print('min_nchannels $ch', d['value'], d['best_value'], d['ms_per_step'], 'kernel', r['kernel_ms'], 'sweep_only', r['sweep_only_ms'], 'halo', r['halo_ms'], 'exposed', c['halo_exposed_ms'], c['validated'], c['rccl_ranks'])" 2>&1 | tail -1 | tee -a $O/xslab_min_nchannels.txt
+    done
+    unset NCCL_MIN_NCHANNELS
+    ;;
+  r5v5)   # several steps per launch for small 2-D subdomains: parity, then BASELINE config 1 on the GPU
+    ( time timeout 900 python -m pytest tests/test_gpu_resident.py -m gpu -q -x --durations=5 ) > $O/pytest_resident.log 2>&1; tail -25 $O/pytest_resident.log
+    ( time timeout 600 python -m pytest tests/test_gpu_runner.py -m gpu -q -x -k "graphs or ldc_2d or poiseuille or checkpoint" ) > $O/pytest_runner_2d.log 2>&1; tail -5 $O/pytest_runner_2d.log
+    timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_resident.jsonl | cut -c1-300
+    SLF_RESIDENT=0 timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_stepping.jsonl | cut -c1-300
+    for st in 4 6 10 12; do SLF_RESIDENT_STEPS=$st timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_resident_steps$st.jsonl | cut -c1-200; done
+    ;;
+  r5v6)   # what the resident kernel spends its time on: kernel trace + SQ counters of BASELINE config 1 on the GPU
+    TRACE_CONFIGS="0" bash tools/gpu.sh tracecfg sqcfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/
+    ;;
+  r5v7)   # resident kernel with the active nodes compacted: parity, config 1 on the GPU against steps per launch, trace + SQ
+    ( time timeout 900 python -m pytest tests/test_gpu_resident.py -m gpu -q -x --durations=3 ) > $O/pytest_resident.log 2>&1; tail -8 $O/pytest_resident.log
+    for st in 8 10 12; do SLF_RESIDENT_STEPS=$st timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_resident_steps$st.jsonl | cut -c1-120; done
+    TRACE_CONFIGS="0" bash tools/gpu.sh tracecfg sqcfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
