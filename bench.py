@@ -262,9 +262,10 @@ def validate(sim, backend, mass0, distributed, axis, rank=0, world=1):
         # whole planes of the UNDIVIDED box across every seam and the wrap (window.GlobalCheck): each rank hands in its
         # share of the windows, rank 0 merges and advances them with no notion of slabs
         def gather(obj):
-            got = [None] * world if rank == 0 else None
-            torch.distributed.gather_object(obj, got, dst=0)
-            return got
+            # all_gather_object: served by RCCL process groups and by gloo alike (gather_object is not, on every torch)
+            got = [None] * world
+            torch.distributed.all_gather_object(got, obj)
+            return got if rank == 0 else None
         gz = nz * world if axis == 'z' else nz
         glob = window.GlobalCheck(backend, sim.desc, sorted(set([1, gz // 2 + 1])), sim.gpu_dist, sim.stride, AXES[axis],
                                   rank, world, gather)

@@ -12,9 +12,9 @@
 // same nodes excluded: in-place steps read the node's own slots and write their opposites (even iteration) or pull
 // from / push to the neighbours (odd iteration), two-copy steps read copy (it & 1) and push into the other one.  What
 // lies beyond the window's edge is missing, so a step is performed only by the nodes whose result the tile still
-// depends on -- a square around the tile that shrinks by two nodes per odd in-place step and by one per two-copy step
-// (the kernel's comment on `lim`; whole waves at the window's top and bottom drop out) -- and the host chooses the halo H
-// so that the first step's square fits
+// depends on -- a rectangle around the tile that shrinks by two nodes per odd in-place step and by one per two-copy step
+// (the kernel's comment on `lim`; the threads are dealt out over that rectangle, so the waves that work are full) -- and
+// the host chooses the halo H so that the first step's rectangle fits
 // (resident_halo()); after the T steps only the TILE -- exact -- is written back, every slot of every node of it.  Tiles cover the whole lattice box (ghost layer included; real nodes only along an
 // axis wrapped in-sweep, where the window wraps too), each node belongs to exactly one tile.
 //
@@ -58,6 +58,7 @@ __device__ __forceinline__ bool resident_coord(int c, int lat, int wrap, int& ou
 constexpr uint32_t RI_ACTIVE = 1u;     // a node the sweep works on (real, not excluded by its node code)
 constexpr uint32_t RI_SIMPLE = 2u;     // ... whose code is the plain one: fluid or full-way bounce-back (node_update<BCL = 0>)
 constexpr uint32_t RI_TILE = 4u;       // node of the tile (the on-GPU invalid-value check looks at these only)
+constexpr uint32_t RI_WALL = 8u;       // a plain node that is a full-way bounce-back node
 constexpr int RI_DIST_SHIFT = 8;       // bits 8..: distance from the tile (0 inside it)
 constexpr int RESIDENT_MAX_COMPLEX = 2048;  // boundary-condition nodes of a window (all of them fit: windows have at most 2048 nodes)
 
@@ -118,6 +119,9 @@ __global__ void __launch_bounds__(1024) resident_kernel(const ResidentParams<L, 
         flags |= RI_ACTIVE;
         if (simple) {
           flags |= RI_SIMPLE;
+          if constexpr (GENERAL) {
+            if ((int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull) == NK_FULL_BB) flags |= RI_WALL;
+          }
         } else {
           s_complex[atomicAdd(&s_ncomplex, 1u)] = (uint16_t)n;
         }
@@ -145,19 +149,27 @@ __global__ void __launch_bounds__(1024) resident_kernel(const ResidentParams<L, 
   const int TW = rp.tile[0], TH = rp.tile[1];
   const int ncomplex = (int)s_ncomplex;
 
-  // one node: read (mode-dependent), node code, write (mode-dependent).  BCL = 0: the plain code (fluid, full-way
-  // bounce-back); BCL = 2: everything.  One instantiation each for every step kind: the propagation mode only matters
-  // to node kinds this kernel does not serve.
-  auto do_node = [&](auto BCL, int n, uint32_t flags, int mode, const R* rd, R* wr) {
+  // one node: read, node code, write -- all three for a compile-time MODE: 0 = local (even in-place iteration: own slots in,
+  // opposite own slots out), 1 = pull, post-collision populations staged in block 1 (odd in-place iteration), 2 / 3 =
+  // two-copy push from block 0 to 1 / from 1 to 0.  BCL = 0: the plain node code (fluid, full-way bounce-back; the kind
+  // comes from the node's flags), BCL = 2: everything.  One instantiation of node_update() per BCL for every step kind:
+  // the propagation mode only matters to node kinds this kernel does not serve.
+  auto do_node = [&](auto MODE, auto BCL, int n, uint32_t flags) {
+    constexpr int mode = decltype(MODE)::value;
+    const R* const rd = (mode == 3) ? win2 : win;
+    R* const wr = (mode == 0 || mode == 3) ? win : win2;
     R f[Q];
-    if (mode == 1) {
+    if constexpr (mode == 1) {
       static_for<0, Q>([&](auto I) { f[I] = rd[(size_t)L::opp(I) * NW + (n - woff(I))]; });
     } else {
       static_for<0, Q>([&](auto I) { f[I] = rd[(size_t)I * NW + n]; });
     }
-    const uint32_t code = GENERAL ? codes[n] : 0u;
-    int kind = NK_FLUID;
-    if constexpr (GENERAL) kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    uint32_t code = 0u;
+    int kind = (flags & RI_WALL) ? NK_FULL_BB : NK_FLUID;
+    if constexpr (GENERAL && decltype(BCL)::value != 0) {
+      code = codes[n];
+      kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+    }
     R rho, v[3];
     bool wet = true;
     node_update<L, R, MODEL, PROP_AA_ODD, GENERAL, false, FORCE_RUNTIME, decltype(BCL)::value>(p, f, code, kind, 0u, none, none, none,
@@ -168,12 +180,52 @@ __global__ void __launch_bounds__(1024) resident_kernel(const ResidentParams<L, 
       resident_coord(ty0 - rp.halo + n / WW, g.lat_ny, g.wrap[1], gy);
       check_invalid<R>(p.status, p.options, rho, gx, gy, 0);
     }
-    if (mode == 0) {
+    if constexpr (mode == 0) {
       static_for<0, Q>([&](auto I) { wr[(size_t)L::opp(I) * NW + n] = f[I]; });
-    } else if (mode == 1) {
+    } else if constexpr (mode == 1) {
       static_for<0, Q>([&](auto I) { wr[(size_t)I * NW + n] = f[I]; });                  // staged at the node itself
     } else {
       static_for<0, Q>([&](auto I) { wr[(size_t)I * NW + (n + woff(I))] = f[I]; });
+    }
+  };
+
+  // One step for a compile-time MODE.  The nodes that still matter are those up to `lim` from the tile -- a rectangle of
+  // (TW + 2 lim) x (TH + 2 lim) nodes; thread t takes its t-th node (row by row), so that the waves that work are full
+  // and the others skip the step: t / width through a multiplication with magic = ceil(2^32 / width) (exact for t < 2^16).
+  auto do_step = [&](auto MODE, int lim) {
+    constexpr int mode = decltype(MODE)::value;
+    const int aw = TW + 2 * lim, ah = TH + 2 * lim;
+    const int count = aw * ah;
+    const uint32_t magic = 0xffffffffu / (uint32_t)aw + 1u;
+    const int base = (rp.halo - lim) * WW + (rp.halo - lim);
+#pragma unroll 1
+    for (int t = (int)threadIdx.x; t < count; t += nthreads) {
+      const int row = (int)__umulhi((uint32_t)t, magic);
+      const int n = base + row * WW + (t - row * aw);
+      const uint32_t flags = info[n];
+      if ((flags & (RI_ACTIVE | RI_SIMPLE)) == (RI_ACTIVE | RI_SIMPLE)) do_node(MODE, std::integral_constant<int, 0>{}, n, flags);
+    }
+    // the listed boundary-condition nodes: ONE wave, the last of the workgroup (the first to run out of nodes above)
+    if ((int)threadIdx.x >= nthreads - 64) {
+#pragma unroll 1
+      for (int c = (int)threadIdx.x - (nthreads - 64); c < ncomplex; c += 64) {
+        const int n = (int)s_complex[c];
+        const uint32_t flags = info[n];
+        if ((int)(flags >> RI_DIST_SHIFT & 0xffu) > lim) continue;
+        do_node(MODE, std::integral_constant<int, 2>{}, n, flags);
+      }
+    }
+    __syncthreads();
+    if constexpr (mode == 1) {
+      // every pull is done: the staged populations go to the neighbours' slots
+#pragma unroll 1
+      for (int t = (int)threadIdx.x; t < count; t += nthreads) {
+        const int row = (int)__umulhi((uint32_t)t, magic);
+        const int n = base + row * WW + (t - row * aw);
+        if (!(info[n] & RI_ACTIVE)) continue;
+        static_for<0, Q>([&](auto I) { win[(size_t)I * NW + (n + woff(I))] = win2[(size_t)I * NW + n]; });
+      }
+      __syncthreads();
     }
   };
 
@@ -182,45 +234,19 @@ __global__ void __launch_bounds__(1024) resident_kernel(const ResidentParams<L, 
   for (int s = 0; s < rp.steps; s++) {
     const int it = rp.it0 + s;
     const bool odd = (it & 1) != 0;
-    // mode of this step: 0 = local (even in-place iteration: own slots in, opposite own slots out), 1 = pull + push
-    // through block 1 (odd in-place iteration), 2 / 3 = two-copy push from block 0 to 1 / from 1 to 0
-    const int mode = AA ? (odd ? 1 : 0) : (odd ? 3 : 2);
-    const R* const rd = (mode == 3) ? win2 : win;
-    R* const wr = (mode == 0 || mode == 3) ? win : win2;
     // Which nodes still matter.  After the last step the tile (distance 0) must be exact.  For the nodes up to distance r
     // to be exact after a step that pushes, the nodes up to r + 1 perform it, from inputs exact up to r + 2 (in place:
     // they pull first) resp. r + 1 (two-copy); a local step needs the same region before as after.  So with r = what
     // the steps AFTER this one need, this step is performed by the nodes up to `lim` from the tile; the window's
     // outermost ring (distance = halo) is never among those of a pushing step.
-    const uint32_t lim = (uint32_t)(AA ? 2 * odd_after + (odd ? 1 : 0) : rp.steps - s);
+    const int lim = AA ? 2 * odd_after + (odd ? 1 : 0) : rp.steps - s;
     if (s + 1 < rp.steps) odd_after -= (it + 1) & 1;
-#pragma unroll 1
-    for (int n = (int)threadIdx.x; n < NW; n += nthreads) {
-      const uint32_t flags = info[n];
-      if (!(flags & RI_ACTIVE) || (flags >> RI_DIST_SHIFT & 0xffu) > lim) continue;
-      if (flags & RI_SIMPLE) do_node(std::integral_constant<int, 0>{}, n, flags, mode, rd, wr);
-    }
-    // the listed boundary-condition nodes: the last wave of the workgroup (its own nodes are the window's last rows,
-    // the first ones a step no longer needs)
-    if ((int)threadIdx.x >= nthreads - 64) {
-#pragma unroll 1
-      for (int c = (int)threadIdx.x - (nthreads - 64); c < ncomplex; c += 64) {
-        const int n = (int)s_complex[c];
-        const uint32_t flags = info[n];
-        if ((flags >> RI_DIST_SHIFT & 0xffu) > lim) continue;
-        do_node(std::integral_constant<int, 2>{}, n, flags, mode, rd, wr);
-      }
-    }
-    __syncthreads();
-    if (mode == 1) {
-      // every pull is done: the staged populations go to the neighbours' slots
-#pragma unroll 1
-      for (int n = (int)threadIdx.x; n < NW; n += nthreads) {
-        const uint32_t flags = info[n];
-        if (!(flags & RI_ACTIVE) || (flags >> RI_DIST_SHIFT & 0xffu) > lim) continue;
-        static_for<0, Q>([&](auto I) { win[(size_t)I * NW + (n + woff(I))] = win2[(size_t)I * NW + n]; });
-      }
-      __syncthreads();
+    if constexpr (AA) {
+      if (odd) do_step(std::integral_constant<int, 1>{}, lim);
+      else do_step(std::integral_constant<int, 0>{}, lim);
+    } else {
+      if (odd) do_step(std::integral_constant<int, 3>{}, lim);
+      else do_step(std::integral_constant<int, 2>{}, lim);
     }
   }
 

@@ -58,5 +58,20 @@ case $NAME in
     for st in 8 10 12; do SLF_RESIDENT_STEPS=$st timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_resident_steps$st.jsonl | cut -c1-120; done
     TRACE_CONFIGS="0" bash tools/gpu.sh tracecfg sqcfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/
     ;;
+  r5v8)   # resident kernel: mode-specialised steps + rectangle compaction; Shan-Chen with the potential as a template parameter
+    ( time timeout 900 python -m pytest tests/test_gpu_resident.py tests/test_gpu_sc.py -m gpu -q -x --durations=3 ) > $O/pytest_resident_sc.log 2>&1; tail -8 $O/pytest_resident_sc.log
+    for st in 8 10 12; do SLF_RESIDENT_STEPS=$st timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_resident_steps$st.jsonl | cut -c1-120; done
+    timeout 600 python tools/bench_configs.py --only 4 2>/dev/null | grep '^{' | tee $O/configs_sc.jsonl | cut -c1-120
+    TRACE_CONFIGS="0 4" bash tools/gpu.sh tracecfg; TRACE_CONFIGS="0" bash tools/gpu.sh sqcfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/
+    ;;
+  r5v9)   # same-box A/B of the binary Shan-Chen kernels: round-4 sources / potential behind one branch / potential as template parameter
+    for rep in 1 2; do
+      for v in r04 branch template; do
+        if [ $v = template ]; then unset SLF_LIBRARY; else export SLF_LIBRARY=$PWD/sailfish_amd/lib/libsailfish_hip_sc_$v.so; fi
+        timeout 300 python tools/bench_configs.py --only 4 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['MLUPS_eff'], d['MLUPS_comp'])" | tee -a $O/sc_ab.txt
+      done
+    done
+    unset SLF_LIBRARY
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
