@@ -190,3 +190,85 @@ def test_face_box_that_leaves_the_arrays_is_refused():
     many = b.get_kernel(sim.module, 'CollectContinuousData', (64,), [sim.gpu_dist[0], dbuf, (1 << 13) - 1, 0, 1, 4, desc.arr_nx, 2], 'PPiiiiii')
     with pytest.raises(HIPFatalError, match='at most 12 directions'):
         b.run_kernel(many, None, sim.stream)
+
+
+@pytest.mark.parametrize('case,pair,high', [('3d_z2_open', '0->1', True), ('3d_z2_open', '1->0', False),
+                                            ('3d_y3_periodic_y', '1->2', True), ('3d_y3_periodic_y', '2->0', True),
+                                            ('3d_y3_periodic_y', '0->2', False), ('2d_y2_periodic_y', '0->1', True),
+                                            ('2d_y2_periodic_y', '0->1', False), ('2d_y2_periodic_y', '1->0', True)])
+def test_reference_face_kernels_move_what_the_reference_connections_transfer(case, pair, high):
+    """The expected values above are restated from the template text in this file; this test pins the same kernels to a
+    fixture that comes from the reference's own objects: tests/golden/connections.json = its LBConnection objects expanded
+    into sets {(population, receiver node)} per ordered pair of subdomains (tools/capture_connections.py).  Collect on the
+    sender + Distribute on the receiver, both under the reference's argument lists, over the interior of the face (where
+    every population of the face has its source inside the sender): the slots that change on the receiver are exactly
+    the fixture's pairs there, and each carries what the sender held for that population one layer beyond its face."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'connections.json')))[case]
+    dim = len(gold['gsize'])
+    grid = sym.D2Q9 if dim == 2 else sym.D3Q19
+    s_id, r_id = [int(v) for v in pair.split('->')]
+    (s_loc, s_size), (r_loc, r_size) = gold['boxes'][s_id], gold['boxes'][r_id]
+    axis = [a for a in range(dim) if s_loc[a] != r_loc[a]][0]
+    # high: the populations leave through the sender's high face (the receiver sits above it, or below across the periodic
+    # seam); a periodic ring of two connects the same pair through both faces
+    n_axis = gold['gsize'][axis]
+    above = (s_loc[axis] + s_size[axis]) % n_axis == r_loc[axis] and (gold['periodic'][axis] or s_loc[axis] + s_size[axis] < n_axis)
+    below = (r_loc[axis] + r_size[axis]) % n_axis == s_loc[axis] and (gold['periodic'][axis] or r_loc[axis] + r_size[axis] < n_axis)
+    assert above if high else below
+    face = 2 * axis + (1 if high else 0)
+    b = _backend()
+    sims = []
+    for size in (s_size, r_size):
+        desc = make_box_desc(grid, tuple(size), precision='double', access_pattern='AB', visc=0.02)
+        sims.append(BoxSim(b, desc))
+    snd, rcv = sims
+    fs = np.arange(grid.Q * snd.nodes, dtype=np.float64).reshape((grid.Q,) + snd.shape) + 1.0     # every slot its own value
+    fr = np.full((grid.Q,) + rcv.shape, -1.0)
+    snd.set_dist(fs, which=0)
+    rcv.set_dist(fr, which=0)
+    dists = _dists(grid, face)
+    # interior of the face: real nodes 1 .. n - 2 along the in-plane axes (array coordinates 2 .. n - 1)
+    inplane = [a for a in range(dim) if a != axis]
+    nx = s_size[0] - 2
+    if dim == 3:
+        other = inplane[1] if inplane[0] == 0 else inplane[0]
+        nother = s_size[other] - 2
+        args = [face, 2, 2, nx, nother * len(dists)]
+        fmt = 'PiiiiiP'
+    else:
+        nother = 1
+        args = [face, 2, nx * len(dists)]
+        fmt = 'PiiiP'
+    dbuf = b.alloc_buf(size=len(dists) * nother * nx * 8)
+    for sim, name in ((snd, 'CollectContinuousData'), (rcv, 'DistributeContinuousData')):
+        k = b.get_kernel(sim.module, name, (64,), [sim.gpu_dist[0]] + args + [dbuf], fmt)
+        b.run_kernel(k, None, sim.stream)
+        sim.sync()
+    got = rcv.get_dist(which=0)
+    changed = np.argwhere(got != fr)
+    # (q, array z, array y, array x) -> the fixture's (q, real x, real y[, real z])
+    moved = set()
+    for idx in changed:
+        q, coords = int(idx[0]), [int(c) - 1 for c in idx[1:]][::-1]       # x, y, z real coordinates
+        moved.add(tuple([q] + coords[:dim]))
+    lo = [1] * dim
+    hi = [n - 2 for n in r_size]
+    layer_r = 0 if high else r_size[axis] - 1              # the receiver's first / last real layer
+    want = set(tuple(t) for t in gold['pairs'][pair]
+               if t[1 + axis] == layer_r and grid.basis[t[0]][axis] == (1 if high else -1) and
+               all(lo[a] <= t[1 + a] <= hi[a] for a in inplane))
+    assert want and moved == want, (sorted(moved ^ want)[:8], len(moved), len(want))
+    assert all(len([t for t in want if t[1:] == node]) == len(dists) for node in set(t[1:] for t in want))
+    # the values: population q of the receiver's node = what the sender held for q in the layer beyond its face
+    layer_s = snd.shape[3 - 1 - axis] - 1 if high else 0                   # the sender's ghost layer of that face
+    for t in want:
+        q, pos = t[0], list(t[1:]) + [0] * (3 - dim)
+        r_idx = [pos[2] + 1 if dim == 3 else 0, pos[1] + 1, pos[0] + 1]
+        s_idx = list(r_idx)
+        s_idx[2 - axis] = layer_s
+        assert got[(q,) + tuple(r_idx)] == fs[(q,) + tuple(s_idx)]
+    b.free_buf(dbuf)
+    for sim in sims:
+        sim.release()

@@ -70,14 +70,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--quick', action='store_true')
-    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,4)')
+    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,3x8,3z8,4)')
     args = ap.parse_args()
     if not args.only:
         # one fresh process per configuration: what a configuration measures must not depend on what ran before it in
         # the same process (stream -> hardware-queue mapping, allocator state; profiles/r02/README.md "config 3")
         import subprocess
         lines = []
-        for cid in ('0', '1', '2', '2b', '2c', '5a', '5b', '3', '3b', '4'):
+        for cid in ('0', '1', '2', '2b', '2c', '5a', '5b', '3', '3b', '3x8', '3z8', '4'):
             cmd = [sys.executable, os.path.abspath(__file__), '--only', cid] + (['--quick'] if args.quick else [])
             out = subprocess.run(cmd, stdout=subprocess.PIPE).stdout.decode(errors='replace')
             for ln in out.splitlines():
@@ -135,6 +135,33 @@ def main():
                        dict(lat_nx=256, lat_ny=512, lat_nz=512, subdomains=2, conn_axis='x', periodic_x=True,
                             periodic_y=True, periodic_z=True, visc=1.0 / 6.0, access_pattern=pattern, grid='D3Q19',
                             max_iters=int(600 * it), benchmark_sample_from=int(200 * it)), 152))
+    # config 3 AS STATED: all eight subdomains of 1024 x 512 x 512, one process each.  On a 1-GPU box the eight ranks share
+    # the device (gloo group, halos staged through the host: functional, `rccl_ranks` 0); with eight GPUs visible the same
+    # call is the RCCL run.  bench.py does the work (and validates the seams + whole planes of the undivided box).
+    for cid, axis in (('3x8', 'x'), ('3z8', 'z')):
+        if only and cid not in only:
+            continue
+        import subprocess
+        import torch
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        if torch.cuda.device_count() < 8:
+            env.update(SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0')
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--scaling', 'strong', '--domain', '1024x512x512',
+               '--axis', axis, '--steps', '20', '--warmup', '5', '--prewarm_steps', '20', '--repeats', '1', '--no_cpu_baseline',
+               '--no_gpu_state', '--min_seconds', '0.1', '--halo_timing_steps', '4']
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env).stdout.decode(errors='replace')
+        lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+        if lines:
+            d = json.loads(lines[-1])
+            c = d['config']
+            r = {'config': '%s: D3Q19 BGK 1024x512x512 in 8 %s-slabs, one process each (%s)' % (cid, axis, c['dist_backend']),
+                 'MLUPS_eff': d['value'], 'ranks': d['n_gpus'], 'rccl_ranks': c['rccl_ranks'], 'validated': c.get('validated'),
+                 'undivided_box_bit_identical': all(v.get('undivided_box', {}).get('populations_bit_identical') for v in c.get('validation', {}).values()),
+                 'halo_overlap_frac': c.get('halo_overlap_frac'), 'access_pattern': c['access_pattern']}
+            print(json.dumps(r), flush=True)
+            res.append(r)
     # config 4: binary Shan-Chen 256^3 (3 passes per step: 516 B per node update)
     res.append(run('4: binary Shan-Chen D3Q19 256^3', SeparationSim, LBGeometry3D,
                    dict(lat_nx=256, lat_ny=256, lat_nz=256, access_pattern='AA', max_iters=int(1500 * it),

@@ -73,5 +73,16 @@ case $NAME in
     done
     unset SLF_LIBRARY
     ;;
+  r5final)   # round-5 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
+    bash tools/gpu.sh host smoke
+    ( time timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > $O/pytest_gpu_final.log 2>&1; tail -22 $O/pytest_gpu_final.log
+    timeout 900 python bench.py 2>&1 | tail -1 > $O/bench_final.json; cut -c1-400 $O/bench_final.json
+    timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
+    for pat in AA AB; do
+      BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh trace pmc; cp $O/kernel_stats.csv $O/kernel_stats_${pat}_final.csv; cp $O/pmc_summary.txt $O/pmc_summary_${pat}_512.txt; rm -rf $O/trace $O/pmc
+    done
+    timeout 1500 python tools/bench_configs.py 2>/dev/null | grep '^{' > $O/configs_final.jsonl; cut -c1-140 $O/configs_final.jsonl
+    bash tools/gpu.sh torchrun; mv $O/torchrun.jsonl $O/torchrun_final.jsonl
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
