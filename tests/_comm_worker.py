@@ -11,6 +11,9 @@ uid = ctypes.create_string_buffer(128)
 _check(lib, lib.slf_comm_unique_id(uid), 'uid')
 comm = ctypes.c_void_p()
 _check(lib, lib.slf_comm_init(b._ctx, 1, 0, uid, ctypes.byref(comm)), 'init')
+cn, cr = ctypes.c_int(-1), ctypes.c_int(-1)
+_check(lib, lib.slf_comm_count(comm, ctypes.byref(cn), ctypes.byref(cr)), 'count')     # ncclCommCount / ncclCommUserRank
+print(mode, 'count ok', (cn.value, cr.value) == (1, 0), flush=True)
 n = 5 * 512 * 512                      # one x-face of the 8-GPU layout
 src = np.arange(n, dtype=np.float32)
 g_src = b.alloc_buf(like=src); g_dst = b.alloc_buf(size=n * 4)

@@ -21,3 +21,4 @@ def test_comm_sendrecv_to_self(mode):
     out = res.stdout.decode(errors='replace')
     assert res.returncode == 0, out[-2000:]
     assert '%s data ok True' % mode in out and '%s end of script' % mode in out, out[-2000:]
+    assert '%s count ok True' % mode in out, out[-2000:]       # slf_comm_count: what RCCL reports for the communicator
