@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04', 'bench_driver_cmd_final.json')))    # the driver's command line
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r05', 'bench_driver_cmd_final.json')))    # the driver's command line
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -17,10 +17,12 @@ def test_committed_bench_line_has_every_contract_field():
     assert d['vs_baseline'] is None and d['dtype'] == 'f32' and 'workload' in d['config'] and 'model' not in d['config']
     assert 'D3Q19 BGK 512^3' in d['metric']
     c = d['config']
-    # round 4: blocks of exactly K steps, repeated until at least half a second has been timed
-    assert c['value_is'].startswith('best block of exactly K steps') and c['timed_blocks'] >= c['repeats']
+    # round 4: blocks of exactly K steps, repeated until at least half a second has been timed;
+    # round 5: the headline is the MEDIAN block, the fastest one an extra key
+    assert c['value_is'].startswith('median block of exactly K steps') and c['timed_blocks'] >= c['repeats']
     assert c['timed_seconds'] >= 0.5 and abs(c['timed_seconds'] / c['timed_blocks'] - d['ms_per_step'] * d['steps'] * 1e-3) < 0.2 * c['timed_seconds'] / c['timed_blocks']
-    assert min(c['runs_mlups']) <= c['median_mlups'] <= max(c['runs_mlups']) and abs(max(c['runs_mlups']) - d['value']) < 1.0
+    assert min(c['runs_mlups']) <= c['median_mlups'] <= max(c['runs_mlups']) and abs(max(c['runs_mlups']) - d['best_value']) < 1.0
+    assert d['value'] == d['median_value'] == c['median_mlups'] and d['value'] <= d['best_value'] < 1.01 * d['value']
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
@@ -34,10 +36,19 @@ def test_committed_bench_line_has_every_contract_field():
     assert all(v['populations_compared'] > 2e7 and v['mass_rel_drift'] < 1e-5 for v in c['validation'].values())
     rp = c['runner_path']
     assert 'SubdomainRunner.step()' in rp['through'] and abs(rp['vs_value'] - 1.0) < 0.03, rp
-    assert abs(d['median_value'] - c['median_mlups']) < 1.0
     b = d['cpu_baseline']
     assert b['kind'] == 'port' and b['unit'] == 'MLUPS' and b['cores'] >= 1 and 'oracle/lbm_fast.c' in b['sample']
     assert b['single_thread_mlups'] > 0 and b['config1_d2q9_256x256_mlups'] > 0 and 0 < b['numpy_twin_mlups'] < b['value']
+
+
+def test_committed_traffic_belongs_to_the_committed_kernels():
+    """profiles/traffic.json is stamped with the hash of the kernel sources in this tree: a kernel change without new PMC
+    passes makes bench.py report `traffic: null` -- and this test say so before a round ends."""
+    from sailfish_amd import build as slf_build
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    assert t['_csrc_sha256'] == slf_build.source_hash(), 'kernel sources changed since the PMC passes: repeat them (tools/gpu.sh pmc, tools/traffic_update.py)'
+    for k in ('D3Q19_bgk_f32_AB_512_fused', 'D3Q19_bgk_f32_AA_512_fused'):
+        assert 0.99 < t[k] / (512 ** 3 * 152) < 1.05
 
 
 def test_strong_scaling_arguments_are_checked_before_any_gpu_work():
