@@ -84,5 +84,10 @@ case $NAME in
     timeout 1500 python tools/bench_configs.py 2>/dev/null | grep '^{' > $O/configs_final.jsonl; cut -c1-140 $O/configs_final.jsonl
     bash tools/gpu.sh torchrun; mv $O/torchrun.jsonl $O/torchrun_final.jsonl
     ;;
+  r5v10)   # resident kernel with two nodes per lane in packed arithmetic: parity, config 1 on the GPU, trace + SQ
+    ( time timeout 900 python -m pytest tests/test_gpu_resident.py -m gpu -q -x --durations=3 ) > $O/pytest_resident.log 2>&1; tail -8 $O/pytest_resident.log
+    for st in 8 10 12; do SLF_RESIDENT_STEPS=$st timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_resident_steps$st.jsonl | cut -c1-120; done
+    TRACE_CONFIGS="0" bash tools/gpu.sh tracecfg sqcfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
