@@ -89,5 +89,12 @@ case $NAME in
     for st in 8 10 12; do SLF_RESIDENT_STEPS=$st timeout 300 python tools/bench_configs.py --only 0 2>/dev/null | grep '^{' | tee $O/configs_0_resident_steps$st.jsonl | cut -c1-120; done
     TRACE_CONFIGS="0" bash tools/gpu.sh tracecfg sqcfg; rm -rf $O/trace_cfg*/ $O/sq_cfg*/
     ;;
+  r5final2)   # after the last test / doc changes: the tests that changed, the bench lines with `traffic` from the re-stamped file, f64
+    ( time timeout 900 python -m pytest tests/test_gpu_face_kernels.py tests/test_gpu_comm.py tests/test_gpu_resident.py tests/test_gpu_sc.py -m gpu -q --durations=3 ) > $O/pytest_changed.log 2>&1; tail -8 $O/pytest_changed.log
+    timeout 900 python bench.py 2>&1 | tail -1 > $O/bench_final.json; cut -c1-300 $O/bench_final.json
+    timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
+    timeout 900 python bench.py --precision double --no_cpu_baseline 2>&1 | tail -1 > $O/bench_f64_final.json; cut -c1-300 $O/bench_f64_final.json
+    timeout 900 python bench.py --model mrt --no_cpu_baseline 2>&1 | tail -1 > $O/bench_mrt_final.json; cut -c1-300 $O/bench_mrt_final.json
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
