@@ -253,6 +253,9 @@ def validate(sim, backend, mass0, distributed, axis, rank=0, world=1):
     else:
         sim.materialise_faces()         # x-face buffers: what crossed the faces goes into the arrays
         zs = sorted(set([1, nz // 2, nz] if axis == 'z' else [1, nz // 3, nz]))
+        if axis == 'z' and world >= 4:
+            zs = [1, nz]          # the seam planes; a z-slab's windows span the whole x-y extent of the box (the mid plane
+            #                       is covered by the undivided-box windows below)
         chk = window.SeamCheck(backend, sim.desc, zs, sim.gpu_dist, sim.stride, fields, AXES[axis], ring_swapper(rank, world))
         out['seam_layers_checked'] = ({'z': 'planes z = 1 and z = nz', 'y': 'rows y = 1 and y = ny',
                                        'x': 'columns x = 1 and x = nx'}[axis] + ' of every sampled plane (windows reach 3 layers '
