@@ -182,7 +182,7 @@ class LocalGroup(object):
             # one subdomain: the runner's own loop (SubdomainRunner.main: HIP graphs for stretches without host
             # interaction, every other step replayed from its step plan)
             return runners[0].run()
-        with placement.holding():   # several subdomains on one GPU: every one gets its own stretch of HBM
+        with placement.holding(len(runners)):   # several subdomains on one GPU: every one gets its own stretch of HBM
             for r in runners:
                 r.prepare()
         cfg = runners[0].config

@@ -79,22 +79,36 @@ class PlacedBuffer(object):
 _held = None        # spacer chunks kept alive by holding(): [(backend, handle)]
 
 
+_held_count = 1     # placements expected inside the holding() block: each takes its share of the free memory for its spacers
+_held_budget = None  # ... that share in bytes, fixed by the first placement of the block
+
+
 class holding(object):
-    """`with placement.holding():` around the set-up of SEVERAL simulations on one GPU in one process (the subdomain
+    """`with placement.holding(count):` around the set-up of SEVERAL simulations on one GPU in one process (the subdomain
     runners of a same-process group).  The spacers of every placement inside stay allocated until the block ends, so
     that the next placement starts behind them.  Without this the later arrays fall into the holes the earlier
-    spacers left: a 0.2 GiB chunk fits sixteen times into the first 4 GiB hole, and the array is not spread at all."""
+    spacers left: a 0.2 GiB chunk fits sixteen times into the first 4 GiB hole, and the array is not spread at all.
+    `count` = how many simulations will place arrays inside the block: every one takes 1 / count of the span and of the
+    free memory for its spacers -- eight subdomains of BASELINE config 4 in one process held 8 x 70 GiB of spacers
+    otherwise and the first plain allocation after them failed (round 5, `tools/bench_configs.py --only 3g8`)."""
+
+    def __init__(self, count=1):
+        self.count = max(1, int(count))
 
     def __enter__(self):
-        global _held
+        global _held, _held_count, _held_budget
         self._outer = _held
+        self._outer_count = _held_count
         if _held is None:
             _held = []
+            _held_count = self.count
+            _held_budget = None
         return self
 
     def __exit__(self, *exc):
-        global _held
+        global _held, _held_count, _held_budget
         if self._outer is None:
+            _held_count, _held_budget = self._outer_count, None
             held, _held = _held, None
             for backend, h in held:
                 try:
@@ -124,6 +138,12 @@ def place(backend, buffers, span=None):
     n = sharers()
     free = backend.free_memory() // n - payload     # what the device has left (this process's share of it), whoever holds the rest
     span = max(payload, min(span // n, payload + int((0.8 if n == 1 else 0.5) * max(0, free))))
+    global _held_budget
+    if _held is not None and _held_count > 1:
+        # spacers stay allocated until the last simulation of the group is placed: a share of the memory for each
+        if _held_budget is None:
+            _held_budget = int(0.6 * max(0, backend.free_memory() // n)) // _held_count
+        span = max(payload, min(span, payload + _held_budget))
     spacer = max(0, (span - payload) // parts) // gran * gran
     spacers = []
     try:

@@ -117,6 +117,29 @@ def test_spacers_of_a_group_are_held_until_every_member_is_placed():
     assert len(b1.live) == 32
 
 
+def test_spacers_of_eight_subdomains_in_one_process_fit_the_device():
+    """BASELINE config 4 the way the reference runs it on ONE device: --subdomains=8 in one process (controller.LocalGroup).
+    The spacers of every placement are held until the last subdomain is placed; with the full span for each (8 x 70 GiB)
+    the device was full and the first plain allocation afterwards failed (round 5, tools/bench_configs.py --only 3g8).
+    placement.holding(count) gives every member 1 / count of 60 % of the free memory for its spacers."""
+    b = FakeVmm()                                   # one device: 288 GiB
+    slab = 19 * 160 * 514 * 514 * 4                 # one 128 x 512 x 512 x-slab, in place
+    with placement.holding(8):
+        low = b.free_memory()
+        for _ in range(8):
+            pb = placement.PlacedBuffer(b, slab)
+            info = placement.place(b, [pb])
+            assert info['spacer_gib'] > 0.5          # still spread: 15 spacers of more than half a GiB between the 16 chunks
+            low = min(low, b.free_memory())
+        assert low > 0.3 * (288 << 30), low          # fields, node maps and halo buffers of eight subdomains still fit
+    assert len(b.live) == 8 * 16                     # chunks stay, spacers are gone
+    # one simulation by itself keeps the full span
+    b1 = FakeVmm()
+    with placement.holding():
+        info = placement.place(b1, [placement.PlacedBuffer(b1, slab)])
+    assert info['span_gib'] > 60
+
+
 @pytest.mark.parametrize('times,chosen', [([3.3, 3.31], 0), ([3.8, 3.3, 3.31], 1), ([3.8, 3.7, 3.3], 2), ([3.3, 3.9, 3.8], 0)])
 def test_placement_by_measurement_keeps_the_best_and_gives_everything_else_back(times, chosen):
     """placement.choose(): place a second set while the first stays allocated, stop when two sets agree with the best

@@ -70,14 +70,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--quick', action='store_true')
-    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,3x8,3z8,4)')
+    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,3g8,3x8,3z8,4)')
     args = ap.parse_args()
     if not args.only:
         # one fresh process per configuration: what a configuration measures must not depend on what ran before it in
         # the same process (stream -> hardware-queue mapping, allocator state; profiles/r02/README.md "config 3")
         import subprocess
         lines = []
-        for cid in ('0', '1', '2', '2b', '2c', '5a', '5b', '3', '3b', '3x8', '3z8', '4'):
+        for cid in ('0', '1', '2', '2b', '2c', '5a', '5b', '3', '3b', '3g8', '3x8', '3z8', '4'):
             cmd = [sys.executable, os.path.abspath(__file__), '--only', cid] + (['--quick'] if args.quick else [])
             out = subprocess.run(cmd, stdout=subprocess.PIPE).stdout.decode(errors='replace')
             for ln in out.splitlines():
@@ -135,6 +135,13 @@ def main():
                        dict(lat_nx=256, lat_ny=512, lat_nz=512, subdomains=2, conn_axis='x', periodic_x=True,
                             periodic_y=True, periodic_z=True, visc=1.0 / 6.0, access_pattern=pattern, grid='D3Q19',
                             max_iters=int(600 * it), benchmark_sample_from=int(200 * it)), 152))
+    # ... and the whole of config 3 in ONE process on this GPU: --subdomains=8 the way the reference runs it on a single
+    # device (controller.LocalGroup: eight runners stepped in lock-step from one group plan, x-face buffers between them)
+    res.append(run('3g8: D3Q19 BGK 1024x512x512 in 8 x-slabs, all in one process on one GPU (AA)', BoxSim,
+                   EqualSubdomainsGeometry3D,
+                   dict(lat_nx=1024, lat_ny=512, lat_nz=512, subdomains=8, conn_axis='x', periodic_x=True,
+                        periodic_y=True, periodic_z=True, visc=1.0 / 6.0, access_pattern='AA', grid='D3Q19',
+                        max_iters=int(300 * it), benchmark_sample_from=int(100 * it)), 152))
     # config 3 AS STATED: all eight subdomains of 1024 x 512 x 512, one process each.  On a 1-GPU box the eight ranks share
     # the device (gloo group, halos staged through the host: functional, `rccl_ranks` 0); with eight GPUs visible the same
     # call is the RCCL run.  bench.py does the work (and validates the seams + whole planes of the undivided box).

@@ -96,5 +96,11 @@ case $NAME in
     timeout 900 python bench.py --precision double --no_cpu_baseline 2>&1 | tail -1 > $O/bench_f64_final.json; cut -c1-300 $O/bench_f64_final.json
     timeout 900 python bench.py --model mrt --no_cpu_baseline 2>&1 | tail -1 > $O/bench_mrt_final.json; cut -c1-300 $O/bench_mrt_final.json
     ;;
+  r5final3)   # the whole GPU suite on the final tree
+    ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
+    ;;
+  r5v11)   # config 4's eight subdomains in ONE process on the one GPU (LocalGroup)
+    timeout 900 python tools/bench_configs.py --only 3g8 2>&1 | tail -5 | tee $O/configs_3g8.jsonl | cut -c1-400
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
