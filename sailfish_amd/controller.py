@@ -138,9 +138,40 @@ class LocalGroup(object):
                 q.wait(sh, src._ev_chunk[par][pos])
                 for (_, _, recv_addr, n), (_, send_addr, _, n_s) in zip([p for p in mine if p[0] == nid], theirs):
                     assert n == n_s, 'x-face piece mismatch between subdomains %d and %d' % (nid, r._spec.id)
-                    self._copy(q, r, src, recv_addr, send_addr, n * r.float().itemsize)
+                    if recv_addr != send_addr:          # shared face buffers (_share_xface_buffers): nothing to move
+                        self._copy(q, r, src, recv_addr, send_addr, n * r.float().itemsize)
             q.record(r._ev_batch[par][pos], sh)
         q.record(r._pev[par]['copied'], sh)
+
+    def _share_xface_buffers(self):
+        """1-D x decompositions inside one process on one GPU: what subdomain A sends through a face is what its neighbour
+        B receives through the opposite one, and both live in the same device memory -- so B's send buffer BECOMES A's
+        receive buffer (per step parity), and the per-step device copies between them (a quarter of the GPU's time in a
+        traced three-slab pipe run, profiles/r05/kernel_stats_pipe_3x_before.csv) disappear; the events that order A's
+        reads after B's sweep stay.  A.recv keeps its memory and content (it may have been primed from a restored state)."""
+        from sailfish_amd import xface
+        if os.environ.get('SLF_XFACE_SHARE', '1') == '0':
+            return
+        done = 0
+        for r in self.runners:
+            if r._xface is None:
+                continue
+            sp = r._spec
+            for face, nid in sp.connecting_subdomains():
+                if face not in (sp.X_LOW, sp.X_HIGH):
+                    continue
+                nb = self.by_id.get(nid)
+                if nb is None or nb._xface is None or nb.backend.gpu_id != r.backend.gpu_id:
+                    continue
+                f = xface.LOW if face == sp.X_LOW else xface.HIGH
+                for par in (0, 1):
+                    if r._xface.recv[par][f] and nb._xface.send[par][1 - f]:
+                        nb._xface.send[par][1 - f] = r._xface.recv[par][f]
+                        done += 1
+                r._xface.shared = nb._xface.shared = True
+                r._xface._bound = nb._xface._bound = None
+        if done:
+            self.runners[0].config.logger.debug('x-face buffers shared between the subdomains of this process: %d' % done)
 
     def step(self, reqs):
         from sailfish_amd.stepqueue import DirectQueue, NotPlannable
@@ -185,6 +216,7 @@ class LocalGroup(object):
         with placement.holding(len(runners)):   # several subdomains on one GPU: every one gets its own stretch of HBM
             for r in runners:
                 r.prepare()
+        self._share_xface_buffers()
         cfg = runners[0].config
         t_prev, it_prev = time.time(), runners[0]._sim.iteration
         t0, it0 = t_prev, it_prev

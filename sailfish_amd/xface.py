@@ -199,16 +199,35 @@ class XFaceHalo(object):
                     seen.append(a)
         return seen
 
+    shared = False      # my send buffers ARE the neighbours' receive buffers (same-process groups: controller.LocalGroup)
+
     def reset(self, stream=None):
-        """All bits set: nothing has crossed the faces yet, the kernels read the arrays."""
-        for a in self._all():
+        """All bits set: nothing has crossed the faces yet, the kernels read the arrays.  With shared buffers only what
+        this subdomain RECEIVES is cleared: its send buffers are a neighbour's input (still valid for that neighbour), and
+        the next step rewrites every entry of them that is ever written."""
+        bufs = self._all()
+        if self.shared:
+            bufs = []
+            for group in self.recv:
+                for a in group:
+                    if a and a not in bufs:
+                        bufs.append(a)
+        for a in bufs:
             self.backend.memset_buf(a, 0xFF, self.nbytes, stream)
 
     @property
     def needs_clear(self):
-        """Rows of the send buffers that a step does not write must read as 'nothing crossed here', not as an older
-        step's value: without in-sweep wrap along y and z nothing is pushed from a ghost row, and with a node map an
-        excluded edge node pushes nothing."""
+        """Clear the send buffers before every step?  No (round 5).  Entries a step does not write -- rows whose source
+        would be a ghost row (y / z not wrapped in-sweep), edge nodes that the node map excludes -- must read as 'nothing
+        crossed here'; rounds 3-4 cleared the buffers every step for that (two fills of the whole face per step and
+        face).  But WHICH entries a step writes is a property of the geometry, not of the step: the node map is static,
+        every row is swept every step, and a send set only ever sees one kind of step (in place: the even steps own set
+        0, the odd ones set 1; two-copy: every step pushes) -- so an entry that is not written now was never written
+        and still holds the all-ones of reset(), which every host-side write of the state repeats.  Traced on a pipe cut
+        into three x-slabs in one process, the fills were 16 % of the GPU's time (profiles/r05/kernel_stats_pipe_3x_before.csv).
+        SLF_XFACE_CLEAR=1 brings the per-step clear back (A/B)."""
+        if os.environ.get('SLF_XFACE_CLEAR', '0') != '1':
+            return False
         d = self.desc
         return not (d.periodic_fused[1] and d.periodic_fused[2]) or not d.fluid_only
 

@@ -113,11 +113,12 @@ def test_controller_branch_two_processes_on_the_gpu(case, monkeypatch):
     assert np.array_equal(got_rho, ref_rho, equal_nan=True)
 
 
-@pytest.mark.parametrize('pattern,axis', [('AA', 'x'), ('AB', 'z')])
-def test_example_starts_its_own_ranks(pattern, axis, tmp_path):
+@pytest.mark.parametrize('pattern,axis,nsub', [('AA', 'x', 2), ('AB', 'z', 2), ('AA', 'x', 8), ('AB', 'y', 8)])
+def test_example_starts_its_own_ranks(pattern, axis, nsub, tmp_path):
     """`python examples/ldc_3d.py --subdomains=2 --gpus 0 0` with NO launcher: the controller starts one process per
-    subdomain itself (sailfish_amd/launch.py; reference master.py:242-312) -- two ranks on the one GPU of the box, hence
-    a gloo group -- and the merged output equals the single-subdomain run of the same script."""
+    subdomain itself (sailfish_amd/launch.py; reference master.py:242-312) -- two (eight: the process count of BASELINE
+    config 4, neighbours all different) ranks on the one GPU of the box, hence a gloo group -- and the merged output
+    equals the single-subdomain run of the same script."""
     import numpy as np
     sys.path.insert(0, ROOT)
     from utils.merge_subdomains import merge_subdomains
@@ -125,9 +126,11 @@ def test_example_starts_its_own_ranks(pattern, axis, tmp_path):
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'SLF_DIST_BACKEND', 'SLF_FORCE_DEVICE'):
         env.pop(k, None)
     steps = 9
-    common = ['--lat_nx=40', '--lat_ny=12', '--lat_nz=10', '--visc=0.03', '--max_iters=%d' % steps, '--every=%d' % steps,
-              '--access_pattern=' + pattern, '--conn_axis=' + axis, '--quiet', '--nooutput_compress', '--perf_stats_every=0']
-    for name, extra in (('two', ['--subdomains=2', '--gpus', '0', '0']), ('one', ['--subdomains=1', '--gpus', '0'])):
+    size = {'x': (48, 12, 10), 'y': (14, 40, 10), 'z': (40, 12, 10)}[axis] if nsub == 8 else (40, 12, 10)
+    common = ['--lat_nx=%d' % size[0], '--lat_ny=%d' % size[1], '--lat_nz=%d' % size[2], '--visc=0.03', '--max_iters=%d' % steps,
+              '--every=%d' % steps, '--access_pattern=' + pattern, '--conn_axis=' + axis, '--quiet', '--nooutput_compress',
+              '--perf_stats_every=0']
+    for name, extra in (('two', ['--subdomains=%d' % nsub, '--gpus'] + ['0'] * nsub), ('one', ['--subdomains=1', '--gpus', '0'])):
         cmd = [sys.executable, os.path.join(ROOT, 'examples', 'ldc_3d.py'), '--output=' + str(tmp_path / name)] + common + extra
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
         assert res.returncode == 0, res.stdout.decode(errors='replace')[-3000:]

@@ -102,5 +102,50 @@ case $NAME in
   r5v11)   # config 4's eight subdomains in ONE process on the one GPU (LocalGroup)
     timeout 900 python tools/bench_configs.py --only 3g8 2>&1 | tail -5 | tee $O/configs_3g8.jsonl | cut -c1-400
     ;;
+  r5v12)   # an example script that starts eight ranks itself
+    ( time timeout 900 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q -x -k "starts_its_own_ranks" --durations=4 ) > $O/pytest_own_ranks.log 2>&1; tail -14 $O/pytest_own_ranks.log
+    ;;
+  r5v13)   # reference-style command lines at realistic sizes with several subdomains in one process (resource checks)
+    for sub in "2 z AA" "4 x AB"; do
+      set -- $sub
+      echo "== binary Shan-Chen 256^3, $1 subdomains along $2, $3" | tee -a $O/multi_subdomain_runs.txt
+      ( timeout 600 python -c "
+import sys; sys.path.insert(0, '.')
+from examples.binary_fluid.sc_separation_3d import SeparationSim
+from sailfish.controller import LBSimulationController
+from sailfish.geo import EqualSubdomainsGeometry3D
+c = LBSimulationController(SeparationSim, EqualSubdomainsGeometry3D, default_config=dict(lat_nx=256, lat_ny=256, lat_nz=256, subdomains=$1, conn_axis='$2', access_pattern='$3', mode='benchmark', max_iters=300, benchmark_sample_from=100, perf_stats_every=0))
+c.run(ignore_cmdline=True)
+" 2>&1 | grep -v amdgpu.ids | tail -4 ) | tee -a $O/multi_subdomain_runs.txt
+    done
+    for cmd in \
+               "examples/ldc_3d.py --lat_nx=512 --lat_ny=512 --lat_nz=512 --model=mrt --subdomains=4 --conn_axis=x --access_pattern=AA --visc=0.0256" \
+               "examples/ldc_3d.py --lat_nx=512 --lat_ny=512 --lat_nz=512 --subdomains=8 --conn_axis=z --access_pattern=AB --visc=0.0256" \
+               "examples/poiseuille_3d.py --lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA" ; do
+      echo "== $cmd" | tee -a $O/multi_subdomain_runs.txt
+      ( timeout 600 python $cmd --mode=benchmark --max_iters=300 --benchmark_sample_from=100 --perf_stats_every=0 2>&1 | grep -v amdgpu.ids | tail -4 ) | tee -a $O/multi_subdomain_runs.txt
+    done
+    ;;
+  r5v14)   # where a pipe cut into three x-slabs in one process loses a third of its rate: kernel trace
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -o trace -- \
+        env SLF_PLACEMENT_TUNE=0 python $GRAFT_REPO_ROOT/examples/poiseuille_3d.py --lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA --mode=benchmark --max_iters=300 --benchmark_sample_from=100 --perf_stats_every=0 > $GRAFT_REPO_ROOT/$O/trace.log 2>&1 )
+    for f in $(find $O/trace -name "*kernel_stats.csv"); do cp $f $O/kernel_stats_pipe_3x.csv; head -14 $f | cut -c1-220; done; rm -rf $O/trace; tail -3 $O/trace.log
+    ;;
+  r5v15)   # x-face buffers without the per-step clear and shared between the subdomains of a process: parity, then the rates
+    ( time timeout 1500 python -m pytest tests/test_gpu_runner.py tests/test_gpu_slab.py tests/test_gpu_kat.py tests/test_gpu_two_ranks.py tests/test_gpu_fullsize.py -m gpu -q -x -k "not eight_subdomains" --durations=4 ) > $O/pytest_xface.log 2>&1; tail -10 $O/pytest_xface.log
+    timeout 900 python tools/bench_configs.py --only 3,3b,3g8 2>/dev/null | grep '^{' | tee $O/configs_xslabs_shared.jsonl | cut -c1-170
+    SLF_XFACE_SHARE=0 timeout 900 python tools/bench_configs.py --only 3,3b,3g8 2>/dev/null | grep '^{' | tee $O/configs_xslabs_copied.jsonl | cut -c1-170
+    for v in "SLF_XFACE_SHARE=1 SLF_XFACE_CLEAR=0" "SLF_XFACE_SHARE=0 SLF_XFACE_CLEAR=0" "SLF_XFACE_SHARE=0 SLF_XFACE_CLEAR=1"; do
+      echo "== pipe 512x256x256 in 3 x-slabs, one process, $v" | tee -a $O/pipe_3x.txt
+      ( env $v timeout 600 python examples/poiseuille_3d.py --lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA --mode=benchmark --max_iters=300 --benchmark_sample_from=100 --perf_stats_every=0 2>&1 | grep "Total MLUPS" ) | tee -a $O/pipe_3x.txt
+    done
+    ;;
+  r5v16)   # the x-slab pair with shared / copied face buffers, alternating on one box
+    for rep in 1 2 3; do
+      for sh in 1 0; do
+        SLF_XFACE_SHARE=$sh timeout 600 python tools/bench_configs.py --only 3 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('share=$sh', d['MLUPS_eff'], d['MLUPS_comp'])" | tee -a $O/pair_share_ab.txt
+      done
+    done
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
