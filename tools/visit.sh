@@ -147,5 +147,14 @@ c.run(ignore_cmdline=True)
       done
     done
     ;;
+  r5v17)   # group fast-forward: parity of every multi-subdomain test, then rates with / without
+    ( time timeout 1500 python -m pytest tests/test_gpu_runner.py tests/test_gpu_sc.py tests/test_gpu_examples.py -m gpu -q -x --durations=4 ) > $O/pytest_groups.log 2>&1; tail -8 $O/pytest_groups.log
+    for ff in 1 0; do
+      echo "== SLF_GROUP_FAST_FORWARD=$ff" | tee -a $O/group_ff.txt
+      SLF_GROUP_FAST_FORWARD=$ff timeout 900 python tools/bench_configs.py --only 3,3g8 2>/dev/null | grep '^{' | cut -c1-150 | tee -a $O/group_ff.txt
+      ( SLF_GROUP_FAST_FORWARD=$ff timeout 600 python examples/poiseuille_3d.py --lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA --mode=benchmark --max_iters=300 --benchmark_sample_from=100 --perf_stats_every=0 2>&1 | grep "Total MLUPS" ) | tee -a $O/group_ff.txt
+      ( SLF_GROUP_FAST_FORWARD=$ff timeout 600 python examples/ldc_3d.py --lat_nx=256 --lat_ny=256 --lat_nz=256 --subdomains=4 --conn_axis=z --visc=0.03 --access_pattern=AA --mode=benchmark --max_iters=600 --benchmark_sample_from=200 --perf_stats_every=0 2>&1 | grep "Total MLUPS" ) | tee -a $O/group_ff.txt
+    done
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
