@@ -347,8 +347,11 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
  * z-planes is one contiguous piece, so the planes a z-chunk of the sweep has completed can travel while the next
  * chunk computes).  Each step the host only moves send_high -> the high neighbour's recv_low and send_low -> the low
  * neighbour's recv_high.  Entries whose bits are all ones (memset 0xFF) mean "nothing crossed the face here" and are
- * ignored by the reader -- fill the receive buffers that way before the first step: the arrays then count; every
- * other value, NaN and infinities included, is delivered.  The pointers may be changed between launches (the
+ * ignored by the reader -- fill ALL FOUR buffers that way before the first step: the arrays then count; every
+ * other value, NaN and infinities included, is delivered.  A send buffer needs no clearing between steps as long as
+ * each buffer only ever serves one kind of step (in place: one set for the even, one for the odd iterations; two-copy:
+ * any): which entries a step writes is fixed by the node map, the others keep their all-ones for good.  The send buffer of
+ * one subdomain may BE the receive buffer of its neighbour (same device: nothing to move).  The pointers may be changed between launches (the
  * runner alternates two sets by step parity).  All CollideAndPropagate kernels of the module use the buffers once set; NULL pointers
  * switch a face back to ghost columns.  D3Q19 single-fluid modules, direct addressing, x not wrapped in-sweep. */
 int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high);
