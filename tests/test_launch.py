@@ -58,14 +58,16 @@ def test_config_travels_to_the_ranks_as_plain_values():
     pickle.dumps(d)
 
 
-@pytest.mark.parametrize('pattern,axis,nsub', [('AA', 'z', 2), ('AB', 'x', 2), ('AA', 'x', 3)])
+@pytest.mark.parametrize('pattern,axis,nsub', [('AA', 'z', 2), ('AB', 'x', 2), ('AA', 'x', 3), ('AB', 'x', 8)])
 def test_controller_starts_its_own_ranks(pattern, axis, nsub, tmp_path):
+    """(nsub = 8: the process count of BASELINE config 4 -- a ring of subdomains whose neighbours are all different
+    ranks, the launcher, the rendezvous and the CPU pinning with eight ranks.)"""
     from sailfish_amd import geo as geo_mod
     from sailfish_amd.controller import LBSimulationController
     from utils.merge_subdomains import merge_subdomains
     sim_cls = _host.load_sim_class('ldc_3d', 'LDCSim')
     steps = 7
-    base = dict(lat_nx=18, lat_ny=10, lat_nz=8, visc=0.03, access_pattern=pattern, conn_axis=axis, max_iters=steps,
+    base = dict(lat_nx=24 if nsub == 8 else 18, lat_ny=10, lat_nz=8, visc=0.03, access_pattern=pattern, conn_axis=axis, max_iters=steps,
                 quiet=True, perf_stats_every=0, every=steps, backends='tests._oracle_backend', output_compress=False)
     env = dict((k, os.environ.pop(k, None)) for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'))
     try:
