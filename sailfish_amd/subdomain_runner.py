@@ -1085,7 +1085,7 @@ class SubdomainRunner(object):
     # ------------------------------------------------------------------ several steps per launch (small 2-D subdomains)
     RESIDENT_STEPS = {'AA': 8, 'AB': 7}       # steps per launch: a halo of 8 nodes either way (csrc/slf_resident.hip)
     RESIDENT_LAUNCHES = (16, 2)               # launches per graph replay, largest first; even: the result is back in the arrays
-    RESIDENT_MAX_NODES = 300000               # beyond this a sweep is no longer launch-bound
+    RESIDENT_MAX_NODES = 90000                # beyond this a launch per step is faster (measured, see _resident_setup)
     _resident = None
 
     @staticmethod
@@ -1107,8 +1107,15 @@ class SubdomainRunner(object):
             return None
         d = self._desc
         ext = [(d.lat_nx - 2) if d.periodic_fused[0] else d.lat_nx, (d.lat_ny - 2) if d.periodic_fused[1] else d.lat_ny]
-        if ext[0] * ext[1] > int(os.environ.get('SLF_RESIDENT_MAX_NODES', self.RESIDENT_MAX_NODES)):
-            return None
+        # Where it pays (256^2 cavity on MI355X, GMLUPS with / without, profiles/r05/ldc2d_resident_variants.txt): in place
+        # 17.5 / 13.7, two-copy 16.9 / 12.6, MRT 15.8 / 13.2, 128^2 5.2 / 3.6 -- and where it does not: 512^2 23.8 / 33.6 (the
+        # windows hold 4 x the nodes and the launch is bound by instruction issue, so its time grows with the subdomain while
+        # a plain sweep of that size is still near its launch-bound plateau), double precision 7.2 / 11.0 (twice the LDS
+        # traffic, half the vector rate).  SLF_RESIDENT_FORCE=1 takes the path wherever the kernel applies (the tests).
+        if os.environ.get('SLF_RESIDENT_FORCE', '0') != '1':
+            if ext[0] * ext[1] > int(os.environ.get('SLF_RESIDENT_MAX_NODES', self.RESIDENT_MAX_NODES)) or \
+                    self.float().itemsize != 4:
+                return None
         aa = cfg.access_pattern == 'AA'
         steps = int(os.environ.get('SLF_RESIDENT_STEPS', self.RESIDENT_STEPS[cfg.access_pattern]))
         halo = self.resident_halo(aa, steps)

@@ -30,7 +30,8 @@ def _state(r):
 @pytest.mark.parametrize('case', sorted(CASES))
 @pytest.mark.parametrize('pattern', ['AA', 'AB'])
 @pytest.mark.parametrize('steps,every', [(75, 37), (301, 301)])
-def test_resident_steps_equal_plain_stepping(case, pattern, steps, every, tmp_path):
+def test_resident_steps_equal_plain_stepping(case, pattern, steps, every, tmp_path, monkeypatch):
+    monkeypatch.setenv('SLF_RESIDENT_FORCE', '1')       # wherever the kernel applies, not only where it pays (double precision)
     module, sim, cfg = CASES[case]
     if case == 'cavity_256' and every == 37:
         pytest.skip('one long stretch is enough at this size')
@@ -51,6 +52,17 @@ def test_resident_steps_equal_plain_stepping(case, pattern, steps, every, tmp_pa
             assert not r._resident
     for a, b in zip(res[True], res[False]):
         assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize('cfg,taken', [(dict(lat_nx=256, lat_ny=256), True), (dict(lat_nx=40, lat_ny=33), True),
+                                       (dict(lat_nx=40, lat_ny=33, precision='double'), False), (dict(lat_nx=512, lat_ny=512), False)])
+def test_resident_path_is_taken_where_it_pays(cfg, taken):
+    """The runner's own choice (no SLF_RESIDENT_FORCE): single precision and at most 90 000 nodes -- a 512^2 cavity runs 23.8
+    GMLUPS with the resident kernel and 33.6 launch by launch, double precision 7.2 against 11.0 at 256^2
+    (profiles/r05/ldc2d_resident_variants.txt)."""
+    ctrl = run_gpu('ldc_2d', 'LDCSim', 2, dict(cfg, visc=0.0254, access_pattern='AA'), 40, extra=dict(every=40))
+    r = ctrl.runners[0]
+    assert bool(r._resident) == taken and r._sim.iteration == 40
 
 
 def test_resident_kernel_is_refused_where_it_does_not_apply():

@@ -156,5 +156,17 @@ c.run(ignore_cmdline=True)
       ( SLF_GROUP_FAST_FORWARD=$ff timeout 600 python examples/ldc_3d.py --lat_nx=256 --lat_ny=256 --lat_nz=256 --subdomains=4 --conn_axis=z --visc=0.03 --access_pattern=AA --mode=benchmark --max_iters=600 --benchmark_sample_from=200 --perf_stats_every=0 2>&1 | grep "Total MLUPS" ) | tee -a $O/group_ff.txt
     done
     ;;
+  r5v18)   # the 256^2 cavity in the two-copy pattern (the reference's default): one launch per step against 7 steps per launch
+    for res in 1 0; do
+      ( SLF_RESIDENT=$res timeout 300 python examples/ldc_2d.py --lat_nx=256 --lat_ny=256 --visc=0.0254 --access_pattern=AB --mode=benchmark --max_iters=40000 --benchmark_sample_from=10000 --perf_stats_every=0 2>&1 | grep "Total MLUPS" | sed "s/^/AB resident=$res /" ) | tee -a $O/ldc2d_ab.txt
+      ( SLF_RESIDENT=$res timeout 300 python examples/ldc_2d.py --lat_nx=256 --lat_ny=256 --visc=0.0254 --access_pattern=AA --model=mrt --mode=benchmark --max_iters=40000 --benchmark_sample_from=10000 --perf_stats_every=0 2>&1 | grep "Total MLUPS" | sed "s/^/AA MRT resident=$res /" ) | tee -a $O/ldc2d_ab.txt
+      ( SLF_RESIDENT=$res timeout 300 python examples/ldc_2d.py --lat_nx=256 --lat_ny=256 --visc=0.0254 --access_pattern=AA --precision=double --mode=benchmark --max_iters=40000 --benchmark_sample_from=10000 --perf_stats_every=0 2>&1 | grep "Total MLUPS" | sed "s/^/AA f64 resident=$res /" ) | tee -a $O/ldc2d_ab.txt
+      ( SLF_RESIDENT=$res timeout 300 python examples/ldc_2d.py --lat_nx=128 --lat_ny=128 --visc=0.0254 --access_pattern=AA --mode=benchmark --max_iters=40000 --benchmark_sample_from=10000 --perf_stats_every=0 2>&1 | grep "Total MLUPS" | sed "s/^/AA 128^2 resident=$res /" ) | tee -a $O/ldc2d_ab.txt
+      ( SLF_RESIDENT=$res timeout 300 python examples/ldc_2d.py --lat_nx=512 --lat_ny=512 --visc=0.0254 --access_pattern=AA --mode=benchmark --max_iters=20000 --benchmark_sample_from=5000 --perf_stats_every=0 2>&1 | grep "Total MLUPS" | sed "s/^/AA 512^2 resident=$res /" ) | tee -a $O/ldc2d_ab.txt
+    done
+    ;;
+  r5v19)   # the resident path's eligibility rule
+    ( time timeout 900 python -m pytest tests/test_gpu_resident.py tests/test_gpu_runner.py -m gpu -q -x --durations=3 ) > $O/pytest_resident_rule.log 2>&1; tail -8 $O/pytest_resident_rule.log
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
