@@ -78,7 +78,14 @@ enum {
   SLF_NK_REGULARIZED_DENSITY = 11, /* boundary.mako:501-506, 817-835 */
   SLF_NK_COPY = 12,               /* NTCopy, boundary.mako:574-587: unknown populations copied from the node
                                      one step along the inward normal (two-copy access pattern only) */
-  SLF_NK_YU_OUTFLOW = 13          /* NTYuOutflow, boundary.mako:589-603: 2 f(x + n) - f(x + 2 n) (AB only) */
+  SLF_NK_YU_OUTFLOW = 13,         /* NTYuOutflow, boundary.mako:589-603: 2 f(x + n) - f(x + 2 n) (AB only) */
+  SLF_NK_DO_NOTHING = 14,         /* NTDoNothing, boundary.mako:862-876: in-place (AA) pattern -- the unknown populations keep
+                                     their value: the node stores them where its next step reads them (its own slot in an odd
+                                     step, the opposite slot of the ghost node behind it in an even one); two-copy pattern: a
+                                     plain fluid node (node_type.py:296-307); refused with indirect addressing (ghost nodes own
+                                     no slot) */
+  SLF_NK_SLIP = 15                /* NTSlip, boundary.mako:837-855 + sym.py:481-497: dry node, specular reflection -- every
+                                     population with a component along the normal swaps with its mirror image */
 };
 
 #define SLF_MAX_NODE_TYPES 16

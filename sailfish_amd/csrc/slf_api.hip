@@ -685,12 +685,20 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
                                        "two-copy (AB) access pattern only, as in the reference (boundary.mako:626-628)");
     }
   }
+  for (int i = 0; i < d->n_types; i++) {
+    if (d->type_kind[i] == SLF_NK_DO_NOTHING && d->access_pattern != SLF_AB && d->node_addressing == SLF_ADDR_INDIRECT) {
+      delete m;
+      return fail(SLF_ERR_UNSUPPORTED, "NTDoNothing nodes of the in-place (AA) pattern keep their unknown populations in the ghost "
+                                       "nodes behind them, which own no slot under indirect addressing (the reference indexes "
+                                       "nodes[] unguarded there, boundary.mako:862-876 with propagation.mako:93-99)");
+    }
+  }
   g.bc_level = 0;
   for (int i = 0; i < d->n_types; i++) {
     const int k = d->type_kind[i];
     const bool plain = k == SLF_NK_FLUID || k == SLF_NK_GHOST || k == SLF_NK_UNUSED || k == SLF_NK_PROPAGATION_ONLY ||
                        k == SLF_NK_FULL_BB;
-    const int level = (k == SLF_NK_COPY || k == SLF_NK_YU_OUTFLOW) ? 2 : (plain ? 0 : 1);
+    const int level = (k == SLF_NK_COPY || k == SLF_NK_YU_OUTFLOW || k == SLF_NK_DO_NOTHING || k == SLF_NK_SLIP) ? 2 : (plain ? 0 : 1);
     if (level > g.bc_level) g.bc_level = level;
   }
   if (const char* ev = getenv("SLF_BC_LEVEL")) {      // tests: force the full instantiation
@@ -955,9 +963,9 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
       return fail(SLF_ERR_UNSUPPORTED, "CollideAndPropagateResident: periodic axes must be wrapped in-sweep (periodic_fused)");
     for (int t = 0; t < 16; t++) {
       const int kind = (int)((g.type_lut >> (4u * t)) & 0xFull);
-      if (kind == slf::NK_HALF_BB || kind == slf::NK_COPY || kind == slf::NK_YU_OUTFLOW)
-        return fail(SLF_ERR_UNSUPPORTED, "CollideAndPropagateResident: half-way bounce-back and outflow nodes read / write "
-                                         "memory from their node code");
+      if (kind == slf::NK_HALF_BB || kind == slf::NK_COPY || kind == slf::NK_YU_OUTFLOW || kind == slf::NK_DO_NOTHING)
+        return fail(SLF_ERR_UNSUPPORTED, "CollideAndPropagateResident: half-way bounce-back, outflow and do-nothing nodes read / "
+                                         "write memory from their node code");
     }
   }
   if (kk == KK_SCS_MACRO && m->sc.enabled != 2)

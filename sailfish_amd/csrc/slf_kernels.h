@@ -28,7 +28,8 @@ struct Geometry {
   int indirect;                // distributions hold active nodes only, addressed through SweepArgs::nodes
   // What the module's node-type table contains (decided once, at module creation): 0 = nothing beyond fluid, ghost,
   // unused, propagation-only and full-way bounce-back nodes; 1 = boundary-condition nodes; 2 = also the outflow
-  // nodes that read neighbouring nodes (two-copy pattern).  The f32 whole-row kernels are instantiated per level: the
+  // nodes that read neighbouring nodes (two-copy pattern), the do-nothing nodes of the in-place pattern and the full-slip
+  // nodes.  The f32 whole-row kernels are instantiated per level: the
   // code of conditions a simulation does not use costs registers (52 instead of 78-80 VGPRs at level 0) and, for
   // the outflow nodes, spills in the hot path of the two-copy kernel.
   int bc_level;

@@ -33,13 +33,15 @@ enum NodeKind : int {
   NK_REGULARIZED_DENSITY = 11,
   NK_COPY = 12,
   NK_YU_OUTFLOW = 13,
-  NK_COUNT = 14
+  NK_DO_NOTHING = 14,       // in-place pattern: keeps its unknown populations (slf_sweep.h); two-copy pattern: a fluid node
+  NK_SLIP = 15,             // dry: specular reflection (slip_reflect)
+  NK_COUNT = 16
 };
 
 SLF_HD bool kind_is_wet(int k) {
   return k == NK_FLUID || k == NK_HALF_BB || k == NK_REGULARIZED_VELOCITY || k == NK_EQUILIBRIUM_DENSITY ||
          k == NK_EQUILIBRIUM_VELOCITY || k == NK_ZOUHE_VELOCITY || k == NK_ZOUHE_DENSITY ||
-         k == NK_REGULARIZED_DENSITY || k == NK_COPY || k == NK_YU_OUTFLOW;
+         k == NK_REGULARIZED_DENSITY || k == NK_COPY || k == NK_YU_OUTFLOW || k == NK_DO_NOTHING;
 }
 SLF_HD bool kind_is_excluded(int k) { return k == NK_GHOST || k == NK_UNUSED || k == NK_PROPAGATION_ONLY; }
 
@@ -410,6 +412,44 @@ SLF_D void bounce_back(R (&f)[L::Q]) {
       f[o] = t;
     }
   });
+}
+
+// The direction whose vector is (x, y, z); -1: the lattice has none.
+template <class L>
+constexpr int dir_of(int x, int y, int z) {
+  for (int i = 0; i < L::Q; i++)
+    if (L::ex(i) == x && L::ey(i) == y && L::ez(i) == z) return i;
+  return -1;
+}
+
+// Full-slip node (NTSlip, boundary.mako:837-855; the pairs are sym.py:481-497 slip_bb_swap_pairs): every population
+// with a component along the normal of orientation o swaps with its mirror image -- the direction with the normal
+// component reversed and the tangential ones kept; o = 0 (no case in the reference's switch): nothing.
+// Written as selects between VALUES, one straight line for all orientations: swaps of f[i] and f[j] inside one branch per
+// orientation get their common code sunk by the compiler into one swap with the indices as phi nodes, and an array
+// indexed by a run-time value lives in scratch memory (every kernel that contains the node code then keeps its
+// populations there: 48-160 bytes of scratch per lane in the first version of this function).
+template <class L, int I, int O>
+constexpr int slip_image() {
+  constexpr int n = L::dir2vecidx(O);
+  if ((L::ex(I) * L::ex(n) + L::ey(I) * L::ey(n) + L::ez(I) * L::ez(n)) == 0) return I;
+  return dir_of<L>(L::ex(n) != 0 ? -L::ex(I) : L::ex(I), L::ey(n) != 0 ? -L::ey(I) : L::ey(I),
+                   L::ez(n) != 0 ? -L::ez(I) : L::ez(I));
+}
+
+template <class L, class R>
+SLF_D void slip_reflect(R (&f)[L::Q], int o) {
+  R g[L::Q];
+  static_for<0, L::Q>([&](auto I) { g[I] = f[I]; });
+  static_for<1, 2 * L::dim + 1>([&](auto O) {
+    const bool on = o == O;
+    static_for<1, L::Q>([&](auto I) {
+      constexpr int J = slip_image<L, I, O>();
+      static_assert(J > 0, "the mirror image of a lattice direction is a lattice direction");
+      if constexpr (J != I) g[I] = on ? f[J] : g[I];
+    });
+  });
+  static_for<1, L::Q>([&](auto I) { f[I] = g[I]; });
 }
 
 // Is population I unknown at a node whose inward normal is orientation O (1..2 dim)?

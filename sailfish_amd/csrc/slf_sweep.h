@@ -284,7 +284,8 @@ __device__ __forceinline__ void check_invalid(uint32_t* status, uint32_t options
 }
 
 // gi: dense node index; si: the node's slot in the distribution arrays (= gi unless INDIRECT).
-// BCL: the module's Geometry::bc_level the instantiation is for (2 = everything).
+// BCL: the module's Geometry::bc_level the instantiation is for (2 = everything; the outflow, do-nothing and full-slip nodes
+// exist at level 2 only, so that the level-1 kernels of the usual wall / inlet / outlet conditions do not carry their code).
 // ROUNDOFF: the --minimize_roundoff formulation (slf_node.h: macro_roundoff, bgk_relax_roundoff): BGK; fluid, full-way
 // and half-way bounce-back nodes (the module is refused otherwise); the per-node kernels only.
 template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, int FORCE = FORCE_RUNTIME, int BCL = 2,
@@ -441,6 +442,30 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
         bounce_back<L, R>(f);
       } else {
         with_orientation<L>(orientation, [&](auto O) { zouhe_bb<L, R, O>(f, rho, rho0, v); });
+      }
+    }
+    if constexpr (BCL == 2) {
+      if (kind == NK_SLIP) slip_reflect<L, R>(f, orientation);   // boundary.mako:837-855
+    }
+    // NTDoNothing, in-place pattern (boundary.mako:862-876): the unknown populations keep their value -- the node stores
+    // what it has just read to where its NEXT step reads it: an odd step (the next one reads the node's own slots) into its
+    // own slot, an even step (the next one pulls from the neighbours' opposite slots) into the opposite slot of the node
+    // the population would have come from -- the ghost node behind the boundary.  Nobody else touches either slot.
+    if constexpr (PROP != PROP_AB && !INDIRECT && BCL == 2) {
+      if (kind == NK_DO_NOTHING) {
+        with_orientation<L>(orientation, [&](auto O) {
+          static_for<1, L::Q>([&](auto I) {
+            if constexpr (is_missing<L, I, O>()) {
+              if constexpr (PROP == PROP_AA_ODD) {
+                (p.dout + ds * (size_t)I)[si] = f[I];
+              } else {
+                constexpr int J = L::opp(I);
+                const int off = dir_offset<L, J>(ox, oy, oz, true);
+                (p.dout + ds * (size_t)J)[(uint32_t)((int)gi + off)] = f[I];
+              }
+            }
+          });
+        });
       }
     }
     // ---- collision (relaxate, relaxation.mako:196-202: wet nodes only)

@@ -154,9 +154,10 @@ class GeoEncoderConst(object):
         kinds = [0] * n          # dense id 0 is never produced (ids start at 1)
         for orig, new in self._type_id_remap.items():
             cls = nt._NODE_TYPES[orig]
-            if cls not in nt.HIP_KIND:
+            kind = nt.hip_kind(cls, getattr(self.config, 'access_pattern', 'AB'))
+            if kind is None:
                 raise NotImplementedError('node type %s is not implemented by the HIP backend' % cls.__name__)
-            kinds[new] = nt.HIP_KIND[cls]
+            kinds[new] = kind
         return dict(nt_type_mask=(1 << self._bits_type) - 1, nt_misc_shift=self._bits_type,
                     nt_param_shift=self._bits_param, nt_scratch_shift=self._bits_scratch,
                     type_kind=kinds, node_params=list(self._geo_params),

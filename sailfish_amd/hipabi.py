@@ -17,7 +17,8 @@ SLF_AB, SLF_AA = 0, 1
 SLF_SIM_LBM, SLF_SIM_SHAN_CHEN_BINARY, SLF_SIM_SHAN_CHEN_SINGLE = 0, 1, 2
 (SLF_NK_FLUID, SLF_NK_GHOST, SLF_NK_UNUSED, SLF_NK_PROPAGATION_ONLY, SLF_NK_FULL_BB, SLF_NK_HALF_BB,
  SLF_NK_REGULARIZED_VELOCITY, SLF_NK_EQUILIBRIUM_DENSITY, SLF_NK_EQUILIBRIUM_VELOCITY, SLF_NK_ZOUHE_VELOCITY,
- SLF_NK_ZOUHE_DENSITY, SLF_NK_REGULARIZED_DENSITY, SLF_NK_COPY, SLF_NK_YU_OUTFLOW) = range(14)
+ SLF_NK_ZOUHE_DENSITY, SLF_NK_REGULARIZED_DENSITY, SLF_NK_COPY, SLF_NK_YU_OUTFLOW, SLF_NK_DO_NOTHING,
+ SLF_NK_SLIP) = range(16)
 
 # SLF_LIBRARY: another build of the library (A/B runs of kernel changes on the same GPU box)
 LIB_PATH = os.environ.get('SLF_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',

@@ -69,7 +69,7 @@ _TABLE = (
     ('NTHalfBBWall', None, dict(_W, link_tags=True, location=-0.5, allow_unused=True, **dict(_S, **_O)), hipabi.SLF_NK_HALF_BB),
     ('NTFullBBWall', None, dict(_S, location=0.5, **_O), hipabi.SLF_NK_FULL_BB),
     ('NTWallTMS', None, dict(_W, link_tags=True, location=0.5, allow_unused=True, **dict(_S, **_O)), None),
-    ('NTSlip', None, dict(_S), None),
+    ('NTSlip', None, dict(_S), hipabi.SLF_NK_SLIP),             # dry, specular reflection; the orientation is given: NTSlip(orientation=...)
     # imposed density (pressure)
     ('NTEquilibriumDensity', 'density', dict(_W, **_O), hipabi.SLF_NK_EQUILIBRIUM_DENSITY),
     ('NTRegularizedDensity', 'density', dict(_W, **_O), hipabi.SLF_NK_REGULARIZED_DENSITY),
@@ -82,7 +82,7 @@ _TABLE = (
     # outflow and friends
     ('NTCopy', None, _OUTFLOW, hipabi.SLF_NK_COPY),                 # two-copy (AB) access pattern only, like the reference
     ('NTYuOutflow', None, _OUTFLOW, hipabi.SLF_NK_YU_OUTFLOW),      # AB only
-    ('NTDoNothing', None, _OUTFLOW, hipabi.SLF_NK_FLUID),           # AB: a plain fluid node; AA: unsupported
+    ('NTDoNothing', None, _OUTFLOW, hipabi.SLF_NK_DO_NOTHING),      # AB: a plain fluid node (hip_kind()); AA: keeps its unknown populations
     ('NTExtendedCopy', None, _OUTFLOW, None),
     ('NTNeumann', None, _OUTFLOW, None),
     ('NTLaminarize', None, _OUTFLOW, None),
@@ -95,6 +95,16 @@ for _name, _value, _flags, _kind in _TABLE:
     globals()[_name] = _cls
     if _kind is not None:
         HIP_KIND[_cls] = _kind
+
+
+def hip_kind(cls, access_pattern):
+    """Kernel kind (SLF_NK_*) of a node type under an access pattern; None: the gfx950 kernels do not implement it.
+    NTDoNothing exists for the in-place pattern only -- "in the AB memory layout, leaving the outflow nodes defined as
+    NTFluid works just fine" (reference node_type.py:296-307), and that is what it is there."""
+    kind = HIP_KIND.get(cls)
+    if kind == hipabi.SLF_NK_DO_NOTHING and access_pattern != 'AA':
+        return hipabi.SLF_NK_FLUID
+    return kind
 
 
 def _number_node_types():

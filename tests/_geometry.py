@@ -13,6 +13,10 @@ TYPE_KIND = [h.SLF_NK_FLUID, h.SLF_NK_GHOST, h.SLF_NK_FULL_BB, h.SLF_NK_REGULARI
 TYPE_KIND_OUTFLOW = TYPE_KIND + [h.SLF_NK_COPY, h.SLF_NK_YU_OUTFLOW]
 (T_FLUID, T_GHOST, T_FULLBB, T_REGVEL, T_HALFBB, T_EQDENS, T_UNUSED, T_ZHVEL, T_ZHDENS, T_REGDENS,
  T_EQVEL, T_COPY, T_YU) = range(13)
+# with the do-nothing outlet (which is a boundary condition under the in-place pattern only) and the full-slip wall:
+# the same dense ids as the two outflow kinds in the table above
+TYPE_KIND_INPLACE = TYPE_KIND + [h.SLF_NK_DO_NOTHING, h.SLF_NK_SLIP]
+T_DONOTHING, T_SLIP = 11, 12
 NT_BITS = (4, 3, 0)          # type bits, param bits, scratch bits
 ORIENT_SHIFT = 7
 
@@ -125,4 +129,18 @@ def channel_inlet_outlet(desc, t_in, t_out, dim):
     m[zs, 2:ny, nx] = encode(t_out, orientation=o_out, param=3 if dim == 3 else 2)
     m[zs, 1, 1:nx + 1] = encode(T_FULLBB)
     m[zs, ny, 1:nx + 1] = encode(T_FULLBB)
+    return m
+
+
+def channel_slip_walls(desc, dim):
+    """Channel along x between two full-slip walls on y (dry nodes; inward normal +y on the row y = 1, -y on y = max:
+    directions 2 / 4 in D2Q9, 3 / 4 in D3Q19), x (and z) periodic, with one full-way bounce-back block in the middle so
+    that the flow has something to go around."""
+    m = empty_map(desc)
+    ny, nx = desc.lat_ny - 2, desc.lat_nx - 2
+    zs = slice(0, 1) if dim == 2 else slice(1, desc.lat_nz - 1)
+    o_low, o_high = (2, 4) if dim == 2 else (3, 4)
+    m[zs, 1, 1:nx + 1] = encode(T_SLIP, orientation=o_low)
+    m[zs, ny, 1:nx + 1] = encode(T_SLIP, orientation=o_high)
+    m[zs, ny // 2:ny // 2 + 2, nx // 3:nx // 3 + 3] = encode(T_FULLBB)
     return m

@@ -10,7 +10,7 @@ property is asserted for f32 fluid-only runs and reported otherwise.
 import numpy as np
 import pytest
 
-from sailfish_amd import sym
+from sailfish_amd import hipabi, sym
 from sailfish_amd.box import BoxSim, make_box_desc
 from tests import _geometry as geo
 from tests._oracle_box import OracleBox, synthetic_fields
@@ -247,6 +247,73 @@ def test_open_channel_outflow_nodes(backend, grid, size, t_out, model):
                   periodic_fused=[0, 0, 1 if dim == 3 else 0])
     assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
     assert r['dist_exact'], r
+
+
+@pytest.mark.parametrize('grid,size', [(sym.D2Q9, (40, 18)), (sym.D2Q9, (150, 12)), (sym.D3Q19, (26, 12, 6)),
+                                       (sym.D3Q19, (70, 8, 5))])
+@pytest.mark.parametrize('model,precision', [('bgk', 'single'), ('mrt', 'single'), ('bgk', 'double')])
+def test_open_channel_do_nothing_outlet_in_place(backend, grid, size, model, precision):
+    """NTDoNothing outlet under the in-place pattern (reference boundary.mako:862-876): the unknown populations of the
+    outlet nodes keep their value -- stored into the node's own slot by the odd steps, into the ghost node behind it by
+    the even ones.  Odd number of steps and even: both halves end a run."""
+    dim = grid.dim
+    params = [0.03, 0.0] + ([0.0] if dim == 3 else []) + [1.0]
+    for steps in (61, 80):
+        r = _run_pair(backend, grid, size, steps, (False, False, dim == 3),
+                      node_map_fn=lambda d: geo.channel_inlet_outlet(d, geo.T_ZHVEL, geo.T_DONOTHING, dim),
+                      u_scale=0.03, init='rest', model=model, precision=precision, access_pattern='AA', visc=0.05,
+                      fluid_only=False, type_kind=geo.TYPE_KIND_INPLACE, nt_bits=geo.NT_BITS, node_params=params,
+                      periodic_fused=[0, 0, 1 if dim == 3 else 0])
+        assert r['rho_err'] < RTOL and r['v_err'] < RTOL, (steps, r)
+        assert r['dist_exact'], (steps, r)
+
+
+@pytest.mark.parametrize('grid,size', [(sym.D2Q9, (40, 18)), (sym.D3Q19, (26, 12, 6))])
+def test_do_nothing_node_is_a_fluid_node_in_the_two_copy_pattern(backend, grid, size):
+    """node_type.py:296-307: "in the AB memory layout, leaving the outflow nodes defined as NTFluid works just fine" --
+    the kind is accepted there and does what a fluid node does: the same arrays as with T_FLUID in its place."""
+    dim = grid.dim
+    params = [0.03, 0.0] + ([0.0] if dim == 3 else []) + [1.0]
+    kw = dict(u_scale=0.03, init='rest', model='bgk', precision='single', access_pattern='AB', visc=0.05,
+              fluid_only=False, type_kind=geo.TYPE_KIND_INPLACE, nt_bits=geo.NT_BITS, node_params=params,
+              periodic_fused=[0, 0, 1 if dim == 3 else 0])
+    r = _run_pair(backend, grid, size, 40, (False, False, dim == 3),
+                  node_map_fn=lambda d: geo.channel_inlet_outlet(d, geo.T_ZHVEL, geo.T_DONOTHING, dim), **kw)
+    assert r['dist_exact'], r
+    dists = []
+    for t_out in (geo.T_DONOTHING, geo.T_FLUID):
+        desc = make_box_desc(grid, size, **{k: v for k, v in kw.items() if k not in ('u_scale', 'init')})
+        s = BoxSim(backend, desc, periodic=(False, False, dim == 3),
+                   node_map=geo.channel_inlet_outlet(desc, geo.T_ZHVEL, t_out, dim))
+        s.set_fields(np.ones(tuple(reversed(size))), [np.zeros(tuple(reversed(size))) for _ in range(dim)])
+        s.initial_conditions()
+        s.run(40, save_last=True)
+        dists.append(s.real_view(s.get_dist()).copy())
+    assert np.array_equal(dists[0], dists[1], equal_nan=True)
+
+
+@pytest.mark.parametrize('grid,size', [(sym.D2Q9, (40, 18)), (sym.D2Q9, (130, 10)), (sym.D3Q19, (26, 12, 6))])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('model', ['bgk', 'mrt'])
+def test_channel_between_slip_walls(backend, grid, size, pattern, model):
+    """NTSlip (reference boundary.mako:837-855, sym.py:481-497): dry wall nodes that reflect specularly."""
+    dim = grid.dim
+    r = _run_pair(backend, grid, size, 50, (True, False, dim == 3),
+                  node_map_fn=lambda d: geo.channel_slip_walls(d, dim), model=model, precision='single',
+                  access_pattern=pattern, visc=0.05, fluid_only=False, type_kind=geo.TYPE_KIND_INPLACE,
+                  nt_bits=geo.NT_BITS, periodic_fused=[1, 0, 1 if dim == 3 else 0])
+    assert r['rho_err'] < RTOL and r['v_err'] < RTOL, r
+    assert r['dist_exact'], r
+
+
+def test_do_nothing_nodes_in_place_need_direct_addressing(backend):
+    from sailfish_amd.backend_hip import HIPFatalError
+    desc = make_box_desc(sym.D2Q9, (16, 8), access_pattern="AA", fluid_only=False, type_kind=geo.TYPE_KIND_INPLACE,
+                         nt_bits=geo.NT_BITS, visc=0.05, periodic_fused=[1, 1, 0])
+    desc.node_addressing = hipabi.SLF_ADDR_INDIRECT
+    desc.dist_stride = 16 * 8
+    with pytest.raises(HIPFatalError, match='NTDoNothing'):
+        backend.build(desc)
 
 
 def test_outflow_nodes_need_the_two_copy_pattern(backend):

@@ -6,6 +6,7 @@ layer, never-written slots and both copies of the two-copy pattern included -- w
 import numpy as np
 import pytest
 
+from tests import _open_sims
 from tests.test_gpu_runner import run_gpu
 
 pytestmark = pytest.mark.gpu
@@ -17,6 +18,9 @@ CASES = {
     'cavity_f64': ('ldc_2d', 'LDCSim', dict(lat_nx=40, lat_ny=33, visc=0.02, precision='double')),
     # x wrapped inside the sweep (the window wraps too), body force, walls along y
     'channel': ('poiseuille', 'PoiseuilleSim', dict(lat_nx=36, lat_ny=30, visc=0.05, horizontal=True, drive='force', wall='fullbb')),
+    # full-slip walls (boundary-condition nodes of the window's list), x wrapped, body force
+    'slip_channel': (_open_sims.SlipChannelSim, None, dict(lat_nx=36, lat_ny=30, visc=0.05, periodic_x=True,
+                                                           force_implementation='guo')),
     # the configuration itself
     'cavity_256': ('ldc_2d', 'LDCSim', dict(lat_nx=256, lat_ny=256, visc=0.0254)),
 }
@@ -52,6 +56,24 @@ def test_resident_steps_equal_plain_stepping(case, pattern, steps, every, tmp_pa
             assert not r._resident
     for a, b in zip(res[True], res[False]):
         assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize('pattern,taken', [('AB', True), ('AA', False)])
+def test_resident_steps_with_a_do_nothing_outlet(pattern, taken, monkeypatch):
+    """An open channel with NTDoNothing on its last column.  Two-copy pattern: those are fluid nodes that read slots nobody
+    ever writes -- the window is a cache of the raw slots, so the resident steps leave what stepping leaves.  In place the
+    nodes store into memory from their node code (the ghost column behind them): the library refuses the kernel and the
+    runner steps."""
+    monkeypatch.setenv('SLF_RESIDENT_FORCE', '1')
+    res = {}
+    for resident in (True, False):
+        ctrl = run_gpu(_open_sims.OpenChannelSim, None, 2, dict(lat_nx=48, lat_ny=36, visc=0.05, access_pattern=pattern), 75,
+                       extra=dict(hip_resident=resident, hip_graphs=resident, every=75))
+        r = ctrl.runners[0]
+        res[resident] = _state(r)
+        assert bool(r._resident) == (resident and taken)
+    for a, b in zip(res[True], res[False]):
+        assert np.array_equal(a, b, equal_nan=True)
 
 
 @pytest.mark.parametrize('cfg,taken', [(dict(lat_nx=256, lat_ny=256), True), (dict(lat_nx=40, lat_ny=33), True),

@@ -18,9 +18,10 @@ GEO = {2: 'EqualSubdomainsGeometry2D', 3: 'EqualSubdomainsGeometry3D'}
 
 
 def run_gpu(module, sim, dim, cfg, steps, extra=None):
+    """module: the name of an example (with `sim` its class name), or a simulation class itself."""
     from sailfish_amd import geo as geo_mod
     from sailfish_amd.controller import LBSimulationController
-    sim_cls = _host.load_sim_class(module, sim)
+    sim_cls = module if isinstance(module, type) else _host.load_sim_class(module, sim)
     defaults = dict(cfg)
     defaults.update(max_iters=steps, quiet=True, perf_stats_every=0)
     if extra:
@@ -52,7 +53,7 @@ def merged_gpu(ctrl, what):
 
 def check_against_oracle(module, sim, dim, cfg, steps, u_scale):
     ctrl = run_gpu(module, sim, dim, cfg, steps)
-    og = OracleGroup(_host.load_sim_class(module, sim), dim, GEO[dim], cfg)
+    og = OracleGroup(module if isinstance(module, type) else _host.load_sim_class(module, sim), dim, GEO[dim], cfg)
     og.run(steps, save_last=True)
     rho_g, rho_o = merged_gpu(ctrl, 'rho'), og.merged('rho')
     wet = np.isfinite(rho_o) & (rho_o != 0)
@@ -601,3 +602,56 @@ def test_sphere_subdomains(pattern, addressing, nsub, axis):
     for what in ('rho', 'v0', 'v1', 'v2', 'dist'):
         assert _masked_equal(merged_gpu(ctrl, what), merged_gpu(one, what)), what
     assert np.nanmax(np.abs(merged_gpu(one, 'v0'))) > 1e-5
+
+
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+@pytest.mark.parametrize('case', ['2d', '2d_y2', '2d_x2', '3d', '3d_z2', '3d_y2'])
+def test_do_nothing_outlet_through_the_runner(pattern, case):
+    """The set-up of the reference's tests/gpu/do_nothing_node.py (and a duct with the outlet on a z face) through the
+    whole host stack -- set_node(NTDoNothing) -> encoder -> type table (a do-nothing kind in place, a fluid node in the
+    two-copy pattern) -> kernels -- against the oracle twin, one subdomain and two (the outlet column then crosses the seam,
+    or lies in the second subdomain)."""
+    from tests import _open_sims as S
+    nsub, axis = (2, case[-2]) if '_' in case else (1, 'x')
+    if case.startswith('2d'):
+        cfg = dict(lat_nx=64, lat_ny=40, visc=0.05, access_pattern=pattern, subdomains=nsub, conn_axis=axis)
+        _, exact = check_against_oracle(S.OpenChannelSim, None, 2, cfg, 61, 0.05)
+    else:
+        cfg = dict(lat_nx=20, lat_ny=14, lat_nz=24, visc=0.05, periodic_x=True, access_pattern=pattern, subdomains=nsub,
+                   conn_axis=axis)
+        _, exact = check_against_oracle(S.OpenDuctSim, None, 3, cfg, 40, 0.04)
+    assert exact
+
+
+def test_do_nothing_outlet_in_place_equals_the_two_copy_run_on_the_gpu():
+    """The reference's own assertion (tests/gpu/do_nothing_node.py: 64 x 64, 1000 steps, AB against AA with
+    numpy.testing.assert_allclose) -- here the fields are the same to the bit."""
+    from tests import _open_sims as S
+    cfg = dict(lat_nx=64, lat_ny=64, visc=0.05)
+    fields = {}
+    for pattern in ('AB', 'AA'):
+        ctrl = run_gpu(S.OpenChannelSim, None, 2, dict(cfg, access_pattern=pattern), 1000)
+        sim = ctrl.runners[0]._sim
+        fields[pattern] = [sim.rho.copy(), sim.vx.copy(), sim.vy.copy()]
+    for a, b in zip(fields['AB'], fields['AA']):
+        np.testing.assert_allclose(a, b)
+        assert np.array_equal(a, b, equal_nan=True)
+    # the outlet lets the flow through: the last fluid column still moves at about the inlet speed
+    assert 0.03 < np.nanmean(fields['AA'][1][1:-1, -1]) < 0.07
+
+
+@pytest.mark.parametrize('pattern', ['AA', 'AB'])
+@pytest.mark.parametrize('case', ['2d', '2d_y2', '3d', '3d_x2'])
+def test_slip_walls_through_the_runner(pattern, case):
+    """NTSlip(orientation=...) through the host stack against the oracle twin: a force-driven flow between two slip walls."""
+    from tests import _open_sims as S
+    nsub, axis = (2, case[-2]) if '_' in case else (1, 'x')
+    if case.startswith('2d'):
+        cfg = dict(lat_nx=70, lat_ny=24, visc=0.05, periodic_x=True, force_implementation='guo', access_pattern=pattern,
+                   subdomains=nsub, conn_axis=axis)
+        _, exact = check_against_oracle(S.SlipChannelSim, None, 2, cfg, 80, 1e-3)
+    else:
+        cfg = dict(lat_nx=20, lat_ny=12, lat_nz=10, visc=0.05, periodic_x=True, periodic_z=True, force_implementation='guo',
+                   access_pattern=pattern, subdomains=nsub, conn_axis=axis)
+        _, exact = check_against_oracle(S.SlipDuctSim, None, 3, cfg, 60, 1e-3)
+    assert exact

@@ -78,6 +78,9 @@ def lattice_tables(grid):
                        for axis in range(dim) for d in (-1, 0, 1)},
         'missing_dists': {str(o): [int(i) for i in sym.get_missing_dists(grid, o)]
                           for o in range(1, 2 * dim + 1)},
+        # full-slip node: which populations swap, per orientation (boundary.mako:837-855)
+        'slip_swap_pairs': {str(o): sorted([int(i), int(j)] for i, j in sym.slip_bb_swap_pairs(grid, o))
+                            for o in range(1, 2 * dim + 1)},
     }
     import itertools
     ib = {}
@@ -583,6 +586,11 @@ def roundoff_bc_goldens(grid, rng, n=12):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'tables':      # the lattice tables only (the .npz files stay as they are)
+        with open(os.path.join(OUT, 'lattices.json'), 'w') as fh:
+            json.dump({g.__name__: lattice_tables(g) for g in (sym.D2Q9, sym.D3Q19)}, fh, indent=1, sort_keys=True)
+        print('wrote lattices.json')
+        return
     rng_sc = np.random.RandomState(777)
     for grid in (sym.D2Q9, sym.D3Q19):
         np.savez_compressed(os.path.join(OUT, 'shan_chen_%s.npz' % grid.__name__), **shan_chen_goldens(grid, rng_sc))

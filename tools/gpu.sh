@@ -42,7 +42,9 @@ while [ $# -gt 0 ]; do
       summarise_trace $O/trace $O/kernel_stats.csv; tail -1 $O/trace.log | cut -c1-400 ;;
     pmc)
       i=0
-      for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+      # PMC_SIZES_ONLY=1: the two passes profiles/traffic.json is made from, without the request-count cross-check
+      for C in "FETCH_SIZE" "WRITE_SIZE" ${PMC_SIZES_ONLY:+SKIP SKIP} "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+        [ "$C" = SKIP ] && break
         i=$((i+1))
         ( cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/pmc/p$i -o pmc -- \
             python $R/bench.py --steps 20 --warmup 4 --no_cpu_baseline --no_runner_path --no_validate --repeats 1 --prewarm_steps 0 $BENCH_ARGS > $O/pmc_p$i.log 2>&1 )

@@ -96,6 +96,21 @@ case $NAME in
     timeout 900 python bench.py --precision double --no_cpu_baseline 2>&1 | tail -1 > $O/bench_f64_final.json; cut -c1-300 $O/bench_f64_final.json
     timeout 900 python bench.py --model mrt --no_cpu_baseline 2>&1 | tail -1 > $O/bench_mrt_final.json; cut -c1-300 $O/bench_mrt_final.json
     ;;
+  r5dn)   # do-nothing outlets (in place) and full-slip walls: their tests first, the headline line and the two PMC passes
+          # profiles/traffic.json is stamped from (the kernel sources changed), then the whole GPU suite
+    ( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_runner.py tests/test_gpu_resident.py -m gpu -q \
+        -k "do_nothing or slip or outflow or boundary_condition_level or open_channel" --durations=5 ) > $O/pytest_open_nodes.log 2>&1; tail -12 $O/pytest_open_nodes.log
+    for pat in AA AB; do
+      PMC_SIZES_ONLY=1 BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh pmc; cp $O/pmc_summary.txt $O/pmc_summary_${pat}_512.txt
+      [ $pat = AA ] && kern="slf::fast_" || kern="slf::fast_row_kernel"
+      python tools/traffic_update.py --from-pmc $O/pmc --kernel "$kern" --key D3Q19_bgk_f32_${pat}_512_fused
+      rm -rf $O/pmc
+    done
+    cp profiles/traffic.json $O/traffic.json
+    timeout 900 python bench.py 2>&1 | tail -1 > $O/bench_final.json; cut -c1-400 $O/bench_final.json
+    timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
+    ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
+    ;;
   r5final3)   # the whole GPU suite on the final tree
     ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
     ;;
