@@ -111,6 +111,16 @@ case $NAME in
     timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
     ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
     ;;
+  r5last)   # the remaining evidence files on the final sources: smoke(), kernel traces of the headline command, f64 / MRT lines,
+            # every single-GPU configuration
+    bash tools/gpu.sh host smoke
+    for pat in AA AB; do
+      BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh trace; cp $O/kernel_stats.csv $O/kernel_stats_${pat}_final.csv; rm -rf $O/trace
+    done
+    timeout 900 python bench.py --precision double --no_cpu_baseline 2>&1 | tail -1 > $O/bench_f64_final.json; cut -c1-300 $O/bench_f64_final.json
+    timeout 900 python bench.py --model mrt --no_cpu_baseline 2>&1 | tail -1 > $O/bench_mrt_final.json; cut -c1-300 $O/bench_mrt_final.json
+    timeout 600 python tools/bench_configs.py 2>/dev/null | grep '^{' > $O/configs_final.jsonl; cut -c1-140 $O/configs_final.jsonl
+    ;;
   r5final3)   # the whole GPU suite on the final tree
     ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
     ;;
