@@ -11,8 +11,6 @@ ghost-layer PBC along x and y, walls, lid -- everything as in the full run), adv
 plane z bit for bit.  Planes whose window would stick out of a non-periodic box are served by a window pushed
 against the box's own ghost plane; a z axis wrapped in-sweep wraps the window.
 """
-import ctypes
-
 import numpy as np
 
 from oracle.oracle import OracleSim

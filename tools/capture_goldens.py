@@ -21,7 +21,6 @@ import ref_shim  # noqa: F401  (installs import stubs, puts /root/reference on s
 
 import numpy as np
 import sympy
-from sympy import Symbol
 
 from sailfish import sym, sym_equilibrium, sym_force  # noqa: E402
 
