@@ -39,6 +39,41 @@ class BoxSim(LBFluidSim):
     subdomain = PeriodicBox
 
 
+class OpenDuct(Subdomain3D):
+    """A duct with an inlet and an outlet (not a BASELINE configuration; ids 6*): full-way bounce-back walls on the two y
+    faces, a regularized-velocity inlet and an NTDoNothing outlet on the two faces of `flow_axis`, periodic along the
+    third axis.  Along x every row holds an inlet and an outlet node, so every row is swept by the instantiation with
+    the boundary-condition code; along z only the rows of the first and the last plane are."""
+    flow_axis = 0
+    u_in = 0.03
+
+    def boundary_conditions(self, hx, hy, hz):
+        from sailfish.node_type import NTDoNothing, NTFullBBWall, NTRegularizedVelocity
+        wall = (hy == 0) | (hy == self.gy - 1)
+        h, g = ((hx, self.gx), None, (hz, self.gz))[self.flow_axis]
+        v = [0.0, 0.0, 0.0]
+        v[self.flow_axis] = self.u_in
+        self.set_node(wall, NTFullBBWall)
+        self.set_node(~wall & (h == 0), NTRegularizedVelocity(tuple(v)))
+        self.set_node(~wall & (h == g - 1), NTDoNothing)
+
+    def initial_conditions(self, sim, hx, hy, hz):
+        sim.rho[:] = 1.0
+        (sim.vx, None, sim.vz)[self.flow_axis][:] = self.u_in
+
+
+class OpenDuctZ(OpenDuct):
+    flow_axis = 2
+
+
+class DuctSimX(LBFluidSim):
+    subdomain = OpenDuct
+
+
+class DuctSimZ(LBFluidSim):
+    subdomain = OpenDuctZ
+
+
 def _run(label, sim_cls, geo, settings, bytes_per_update):
     cfg = dict(mode='benchmark', quiet=True, perf_stats_every=0)
     cfg.update(settings)
@@ -70,7 +105,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--quick', action='store_true')
-    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,3g8,3x8,3z8,4)')
+    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,3g8,3x8,3z8,4; not in the default set: 6xa,6xb,6za,6zb)')
     args = ap.parse_args()
     if not args.only:
         # one fresh process per configuration: what a configuration measures must not depend on what ran before it in
@@ -173,6 +208,14 @@ def main():
     res.append(run('4: binary Shan-Chen D3Q19 256^3', SeparationSim, LBGeometry3D,
                    dict(lat_nx=256, lat_ny=256, lat_nz=256, access_pattern='AA', max_iters=int(1500 * it),
                         benchmark_sample_from=int(500 * it)), 516))
+    # not BASELINE configurations (only with --only): an open duct, inlet + do-nothing outlet on the x faces / the z faces
+    for cid, sim_cls, pattern, per in (('6xa', DuctSimX, 'AA', dict(periodic_z=True)), ('6xb', DuctSimX, 'AB', dict(periodic_z=True)),
+                                       ('6za', DuctSimZ, 'AA', dict(periodic_x=True)), ('6zb', DuctSimZ, 'AB', dict(periodic_x=True))):
+        if cid in only:
+            res.append(run('%s: D3Q19 BGK open duct 512x256x256, inlet / do-nothing outlet on the %s faces (%s)' % (cid, cid[1], pattern),
+                           sim_cls, LBGeometry3D,
+                           dict(lat_nx=512, lat_ny=256, lat_nz=256, visc=0.05, access_pattern=pattern, max_iters=int(1500 * it),
+                                benchmark_sample_from=int(500 * it), **per), 152))
     if args.out:
         with open(args.out, 'w') as fh:
             for r in filter(None, res):

@@ -121,6 +121,9 @@ case $NAME in
     timeout 900 python bench.py --model mrt --no_cpu_baseline 2>&1 | tail -1 > $O/bench_mrt_final.json; cut -c1-300 $O/bench_mrt_final.json
     timeout 600 python tools/bench_configs.py 2>/dev/null | grep '^{' > $O/configs_final.jsonl; cut -c1-140 $O/configs_final.jsonl
     ;;
+  r5duct)   # what the level-2 kernels cost where EVERY row holds boundary nodes: an open duct along x against one along z
+    timeout 500 python tools/bench_configs.py --only 6xa,6xb,6za,6zb 2>/dev/null | grep '^{' | tee $O/configs_open_duct.jsonl | cut -c1-200
+    ;;
   r5final3)   # the whole GPU suite on the final tree
     ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
     ;;
