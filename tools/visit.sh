@@ -124,6 +124,15 @@ case $NAME in
   r5duct)   # what the level-2 kernels cost where EVERY row holds boundary nodes: an open duct along x against one along z
     timeout 500 python tools/bench_configs.py --only 6xa,6xb,6za,6zb 2>/dev/null | grep '^{' | tee $O/configs_open_duct.jsonl | cut -c1-200
     ;;
+  r5bcw)   # A/B on one box: the boundary-condition instantiations of the whole-row kernels asked for 6 (ships), 7 or 8 resident
+           # waves per SIMD (sailfish_amd/lib/variants/, built with -DSLF_BC_WAVES=N), on the duct whose every row holds boundary nodes
+    for round in 1 2; do
+      for lib in "" sailfish_amd/lib/variants/libsailfish_hip_w7.so sailfish_amd/lib/variants/libsailfish_hip_w8.so; do
+        echo "== library: ${lib:-shipped}" | tee -a $O/bc_waves_ab.txt
+        SLF_LIBRARY=${lib:+$PWD/$lib} timeout 200 python tools/bench_configs.py --only 6xa,6xb 2>/dev/null | grep '^{' | cut -c1-150 | tee -a $O/bc_waves_ab.txt
+      done
+    done
+    ;;
   r5final3)   # the whole GPU suite on the final tree
     ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
     ;;
