@@ -133,6 +133,14 @@ case $NAME in
       done
     done
     ;;
+  r5bcw2)   # the same A/B, shipped against 7 waves only, full-length runs (1500 steps each)
+    for round in 1 2; do
+      for lib in "" sailfish_amd/lib/variants/libsailfish_hip_w7.so; do
+        echo "== library: ${lib:-shipped}" | tee -a $O/bc_waves_ab_long.txt
+        SLF_LIBRARY=${lib:+$PWD/$lib} timeout 200 python tools/bench_configs.py --only 6xa,6xb 2>/dev/null | grep '^{' | cut -c1-150 | tee -a $O/bc_waves_ab_long.txt
+      done
+    done
+    ;;
   r5final3)   # the whole GPU suite on the final tree
     ( time timeout 2400 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
     ;;
