@@ -125,15 +125,32 @@ def median_block(blocks):
     return int(order[(len(order) - 1) // 2])
 
 
-def rccl_ranks_of(exchanger, dist_backend, world):
+def rccl_ranks_of(exchanger, dist_backend, world, peer=None):
     """How many ranks RCCL itself reports for the communicator the halos travel over (C ABI slf_comm_count ->
-    ncclCommCount); 0 when they do not travel over RCCL (gloo / host staging, plain copies).  With
+    ncclCommCount); 0 when they do not travel over RCCL (peer transport, gloo / host staging, plain copies).  With
     SLF_HALO_TRANSPORT=torch on an RCCL process group the communicator is torch's: its world size."""
+    if peer is not None:
+        return 0
     if exchanger is not None and getattr(exchanger, 'direct', False):
         return int(exchanger.rccl.count()[0])
     if dist_backend == 'nccl':
         return int(world)
     return 0
+
+
+def halo_transport_of(sim):
+    """How the halo of `sim` travels, in words (the line's `halo_transport`)."""
+    from sailfish_amd import peer as peer_mod
+    if getattr(sim, 'peer', None) is not None:
+        return ('peer: the sweep / the pack kernels store into the neighbours\' receive buffers (HIP IPC mappings), ordered by '
+                'progress counters (slf_peer_signal / slf_peer_wait inside the step plan); no copies, no RCCL kernels')
+    ex = getattr(sim, 'exchanger', None)
+    why = ' (peer transport unavailable: %s)' % peer_mod.unavailable_reason if peer_mod.unavailable_reason else ''
+    if ex is not None and getattr(ex, 'direct', False):
+        return 'RCCL through the C ABI (slf_comm_exchange inside the step plan)' + why
+    if ex is not None and ex.plain_copy():
+        return 'device copies (a ring of one without a process group)' + why
+    return 'torch.distributed' + why
 
 
 def self_launch(n):
@@ -147,6 +164,11 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '1')
+    if env.get('SLF_FORCE_DEVICE') is not None:
+        # the ranks share ONE device: with the runtime's default of four hardware queues per process eight processes
+        # oversubscribe the device's queue slots, and a counter hop of the peer transport costs 2.7 ms instead of 13 us
+        # (profiles/r06/ipc_probe.txt)
+        env.setdefault('GPU_MAX_HW_QUEUES', '2')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -332,17 +354,54 @@ def device_report(local_rank):
     return rep
 
 
+class NoWatchdog(object):
+    """Single process, no neighbours: nothing to wait for."""
+    def phase(self, *a, **k):
+        pass
+    note = failed = close = phase
+
+
 def main():
     args = parse_args()
-    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit(self_launch(args.gpus))
+    wd = NoWatchdog()
+    if world > 1 or args.force_distributed:
+        # every phase of a multi-process run has a deadline (sailfish_amd/watchdog.py): a rendezvous, a communicator or
+        # an exchange that never completes ends in ONE line with "error", the phase and every rank's last state, and a
+        # non-zero status -- not in the launcher's time limit (reference: master.py:268-312 polls and tears down)
+        from sailfish_amd.watchdog import Watchdog
+
+        def report(diag):
+            out = {'metric': 'MLUPS (million lattice updates/s), D3Q19 %s' % args.model.upper(), 'value': None, 'unit': 'MLUPS',
+                   'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': args.scaling}
+            out.update(diag)
+            print(json.dumps(out), flush=True)
+        wd = Watchdog(rank, world, report, extra=lambda: WATCH_DETAIL() if WATCH_DETAIL else None)
+    try:
+        run(args, world, rank, wd)
+    except BaseException as e:      # noqa: BLE001 -- the others must hear of it before this process goes
+        if not isinstance(e, SystemExit) or e.code not in (0, None):
+            wd.failed('%s: %s' % (type(e).__name__, e))
+            if rank == 0 and not isinstance(wd, NoWatchdog):
+                time.sleep(0.5)
+                wd._fire('rank 0: %s: %s' % (type(e).__name__, str(e)[:300]), 'failed')
+        raise
+    wd.close()
+
+
+WATCH_DETAIL = None      # set by run(): what the watchdog adds to a rank's state (transport counters)
+
+
+def run(args, world, rank, wd):
+    global WATCH_DETAIL
+    import torch
     # SLF_FORCE_DEVICE: every rank on that GPU (functional runs of the N > 1 path on a 1-GPU box, with SLF_DIST_BACKEND=gloo)
     local_rank = int(os.environ.get('SLF_FORCE_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit(self_launch(args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP backend has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -372,9 +431,23 @@ def main():
             pinned = {'numa_node': nodes[me], 'cpus': len(sets[me])}
         except Exception as e:  # noqa: BLE001 -- pinning is an optimisation, never a reason to fail
             pinned = {'error': str(e)[:80]}
+    test_stall(wd, rank, 'start')
     if distributed:
-        from sailfish_amd.connector import init_distributed
+        from sailfish_amd.connector import init_distributed, process_rccl
+        from sailfish_amd import peer as peer_mod
+        wd.phase('rendezvous')
         init_distributed(force=True)
+        test_stall(wd, rank, 'rendezvous')
+        # the transport of the halos, set up here so that it has a phase (and a deadline) of its own: peer mappings where
+        # the ranks can map each other's memory, else an RCCL communicator (ncclCommInitRank is where a multi-GPU run
+        # that cannot reach its peers stops)
+        wd.phase('transport')
+        pt = peer_mod.process_transport(backend, rank, world)
+        if pt is not None:
+            WATCH_DETAIL = pt.snapshot
+        elif torch.distributed.get_backend() == 'nccl' and os.environ.get('SLF_HALO_TRANSPORT', 'auto') != 'torch':
+            process_rccl(backend, rank, world)
+        test_stall(wd, rank, 'transport')
     axis = AXES[args.axis]
     if args.scaling == 'weak':
         local = [args.size] * 3
@@ -395,6 +468,7 @@ def main():
             torch.distributed.barrier()
 
     def measure(pattern, check=False):
+        wd.phase('setup', pattern=pattern)
         sim = SlabSim(backend, sym.D3Q19, tuple(local), rank=rank, world=world, model=args.model,
                       precision=args.precision, access_pattern=pattern, visc=args.visc,
                       fused_periodic=not args.no_fused_periodic, axis=args.axis, force_halo=args.force_distributed,
@@ -407,6 +481,12 @@ def main():
             r64 = sim.real_view(sim.rho).astype(np.float64)
             mass0[0] = [float(r64.sum())] + [float((r64 * sim.real_view(c)).sum()) for c in sim.v]
         if sim.halo:
+            wd.phase('first_exchange', pattern=pattern)
+            for _ in range(2):
+                sim.step()
+            barrier(sim)
+            test_stall(wd, rank, 'first_exchange')
+            wd.phase('setup', pattern=pattern, what='sweep-only reference')
             # what the sweep launches cost when nothing is waited for (reference for the overlap figure)
             for _ in range(10):
                 sim.step_sweep_only()
@@ -418,15 +498,18 @@ def main():
             e1.synchronize()
             res['sweep_only_ms'] = e1.time_since(e0) / 20
             sim.init_synthetic(seed=1234)
+        wd.phase('warmup', pattern=pattern)
         for _ in range(args.prewarm_steps + (args.prewarm_steps & 1)):   # untimed, even count: GPU clocks ramp up
             sim.step()
         for _ in range(args.warmup):
             sim.step()
+        test_stall(wd, rank, 'warmup')
         # timed region: blocks of EXACTLY K steps, each bracketed by barrier + synchronize, max over ranks; repeated until
         # --min_seconds have been timed (the driver's K = 20 is 64 ms at 512^3: too short a sample on its own)
         blocks, host, kernel = [], [], []
         total = 0.0
         while True:
+            wd.phase('timed', pattern=pattern, block=len(blocks))
             barrier(sim)
             ev0 = backend.make_event(sim.calc_stream, timing=True)
             t0 = time.perf_counter()
@@ -462,15 +545,20 @@ def main():
         if sim.halo:
             # a separate short leg with timing events around the halo stream's work (entry-by-entry enqueue: the timed
             # region above replays step plans, which carry no timing events)
+            wd.phase('halo_timing', pattern=pattern)
             sim.start_halo_timing()
             for _ in range(args.halo_timing_steps + (args.halo_timing_steps & 1)):
                 sim.step()
             res['halo_ms'] = sim.stop_halo_timing()
             res['step_plans'] = sorted(str(k) for k in getattr(sim, '_plans', {}))
             res['rccl_ranks'] = rccl_ranks_of(getattr(sim, 'exchanger', None),
-                                              torch.distributed.get_backend() if torch.distributed.is_initialized() else None, world)
+                                              torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                                              world, getattr(sim, 'peer', None))
+            res['halo_transport'] = halo_transport_of(sim)
         if check:
+            wd.phase('validate', pattern=pattern)
             res['validation'] = validate(sim, backend, mass0[0], distributed, args.axis, rank, world)
+        wd.phase('finish', pattern=pattern)
         sim.release()
         return res
 
@@ -483,6 +571,7 @@ def main():
         for pat in patterns:
             runs[pat].append(measure(pat, check=(i == reps - 1 and not args.no_validate)))
     st_after = None if (args.no_gpu_state or rank) else gpu_state()
+    wd.phase('report')
     # per access pattern: every timed block of every repeat; the pattern with the better MEDIAN block is reported
     pooled = dict((p, [b for r in rs for b in r['blocks']]) for p, rs in runs.items())
     med_of = dict((p, bl[median_block(bl)]) for p, bl in pooled.items())
@@ -496,6 +585,7 @@ def main():
         mine = dict((k, round(best[k], 4)) for k in ('kernel_ms', 'halo_ms', 'sweep_only_ms', 'host_ms', 'host_ms_median') if k in best)
         mine['rank'] = rank
         mine['step_plans'] = best.get('step_plans')
+        mine['halo_transport'] = best.get('halo_transport')
         mine['pinned'] = pinned
         mine.update(device_report(local_rank))
         gathered = [None] * world
@@ -521,7 +611,8 @@ def main():
                            % (args.model.upper(), shape, 'x'.join(map(str, domain))),
                'access_pattern': args.access_pattern,
                'periodic': 'in-sweep wrap' if not args.no_fused_periodic else 'ghost-layer PBC kernels',
-               'decomposition': ('%s-slabs x%d, RCCL halo' % (args.axis, world)) if distributed else 'single subdomain',
+               'decomposition': ('%s-slabs x%d, halo: %s' % (args.axis, world, (best.get('halo_transport') or '?').split(':')[0].split(' (')[0]))
+               if distributed else 'single subdomain',
                'visc': args.visc, 'block_x': best['block'], 'repeats': max(1, args.repeats),
                'value_is': 'median block of exactly K steps (blocks repeated until --min_seconds are timed, per repeat); '
                            'best_value = the fastest block',
@@ -544,8 +635,7 @@ def main():
                                          '0 = not over RCCL',
                         'world_size': torch.distributed.get_world_size(),
                         'dist_backend': torch.distributed.get_backend(),
-                        'halo_transport': 'RCCL through the C ABI (slf_comm_exchange inside the step plan)'
-                        if best.get('step_plans') else 'torch.distributed',
+                        'halo_transport': best.get('halo_transport'),
                         'host_ms_median': round(max(r.get('host_ms_median', 0.0) for r in per_rank), 4),
                         'per_rank': per_rank,
                         'halo_overlap_frac': round(max(0.0, min(1.0, 1.0 - exposed / hm)), 3) if hm > 0 else None,
@@ -572,8 +662,24 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))
     if distributed:
+        wd.phase('finish')
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def test_stall(wd, rank, phase):
+    """SLF_BENCH_TEST_STALL=<rank>:<phase>[:exit]: that rank stops (or leaves) at the end of that phase -- what the tests of
+    the deadlines use to make a run hang the way a lost neighbour would."""
+    spec = os.environ.get('SLF_BENCH_TEST_STALL')
+    if not spec:
+        return
+    parts = spec.split(':')
+    if int(parts[0]) != rank or parts[1] != phase:
+        return
+    if len(parts) > 2 and parts[2] == 'exit':
+        os._exit(17)
+    while True:
+        time.sleep(1.0)
 
 
 if __name__ == '__main__':

@@ -233,6 +233,56 @@ typedef struct slf_comm_op {
 } slf_comm_op;
 int slf_comm_exchange(slf_comm* comm, const slf_comm_op* ops, int n, slf_stream* stream);
 
+/* ---- peer transport (round 6): halo buffers of one subdomain process mapped into its neighbours' address space.
+ *      The reference left the hook for it -- backend.ipc_handle / ipc_handle_wrap (backend_cuda.py:122-126), unused --
+ *      and moves its halos device -> host -> socket -> host -> device (connector.py:73-174).  On one node every GPU
+ *      reaches every other one's memory over xGMI, so the kernels that PRODUCE a halo (edge lanes of the sweep, the
+ *      pack kernels) store straight into the receive buffers of the neighbouring process, and what is left of the
+ *      exchange is ordering: a progress counter per (sender, receiver, channel) that the sender advances with a
+ *      one-lane kernel behind its writes and the receiver's stream waits for with a one-lane kernel -- no copy, no
+ *      RCCL kernels, nothing on the host.  Works between processes that SHARE a device as well (HIP IPC maps the same
+ *      physical memory), which is what makes the multi-process step measurable on a single-GPU box.
+ *        slf_peer_create      the progress counters of this process (uncached device memory), one block per process;
+ *        slf_peer_flags_handle / slf_peer_connect   hand the block's IPC handle to the other ranks (any side channel;
+ *                             64 opaque bytes) / map theirs; the own rank needs no connect;
+ *        slf_peer_alloc       a device buffer other processes can map + its 64-byte handle; slf_peer_open maps a buffer
+ *                             of another process (whole allocation; offsets are the caller's business);
+ *        slf_peer_signal      after everything enqueued on `stream` so far (its writes released to system scope):
+ *                             counter[me -> r][channel] = ++sent[r][channel] in the memory of every listed rank r;
+ *        slf_peer_wait        `stream` continues when counter[r -> me][channel] >= ++awaited[r][channel] for every
+ *                             listed rank r.  The k-th wait for (r, channel) matches r's k-th signal to this rank on
+ *                             that channel: both sides enqueue the same sequence per pair, as they must for RCCL.
+ *      A wait gives up after the time-out (slf_peer_set_timeout, default 60 s; the spin is bounded so that a lost
+ *      neighbour cannot hang the device) and leaves {1, rank, channel, expected, seen} in slf_peer_status, which the
+ *      host polls when it synchronises anyway.  Write-after-read is the caller's: a receive buffer must not be written
+ *      again before its reader is done -- sailfish_amd alternates two buffer sets by step parity and orders the rest
+ *      through the same counters (xface.ChunkPlan.peer_need).
+ *      slf_peer_selftest_* : fill a (mapped) buffer with a pattern / count the words of a local buffer that differ from
+ *      it -- the transport checks at start-up, on the real mappings, that plain device memory written through a mapping
+ *      and released by a signal is what the waiting process reads (dense and one-word-per-line stores). ---- */
+typedef struct slf_peer slf_peer;
+enum { SLF_PEER_HANDLE_BYTES = 64, SLF_PEER_CHANNELS = 4 };
+int slf_peer_create(slf_ctx* ctx, int nranks, int rank, slf_peer** out);
+int slf_peer_destroy(slf_peer* peer);
+int slf_peer_flags_handle(slf_peer* peer, void* handle64);
+int slf_peer_connect(slf_peer* peer, int rank, const void* handle64);
+int slf_peer_alloc(slf_peer* peer, size_t bytes, void** dptr, void* handle64);
+int slf_peer_free(slf_peer* peer, void* dptr);
+int slf_peer_open(slf_peer* peer, const void* handle64, void** mapped);
+int slf_peer_close(slf_peer* peer, void* mapped);
+int slf_peer_signal(slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
+int slf_peer_wait(slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
+int slf_peer_set_timeout(slf_peer* peer, double seconds);
+/* out = {timed out (0 | 1), rank waited for, channel, expected count, count seen, waits timed out so far, 0, 0} */
+int slf_peer_status(slf_peer* peer, int64_t out[8]);
+/* what this process has enqueued / seen for one (rank, channel): signals sent to it, signals awaited from it, and the
+ * counter it has advanced here so far (read from the device: synchronises the NULL stream only) */
+int slf_peer_progress(slf_peer* peer, int rank, int channel, uint64_t* sent, uint64_t* awaited, uint64_t* arrived);
+int slf_peer_selftest_fill(slf_peer* peer, void* dst, size_t nwords, uint32_t pattern, int one_word_per_block,
+                           slf_stream* stream);
+int slf_peer_selftest_check(slf_peer* peer, const void* src, size_t nwords, uint32_t pattern, slf_stream* stream,
+                            uint32_t* bad_words);                      /* waits for `stream` */
+
 /* ---- streams / events: make_stream, make_event, sync_stream
  *      (backend_cuda.py:291-308, 24-52) ---- */
 int slf_stream_create(slf_ctx* ctx, slf_stream** out);
@@ -402,6 +452,8 @@ int slf_plan_add_memset(slf_plan* plan, void* dptr, int value, size_t bytes, slf
 int slf_plan_add_copy(slf_plan* plan, void* dst, const void* src, size_t bytes, slf_stream* stream);    /* same device */
 int slf_plan_add_xface_buffers(slf_plan* plan, slf_module* m, void* send_low, void* send_high, void* recv_low,
                                void* recv_high);                                /* slf_module_set_xface_buffers */
+int slf_plan_add_peer_signal(slf_plan* plan, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
+int slf_plan_add_peer_wait(slf_plan* plan, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
 int slf_plan_run(slf_plan* plan, uint32_t iteration);
 
 const char* slf_last_error(void);

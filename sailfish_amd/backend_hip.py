@@ -216,6 +216,18 @@ class HIPPlan(object):
                'slf_plan_add_exchange')
         self._keep += [rccl, stream]
 
+    def peer_signal(self, peer, ranks, channel, stream):
+        arr, n = peer.ranks_array(ranks)
+        _check(self._lib, self._lib.slf_plan_add_peer_signal(self.handle, peer.handle, arr, n, int(channel), self._h(stream)),
+               'slf_plan_add_peer_signal')
+        self._keep += [peer, stream]
+
+    def peer_wait(self, peer, ranks, channel, stream):
+        arr, n = peer.ranks_array(ranks)
+        _check(self._lib, self._lib.slf_plan_add_peer_wait(self.handle, peer.handle, arr, n, int(channel), self._h(stream)),
+               'slf_plan_add_peer_wait')
+        self._keep += [peer, stream]
+
     def memset(self, addr, value, nbytes, stream):
         for a, _, n in self.backend._segments(addr, nbytes):
             _check(self._lib, self._lib.slf_plan_add_memset(self.handle, ctypes.c_void_p(a), int(value), n, self._h(stream)),

@@ -426,6 +426,297 @@ int slf_comm_exchange(slf_comm* c, const slf_comm_op* ops, int n, slf_stream* st
   return rc2 ? rccl_fail(rc2, "ncclGroupEnd") : SLF_OK;
 }
 
+// ---- peer transport: receive buffers mapped into the neighbouring processes, progress counters instead of messages ---
+// (include/sailfish_hip.h "peer transport".)  The producers of a halo store into the neighbour's memory themselves;
+// what these entry points add is the ordering.
+namespace {
+typedef unsigned long long peer_u64;
+constexpr int PEER_SLOT = 8;        // 64-bit words per counter: every counter has a 64-byte line to itself
+constexpr int PEER_MAX = 32;        // ranks per signal / wait call (a block decomposition has at most 26 neighbours)
+
+struct PeerSignalArgs {
+  peer_u64* flag[PEER_MAX];
+  peer_u64 value[PEER_MAX];
+  int n;
+};
+struct PeerWaitArgs {
+  const peer_u64* flag[PEER_MAX];
+  peer_u64 value[PEER_MAX];
+  int rank[PEER_MAX];
+  int n, channel;
+  peer_u64 timeout;                 // ticks of the 100 MHz wall clock
+  volatile long long* status;       // pinned host memory
+};
+
+// One lane per counter.  The release makes everything this PROCESS enqueued before the launch on the same stream
+// visible first (slf_peer_signal records an event in front: a system-scope release of the whole device, not only of
+// the one XCD this wave runs on).
+__global__ void peer_signal_kernel(PeerSignalArgs a) {
+  const int i = threadIdx.x;
+  if (i < a.n) __hip_atomic_store(a.flag[i], a.value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One lane per counter, spinning (with sleeps) until it has reached its value -- bounded: after `timeout` ticks the lane
+// reports and gives up, so that a neighbour that died leaves an error on the host instead of a device nobody can use.
+__global__ void peer_wait_kernel(PeerWaitArgs a) {
+  const int i = threadIdx.x;
+  if (i < a.n) {
+    const peer_u64 t0 = wall_clock64();
+    peer_u64 seen;
+    while ((seen = __hip_atomic_load(a.flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < a.value[i]) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > a.timeout) {
+        a.status[1] = a.rank[i];
+        a.status[2] = a.channel;
+        a.status[3] = (long long)a.value[i];
+        a.status[4] = (long long)seen;
+        a.status[5] = a.status[5] + 1;
+        a.status[0] = 1;
+        break;
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
+__global__ void peer_fill_kernel(uint32_t* dst, size_t n, uint32_t pattern, int one_word_per_block) {
+  if (one_word_per_block) {
+    const size_t i = blockIdx.x;
+    if (threadIdx.x == 0 && i < n) dst[i] = pattern ^ (uint32_t)i;
+    return;
+  }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = pattern ^ (uint32_t)i;
+}
+
+__global__ void peer_check_kernel(const uint32_t* src, size_t n, uint32_t pattern, uint32_t* bad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && src[i] != (pattern ^ (uint32_t)i)) atomicAdd(bad, 1u);
+}
+}  // namespace
+
+struct slf_peer {
+  slf_ctx* ctx;
+  int nranks, rank;
+  peer_u64* flags;                       // my block: counter[src rank][channel], PEER_SLOT words each
+  std::vector<peer_u64*> remote;         // the blocks of the other ranks as mapped here (mine: flags)
+  std::vector<peer_u64> sent, awaited;   // [rank * SLF_PEER_CHANNELS + channel]
+  long long* status;                     // pinned host memory, 8 words
+  peer_u64 timeout;
+  hipEvent_t ev;
+  uint32_t* bad;                         // device word of the self-test
+};
+
+static int peer_check_ranks(slf_peer* p, const int32_t* ranks, int n, int channel) {
+  if (!p || (!ranks && n > 0)) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (n < 0 || n > PEER_MAX) return fail(SLF_ERR_INVALID, "at most 32 ranks per peer signal / wait");
+  if (channel < 0 || channel >= SLF_PEER_CHANNELS) return fail(SLF_ERR_INVALID, "bad peer channel");
+  for (int i = 0; i < n; i++) {
+    if (ranks[i] < 0 || ranks[i] >= p->nranks) return fail(SLF_ERR_INVALID, "peer rank out of range");
+    if (!p->remote[ranks[i]]) return fail(SLF_ERR_INVALID, "peer rank not connected (slf_peer_connect)");
+  }
+  return SLF_OK;
+}
+
+int slf_peer_create(slf_ctx* ctx, int nranks, int rank, slf_peer** out) {
+  if (!ctx || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SLF_ERR_INVALID, "bad rank / nranks");
+  SLF_HIP(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)nranks * SLF_PEER_CHANNELS * PEER_SLOT * sizeof(peer_u64);
+  void* f = nullptr;
+  // uncached: a counter stored by another process (another device) is seen by the spinning lane without any cache
+  // maintenance; fine-grained as the second choice
+  if (hipExtMallocWithFlags(&f, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    SLF_HIP(hipExtMallocWithFlags(&f, bytes, hipDeviceMallocFinegrained));
+  }
+  SLF_HIP(hipMemset(f, 0, bytes));
+  slf_peer* p = new slf_peer;
+  p->ctx = ctx;
+  p->nranks = nranks;
+  p->rank = rank;
+  p->flags = (peer_u64*)f;
+  p->remote.assign(nranks, nullptr);
+  p->remote[rank] = p->flags;
+  p->sent.assign((size_t)nranks * SLF_PEER_CHANNELS, 0);
+  p->awaited.assign((size_t)nranks * SLF_PEER_CHANNELS, 0);
+  p->status = nullptr;
+  p->timeout = 60ull * 100000000ull;
+  p->ev = nullptr;
+  p->bad = nullptr;
+  hipError_t e = hipHostMalloc((void**)&p->status, 8 * sizeof(long long), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->bad, sizeof(uint32_t));
+  if (e != hipSuccess) {
+    slf_peer_destroy(p);
+    return hip_fail(e, "slf_peer_create");
+  }
+  memset(p->status, 0, 8 * sizeof(long long));
+  SLF_HIP(hipDeviceSynchronize());
+  *out = p;
+  return SLF_OK;
+}
+
+int slf_peer_destroy(slf_peer* p) {
+  if (!p) return SLF_OK;
+  for (int r = 0; r < p->nranks; r++)
+    if (r != p->rank && p->remote[r]) hipIpcCloseMemHandle(p->remote[r]);
+  if (p->flags) hipFree(p->flags);
+  if (p->status) hipHostFree(p->status);
+  if (p->ev) hipEventDestroy(p->ev);
+  if (p->bad) hipFree(p->bad);
+  delete p;
+  return SLF_OK;
+}
+
+int slf_peer_flags_handle(slf_peer* p, void* handle64) {
+  if (!p || !handle64) return fail(SLF_ERR_INVALID, "NULL argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == SLF_PEER_HANDLE_BYTES, "IPC handle size");
+  hipIpcMemHandle_t h;
+  SLF_HIP(hipIpcGetMemHandle(&h, p->flags));
+  memcpy(handle64, &h, sizeof(h));
+  return SLF_OK;
+}
+
+int slf_peer_connect(slf_peer* p, int rank, const void* handle64) {
+  if (!p || !handle64) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (rank < 0 || rank >= p->nranks) return fail(SLF_ERR_INVALID, "peer rank out of range");
+  if (rank == p->rank || p->remote[rank]) return SLF_OK;
+  SLF_HIP(hipSetDevice(p->ctx->device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  void* m = nullptr;
+  SLF_HIP(hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
+  p->remote[rank] = (peer_u64*)m;
+  return SLF_OK;
+}
+
+int slf_peer_alloc(slf_peer* p, size_t bytes, void** dptr, void* handle64) {
+  if (!p || !dptr || !handle64) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(p->ctx->device));
+  void* m = nullptr;
+  SLF_HIP(hipMalloc(&m, bytes ? bytes : 1));      // plain (cacheable) memory: one-word stores merge into lines in the L2
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, m);
+  if (e != hipSuccess) {
+    hipFree(m);
+    return hip_fail(e, "hipIpcGetMemHandle");
+  }
+  memcpy(handle64, &h, sizeof(h));
+  *dptr = m;
+  return SLF_OK;
+}
+
+int slf_peer_free(slf_peer* p, void* dptr) {
+  if (!p) return fail(SLF_ERR_INVALID, "peer is NULL");
+  if (dptr) SLF_HIP(hipFree(dptr));
+  return SLF_OK;
+}
+
+int slf_peer_open(slf_peer* p, const void* handle64, void** mapped) {
+  if (!p || !handle64 || !mapped) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(p->ctx->device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  SLF_HIP(hipIpcOpenMemHandle(mapped, h, hipIpcMemLazyEnablePeerAccess));
+  return SLF_OK;
+}
+
+int slf_peer_close(slf_peer* p, void* mapped) {
+  if (!p) return fail(SLF_ERR_INVALID, "peer is NULL");
+  if (mapped) SLF_HIP(hipIpcCloseMemHandle(mapped));
+  return SLF_OK;
+}
+
+int slf_peer_signal(slf_peer* p, const int32_t* ranks, int n, int channel, slf_stream* stream) {
+  if (int e = peer_check_ranks(p, ranks, n, channel)) return e;
+  if (n == 0) return SLF_OK;
+  SLF_HIP(hipSetDevice(p->ctx->device));
+  // the stream's work so far, released to system scope by the command processor (every XCD's L2, not only the one the
+  // signalling wave will run on): the writes into the neighbours' buffers are in memory before the counters move
+  SLF_HIP(hipEventRecord(p->ev, native(stream)));
+  PeerSignalArgs a;
+  a.n = n;
+  for (int i = 0; i < n; i++) {
+    const size_t k = (size_t)ranks[i] * SLF_PEER_CHANNELS + channel;
+    a.flag[i] = p->remote[ranks[i]] + ((size_t)p->rank * SLF_PEER_CHANNELS + channel) * PEER_SLOT;
+    a.value[i] = ++p->sent[k];
+  }
+  hipLaunchKernelGGL(peer_signal_kernel, dim3(1), dim3(64), 0, native(stream), a);
+  SLF_HIP(hipGetLastError());
+  return SLF_OK;
+}
+
+int slf_peer_wait(slf_peer* p, const int32_t* ranks, int n, int channel, slf_stream* stream) {
+  if (int e = peer_check_ranks(p, ranks, n, channel)) return e;
+  if (n == 0) return SLF_OK;
+  SLF_HIP(hipSetDevice(p->ctx->device));
+  PeerWaitArgs a;
+  a.n = n;
+  a.channel = channel;
+  a.timeout = p->timeout;
+  a.status = p->status;
+  for (int i = 0; i < n; i++) {
+    const size_t k = (size_t)ranks[i] * SLF_PEER_CHANNELS + channel;
+    a.flag[i] = p->flags + k * PEER_SLOT;
+    a.value[i] = ++p->awaited[k];
+    a.rank[i] = ranks[i];
+  }
+  hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, native(stream), a);
+  SLF_HIP(hipGetLastError());
+  return SLF_OK;
+}
+
+int slf_peer_set_timeout(slf_peer* p, double seconds) {
+  if (!p || !(seconds > 0)) return fail(SLF_ERR_INVALID, "bad argument");
+  p->timeout = (peer_u64)(seconds * 1e8);
+  return SLF_OK;
+}
+
+int slf_peer_status(slf_peer* p, int64_t out[8]) {
+  if (!p || !out) return fail(SLF_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < 8; i++) out[i] = (int64_t)((volatile long long*)p->status)[i];
+  return SLF_OK;
+}
+
+int slf_peer_progress(slf_peer* p, int rank, int channel, uint64_t* sent, uint64_t* awaited, uint64_t* arrived) {
+  if (!p) return fail(SLF_ERR_INVALID, "peer is NULL");
+  if (rank < 0 || rank >= p->nranks || channel < 0 || channel >= SLF_PEER_CHANNELS) return fail(SLF_ERR_INVALID, "bad rank / channel");
+  const size_t k = (size_t)rank * SLF_PEER_CHANNELS + channel;
+  if (sent) *sent = p->sent[k];
+  if (awaited) *awaited = p->awaited[k];
+  if (arrived) {
+    peer_u64 v = 0;
+    SLF_HIP(hipMemcpy(&v, p->flags + k * PEER_SLOT, sizeof(v), hipMemcpyDeviceToHost));
+    *arrived = v;
+  }
+  return SLF_OK;
+}
+
+int slf_peer_selftest_fill(slf_peer* p, void* dst, size_t nwords, uint32_t pattern, int one_word_per_block, slf_stream* stream) {
+  if (!p || !dst) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (nwords == 0) return SLF_OK;
+  SLF_HIP(hipSetDevice(p->ctx->device));
+  const unsigned blocks = one_word_per_block ? (unsigned)nwords : (unsigned)((nwords + 255) / 256);
+  hipLaunchKernelGGL(peer_fill_kernel, dim3(blocks), dim3(one_word_per_block ? 64 : 256), 0, native(stream), (uint32_t*)dst, nwords,
+                     pattern, one_word_per_block);
+  SLF_HIP(hipGetLastError());
+  return SLF_OK;
+}
+
+int slf_peer_selftest_check(slf_peer* p, const void* src, size_t nwords, uint32_t pattern, slf_stream* stream, uint32_t* bad_words) {
+  if (!p || !src || !bad_words) return fail(SLF_ERR_INVALID, "NULL argument");
+  SLF_HIP(hipSetDevice(p->ctx->device));
+  SLF_HIP(hipMemsetAsync(p->bad, 0, sizeof(uint32_t), native(stream)));
+  if (nwords)
+    hipLaunchKernelGGL(peer_check_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, native(stream), (const uint32_t*)src,
+                       nwords, pattern, p->bad);
+  SLF_HIP(hipGetLastError());
+  SLF_HIP(hipMemcpyAsync(bad_words, p->bad, sizeof(uint32_t), hipMemcpyDeviceToHost, native(stream)));
+  SLF_HIP(hipStreamSynchronize(native(stream)));
+  return SLF_OK;
+}
+
 int slf_host_alloc_pinned(size_t bytes, void** hptr) {
   if (!hptr) return fail(SLF_ERR_INVALID, "hptr is NULL");
   SLF_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
@@ -1389,7 +1680,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
 // (include/sailfish_hip.h "step plans".)  Every entry is what the corresponding slf_* call would do; slf_plan_run()
 // walks the list on the calling thread -- no Python, no argument marshalling between the entries.
 namespace {
-enum PlanKind { PL_LAUNCH, PL_RECORD, PL_WAIT, PL_EXCHANGE, PL_MEMSET, PL_COPY, PL_XFACE };
+enum PlanKind { PL_LAUNCH, PL_RECORD, PL_WAIT, PL_EXCHANGE, PL_MEMSET, PL_COPY, PL_XFACE, PL_PEER_SIGNAL, PL_PEER_WAIT };
 struct PlanOp {
   PlanKind kind;
   slf_kernel* k = nullptr;
@@ -1405,6 +1696,9 @@ struct PlanOp {
   size_t bytes = 0;
   slf_module* mod = nullptr;
   void* xf[4] = {nullptr, nullptr, nullptr, nullptr};
+  slf_peer* peer = nullptr;
+  std::vector<int32_t> ranks;
+  int channel = 0;
 };
 }  // namespace
 
@@ -1519,6 +1813,29 @@ int slf_plan_add_xface_buffers(slf_plan* p, slf_module* m, void* send_low, void*
   return SLF_OK;
 }
 
+static int plan_add_peer(slf_plan* p, PlanKind kind, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream) {
+  if (!p) return fail(SLF_ERR_INVALID, "NULL argument");
+  // validated now, with the transport's rules, so that slf_plan_run cannot fail on it
+  if (int e = peer_check_ranks(peer, ranks, n, channel)) return e;
+  if (!stream) return fail(SLF_ERR_INVALID, "plan entries are asynchronous: a stream is needed");
+  PlanOp o;
+  o.kind = kind;
+  o.peer = peer;
+  o.ranks.assign(ranks, ranks + n);
+  o.channel = channel;
+  o.stream = stream;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
+int slf_plan_add_peer_signal(slf_plan* p, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream) {
+  return plan_add_peer(p, PL_PEER_SIGNAL, peer, ranks, n, channel, stream);
+}
+
+int slf_plan_add_peer_wait(slf_plan* p, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream) {
+  return plan_add_peer(p, PL_PEER_WAIT, peer, ranks, n, channel, stream);
+}
+
 int slf_plan_run(slf_plan* p, uint32_t iteration) {
   if (!p) return fail(SLF_ERR_INVALID, "plan is NULL");
   for (PlanOp& o : p->ops) {
@@ -1537,6 +1854,8 @@ int slf_plan_run(slf_plan* p, uint32_t iteration) {
         o.mod->xsend[0] = o.xf[0]; o.mod->xsend[1] = o.xf[1];
         o.mod->xrecv[0] = o.xf[2]; o.mod->xrecv[1] = o.xf[3];
         break;
+      case PL_PEER_SIGNAL: e = slf_peer_signal(o.peer, o.ranks.data(), (int)o.ranks.size(), o.channel, o.stream); break;
+      case PL_PEER_WAIT: e = slf_peer_wait(o.peer, o.ranks.data(), (int)o.ranks.size(), o.channel, o.stream); break;
     }
     if (e) return e;
   }

@@ -147,7 +147,25 @@ SIGNATURES = {
     'slf_plan_add_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'slf_plan_add_copy': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'slf_plan_add_xface_buffers': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'slf_plan_add_peer_signal': (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
+    'slf_plan_add_peer_wait': (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
     'slf_plan_run': (c_int, [c_void_p, c_uint32]),
+    'slf_peer_create': (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    'slf_peer_destroy': (c_int, [c_void_p]),
+    'slf_peer_flags_handle': (c_int, [c_void_p, c_void_p]),
+    'slf_peer_connect': (c_int, [c_void_p, c_int, c_void_p]),
+    'slf_peer_alloc': (c_int, [c_void_p, c_size_t, POINTER(c_void_p), c_void_p]),
+    'slf_peer_free': (c_int, [c_void_p, c_void_p]),
+    'slf_peer_open': (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
+    'slf_peer_close': (c_int, [c_void_p, c_void_p]),
+    'slf_peer_signal': (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
+    'slf_peer_wait': (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
+    'slf_peer_set_timeout': (c_int, [c_void_p, c_double]),
+    'slf_peer_status': (c_int, [c_void_p, POINTER(ctypes.c_int64 * 8)]),
+    'slf_peer_progress': (c_int, [c_void_p, c_int, c_int, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64),
+                                  POINTER(ctypes.c_uint64)]),
+    'slf_peer_selftest_fill': (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_int, c_void_p]),
+    'slf_peer_selftest_check': (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, POINTER(c_uint32)]),
     'slf_last_error': (c_char_p, []),
 }
 
@@ -155,6 +173,7 @@ SLF_ADDR_DIRECT, SLF_ADDR_INDIRECT = 0, 1
 SLF_DENSITY_COMPRESSIBLE, SLF_DENSITY_INCOMPRESSIBLE, SLF_DENSITY_ROUNDOFF = 0, 1, 2
 SLF_FORCE_GUO, SLF_FORCE_EDM = 0, 1
 SLF_INVALID_NODE = 0xffffffff
+SLF_PEER_HANDLE_BYTES, SLF_PEER_CHANNELS = 64, 4
 
 _lib = None
 

@@ -138,6 +138,10 @@ def rank_main(rank, world, port, gpu, dist_backend, cpus, lb_class, lb_geo, defa
                        'SLF_SPAWNED_RANK': '1'})
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ.setdefault('OMP_NUM_THREADS', '1')
+    if dist_backend == 'gloo':
+        # ranks that share a device: two hardware queues each, so that many processes do not oversubscribe the device's
+        # queue slots (a counter hop of the peer transport: 13 us instead of 2.7 ms, profiles/r06/ipc_probe.txt)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')
     if cpus and hasattr(os, 'sched_setaffinity'):
         try:
             os.sched_setaffinity(0, cpus)

@@ -115,11 +115,18 @@ class SlabSim(BoxSim):
     def _init_halo(self, exchanger):
         import torch
         from sailfish_amd.connector import init_distributed, make_ring_exchanger
+        from sailfish_amd import peer as peer_mod
+        b = self.backend
+        self.peer = self.peer_group = None
         if exchanger is None:
             init_distributed()
-        b = self.backend
+            # the neighbours' receive buffers mapped into this process (sailfish_amd/peer.py): what the sweep's edge lanes
+            # / the pack kernels write IS what the neighbour reads, the exchange is a pair of counters.  None where the
+            # ranks cannot map each other's memory (or SLF_HALO_TRANSPORT says otherwise): RCCL / torch.distributed then
+            self.peer = peer_mod.process_transport(b, self.rank, self.world)
         self.plan = SlabPlan(self.grid, self.desc, self.axis)
-        self.exchanger = exchanger or make_ring_exchanger(self.rank, self.world, b)
+        self.exchanger = exchanger or (None if self.peer is not None else make_ring_exchanger(self.rank, self.world, b))
+        self.neighbours = sorted(set([(self.rank + 1) % self.world, (self.rank - 1) % self.world]))
         self.halo_stream = b.make_stream(high_priority=os.environ.get('SLF_HALO_PRIORITY', '1') != '0')
         self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
         # a second calc stream: z / y slabs sweep their face layers on it, so that the stream of the interior sweep never
@@ -129,7 +136,7 @@ class SlabSim(BoxSim):
         # an exchanger that can be called in the middle of a step (RCCL / gloo / ring of one): the step is one program
         # (_program), replayed from a C-ABI step plan where the transport allows; exchangers that move whole buffers
         # between step_compute() and step_finish() (tests: two slabs in one process) keep the three-phase protocol
-        self.mid_step = hasattr(self.exchanger, 'exchange_range')
+        self.mid_step = hasattr(self.exchanger, 'exchange_range') or self.peer is not None
         self._plans = {}
         self._plan_ok = getattr(b, 'supports_step_plans', False) and os.environ.get('SLF_STEP_PLAN', '1') != '0'
         tdtype = torch.float32 if self.desc.precision == 4 else torch.float64
@@ -145,11 +152,21 @@ class SlabSim(BoxSim):
             def alloc(n):
                 tensors.append(torch.empty(n, dtype=tdtype, device=dev))
                 return tensors[-1].data_ptr()
-            self.xface = xface.XFaceHalo.allocate(b, self.module, self.grid, self.desc, (True, True), alloc)
-            # per parity: send low, send high, receive low, receive high  ->  s_up s_down r_low r_high
-            self.t_sets = [[tensors[4 * p + 1], tensors[4 * p + 0], tensors[4 * p + 2], tensors[4 * p + 3]] for p in (0, 1)]
-            self.t_bufs = self.t_sets[0]
-            self.xface.reset()
+            if self.peer is not None:
+                # my send planes ARE the neighbours' receive planes: what leaves through my low face is what the rank
+                # below receives through its high face
+                recv = self._peer_buffers(xface.face_count(self.desc))
+                up, down = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+                send = [[self.peer_group.lookup(down, ('recv', par, xface.HIGH)),
+                         self.peer_group.lookup(up, ('recv', par, xface.LOW))] for par in (0, 1)]
+                self.xface = xface.XFaceHalo(b, self.module, self.grid, self.desc, send, recv, shared=True)
+                self.t_sets = self.t_bufs = None
+            else:
+                self.xface = xface.XFaceHalo.allocate(b, self.module, self.grid, self.desc, (True, True), alloc)
+                # per parity: send low, send high, receive low, receive high  ->  s_up s_down r_low r_high
+                self.t_sets = [[tensors[4 * p + 1], tensors[4 * p + 0], tensors[4 * p + 2], tensors[4 * p + 3]] for p in (0, 1)]
+                self.t_bufs = self.t_sets[0]
+            self._reset_faces()
             # overlap = every batch of planes is exchanged as soon as its chunks are done
             self.overlap = self.mid_step
             self.chunks = xface.ChunkPlan(self.size[2], self.desc.periodic_fused[2], None if self.overlap else 1)
@@ -159,24 +176,67 @@ class SlabSim(BoxSim):
             self._ev_chunk = [[HIPEvent(b) for _ in range(n)] for _ in (0, 1)]
             self._ev_batch = [[HIPEvent(b) for _ in range(n)] for _ in (0, 1)]
             return
-        n = self.plan.count
-        self.t_bufs = [torch.empty(n, dtype=tdtype, device=dev) for _ in range(4)]  # s_up s_down r_low r_high
+        n = self._count = self.plan.count
+        if self.peer is not None:
+            # the pack kernels write the neighbours' receive buffers themselves; two sets that alternate by step parity,
+            # so that a set is written again only after the neighbour's unpack of two steps ago -- which precedes, on its
+            # halo stream, the signal of the step in between that this rank has waited for by then
+            recv = self._peer_buffers(n)
+            up, down = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+            bufs = [[self.peer_group.lookup(up, ('recv', par, 0)), self.peer_group.lookup(down, ('recv', par, 1)),
+                     recv[par][0], recv[par][1]] for par in (0, 1)]
+            self.t_bufs = None
+        else:
+            self.t_bufs = [torch.empty(n, dtype=tdtype, device=dev) for _ in range(4)]  # s_up s_down r_low r_high
+            bufs = [[t.data_ptr() for t in self.t_bufs]] * 2
         self.k_halo = {}
         for swap in ((False, True) if self.aa else (False,)):
             boxes = self.plan.boxes(swap)
             for di, dbuf in enumerate(self.gpu_dist):
+                # the step that uses these kernels: in place the even ones (swap), two-copy the ones that write copy di
+                par = (0 if swap else 1) if self.aa else 1 - di
                 ks = []
                 for j in range(4):
                     name = 'CollectContinuousData' if j < 2 else 'DistributeContinuousData'
-                    ks.append(b.get_kernel(self.module, name, (64,), [dbuf, self.t_bufs[j].data_ptr()] + list(boxes[j]),
-                                           'PPiiiiii'))
+                    ks.append(b.get_kernel(self.module, name, (64,), [dbuf, bufs[par][j]] + list(boxes[j]), 'PPiiiiii'))
                 self.k_halo[(swap, di)] = ks
         self._ev = [dict((name, HIPEvent(b)) for name in ('bnd', 'bulk', 'halo')) for _ in (0, 1)]
+
+    def _peer_buffers(self, count):
+        """[parity][low, high] receive buffers of `count` reals other processes can map, published under
+        ('recv', parity, face): collective, every rank in the same order."""
+        isz = 4 if self.desc.precision == 4 else 8
+        grp = self.peer_group = self.peer.group()
+        recv = [[grp.alloc(count * isz) for _ in (0, 1)] for _ in (0, 1)]
+        for par in (0, 1):
+            for a in recv[par]:
+                self.backend.memset_buf(a, 0xFF, count * isz)
+        self.backend.sync()
+        grp.publish(dict((('recv', par, f), recv[par][f]) for par in (0, 1) for f in (0, 1)))
+        return recv
+
+    def _reset_faces(self):
+        """x-face buffers: nothing has crossed the faces (initial state, a state written from the host).  With the peer
+        transport the neighbours write into my receive planes: nobody is stepping while they are filled."""
+        if self.peer is not None:
+            self.sync()
+            self.peer.barrier()
+        self.xface.reset(self.stream)
+        self._batch_events, self._prev_kind = None, None
+        if self.peer is not None:
+            self.sync()
+            self.peer.barrier()
 
     # -- one step as a program: written once against the DirectQueue / HIPPlan interface (backend_hip.py) -------------
     def _exchange(self, q, ranges):
         """One group of transfers on the halo stream: the element ranges [(first, count)] of the four face buffers
         (send up, send down, receive low, receive high)."""
+        if self.peer is not None:
+            # nothing to move: what the halo stream has waited for so far is in the neighbours' memory already
+            from sailfish_amd.peer import CH_DIST
+            q.peer_signal(self.peer, self.neighbours, CH_DIST, self.halo_stream)
+            q.peer_wait(self.peer, self.neighbours, CH_DIST, self.halo_stream)
+            return
         ex = self.exchanger
         bufs = self.t_bufs
         if getattr(ex, 'direct', False):                    # straight to RCCL (connector.RcclRingExchanger)
@@ -233,7 +293,7 @@ class SlabSim(BoxSim):
         t0 = self.backend.make_event(sh, timing=True) if (self.time_halo and not q.planned) else None
         q.launch(ks[0], None, sh)
         q.launch(ks[1], None, sh)
-        self._exchange(q, [(0, self.t_bufs[0].numel())])
+        self._exchange(q, [(0, self._count)])
         q.launch(ks[2], None, sh)
         q.launch(ks[3], None, sh)
         q.record(ev['halo'], sh)
@@ -250,7 +310,8 @@ class SlabSim(BoxSim):
         kind = 'own' if (self.aa and (it & 1) == 0) else 'push'
         prev_kind = 'push' if (not self.aa or kind == 'own') else 'own'
         par = it & 1
-        self.t_bufs = self.t_sets[par]
+        if self.t_sets is not None:
+            self.t_bufs = self.t_sets[par]
         # the z-chunks alternate between the two calc streams only on request (SLF_XFACE_STREAMS=2): a chunk that starts
         # while the one before it drains was measured SLOWER than the drain it avoids (profiles/r04/NOTES.md)
         streams = [self.calc_stream, self.calc_stream2 if os.environ.get('SLF_XFACE_STREAMS', '1') == '2' else self.calc_stream]
@@ -264,7 +325,8 @@ class SlabSim(BoxSim):
                     q.memset(a, 0xFF, x.nbytes, streams[0])
         evc, evb = self._ev_chunk[par], self._ev_batch[par]
         pevc, pevb = self._ev_chunk[1 - par], self._ev_batch[1 - par]
-        need = plan.need[prev_kind]
+        # buffers that are not copied (peer transport): a chunk also waits until the planes it writes have been read
+        need = plan.peer_need(kind, prev_kind) if x.shared else plan.need[prev_kind]
         pos_of = dict((c, pos) for pos, c in enumerate(plan.order))
         sh = self.halo_stream
         t0 = None
@@ -278,14 +340,14 @@ class SlabSim(BoxSim):
                 if streams[pos_of[c2] & 1] is not st:
                     q.wait(st, pevc[pos_of[c2]])
             q.launch(k, plan.region(c, ny), st)
-            if not plan.exchanges_at(pos) and streams[0] is streams[1]:
+            if not plan.exchanges_at(pos) and streams[0] is streams[1] and not x.shared:
                 continue                 # nothing travels after this chunk and nobody waits for it
             q.record(evc[pos], st)
             q.wait(sh, evc[pos])
             if self.time_halo and not q.planned and t0 is None:
                 t0 = self.backend.make_event(sh, timing=True)
             runs = plan.batches[kind][pos]
-            if runs:
+            if runs or x.shared:
                 self._exchange(q, [(p0 * x.plane, (p1 - p0) * x.plane) for p0, p1 in runs])
             q.record(evb[pos], sh)
         if t0 is not None:
@@ -372,7 +434,7 @@ class SlabSim(BoxSim):
                 except NotPlannable:            # the transport needs Python between the launches
                     self._plan_ok, plan = False, None
             if plan is not None:
-                if self.xface is not None:
+                if self.xface is not None and self.t_sets is not None:
                     self.t_bufs = self.t_sets[it & 1]
                 plan.run(it)
                 self.iteration += 1
@@ -386,6 +448,12 @@ class SlabSim(BoxSim):
         b.set_iteration(self.iteration)
         if self.xface is not None:
             self.xface._bound = None
+
+    def release(self):
+        BoxSim.release(self)
+        if getattr(self, 'peer_group', None) is not None:
+            self.peer_group.release()       # collective: every rank lets go of its simulation at the same point
+            self.peer_group = None
 
     def step_sweep_only(self):
         """The sweep launches of one step without any halo traffic (timing reference: what the calc stream costs
@@ -422,14 +490,17 @@ class SlabSim(BoxSim):
             if self.calc_stream2 is not self.stream:
                 self.calc_stream2.synchronize()
             self.halo_stream.synchronize()
+            if self.peer is not None:
+                self.peer.check()       # a wait that gave up (neighbour gone): an error here, not wrong numbers later
 
     def initial_conditions(self):
         BoxSim.initial_conditions(self)
         if self.halo and self.xface is not None:
-            self.xface.reset(self.stream)
-            self._batch_events, self._prev_kind = None, None
+            self._reset_faces()
         if self.halo:
             self.sync()          # the first step starts on several streams
+            if self.peer is not None:
+                self.peer.barrier()      # ... and in several processes: nobody writes into a neighbour that is not ready
 
     def materialise_faces(self):
         """With x-face buffers the arrays are stale at the faces: write the received values into them (before anything
@@ -456,11 +527,12 @@ class SlabSim(BoxSim):
         """A state written from the host: whatever crossed the x faces before no longer counts."""
         BoxSim.set_dist(self, host, which)
         if self.halo and self.xface is not None:
-            self.xface.reset(self.stream)
-            self._batch_events, self._prev_kind = None, None
+            self._reset_faces()
             self._prime_pull()
         if self.halo:
             self.sync()
+            if self.peer is not None:
+                self.peer.barrier()
 
     # -- initial state ---------------------------------------------------------
     def init_synthetic(self, seed=1234):

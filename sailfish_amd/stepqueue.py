@@ -40,6 +40,14 @@ class DirectQueue(object):
         """batch: DirectRccl.prepare(ops) -- one RCCL group"""
         rccl.run(batch, stream)
 
+    def peer_signal(self, peer, ranks, channel, stream):
+        """peer transport (sailfish_amd/peer.py): what this stream has written into the buffers of `ranks` is complete"""
+        peer.signal(ranks, channel, stream)
+
+    def peer_wait(self, peer, ranks, channel, stream):
+        """the stream continues once every rank of `ranks` has sent its matching signal"""
+        peer.wait(ranks, channel, stream)
+
     def memset(self, addr, value, nbytes, stream):
         self._of(stream).memset_buf(addr, value, nbytes, stream)
 

@@ -120,6 +120,24 @@ class ChunkPlan(object):
             need.append(max(js) if js else -1)
         return batches, need
 
+    def peer_need(self, kind, prev_kind):
+        """`need` for face buffers that are NOT copied: my send planes ARE the neighbour's receive planes (peer transport
+        between processes, sailfish_amd/peer.py; subdomains of one process, controller.LocalGroup).  Chunk c of a step of
+        kind `kind` then waits for the position of the neighbours' PREVIOUS step after which (a) the planes it reads are
+        complete -- need[prev_kind][c], as with copies -- and (b) the planes it WRITES are no longer being read: the
+        neighbours' previous step read the set this step writes (the sets alternate by step parity), chunk c' of it the
+        planes reads_after(kind, c') -- what the step before, of this step's kind, had left there.  Both sides run the
+        same plan (1-D x decomposition: equal y / z extents, same chunk count), and a position's signal follows the
+        completion of its chunk, so one position per chunk covers both.  Needs a signal after EVERY position
+        (exchanges_at is not consulted by the callers in this mode)."""
+        pos_of = dict((c, pos) for pos, c in enumerate(self.order))
+        out = []
+        for c in range(len(self.chunks)):
+            mine = set(self.writes(kind, c))
+            war = [pos_of[c2] for c2 in range(len(self.chunks)) if mine & set(self.reads_after(kind, c2))]
+            out.append(max([self.need[prev_kind][c]] + war))
+        return out
+
     def exchanges_at(self, pos):
         """Does a transfer (of either step kind) start after the chunk at position `pos`?  Positions without one need no
         event either: nothing waits for them."""
@@ -145,9 +163,11 @@ class ChunkPlan(object):
 
 
 class XFaceHalo(object):
-    def __init__(self, backend, module, grid, desc, send, recv):
+    def __init__(self, backend, module, grid, desc, send, recv, shared=False):
         """send / recv: [parity][face] device addresses of buffers of face_count(desc) reals each, 0 for a face that
-        is not connected (or one [face] list: no alternation)."""
+        is not connected (or one [face] list: no alternation).  shared: the send buffers are a neighbour's receive
+        buffers (its memory, mapped here: peer transport) -- this side never fills them.  Every buffer this subdomain
+        owns starts out as 'nothing has crossed here' (reset(); the C ABI's contract, include/sailfish_hip.h)."""
         self.backend, self.module, self.grid, self.desc = backend, module, grid, desc
         self.dtype = np.float32 if desc.precision == 4 else np.float64
         self.plane = NXD * desc.arr_ny                  # elements of one z-plane of a face buffer
@@ -160,7 +180,9 @@ class XFaceHalo(object):
         self.enter = [sym.get_prop_dists(grid, 1, 0), sym.get_prop_dists(grid, -1, 0)]
         self._kernels = {}
         self._bound = None
+        self.shared = bool(shared)
         self.bind(0, 1)
+        self.reset()
 
     @classmethod
     def allocate(cls, backend, module, grid, desc, faces, alloc):

@@ -213,5 +213,40 @@ c.run(ignore_cmdline=True)
   r5v19)   # the resident path's eligibility rule
     ( time timeout 900 python -m pytest tests/test_gpu_resident.py tests/test_gpu_runner.py -m gpu -q -x --durations=3 ) > $O/pytest_resident_rule.log 2>&1; tail -8 $O/pytest_resident_rule.log
     ;;
+  r6v1)   # peer transport (HIP IPC mappings + progress counters): one rank against itself, then 2 / 8 processes on the one GPU
+    export SLF_PEER_TIMEOUT_S=30
+    X="--steps 40 --warmup 10 --prewarm_steps 40 --repeats 1 --no_cpu_baseline --no_gpu_state --min_seconds 0.3 --halo_timing_steps 6"
+    line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d.get('config',{}); r=(c.get('per_rank') or [{}])[0]; print('$1', d.get('value'), d.get('ms_per_step'), c.get('access_pattern'), 'validated', c.get('validated'), 'rccl_ranks', c.get('rccl_ranks'), 'exposed', c.get('halo_exposed_ms'), 'sweep_only', r.get('sweep_only_ms'), '|', (c.get('halo_transport') or '')[:60], d.get('error'))" 2>&1 | tail -1; }
+    for tr in peer rccl; do
+      for ax in x z; do
+        SLF_HALO_TRANSPORT=$tr timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 \
+          bench.py --gpus 1 --force_distributed --scaling strong --domain 128x512x512 --axis $ax $X 2> $O/one_${tr}_$ax.err | tail -1 > $O/one_${tr}_$ax.json
+        line "one rank $tr $ax" < $O/one_${tr}_$ax.json | tee -a $O/summary.txt
+      done
+    done
+    for n in 2 8; do
+      for ax in x z; do
+        SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus $n --scaling strong --domain 1024x512x512 --axis $ax $X 2> $O/n${n}_$ax.err | tail -1 > $O/n${n}_$ax.json
+        line "$n processes $ax" < $O/n${n}_$ax.json | tee -a $O/summary.txt
+      done
+    done
+    tail -n 5 $O/*.err | tail -n 60
+    ;;
+  r6v2)   # eight processes on the one GPU: hardware queues per process x z-chunks of the x-split sweep
+    export SLF_PEER_TIMEOUT_S=30
+    X="--steps 40 --warmup 10 --prewarm_steps 40 --repeats 1 --no_cpu_baseline --no_gpu_state --min_seconds 0.3 --halo_timing_steps 6 --access_pattern AA --no_validate"
+    line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d.get('config',{}); r=(c.get('per_rank') or [{}])[0]; print('$1', d.get('value'), d.get('ms_per_step'), c.get('access_pattern'), 'validated', c.get('validated'), 'exposed', c.get('halo_exposed_ms'), 'sweep_only', r.get('sweep_only_ms'), d.get('error'))" 2>&1 | tail -1; }
+    for q in 3 4; do GPU_MAX_HW_QUEUES=$q timeout 120 tools/probe/ipc_probe 8 262144 10 256 2>&1 | grep "ring ping" | sed "s/^/queues $q: /" | tee -a $O/summary.txt; done
+    for q in 2 3 4; do
+      for ch in 4 2 1; do
+        GPU_MAX_HW_QUEUES=$q SLF_XFACE_CHUNKS=$ch SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 600 python bench.py --gpus 8 --scaling strong --domain 1024x512x512 --axis x $X 2> $O/n8_x_q${q}_c$ch.err | tail -1 > $O/n8_x_q${q}_c$ch.json
+        line "8 processes x, $q queues, $ch chunks" < $O/n8_x_q${q}_c$ch.json | tee -a $O/summary.txt
+      done
+    done
+    for q in 3 4; do
+      GPU_MAX_HW_QUEUES=$q SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 600 python bench.py --gpus 8 --scaling strong --domain 1024x512x512 --axis z $X 2> $O/n8_z_q$q.err | tail -1 > $O/n8_z_q$q.json
+      line "8 processes z, $q queues" < $O/n8_z_q$q.json | tee -a $O/summary.txt
+    done
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
