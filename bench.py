@@ -169,6 +169,9 @@ def self_launch(n):
         # oversubscribe the device's queue slots, and a counter hop of the peer transport costs 2.7 ms instead of 13 us
         # (profiles/r06/ipc_probe.txt)
         env.setdefault('GPU_MAX_HW_QUEUES', '2')
+        # ... and no stream priorities: a high-priority queue with a waiting kernel in it holds the other processes'
+        # sweeps back (eight z-slab processes: 29.5 GMLUPS with, 35.4 without, profiles/r06/peer_eight_processes.txt)
+        env.setdefault('SLF_HALO_PRIORITY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -644,8 +647,8 @@ def run(args, world, rank, wd):
             cfg['gpu_state'] = {'before': st_before, 'after': st_after}
         out = {
             'metric': 'MLUPS (million lattice updates/s), %s' % what,
-            'value': round(to_mlups(elapsed), 1), 'best_value': round(max(all_mlups), 1),
-            'median_value': round(to_mlups(elapsed), 1),
+            'value': round(to_mlups(elapsed), 1), 'value_kind': 'median block (rounds 3-4 reported the fastest block: best_value)',
+            'best_value': round(max(all_mlups), 1),
             'unit': 'MLUPS', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,

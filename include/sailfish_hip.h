@@ -249,9 +249,10 @@ int slf_comm_exchange(slf_comm* comm, const slf_comm_op* ops, int n, slf_stream*
  *                             of another process (whole allocation; offsets are the caller's business);
  *        slf_peer_signal      after everything enqueued on `stream` so far (its writes released to system scope):
  *                             counter[me -> r][channel] = ++sent[r][channel] in the memory of every listed rank r;
- *        slf_peer_wait        `stream` continues when counter[r -> me][channel] >= ++awaited[r][channel] for every
- *                             listed rank r.  The k-th wait for (r, channel) matches r's k-th signal to this rank on
- *                             that channel: both sides enqueue the same sequence per pair, as they must for RCCL.
+ *        slf_peer_wait        `stream` continues when `count` further signals of every listed rank r have arrived:
+ *                             counter[r -> me][channel] >= (awaited[r][channel] += count).  Waits and signals of a
+ *                             pair match by order on the channel: both sides enqueue the same sequence per pair, as
+ *                             they must for RCCL; one wait may cover several signals (count > 1).
  *      A wait gives up after the time-out (slf_peer_set_timeout, default 60 s; the spin is bounded so that a lost
  *      neighbour cannot hang the device) and leaves {1, rank, channel, expected, seen} in slf_peer_status, which the
  *      host polls when it synchronises anyway.  Write-after-read is the caller's: a receive buffer must not be written
@@ -271,7 +272,7 @@ int slf_peer_free(slf_peer* peer, void* dptr);
 int slf_peer_open(slf_peer* peer, const void* handle64, void** mapped);
 int slf_peer_close(slf_peer* peer, void* mapped);
 int slf_peer_signal(slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
-int slf_peer_wait(slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
+int slf_peer_wait(slf_peer* peer, const int32_t* ranks, int n, int channel, int count, slf_stream* stream);
 int slf_peer_set_timeout(slf_peer* peer, double seconds);
 /* out = {timed out (0 | 1), rank waited for, channel, expected count, count seen, waits timed out so far, 0, 0} */
 int slf_peer_status(slf_peer* peer, int64_t out[8]);
@@ -453,7 +454,8 @@ int slf_plan_add_copy(slf_plan* plan, void* dst, const void* src, size_t bytes, 
 int slf_plan_add_xface_buffers(slf_plan* plan, slf_module* m, void* send_low, void* send_high, void* recv_low,
                                void* recv_high);                                /* slf_module_set_xface_buffers */
 int slf_plan_add_peer_signal(slf_plan* plan, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
-int slf_plan_add_peer_wait(slf_plan* plan, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
+int slf_plan_add_peer_wait(slf_plan* plan, slf_peer* peer, const int32_t* ranks, int n, int channel, int count,
+                           slf_stream* stream);
 int slf_plan_run(slf_plan* plan, uint32_t iteration);
 
 const char* slf_last_error(void);

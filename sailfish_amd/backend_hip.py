@@ -222,9 +222,9 @@ class HIPPlan(object):
                'slf_plan_add_peer_signal')
         self._keep += [peer, stream]
 
-    def peer_wait(self, peer, ranks, channel, stream):
+    def peer_wait(self, peer, ranks, channel, stream, count=1):
         arr, n = peer.ranks_array(ranks)
-        _check(self._lib, self._lib.slf_plan_add_peer_wait(self.handle, peer.handle, arr, n, int(channel), self._h(stream)),
+        _check(self._lib, self._lib.slf_plan_add_peer_wait(self.handle, peer.handle, arr, n, int(channel), int(count), self._h(stream)),
                'slf_plan_add_peer_wait')
         self._keep += [peer, stream]
 

@@ -43,6 +43,14 @@ def init_distributed(backend=None, force=False):
     return rank, world
 
 
+class NoQuiesce(object):
+    def quiesce(self, runner):
+        """Nobody else writes into this runner's halo buffers behind its back: nothing to wait for."""
+
+    def release(self, runner):
+        pass
+
+
 class RingExchanger(object):
     """Nearest-neighbour exchange on a periodic 1-D ring of ranks (slab decomposition).
 
@@ -206,7 +214,7 @@ def make_ring_exchanger(rank, world, backend):
     return RingExchanger(rank, world)
 
 
-class LocalConnector(object):
+class LocalConnector(NoQuiesce):
     """All subdomains live in this process (one or several GPUs): halos move with device-to-device
     copies driven by the group driver (controller.LocalGroup); the reference's counterpart is
     MPSubdomainConnector (connector.py:120-174), which stages through shared host memory."""
@@ -227,7 +235,7 @@ class LocalConnector(object):
             raise RuntimeError('LocalConnector exchanges are driven by controller.LocalGroup')
 
 
-class TorchDistConnector(object):
+class TorchDistConnector(NoQuiesce):
     """Neighbours live in other processes (one process per GPU): point-to-point send / receive of the
     packed halo buffers with torch.distributed (RCCL over xGMI for CUDA tensors, gloo for CPU tensors in
     the tests).  Replaces ZMQSubdomainConnector (reference connector.py:73-117)."""
@@ -398,3 +406,99 @@ class TorchDistConnector(object):
                                                      device=torch.device('cuda', runner.backend.gpu_id))
         with torch.cuda.stream(self._stream):
             self.exchange_tensors(sends, recvs)
+
+
+class PeerConnector(TorchDistConnector):
+    """Neighbours live in other processes of this node and every process can map the others' device memory
+    (sailfish_amd/peer.py): a halo is never sent.  Each runner allocates its RECEIVE buffers -- two sets that alternate
+    by step parity -- and publishes them; the buffers its pack kernels (or the edge lanes of its x-split sweep) write
+    into are the neighbours' receive buffers, mapped here.  What remains of the exchange is a pair of plan entries:
+    signal "my writes of this step are in your memory", wait for the neighbours' signal.
+
+    Why two sets are enough (general faces; the x-face buffers add xface.ChunkPlan.peer_need): set p is written by my
+    pack of step it (p = it & 1) and read by the neighbour's unpack of step it; it is written again by my pack of step
+    it + 2, which follows -- on my data stream -- my wait for the neighbour's signal of step it + 1, and the neighbour
+    enqueued that signal behind its unpack of step it on ITS data stream."""
+    zero_copy = True
+    mid_step = True
+
+    def __init__(self, id_to_rank, transport):
+        TorchDistConnector.__init__(self, id_to_rank)
+        self.peer = transport
+        self._groups = {}
+
+    def _group(self, runner):
+        g = self._groups.get(id(runner))
+        if g is None:
+            g = self._groups[id(runner)] = {'group': self.peer.group(), 'names': {}, 'published': False}
+        return g
+
+    def alloc_recv(self, runner, kind, nid, parity, nelems, dtype):
+        """My receive buffer for what subdomain `nid` sends me (`kind`: 'dist' | 'macro') in the steps of `parity`."""
+        import numpy as np
+        g = self._group(runner)
+        nbytes = max(1, int(nelems)) * np.dtype(dtype).itemsize
+        addr = g['group'].alloc(nbytes)
+        g['names'][(kind, int(runner._spec.id), int(nid), int(parity))] = addr
+        return addr
+
+    def resolve(self, runner):
+        """Collective (every rank once per call site of its set-up, in the same order): afterwards send_addr() works."""
+        g = self._group(runner)
+        g['group'].publish(g['names'])
+
+    def send_addr(self, runner, kind, nid, parity):
+        """Where this process reaches the buffer in which subdomain `nid` receives what `runner` sends it."""
+        g = self._group(runner)
+        return g['group'].lookup(self.id_to_rank[nid], (kind, int(nid), int(runner._spec.id), int(parity)))
+
+    def _ranks(self, nids):
+        return sorted(set(self.id_to_rank[n] for n in nids))
+
+    def enqueue_exchange(self, q, runner, kind='dist'):
+        from sailfish_amd import peer as peer_mod
+        nids = [m[0] for m in runner.halo_messages(kind) if m[2] or m[4]]
+        if not nids:
+            return
+        ch = peer_mod.CH_DIST if kind == 'dist' else peer_mod.CH_MACRO
+        q.peer_signal(self.peer, self._ranks(nids), ch, runner._data_stream)
+        q.peer_wait(self.peer, self._ranks(nids), ch, runner._data_stream)
+
+    def enqueue_pieces(self, q, runner, pieces):
+        """x-face buffers: nothing to move, the planes are in the neighbours' memory when the chunk is done."""
+        from sailfish_amd import peer as peer_mod
+        ranks = self._ranks(nid for nid, _ in runner._xface_routes)
+        q.peer_signal(self.peer, ranks, peer_mod.CH_DIST, runner._data_stream)
+        q.peer_wait(self.peer, ranks, peer_mod.CH_DIST, runner._data_stream)
+
+    def exchange(self, runner, kind='dist'):
+        from sailfish_amd.stepqueue import DirectQueue
+        self.enqueue_exchange(DirectQueue(runner.backend), runner, kind)
+
+    def exchange_pieces(self, runner, pieces):
+        from sailfish_amd.stepqueue import DirectQueue
+        self.enqueue_pieces(DirectQueue(runner.backend), runner, pieces)
+
+    def quiesce(self, runner):
+        """The neighbours write into this runner's buffers themselves: before the host touches them (initial state, a
+        restored checkpoint) every process has stopped stepping, and nobody starts again before all are done."""
+        runner.backend.sync_stream(*runner._all_streams())
+        self.peer.check()
+        self.peer.barrier()
+
+    def release(self, runner):
+        g = self._groups.pop(id(runner), None)
+        if g is not None:
+            # not collective (runners are let go of wherever their owner pleases): a neighbour that still has a buffer
+            # mapped keeps the memory behind it alive until it closes the mapping
+            g['group'].release(collective=False)
+
+
+def make_connector(id_to_rank, backend, rank, world):
+    """The connector of a runner that owns its process: peer mappings where the processes of the run can map each other's
+    memory (collective: every rank asks here), else torch.distributed / RCCL."""
+    from sailfish_amd import peer as peer_mod
+    pt = peer_mod.process_transport(backend, rank, world)
+    if pt is not None:
+        return PeerConnector(id_to_rank, pt)
+    return TorchDistConnector(id_to_rank)

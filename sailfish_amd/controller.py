@@ -24,7 +24,7 @@ import sys
 import time
 
 from sailfish_amd import config, io, subdomain_connection, util
-from sailfish_amd.connector import LocalConnector, TorchDistConnector, init_distributed
+from sailfish_amd.connector import LocalConnector, TorchDistConnector, init_distributed, make_connector  # noqa: F401
 from sailfish_amd.geo import LBGeometry2D, LBGeometry3D
 
 
@@ -409,9 +409,10 @@ class LBSimulationController(object):
         gpus = cfg.gpus if isinstance(cfg.gpus, (list, tuple)) else [cfg.gpus]
         output_cls = io.format_name_to_cls[cfg.output_format]
 
-        def make_runner(spec, gpu, connector):
+        def make_runner(spec, gpu, connector, backend=None):
             sim = self._lb_class(cfg)
-            backend = backend_cls(cfg, gpu)
+            if backend is None:
+                backend = backend_cls(cfg, gpu)
             output = output_cls(cfg, spec.id)
             runner_cls = sim.subdomain_runner
             runner = runner_cls(sim, spec, output, backend, None)
@@ -439,8 +440,11 @@ class LBSimulationController(object):
                                     '(%d subdomains, %d ranks)' % (len(subdomains), world))
             # (SLF_FORCE_DEVICE: every rank on that GPU, with SLF_DIST_BACKEND=gloo -- tests/test_gpu_two_ranks.py)
             local_rank = int(os.environ.get('SLF_FORCE_DEVICE', os.environ.get('LOCAL_RANK', rank)))
-            connector = TorchDistConnector(dict((s.id, s.id) for s in subdomains))
-            runner = make_runner(subdomains[rank], local_rank, connector)
+            # the neighbours' receive buffers mapped into this process where the ranks can map each other's memory (one
+            # node; also ranks that share a device), RCCL / torch.distributed otherwise
+            backend = backend_cls(cfg, local_rank)
+            connector = make_connector(dict((s.id, s.id) for s in subdomains), backend, rank, world)
+            runner = make_runner(subdomains[rank], local_rank, connector, backend)
             self.runners = [runner]
             runner.run()
         else:

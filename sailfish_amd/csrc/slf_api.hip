@@ -647,8 +647,9 @@ int slf_peer_signal(slf_peer* p, const int32_t* ranks, int n, int channel, slf_s
   return SLF_OK;
 }
 
-int slf_peer_wait(slf_peer* p, const int32_t* ranks, int n, int channel, slf_stream* stream) {
+int slf_peer_wait(slf_peer* p, const int32_t* ranks, int n, int channel, int count, slf_stream* stream) {
   if (int e = peer_check_ranks(p, ranks, n, channel)) return e;
+  if (count < 1) return fail(SLF_ERR_INVALID, "peer wait: count must be at least 1");
   if (n == 0) return SLF_OK;
   SLF_HIP(hipSetDevice(p->ctx->device));
   PeerWaitArgs a;
@@ -659,7 +660,7 @@ int slf_peer_wait(slf_peer* p, const int32_t* ranks, int n, int channel, slf_str
   for (int i = 0; i < n; i++) {
     const size_t k = (size_t)ranks[i] * SLF_PEER_CHANNELS + channel;
     a.flag[i] = p->flags + k * PEER_SLOT;
-    a.value[i] = ++p->awaited[k];
+    a.value[i] = (p->awaited[k] += (peer_u64)count);
     a.rank[i] = ranks[i];
   }
   hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, native(stream), a);
@@ -1361,7 +1362,9 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     const long long nw = (long long)(tx + 2 * halo) * (long long)(ty + 2 * halo);
     if (nw > 2 * 1024) return fail(SLF_ERR_INVALID, "CollideAndPropagateResident: window larger than 2048 nodes");
     const int q = 9;
-    if (slf::resident_lds_bytes(q, k->mod->sel.precision, aa, tx + 2 * halo, ty + 2 * halo) > 160 * 1024)
+    // the window (dynamic LDS) + the kernel's own tables (static: the list of a window's boundary-condition nodes,
+    // slf_resident.hip) share the 160 KiB of a workgroup
+    if (slf::resident_lds_bytes(q, k->mod->sel.precision, aa, tx + 2 * halo, ty + 2 * halo) + 4352 > 160 * 1024)
       return fail(SLF_ERR_INVALID, "CollideAndPropagateResident: window does not fit the 160 KiB of LDS");
   }
   if (k->mod->geo.indirect && (k->kind == KK_SC_FUSED || k->sc_local_velocity))
@@ -1813,8 +1816,10 @@ int slf_plan_add_xface_buffers(slf_plan* p, slf_module* m, void* send_low, void*
   return SLF_OK;
 }
 
-static int plan_add_peer(slf_plan* p, PlanKind kind, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream) {
+static int plan_add_peer(slf_plan* p, PlanKind kind, slf_peer* peer, const int32_t* ranks, int n, int channel, int count,
+                         slf_stream* stream) {
   if (!p) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (count < 1) return fail(SLF_ERR_INVALID, "peer wait: count must be at least 1");
   // validated now, with the transport's rules, so that slf_plan_run cannot fail on it
   if (int e = peer_check_ranks(peer, ranks, n, channel)) return e;
   if (!stream) return fail(SLF_ERR_INVALID, "plan entries are asynchronous: a stream is needed");
@@ -1823,17 +1828,18 @@ static int plan_add_peer(slf_plan* p, PlanKind kind, slf_peer* peer, const int32
   o.peer = peer;
   o.ranks.assign(ranks, ranks + n);
   o.channel = channel;
+  o.value = count;
   o.stream = stream;
   p->ops.push_back(o);
   return SLF_OK;
 }
 
 int slf_plan_add_peer_signal(slf_plan* p, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream) {
-  return plan_add_peer(p, PL_PEER_SIGNAL, peer, ranks, n, channel, stream);
+  return plan_add_peer(p, PL_PEER_SIGNAL, peer, ranks, n, channel, 1, stream);
 }
 
-int slf_plan_add_peer_wait(slf_plan* p, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream) {
-  return plan_add_peer(p, PL_PEER_WAIT, peer, ranks, n, channel, stream);
+int slf_plan_add_peer_wait(slf_plan* p, slf_peer* peer, const int32_t* ranks, int n, int channel, int count, slf_stream* stream) {
+  return plan_add_peer(p, PL_PEER_WAIT, peer, ranks, n, channel, count, stream);
 }
 
 int slf_plan_run(slf_plan* p, uint32_t iteration) {
@@ -1855,7 +1861,7 @@ int slf_plan_run(slf_plan* p, uint32_t iteration) {
         o.mod->xrecv[0] = o.xf[2]; o.mod->xrecv[1] = o.xf[3];
         break;
       case PL_PEER_SIGNAL: e = slf_peer_signal(o.peer, o.ranks.data(), (int)o.ranks.size(), o.channel, o.stream); break;
-      case PL_PEER_WAIT: e = slf_peer_wait(o.peer, o.ranks.data(), (int)o.ranks.size(), o.channel, o.stream); break;
+      case PL_PEER_WAIT: e = slf_peer_wait(o.peer, o.ranks.data(), (int)o.ranks.size(), o.channel, o.value, o.stream); break;
     }
     if (e) return e;
   }

@@ -60,6 +60,7 @@ constexpr uint32_t RI_SIMPLE = 2u;     // ... whose code is the plain one: fluid
 constexpr uint32_t RI_TILE = 4u;       // node of the tile (the on-GPU invalid-value check looks at these only)
 constexpr uint32_t RI_WALL = 8u;       // a plain node that is a full-way bounce-back node
 constexpr int RI_DIST_SHIFT = 8;       // bits 8..: distance from the tile (0 inside it)
+// (s_complex + s_ncomplex below: 4100 bytes of STATIC LDS next to the window -- the hosts' 160 KiB bound counts 4352 for it)
 constexpr int RESIDENT_MAX_COMPLEX = 2048;  // boundary-condition nodes of a window (all of them fit: windows have at most 2048 nodes)
 
 template <class L, class R, int MODEL, bool AA, bool GENERAL>

@@ -148,7 +148,7 @@ SIGNATURES = {
     'slf_plan_add_copy': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'slf_plan_add_xface_buffers': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'slf_plan_add_peer_signal': (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
-    'slf_plan_add_peer_wait': (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
+    'slf_plan_add_peer_wait': (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_int, c_void_p]),
     'slf_plan_run': (c_int, [c_void_p, c_uint32]),
     'slf_peer_create': (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     'slf_peer_destroy': (c_int, [c_void_p]),
@@ -159,7 +159,7 @@ SIGNATURES = {
     'slf_peer_open': (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
     'slf_peer_close': (c_int, [c_void_p, c_void_p]),
     'slf_peer_signal': (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
-    'slf_peer_wait': (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
+    'slf_peer_wait': (c_int, [c_void_p, POINTER(c_int32), c_int, c_int, c_int, c_void_p]),
     'slf_peer_set_timeout': (c_int, [c_void_p, c_double]),
     'slf_peer_status': (c_int, [c_void_p, POINTER(ctypes.c_int64 * 8)]),
     'slf_peer_progress': (c_int, [c_void_p, c_int, c_int, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64),

@@ -142,6 +142,7 @@ def rank_main(rank, world, port, gpu, dist_backend, cpus, lb_class, lb_geo, defa
         # ranks that share a device: two hardware queues each, so that many processes do not oversubscribe the device's
         # queue slots (a counter hop of the peer transport: 13 us instead of 2.7 ms, profiles/r06/ipc_probe.txt)
         os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')
+        os.environ.setdefault('SLF_HALO_PRIORITY', '0')     # a waiting kernel in a high-priority queue holds the other processes back
     if cpus and hasattr(os, 'sched_setaffinity'):
         try:
             os.sched_setaffinity(0, cpus)

@@ -48,6 +48,7 @@ class PeerGroup(object):
     def __init__(self, transport):
         self.t = transport
         self._own = []           # device addresses allocated through this group
+        self._opened = {}        # (rank, handle) -> where that buffer of another process is mapped here
         self._tables = None
 
     def alloc(self, nbytes):
@@ -70,7 +71,13 @@ class PeerGroup(object):
         if rank == self.t.rank:
             return self._names[name]
         handle, off = self._tables[rank][name]
-        return self.t.open(rank, handle) + off
+        key = (rank, handle)
+        if key not in self._opened:
+            # mapped per group and closed with it: a handle names an ALLOCATION, and an allocation that is freed and made
+            # again (the next simulation of the same process) may come back under the same handle -- a mapping kept
+            # beyond its group would then point at memory nobody owns any more
+            self._opened[key] = self.t.open(rank, handle)
+        return self._opened[key] + off
 
     def release(self, collective=True):
         """Frees this group's buffers.  collective: every rank is doing the same right now, so wait until nobody can
@@ -80,6 +87,9 @@ class PeerGroup(object):
                 self.t.barrier()
             except Exception:  # noqa: BLE001 -- a rank that has gone cannot hold the others back here
                 pass
+        for addr in self._opened.values():
+            self.t.close_mapping(addr)
+        self._opened = {}
         for addr in self._own:
             self.t.free(addr)
         self._own = []
@@ -93,7 +103,6 @@ class PeerTransport(object):
         self.backend, self.rank, self.world = backend, int(rank), int(world)
         self.lib = backend._lib
         self._allocs = {}            # base address -> (bytes, handle)
-        self._opened = {}            # (rank, handle) -> mapped base address
         self._arrays = {}
         self.handle = None
         d = _dist()
@@ -219,13 +228,15 @@ class PeerTransport(object):
         raise KeyError('address %#x is not inside a peer buffer of this process' % addr)
 
     def open(self, rank, handle):
-        key = (rank, handle)
-        if key not in self._opened:
-            p = ctypes.c_void_p()
-            _check(self.lib, self.lib.slf_peer_open(self.handle, ctypes.create_string_buffer(handle, len(handle)), ctypes.byref(p)),
-                   'slf_peer_open(rank %d)' % rank)
-            self._opened[key] = p.value
-        return self._opened[key]
+        """Maps a buffer of another process (whole allocation); the caller closes it (PeerGroup does)."""
+        p = ctypes.c_void_p()
+        _check(self.lib, self.lib.slf_peer_open(self.handle, ctypes.create_string_buffer(handle, len(handle)), ctypes.byref(p)),
+               'slf_peer_open(rank %d)' % rank)
+        return p.value
+
+    def close_mapping(self, addr):
+        if self.handle is not None:
+            self.lib.slf_peer_close(self.handle, ctypes.c_void_p(addr))
 
     def group(self):
         return PeerGroup(self)
@@ -242,9 +253,10 @@ class PeerTransport(object):
         arr, n = self.ranks_array(ranks)
         _check(self.lib, self.lib.slf_peer_signal(self.handle, arr, n, int(channel), stream.handle), 'slf_peer_signal')
 
-    def wait(self, ranks, channel, stream):
+    def wait(self, ranks, channel, stream, count=1):
+        """`stream` continues once `count` further signals of every rank of `ranks` have arrived."""
         arr, n = self.ranks_array(ranks)
-        _check(self.lib, self.lib.slf_peer_wait(self.handle, arr, n, int(channel), stream.handle), 'slf_peer_wait')
+        _check(self.lib, self.lib.slf_peer_wait(self.handle, arr, n, int(channel), int(count), stream.handle), 'slf_peer_wait')
 
     def set_timeout(self, seconds):
         _check(self.lib, self.lib.slf_peer_set_timeout(self.handle, float(seconds)), 'slf_peer_set_timeout')
@@ -285,9 +297,6 @@ class PeerTransport(object):
 
     def close(self):
         if self.handle is not None:
-            for addr in self._opened.values():
-                self.lib.slf_peer_close(self.handle, ctypes.c_void_p(addr))
-            self._opened = {}
             for addr in list(self._allocs):
                 self.free(addr)
             self.lib.slf_peer_destroy(self.handle)

@@ -127,6 +127,7 @@ class SlabSim(BoxSim):
         self.plan = SlabPlan(self.grid, self.desc, self.axis)
         self.exchanger = exchanger or (None if self.peer is not None else make_ring_exchanger(self.rank, self.world, b))
         self.neighbours = sorted(set([(self.rank + 1) % self.world, (self.rank - 1) % self.world]))
+        self._peer_open = None     # x faces over the peer transport: (kind of the last step, kind of the next) while its signals are unconsumed
         self.halo_stream = b.make_stream(high_priority=os.environ.get('SLF_HALO_PRIORITY', '1') != '0')
         self.t_halo_stream = torch.cuda.ExternalStream(self.halo_stream.native, device=torch.device('cuda', b.gpu_id))
         # a second calc stream: z / y slabs sweep their face layers on it, so that the stream of the interior sweep never
@@ -258,8 +259,67 @@ class SlabSim(BoxSim):
 
     def _program(self, q, it, save_macro):
         if self.xface is not None:
+            if self.peer is not None:
+                return self._program_xface_peer(q, it, save_macro)
             return self._program_xface(q, it, save_macro)
         return self._program_box(q, it, save_macro)
+
+    def _step_kinds(self, it):
+        kind = 'own' if (self.aa and (it & 1) == 0) else 'push'
+        other = 'push' if (not self.aa or kind == 'own') else 'own'        # the step before and the step after
+        return kind, other
+
+    def _program_xface_peer(self, q, it, save_macro):
+        """x slabs whose send planes ARE the neighbours' receive planes (peer transport).  Calc stream: [wait] chunk
+        [wait] chunk ...; halo stream: after every chunk the neighbours' next step counts on, a signal.  A wait is a
+        one-lane kernel IN FRONT OF THE CHUNK THAT NEEDS IT: it asks for the signals of the neighbours' previous step up
+        to the position after which the planes the chunk reads are complete and the planes it writes have been read
+        (xface.ChunkPlan.peer_counts) -- by then they have normally arrived, and a neighbour that is late holds back
+        exactly the work that depends on it (a wait enqueued right behind this step's own signal, on a stream of its
+        own, spins until the neighbours are as far as this rank -- and stalls whatever shares its hardware queue: eight
+        processes on one device ran at 7-28 instead of 38 GMLUPS that way, profiles/r06/peer_eight_processes.txt).
+        The first step after the counters were drained (self._peer_open is None) has nothing to wait for."""
+        from sailfish_amd.peer import CH_DIST
+        x, plan, ny = self.xface, self.chunks, self.size[1]
+        k = self.k_sweep[int(save_macro)][0] if self.aa else self.k_sweep[int(save_macro)][it & 1]
+        kind, other = self._step_kinds(it)
+        par = it & 1
+        snd, rcv = x.send[par], x.recv[1 - par]
+        q.xface(self.module, snd[xface.LOW], snd[xface.HIGH], rcv[xface.LOW], rcv[xface.HIGH])
+        sk, sh = self.calc_stream, self.halo_stream
+        evc = self._ev_chunk[par]
+        waits = dict(plan.peer_counts(kind, other)) if self._peer_open is not None else {}
+        signals = set(plan.peer_signals(kind, other))
+        t0 = None
+        for pos, c in enumerate(plan.order):
+            if pos in waits:
+                q.peer_wait(self.peer, self.neighbours, CH_DIST, sk, waits[pos])
+            q.launch(k, plan.region(c, ny), sk)
+            if pos not in signals:
+                continue
+            q.record(evc[pos], sk)
+            q.wait(sh, evc[pos])
+            if self.time_halo and not q.planned and t0 is None:
+                t0 = self.backend.make_event(sh, timing=True)
+            q.peer_signal(self.peer, self.neighbours, CH_DIST, sh)
+        if t0 is not None:
+            self._halo_events.append((t0, self.backend.make_event(sh, timing=True)))
+
+    def _peer_drain(self):
+        """Consumes the signals of the neighbours' last step that no step of this rank has waited for yet (the waits of
+        a step refer to the step before): afterwards the counters of both sides agree again and the next step starts
+        as a first step.  Before anything rewrites the state or lets go of the buffers."""
+        if self.peer is None or getattr(self, '_peer_open', None) is None:
+            return
+        if self.xface is None:
+            self._box_back(DirectQueue(self.backend), self.iteration - 1)
+        else:
+            from sailfish_amd.peer import CH_DIST
+            kind, nxt = self._peer_open
+            n = len(self.chunks.peer_signals(kind, nxt))
+            if n:
+                self.peer.wait(self.neighbours, CH_DIST, self.calc_stream, n)
+        self._peer_open = None
 
     def _program_box(self, q, it, save_macro):
         """z / y slabs.  Boundary stream: wait(previous halo, previous interior) -> the two face layers -> event;
@@ -273,6 +333,8 @@ class SlabSim(BoxSim):
             k, out, swap = self.k_sweep[int(save_macro)][it & 1], 1 - (it & 1), False
         ev, pev = self._ev[it & 1], self._ev[1 - (it & 1)]
         sk, sb, sh = self.calc_stream, self.calc_stream2, self.halo_stream
+        if self.peer is not None and self._peer_open is not None:
+            self._box_back(q, it - 1)
         if self.regs_bnd:
             q.wait(sb, pev['halo'])
             if sb is not sk:
@@ -293,12 +355,33 @@ class SlabSim(BoxSim):
         t0 = self.backend.make_event(sh, timing=True) if (self.time_halo and not q.planned) else None
         q.launch(ks[0], None, sh)
         q.launch(ks[1], None, sh)
-        self._exchange(q, [(0, self._count)])
-        q.launch(ks[2], None, sh)
-        q.launch(ks[3], None, sh)
-        q.record(ev['halo'], sh)
+        if self.peer is not None:
+            # the pack kernels have written the neighbours' receive buffers: tell them.  The other half of the exchange --
+            # wait for THEIR signal, unpack -- is enqueued in front of the next step (_box_back): by then the signal has
+            # normally arrived, and a wait that does spin holds back the face layers that depend on it, nothing else
+            from sailfish_amd.peer import CH_DIST
+            q.peer_signal(self.peer, self.neighbours, CH_DIST, sh)
+        else:
+            self._exchange(q, [(0, self._count)])
+            q.launch(ks[2], None, sh)
+            q.launch(ks[3], None, sh)
+            q.record(ev['halo'], sh)
         if t0 is not None:
             self._halo_events.append((t0, self.backend.make_event(sh, timing=True)))
+
+    def _box_back(self, q, it):
+        """Peer transport, z / y slabs: the second half of step `it`'s exchange -- wait for the neighbours' signal of that
+        step, unpack what they wrote, record the event the next face layers wait for."""
+        from sailfish_amd.peer import CH_DIST
+        if self.aa:
+            out, swap = 0, (it & 1) == 0
+        else:
+            out, swap = 1 - (it & 1), False
+        ks, sh = self.k_halo[(swap, out)], self.halo_stream
+        q.peer_wait(self.peer, self.neighbours, CH_DIST, sh, 1)
+        q.launch(ks[2], None, sh)
+        q.launch(ks[3], None, sh)
+        q.record(self._ev[it & 1]['halo'], sh)
 
     def _program_xface(self, q, it, save_macro):
         """x slabs: the sweep in z-chunks, alternating between the two calc streams (a chunk starts while the one
@@ -423,7 +506,9 @@ class SlabSim(BoxSim):
             return
         b = self.backend
         it = self.iteration
-        if self._plan_ok and not self.time_halo:
+        peer_x = self.peer is not None
+        first = peer_x and self._peer_open is None      # nothing of a previous step to wait for: not the plan's program
+        if self._plan_ok and not self.time_halo and not first:
             key = (it & 1, int(bool(save_macro)))
             plan = self._plans.get(key)
             if plan is None:
@@ -441,6 +526,8 @@ class SlabSim(BoxSim):
                 b.set_iteration(self.iteration)     # kernels launched through run_kernel() next see the new parity
                 if self.xface is not None:
                     self.xface._bound = None        # the plan set the module's face buffers itself
+                if peer_x:
+                    self._peer_open = self._step_kinds(it)
                 return
         b.set_iteration(it)
         self._program(DirectQueue(b), it, save_macro)
@@ -448,9 +535,11 @@ class SlabSim(BoxSim):
         b.set_iteration(self.iteration)
         if self.xface is not None:
             self.xface._bound = None
+        if peer_x:
+            self._peer_open = self._step_kinds(it)      # (kind of the step just enqueued, kind of the one that follows)
 
     def release(self):
-        BoxSim.release(self)
+        BoxSim.release(self)            # (sync() drains the peer counters)
         if getattr(self, 'peer_group', None) is not None:
             self.peer_group.release()       # collective: every rank lets go of its simulation at the same point
             self.peer_group = None
@@ -485,6 +574,10 @@ class SlabSim(BoxSim):
         return float(np.mean(ms)) if ms else 0.0
 
     def sync(self):
+        """Everything this slab has enqueued is done -- and, with the peer transport, everything its neighbours' last
+        step wrote into its face buffers (the waits of a step refer to the step before: the last step's are due now)."""
+        if self.halo:
+            self._peer_drain()
         self.stream.synchronize()
         if self.halo:
             if self.calc_stream2 is not self.stream:

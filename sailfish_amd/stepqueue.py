@@ -44,9 +44,9 @@ class DirectQueue(object):
         """peer transport (sailfish_amd/peer.py): what this stream has written into the buffers of `ranks` is complete"""
         peer.signal(ranks, channel, stream)
 
-    def peer_wait(self, peer, ranks, channel, stream):
-        """the stream continues once every rank of `ranks` has sent its matching signal"""
-        peer.wait(ranks, channel, stream)
+    def peer_wait(self, peer, ranks, channel, stream, count=1):
+        """the stream continues once `count` further signals of every rank of `ranks` have arrived"""
+        peer.wait(ranks, channel, stream, count)
 
     def memset(self, addr, value, nbytes, stream):
         self._of(stream).memset_buf(addr, value, nbytes, stream)

@@ -395,17 +395,33 @@ class SubdomainRunner(object):
         if self._connector is None:
             from sailfish_amd.connector import LocalConnector
             self._connector = LocalConnector()
-        modes = ('push', 'pull') if self.config.access_pattern == 'AA' else ('push',)
+        aa = self.config.access_pattern == 'AA'
+        modes = ('push', 'pull') if aa else ('push',)
         n_grids = len(self._gpu_grids_primary)
         isz = np.dtype(self.float).itemsize
+        # zero-copy connectors (connector.PeerConnector): my pack kernels write the neighbour's receive buffer, which is
+        # mapped here; two sets that alternate by step parity
+        zc = getattr(self._connector, 'zero_copy', False)
+        todo = []
         for nid in sorted(links):
             link = links[nid]
             n_send = max(len(link.push_send), len(link.pull_send))
             n_recv = max(len(link.push_recv), len(link.pull_recv))
             if n_send == 0 and n_recv == 0:
                 continue
-            link.send_buf = self._connector.alloc_buffer(self, n_send * n_grids, self.float)
-            link.recv_buf = self._connector.alloc_buffer(self, n_recv * n_grids, self.float)
+            if zc:
+                link.recv_bufs = [self._connector.alloc_recv(self, 'dist', nid, par, n_recv * n_grids, self.float) for par in (0, 1)]
+            else:
+                link.send_buf = self._connector.alloc_buffer(self, n_send * n_grids, self.float)
+                link.recv_buf = self._connector.alloc_buffer(self, n_recv * n_grids, self.float)
+                link.send_bufs, link.recv_bufs = [link.send_buf] * 2, [link.recv_buf] * 2
+            todo.append((nid, link))
+        if zc:
+            self._connector.resolve(self)            # collective: every rank, whatever its links
+        for nid, link in todo:
+            if zc:
+                link.send_bufs = [self._connector.send_addr(self, 'dist', nid, par) for par in (0, 1)]
+                link.send_buf, link.recv_buf = link.send_bufs[0], link.recv_bufs[0]
             link.kernels = {}
             for mode in modes:
                 s_idx = getattr(link, mode + '_send')
@@ -413,15 +429,18 @@ class SubdomainRunner(object):
                 g_s = b.alloc_buf(like=s_idx) if len(s_idx) else 0
                 g_r = b.alloc_buf(like=r_idx) if len(r_idx) else 0
                 for copy in range(1 if not self._gpu_grids_secondary else 2):
+                    # the parity of the steps these kernels serve: in place the even steps pull, two-copy the steps that
+                    # write copy `copy`
+                    par = (0 if mode == 'pull' else 1) if aa else 1 - copy
                     packs, unpacks = [], []
                     for g in range(n_grids):
                         dist = self.gpu_dist(g, copy)
                         if len(s_idx):
                             packs.append(self.get_kernel('CollectSparseData', [
-                                g_s, dist, link.send_buf + g * len(s_idx) * isz, len(s_idx)], 'PPPi'))
+                                g_s, dist, link.send_bufs[par] + g * len(s_idx) * isz, len(s_idx)], 'PPPi'))
                         if len(r_idx):
                             unpacks.append(self.get_kernel('DistributeSparseData', [
-                                g_r, dist, link.recv_buf + g * len(r_idx) * isz, len(r_idx)], 'PPPi'))
+                                g_r, dist, link.recv_bufs[par] + g * len(r_idx) * isz, len(r_idx)], 'PPPi'))
                     link.kernels[(mode, copy)] = (packs, unpacks, len(s_idx) * n_grids, len(r_idx) * n_grids)
             self._links[nid] = link
 
@@ -464,11 +483,25 @@ class SubdomainRunner(object):
             by_neighbour.setdefault(nid, []).append(xface.LOW if face == spec.X_LOW else xface.HIGH)
         send, recv = [[0, 0], [0, 0]], [[0, 0], [0, 0]]
         self._xface_routes = []          # (neighbour id, my face, parity -> send address, parity -> receive address)
+        zc = getattr(self._connector, 'zero_copy', False)
         for nid in sorted(by_neighbour):
             faces = sorted(by_neighbour[nid])
             link = subdomain_connection.HaloLink(nid)
-            link.send_bufs = [self._connector.alloc_buffer(self, n * len(faces), self.float) for _ in (0, 1)]
-            link.recv_bufs = [self._connector.alloc_buffer(self, n * len(faces), self.float) for _ in (0, 1)]
+            link.faces = faces
+            if zc:
+                link.recv_bufs = [self._connector.alloc_recv(self, 'dist', nid, par, n * len(faces), self.float) for par in (0, 1)]
+            else:
+                link.send_bufs = [self._connector.alloc_buffer(self, n * len(faces), self.float) for _ in (0, 1)]
+                link.recv_bufs = [self._connector.alloc_buffer(self, n * len(faces), self.float) for _ in (0, 1)]
+            self._links[nid] = link
+        if zc:
+            # my send planes ARE the neighbours' receive planes: [through my low face | through my high face] on this side
+            # is [its high-face input | its low-face input] on the other, the layout of its receive buffer
+            self._connector.resolve(self)
+            for nid, link in self._links.items():
+                link.send_bufs = [self._connector.send_addr(self, 'dist', nid, par) for par in (0, 1)]
+        for nid in sorted(by_neighbour):
+            link, faces = self._links[nid], self._links[nid].faces
             link.send_buf, link.recv_buf = link.send_bufs[0], link.recv_bufs[0]
             for par in (0, 1):
                 for k, face in enumerate(faces):                       # my send order: low, high
@@ -481,9 +514,7 @@ class SubdomainRunner(object):
             for mode in ('push', 'pull'):
                 for copy in (0, 1):
                     link.kernels[(mode, copy)] = ([], [], n * len(faces), n * len(faces))
-            self._links[nid] = link
-        self._xface = xface.XFaceHalo(self.backend, self.module, self._sim.grid, self._desc, send, recv)
-        self._xface.reset()
+        self._xface = xface.XFaceHalo(self.backend, self.module, self._sim.grid, self._desc, send, recv, shared=zc)
         lat = list(reversed(self._lat_size))
         # several launches per step pay off where the transfer is slow (another process / GPU: a connector that can be
         # called in the middle of a step); runners stepped in lock-step by one Python process are bound by that process
@@ -516,6 +547,7 @@ class SubdomainRunner(object):
         count, nothing that crossed the x faces before does."""
         if self._xface is not None:
             self.backend.sync_stream(*self._all_streams())
+            self._connector.quiesce(self)       # peer transport: the neighbours write into these buffers themselves
             self._xface.reset(self._calc_stream)
             it = self._sim.iteration
             if self.config.access_pattern == 'AA' and (it & 1):
@@ -524,6 +556,7 @@ class SubdomainRunner(object):
                 # them from the ghost columns of the state just written (a checkpoint taken at an odd iteration)
                 self._xface.prime_pull(self.gpu_dist(0, 0), self._calc_stream, parity=1 - (it & 1))
             self.backend.sync_stream(self._calc_stream)
+            self._connector.quiesce(self)
             self.__dict__.pop('_halo_mode', None)
     
     def _materialise_halo(self):
@@ -776,7 +809,7 @@ class SubdomainRunner(object):
             prof.record_gpu_start(tp, sh)
         for nid in sorted(links):
             link = links[nid]
-            packs = link.kernels[(self._halo_mode, self._halo_copy)][0] if kind == 'dist' else link.packs
+            packs = link.kernels[(self._halo_mode, self._halo_copy)][0] if kind == 'dist' else link.packs[it & 1]
             for pack in packs:
                 q.launch(pack, None, sh)
         if timed:
@@ -828,7 +861,10 @@ class SubdomainRunner(object):
                     q.memset(a, 0xFF, x.nbytes, streams[0])
         evc, evb = self._ev_chunk[par], self._ev_batch[par]
         pevc, pevb = self._ev_chunk[1 - par], self._ev_batch[1 - par]
-        need = plan.need[prev_kind]
+        # face buffers that are not copied (the neighbour's receive planes ARE my send planes: peer transport, subdomains of
+        # one process): a chunk also waits until the planes it writes have been read (xface.ChunkPlan.peer_need)
+        need = plan.peer_need(kind, prev_kind) if x.shared else plan.need[prev_kind]
+        every = x.shared and group is None      # a signal after every chunk: the neighbours' chunks count on it
         pos_of = dict((c, pos) for pos, c in enumerate(plan.order))
         sh = self._data_stream
         if timed:
@@ -844,7 +880,7 @@ class SubdomainRunner(object):
                     q.wait(st, pevc[pos_of[c2]])
             for k in kernels:
                 q.launch(k, plan.region(c, ny), st)
-            if not plan.exchanges_at(pos) and streams[0] is streams[1]:
+            if not plan.exchanges_at(pos) and streams[0] is streams[1] and not every:
                 continue                 # nothing travels after this chunk and nobody waits for it
             q.record(evc[pos], st)
             if group is None:
@@ -905,6 +941,8 @@ class SubdomainRunner(object):
         else:
             raw[:, :self._get_nodes()] = dense
         self.backend.to_buf(self.gpu_dist(grid_num, copy), raw)
+        if isinstance(getattr(self, '_resident', None), dict):
+            self._resident['equalised'] = False      # the scratch copies of the resident launches no longer agree with the arrays
         self._reset_xface()
 
     def _debug_global_idx_to_tuple(self, gi):
@@ -1123,7 +1161,7 @@ class SubdomainRunner(object):
         # tiles: at most 16 x 16 of them (one workgroup per CU on 256 CUs), windows of at most 2048 nodes in 160 KiB of LDS
         tile = [max(1, -(-e // 16)) for e in ext]
         while (tile[0] + 2 * halo) * (tile[1] + 2 * halo) > 2048 or \
-                (tile[0] + 2 * halo) * (tile[1] + 2 * halo) * (9 * isz * 2 + 8) > 160 * 1024:
+                (tile[0] + 2 * halo) * (tile[1] + 2 * halo) * (9 * isz * 2 + 8) + 4352 > 160 * 1024:   # + the kernel's static tables
             a = 0 if tile[0] >= tile[1] else 1
             if tile[a] == 1:
                 return None
@@ -1168,14 +1206,22 @@ class SubdomainRunner(object):
                         r['graphs'][key] = b.capture_graph(stream, enqueue)
                     except b.FatalError as e:
                         self.config.logger.warning('HIP graph capture of the resident launches failed (%s)' % e)
+                        # the path is given up for good: its scratch copies of the arrays and the graphs go with it
+                        b.sync_stream(stream)
+                        r['graphs'].clear()
+                        for _, scratch in r['pairs']:
+                            b.free_buf(scratch)
                         self._resident = False
                         b.set_iteration(self._sim.iteration)
                         return done
-                if first:
-                    # what no tile covers (padding, the ghost columns of an axis wrapped in-sweep) is the same in both buffers
+                if first and not r.get('equalised'):
+                    # what no tile covers (padding, the ghost columns of an axis wrapped in-sweep) is the same in both
+                    # buffers: no kernel ever writes there, so once is enough -- until the host rewrites the arrays
+                    # (_debug_set_dist clears the flag)
                     for dist, scratch in r['pairs']:
                         b.copy_buf_async(scratch, dist, r['nbytes'], stream)
-                    first = False
+                    r['equalised'] = True
+                first = False
                 prof.start_step()
                 prof.record_gpu_start(TimeProfile.BULK, stream)
                 r['graphs'][key].launch(stream)
@@ -1241,6 +1287,9 @@ class SubdomainRunner(object):
 
     def finish(self):
         self.backend.sync_stream(*self._all_streams())
+        peer = getattr(self._connector, 'peer', None)
+        if peer is not None:
+            peer.check()        # a wait that gave up (a neighbour that is gone): an error, not wrong numbers
         self.check_gpu_invalid()
         if getattr(self.config, 'final_checkpoint', False) and self.config.checkpoint_file:
             self.save_checkpoint()
@@ -1255,6 +1304,8 @@ class SubdomainRunner(object):
         self.backend.sync_stream(*self._all_streams())
         self._kernels_full = self._kernels_none = self._pbc_kernels = None
         self._links, self._macro_links = {}, {}
+        if self._connector is not None:
+            self._connector.release(self)
         self.backend.close()
 
     def main(self):
@@ -1306,7 +1357,7 @@ class NNSubdomainRunner(SubdomainRunner):
         fields the non-local force reads at neighbouring nodes (reference _init_interblock_kernels /
         _send_macro / _recv_macro, subdomain_runner.py:1907-2100)."""
         SubdomainRunner._init_halo(self)
-        if not self._links:
+        if self._all_specs is None or len(self._all_specs) < 2:
             return
         cfg = self.config
         arr = list(reversed(self._physical_size))
@@ -1320,20 +1371,34 @@ class NNSubdomainRunner(SubdomainRunner):
         b = self.backend
         fields = [self.gpu_field(fp.buffer) for fp in self._sim._scalar_fields if fp.abstract.need_nn]
         isz = np.dtype(self.float).itemsize
+        zc = getattr(self._connector, 'zero_copy', False)
+        todo = []
         for nid in sorted(links):
             link = links[nid]
             ns, nr = len(link.send), len(link.recv)
             if ns == 0 and nr == 0:
                 continue
             link.n_send, link.n_recv = ns * len(fields), nr * len(fields)
-            link.send_buf = self._connector.alloc_buffer(self, link.n_send, self.float)
-            link.recv_buf = self._connector.alloc_buffer(self, link.n_recv, self.float)
+            if zc:          # the neighbour's receive buffers mapped here, two sets by step parity (connector.PeerConnector)
+                link.recv_bufs = [self._connector.alloc_recv(self, 'macro', nid, par, link.n_recv, self.float) for par in (0, 1)]
+            else:
+                link.send_buf = self._connector.alloc_buffer(self, link.n_send, self.float)
+                link.recv_buf = self._connector.alloc_buffer(self, link.n_recv, self.float)
+                link.send_bufs, link.recv_bufs = [link.send_buf] * 2, [link.recv_buf] * 2
+            todo.append((nid, link, ns, nr))
+        if zc:
+            self._connector.resolve(self)
+        for nid, link, ns, nr in todo:
+            if zc:
+                link.send_bufs = [self._connector.send_addr(self, 'macro', nid, par) for par in (0, 1)]
+                link.send_buf, link.recv_buf = link.send_bufs[0], link.recv_bufs[0]
             g_s = b.alloc_buf(like=link.send) if ns else 0
             g_r = b.alloc_buf(like=link.recv) if nr else 0
-            link.packs = [self.get_kernel('CollectSparseData', [g_s, f, link.send_buf + i * ns * isz, ns], 'PPPi')
-                          for i, f in enumerate(fields)] if ns else []
-            link.unpacks = [self.get_kernel('DistributeSparseData', [g_r, f, link.recv_buf + i * nr * isz, nr], 'PPPi')
-                            for i, f in enumerate(fields)] if nr else []
+            # [parity of the step] -> kernels
+            link.packs = [[self.get_kernel('CollectSparseData', [g_s, f, link.send_bufs[par] + i * ns * isz, ns], 'PPPi')
+                           for i, f in enumerate(fields)] if ns else [] for par in (0, 1)]
+            link.unpacks = [[self.get_kernel('DistributeSparseData', [g_r, f, link.recv_bufs[par] + i * nr * isz, nr], 'PPPi')
+                             for i, f in enumerate(fields)] if nr else [] for par in (0, 1)]
             self._macro_links[nid] = link
 
     def _prepare_compute_kernels(self):
@@ -1400,7 +1465,7 @@ class NNSubdomainRunner(SubdomainRunner):
         if timed:
             prof.record_gpu_start(TimeProfile.MACRO_DISTRIB, sh)
         for nid in sorted(self._macro_links):
-            for k in self._macro_links[nid].unpacks:
+            for k in self._macro_links[nid].unpacks[it & 1]:
                 q.launch(k, None, sh)
         if timed:
             prof.record_gpu_end(TimeProfile.MACRO_DISTRIB, sh)

@@ -59,6 +59,12 @@ def run_directory(run_id=None):
 
 
 def _alive(pid):
+    """Is process `pid` still running?  A zombie (exited, not yet reaped by its launcher) is not."""
+    try:
+        with open('/proc/%d/stat' % int(pid)) as fh:
+            return fh.read().rsplit(')', 1)[1].split()[0] not in ('Z', 'X')
+    except (OSError, IndexError, ValueError):
+        pass
     try:
         os.kill(int(pid), 0)
     except ProcessLookupError:
@@ -188,9 +194,13 @@ class Watchdog(object):
         return signal.SIGTERM in data
 
     def _fire(self, error, status):
-        if self._fired:
-            return
-        self._fired = True
+        with self._lock:
+            first, self._fired = not self._fired, True
+        if not first:
+            # another thread of this process is writing the diagnosis and will end the process: do not return into code
+            # that might end it first (the main thread re-raising its exception)
+            while True:
+                time.sleep(1.0)
         more = {}
         if self.extra is not None:
             try:

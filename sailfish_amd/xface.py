@@ -138,6 +138,28 @@ class ChunkPlan(object):
             out.append(max([self.need[prev_kind][c]] + war))
         return out
 
+    def peer_signals(self, kind, next_kind):
+        """Positions of a step of kind `kind` after which the neighbours need a signal: those some chunk of THEIR next
+        step (kind `next_kind`) waits for.  Signals are counted, so a wait for position p is a wait for the signals up to
+        and including p -- peer_counts() turns positions into counts."""
+        return sorted(set(self.peer_need(next_kind, kind)))
+
+    def peer_counts(self, kind, prev_kind):
+        """[(chunk position, signals of the neighbours' previous step to wait for before it)] for a step of kind `kind`
+        that follows a step of kind `prev_kind`: the first chunk whose need is a signalled position waits for every
+        signal up to that position that no earlier chunk has waited for.  The counts add up to len(peer_signals(prev_kind,
+        kind)): a step consumes exactly what the step before produced."""
+        signalled = self.peer_signals(prev_kind, kind)
+        need = self.peer_need(kind, prev_kind)
+        out, consumed = [], 0
+        for pos, c in enumerate(self.order):
+            upto = sum(1 for p in signalled if p <= need[c])
+            if upto > consumed:
+                out.append((pos, upto - consumed))
+                consumed = upto
+        assert consumed == len(signalled)
+        return out
+
     def exchanges_at(self, pos):
         """Does a transfer (of either step kind) start after the chunk at position `pos`?  Positions without one need no
         event either: nothing waits for them."""

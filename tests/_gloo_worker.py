@@ -133,7 +133,10 @@ def controller_worker(rank, world, port, case, steps, outdir):
     assert len(ctrl.runners) == 1
     r = ctrl.runners[0]
     assert r._spec.id == rank and r._links, 'the runner of this rank must have halo links'
-    assert type(r._connector).__name__ == 'TorchDistConnector' and r._sim.iteration == steps
+    # on the GPU the ranks share the device and can map each other's memory: the peer transport (unless the test asks for
+    # host staging with SLF_HALO_TRANSPORT=torch); the CPU test backend has nothing to map
+    want = 'PeerConnector' if (on_gpu and os.environ.get('SLF_HALO_TRANSPORT', 'auto') in ('auto', 'peer')) else 'TorchDistConnector'
+    assert type(r._connector).__name__ == want and r._sim.iteration == steps, type(r._connector).__name__
     f = r._debug_get_dist()
     sl = (slice(None),) + tuple(r._spec._nonghost_slice)
     np.savez(os.path.join(outdir, 'rank%d.npz' % rank), dist=np.ascontiguousarray(f[sl]),

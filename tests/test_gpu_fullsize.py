@@ -191,13 +191,15 @@ def test_config4_x_slab_pair_full_size(pattern):
     assert res['dist_exact'], res
 
 
-@pytest.mark.parametrize('axis', ['x', 'z'])
-def test_config4_eight_subdomains_full_extent(axis):
+@pytest.mark.parametrize('axis,transport', [('x', 'peer'), ('z', 'peer'), ('x', 'torch')])
+def test_config4_eight_subdomains_full_extent(axis, transport):
     """BASELINE config 4 as stated: D3Q19 BGK 1024 x 512 x 512 cut into EIGHT subdomains (reference geo.py:100-135
     EqualSubdomainsGeometry3D; x = its default axis: 128 x 512 x 512 each, z: 1024 x 512 x 64), one process per subdomain
     -- a ring whose neighbours are all different ranks, with the wrap 7 -> 0 -- at full size.  The box of the build pool
-    has ONE GPU, so the eight ranks share it (gloo group, halo buffers staged through the host: `rccl_ranks` 0); on an
-    8-GPU node the same command line without the two environment variables is the RCCL run.  After the timed steps every
+    has ONE GPU, so the eight ranks share it (gloo group for the rendezvous, `rccl_ranks` 0).  transport = peer (round 6,
+    the default wherever processes can map each other's memory -- the eight GPUs of a node, or one GPU shared): the sweep's
+    edge lanes / the pack kernels store into the neighbouring PROCESS's receive buffers, ordered by progress counters
+    (sailfish_amd/peer.py); torch: halo buffers staged through the host by torch.distributed, as in round 5.  After the timed steps every
     rank checks its seam layers through windows that reach into both neighbours (window.SeamCheck) and rank 0 checks
     whole planes of the merged slabs against oracle windows of the UNDIVIDED 1024 x 512 x 512 box (window.GlobalCheck),
     populations bit for bit, both access patterns."""
@@ -205,7 +207,8 @@ def test_config4_eight_subdomains_full_extent(axis):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               SLF_HALO_TRANSPORT=transport)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--scaling', 'strong', '--domain', '1024x512x512',
@@ -219,6 +222,7 @@ def test_config4_eight_subdomains_full_extent(axis):
     d = json.loads(lines[0])
     c = d['config']
     assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and c['world_size'] == 8 and c['rccl_ranks'] == 0
+    assert c['halo_transport'].startswith('peer:' if transport == 'peer' else 'torch.distributed'), c['halo_transport']
     assert '1024x512x512' in c['workload'] and ('128x512x512' if axis == 'x' else '1024x512x64') in c['workload']
     assert sorted(r['rank'] for r in c['per_rank']) == list(range(8))
     assert c['validated'] is True, c['validation']
@@ -228,7 +232,7 @@ def test_config4_eight_subdomains_full_extent(axis):
         u = v['undivided_box']
         assert u['box'] == '1024x512x512' and u['slabs'] == 8 and u['populations_bit_identical']
         assert u['populations_compared'] == 19 * 2 * 1024 * 512
-    print('config 4, 8 ranks on one GPU, %s-slabs: %.0f MLUPS (functional: gloo, host staging)' % (axis, d['value']))
+    print('config 4, 8 ranks on one GPU, %s-slabs, halo transport %s: %.0f MLUPS' % (axis, transport, d['value']))
 
 
 def _plane(backend, sim, q, z):

@@ -1,6 +1,7 @@
 """bench.py with TWO ranks (python -m torch.distributed.run --nproc-per-node 2), both on the one GPU of the box: RCCL
-refuses two ranks per device, so the process group is gloo and the exchanger stages the halo tensors through the host
-(SLF_DIST_BACKEND=gloo, SLF_FORCE_DEVICE=0).  Everything else is what the driver's N > 1 runs execute: rank / world
+refuses two ranks per device, so the process group is gloo (SLF_DIST_BACKEND=gloo, SLF_FORCE_DEVICE=0); the halos travel
+through the peer transport -- the neighbour's receive buffers mapped into this process, ordered by progress counters
+(sailfish_amd/peer.py; round 6) -- or, with SLF_HALO_TRANSPORT=torch, staged through the host by the exchanger.  Everything else is what the driver's N > 1 runs execute: rank / world
 bookkeeping, the global box of the initial state, ring neighbours, barrier + max-over-ranks timing, the gathered
 per-rank figures in the JSON line.  Functional, not a performance number."""
 import json
@@ -23,12 +24,16 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize('transport', ['peer', 'torch'])
 @pytest.mark.parametrize('mode', [['--scaling', 'weak', '--size', '96'],
                                   ['--scaling', 'strong', '--domain', '128x64x96', '--axis', 'z'],
                                   ['--scaling', 'strong', '--domain', '256x48x40', '--axis', 'x']],
                          ids=['weak_z', 'strong_z', 'strong_x'])
-def test_bench_with_two_ranks_on_one_gpu(mode):
-    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+def test_bench_with_two_ranks_on_one_gpu(mode, transport):
+    if transport == 'torch' and mode[1] == 'weak':
+        pytest.skip('host staging is covered by the two strong-scaling cases')
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               SLF_HALO_TRANSPORT=transport, GPU_MAX_HW_QUEUES='2')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
            '--prewarm_steps', '2', '--repeats', '1', '--no_cpu_baseline', '--no_gpu_state'] + mode
@@ -41,6 +46,8 @@ def test_bench_with_two_ranks_on_one_gpu(mode):
     c = d['config']
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['scaling'] == mode[1]
     assert c['rccl_ranks'] == 0 and c['world_size'] == 2 and c['dist_backend'] == 'gloo'      # gloo: nothing went over RCCL
+    assert c['halo_transport'].startswith('peer:' if transport == 'peer' else 'torch.distributed'), c['halo_transport']
+    assert c['validated'] is True, c['validation']
     assert sorted(r['rank'] for r in c['per_rank']) == [0, 1]
     assert all(r['kernel_ms'] > 0 and r['halo_ms'] > 0 for r in c['per_rank'])
     assert set(c['candidates_mlups']) == {'AA', 'AB'}
@@ -67,11 +74,43 @@ def test_bench_launches_two_ranks_itself():
     assert all(v['undivided_box']['populations_bit_identical'] and v['undivided_box']['slabs'] == 2 for v in c['validation'].values())
 
 
-@pytest.mark.parametrize('axis,pattern,model', [('z', 'AA', 'bgk'), ('z', 'AB', 'mrt'), ('x', 'AA', 'bgk'), ('x', 'AB', 'bgk'),
-                                                ('y', 'AB', 'bgk')])
-def test_two_processes_equal_one_box(axis, pattern, model):
-    """Two OS processes, one slab each, halos through torch.distributed: bit-identical to the undivided box."""
-    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+@pytest.mark.parametrize('how', ['stall', 'exit'])
+def test_a_rank_that_stops_ends_the_bench_with_an_error_line(how):
+    """One of two ranks stops advancing (or leaves) after the rendezvous: instead of hanging until the launcher's limit,
+    rank 0 prints ONE line with "error", the phase and every rank's last state, and the run returns a non-zero status
+    within the deadline (sailfish_amd/watchdog.py; reference master.py:268-312)."""
+    import time
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               SLF_BENCH_TEST_STALL='1:first_exchange' + (':exit' if how == 'exit' else ''), SLF_DEADLINE_SCALE='0.1',
+               SLF_DEADLINE_FIRST_EXCHANGE='8', SLF_DEADLINE_START='300', SLF_PEER_TIMEOUT_S='60', GPU_MAX_HW_QUEUES='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--size', '64',
+           '--prewarm_steps', '2', '--repeats', '1', '--no_cpu_baseline', '--no_gpu_state', '--access_pattern', 'AA']
+    t0 = time.time()
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=300)
+    took = time.time() - t0
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode != 0, out[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d['value'] is None and d['error'] and len(d['ranks']) == 2 and took < 150, (took, d)
+    states = dict((s['rank'], s) for s in d['ranks'])
+    if how == 'stall':
+        assert states[1]['phase'] == 'first_exchange' and 'first_exchange' in d['error']
+    else:
+        assert 'rank 1' in d['error'] or 'SIGTERM' in d['error']
+
+
+@pytest.mark.parametrize('axis,pattern,model,transport', [('z', 'AA', 'bgk', 'peer'), ('z', 'AB', 'mrt', 'peer'), ('x', 'AA', 'bgk', 'peer'),
+                                                          ('x', 'AB', 'bgk', 'peer'), ('y', 'AB', 'bgk', 'peer'),
+                                                          ('z', 'AA', 'bgk', 'torch'), ('x', 'AA', 'bgk', 'torch')])
+def test_two_processes_equal_one_box(axis, pattern, model, transport):
+    """Two OS processes, one slab each, halos written straight into the neighbour's buffers (peer) or staged through
+    torch.distributed (torch): bit-identical to the undivided box."""
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               SLF_HALO_TRANSPORT=transport, GPU_MAX_HW_QUEUES='2')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', '_two_rank_worker.py'), axis, pattern, model]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)

@@ -71,3 +71,50 @@ def test_two_transfers_per_step_on_request(monkeypatch):
             assert all(sent[pl] == max(done[pl], 2) for pl in done)
             assert p.need[kind][p.order[0]] == 2 and all(n == 3 for c, n in enumerate(p.need[kind]) if c != p.order[0] and
                                                          (wrap or c != 1))
+
+
+@pytest.mark.parametrize('nz', [8, 12, 33, 64, 512])
+@pytest.mark.parametrize('wrap', [True, False])
+@pytest.mark.parametrize('nchunks', [1, 2, 4, 7])
+@pytest.mark.parametrize('kinds', [('push', 'push'), ('own', 'push'), ('push', 'own')])
+def test_uncopied_face_buffers_are_neither_read_too_early_nor_overwritten_too_early(nz, wrap, nchunks, kinds):
+    """Peer transport / shared buffers: my send planes ARE the neighbour's receive planes, two sets alternating by step
+    parity.  Chunk c of a step of kind `kind` starts when the neighbour's previous step (kind `prev`) has completed the
+    chunks up to position peer_need[c]; by then (a) every plane c reads has been written by all its writers of that
+    step, and (b) every plane c writes -- into the set the neighbour's previous step READ -- has been read by all its
+    readers of that step."""
+    kind, prev = kinds
+    p = ChunkPlan(nz, wrap, nchunks)
+    need = p.peer_need(kind, prev)
+    pos_of = dict((c, pos) for pos, c in enumerate(p.order))
+    for c in range(len(p.chunks)):
+        done = set(c2 for c2 in range(len(p.chunks)) if pos_of[c2] <= need[c])       # neighbour's chunks of the previous step
+        reads = set(p.reads_after(prev, c))
+        for c2 in range(len(p.chunks)):
+            if reads & set(p.writes(prev, c2)):
+                assert c2 in done, 'chunk %d would read planes chunk %d of the previous step is still writing' % (c, c2)
+        # the previous step read what the step before it (of THIS step's kind) had written into the same set
+        writes = set(p.writes(kind, c))
+        for c2 in range(len(p.chunks)):
+            if writes & set(p.reads_after(kind, c2)):
+                assert c2 in done, 'chunk %d would overwrite planes chunk %d of the previous step is still reading' % (c, c2)
+        assert need[c] >= p.need[prev][c]
+
+
+@pytest.mark.parametrize('nz,wrap,nchunks', [(512, True, 4), (512, True, 8), (64, False, 4), (33, True, 7), (12, False, 1)])
+def test_signals_and_waits_of_the_peer_schedule_balance(nz, wrap, nchunks):
+    """A step sends a signal after every position some chunk of the neighbours' NEXT step waits for, and its own chunks
+    wait -- each in front of the chunk that needs it -- for exactly the signals of the step before: the counts add up,
+    they never ask for a position beyond the one the chunk needs, and never for less."""
+    p = ChunkPlan(nz, wrap, nchunks)
+    for kind, prev in (('push', 'push'), ('own', 'push'), ('push', 'own')):
+        signalled = p.peer_signals(prev, kind)
+        need = p.peer_need(kind, prev)
+        assert set(signalled) == set(need)
+        counts = p.peer_counts(kind, prev)
+        assert sum(n for _, n in counts) == len(signalled)
+        consumed = 0
+        by_pos = dict(counts)
+        for pos, c in enumerate(p.order):
+            consumed += by_pos.get(pos, 0)
+            assert signalled[consumed - 1] == max(need[c2] for c2 in p.order[:pos + 1])     # exactly up to what is needed so far

@@ -248,5 +248,70 @@ c.run(ignore_cmdline=True)
       line "8 processes z, $q queues" < $O/n8_z_q$q.json | tee -a $O/summary.txt
     done
     ;;
+  r6v3)   # peer transport, waits in front of the chunks that need them: parity tests, then 1 / 2 / 8 processes
+    export SLF_PEER_TIMEOUT_S=30
+    ( time timeout 1500 python -m pytest tests/test_gpu_peer.py tests/test_gpu_two_ranks.py tests/test_gpu_slab.py tests/test_gpu_comm.py -m gpu -q -x --durations=8 ) > $O/pytest_peer.log 2>&1; tail -25 $O/pytest_peer.log
+    X="--steps 40 --warmup 10 --prewarm_steps 40 --repeats 1 --no_cpu_baseline --no_gpu_state --min_seconds 0.3 --halo_timing_steps 6"
+    line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d.get('config',{}); r=(c.get('per_rank') or [{}])[0]; print('$1', d.get('value'), d.get('ms_per_step'), c.get('access_pattern'), 'validated', c.get('validated'), 'exposed', c.get('halo_exposed_ms'), 'sweep_only', r.get('sweep_only_ms'), '|', (c.get('halo_transport') or '')[:24], d.get('error'))" 2>&1 | tail -1; }
+    for tr in peer rccl; do
+      SLF_HALO_TRANSPORT=$tr timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 \
+        bench.py --gpus 1 --force_distributed --scaling strong --domain 128x512x512 --axis x $X 2> $O/one_${tr}_x.err | tail -1 > $O/one_${tr}_x.json
+      line "one rank $tr x" < $O/one_${tr}_x.json | tee -a $O/summary.txt
+    done
+    for ch in 4 2 1; do
+      SLF_XFACE_CHUNKS=$ch SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 8 --scaling strong --domain 1024x512x512 --axis x $X 2> $O/n8_x_c$ch.err | tail -1 > $O/n8_x_c$ch.json
+      line "8 processes x, $ch chunks" < $O/n8_x_c$ch.json | tee -a $O/summary.txt
+    done
+    for v in "SLF_HALO_PRIORITY=1 SLF_CALC_STREAMS=2" "SLF_HALO_PRIORITY=0 SLF_CALC_STREAMS=2" "SLF_HALO_PRIORITY=1 SLF_CALC_STREAMS=1"; do
+      env $v SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 8 --scaling strong --domain 1024x512x512 --axis z $X --no_validate --access_pattern AA 2> $O/n8_z.err | tail -1 > $O/n8_z.json
+      line "8 processes z, $v" < $O/n8_z.json | tee -a $O/summary.txt
+    done
+    SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 2 --scaling strong --domain 1024x512x512 --axis x $X 2> $O/n2_x.err | tail -1 > $O/n2_x.json
+    line "2 processes x" < $O/n2_x.json | tee -a $O/summary.txt
+    tail -n 5 $O/*.err | tail -n 40
+    ;;
+  r6v4)   # peer transport with deferred waits on both paths, no stream priority between processes that share the device
+    export SLF_PEER_TIMEOUT_S=30
+    ( time timeout 1500 python -m pytest tests/test_gpu_peer.py tests/test_gpu_two_ranks.py tests/test_gpu_slab.py tests/test_gpu_comm.py -m gpu -q --durations=8 ) > $O/pytest_peer.log 2>&1; tail -25 $O/pytest_peer.log
+    X="--steps 40 --warmup 10 --prewarm_steps 40 --repeats 1 --no_cpu_baseline --no_gpu_state --min_seconds 0.3 --halo_timing_steps 6"
+    line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d.get('config',{}); r=(c.get('per_rank') or [{}])[0]; print('$1', d.get('value'), d.get('ms_per_step'), c.get('access_pattern'), 'validated', c.get('validated'), 'exposed', c.get('halo_exposed_ms'), 'sweep_only', r.get('sweep_only_ms'), '|', (c.get('halo_transport') or '')[:24], d.get('error'))" 2>&1 | tail -1; }
+    for tr in peer rccl; do
+      for ax in x z; do
+        SLF_HALO_TRANSPORT=$tr timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 \
+          bench.py --gpus 1 --force_distributed --scaling strong --domain 128x512x512 --axis $ax $X 2> $O/one_${tr}_$ax.err | tail -1 > $O/one_${tr}_$ax.json
+        line "one rank $tr $ax" < $O/one_${tr}_$ax.json | tee -a $O/summary.txt
+      done
+    done
+    for ch in 4 2 1; do
+      SLF_XFACE_CHUNKS=$ch SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 8 --scaling strong --domain 1024x512x512 --axis x $X 2> $O/n8_x_c$ch.err | tail -1 > $O/n8_x_c$ch.json
+      line "8 processes x, $ch chunks" < $O/n8_x_c$ch.json | tee -a $O/summary.txt
+    done
+    for v in "SLF_CALC_STREAMS=2" "SLF_CALC_STREAMS=1"; do
+      env $v SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 8 --scaling strong --domain 1024x512x512 --axis z $X 2> $O/n8_z.err | tail -1 > $O/n8_z_$v.json
+      line "8 processes z, $v" < $O/n8_z_$v.json | tee -a $O/summary.txt
+    done
+    for ax in x z; do
+      SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 2 --scaling strong --domain 1024x512x512 --axis $ax $X 2> $O/n2_$ax.err | tail -1 > $O/n2_$ax.json
+      line "2 processes $ax" < $O/n2_$ax.json | tee -a $O/summary.txt
+    done
+    grep -v "socket.cpp\|amdgpu.ids" $O/*.err | tail -n 30
+    ;;
+  r6v5)   # the AB failures of r6v4: the second simulation of a process, or the two-copy pattern?  + the failed tests again
+    export SLF_PEER_TIMEOUT_S=30
+    X="--steps 40 --warmup 10 --prewarm_steps 40 --repeats 1 --no_cpu_baseline --no_gpu_state --min_seconds 0.3 --halo_timing_steps 6"
+    line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d.get('config',{}); r=(c.get('per_rank') or [{}])[0]; print('$1', d.get('value'), d.get('ms_per_step'), c.get('access_pattern'), 'validated', c.get('validated'), dict((k, v.get('populations_bit_identical')) for k, v in c.get('validation', {}).items()), 'exposed', c.get('halo_exposed_ms'), '|', (c.get('halo_transport') or '')[:24], d.get('error'))" 2>&1 | tail -1; }
+    for ax in x z; do
+      for pat in AB auto; do
+        SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 2 --scaling strong --domain 512x256x256 --axis $ax --access_pattern $pat $X 2> $O/n2_${ax}_$pat.err | tail -1 > $O/n2_${ax}_$pat.json
+        line "2 processes $ax $pat" < $O/n2_${ax}_$pat.json | tee -a $O/summary.txt
+      done
+    done
+    ( time timeout 1500 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q --durations=8 -k "stops or controller_branch or equal_one_box" ) > $O/pytest_peer.log 2>&1; tail -12 $O/pytest_peer.log
+    for ax in x z; do
+      SLF_DIST_BACKEND=gloo SLF_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 8 --scaling strong --domain 1024x512x512 --axis $ax $X 2> $O/n8_$ax.err | tail -1 > $O/n8_$ax.json
+      line "8 processes $ax" < $O/n8_$ax.json | tee -a $O/summary.txt
+    done
+    grep -v "socket.cpp\|amdgpu.ids" $O/*.err | tail -n 30
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
