@@ -59,6 +59,7 @@ enum { SLF_ADDR_DIRECT = 0, SLF_ADDR_INDIRECT = 1 };
  * GUO: feq at u + a/2 plus Guo's source term; EDM (exact difference method): feq at u, then
  * f_i += feq_i(rho, u + a) - feq_i(rho, u).  The output velocity is u + a/2 in both. */
 enum { SLF_FORCE_GUO = 0, SLF_FORCE_EDM = 1 };
+enum { SLF_SUBGRID_NONE = 0, SLF_SUBGRID_LES_SMAGORINSKY = 1 };
 #define SLF_INVALID_NODE 0xffffffffu
 
 /* Canonical node kinds understood by the kernels (reference node_type.py:86-109,
@@ -144,6 +145,15 @@ typedef struct slf_module_desc {
   int32_t force_implementation;  /* SLF_FORCE_GUO | SLF_FORCE_EDM (--force_implementation, lb_base.py:325-330) */
   int32_t sparse_geometry;       /* hint: a sizeable fraction of the real nodes is excluded (unused / ghost-like):
                                     kernels predicate their loads on the node map instead of issuing them early */
+  /* round 6: the two options of the BGK relaxation preamble (relaxation_common.mako:166-237) no example of the
+   * reference uses.  regularized (--regularized, lb_single.py:27-30): before the collision the populations are replaced
+   * by feq + the projection of their non-equilibrium momentum flux (sym.reglb_flux_tensor).  subgrid = SLF_SUBGRID_*
+   * (--subgrid=les-smagorinsky, lb_single.py:38-42): the relaxation time of a node follows the local non-equilibrium
+   * stress, tau0 = 1/2 + 3 visc, tau0 += (sqrt(tau0^2 + 36 C^2 sqrt(T_ab T_ab)) - tau0) / 2 with C = smagorinsky_const.
+   * Single-fluid BGK modules, standard density models, Guo or no body force; served by the per-node kernels. */
+  int32_t regularized;
+  int32_t subgrid;
+  double smagorinsky_const;
 } slf_module_desc;
 
 /* Region of the lattice a sweep launch covers (replaces the reference's

@@ -605,7 +605,8 @@ class HIPBackend(placement.VmmMixin):
     def supports_row_classes(desc):
         """Modules the row classes exist for: D3Q19 single-fluid with a node map, direct addressing."""
         return (desc.lattice == hipabi.SLF_D3Q19 and not desc.fluid_only and not int(desc.node_addressing) and
-                not int(desc.simtype) and int(desc.incompressible) != hipabi.SLF_DENSITY_ROUNDOFF)
+                not int(desc.simtype) and int(desc.incompressible) != hipabi.SLF_DENSITY_ROUNDOFF and
+                not int(desc.regularized) and not int(desc.subgrid))      # (those run the per-node kernels)
 
     # -- streams / events -----------------------------------------------------
     def poll_invalid(self, module, stream):

@@ -22,7 +22,7 @@ def padded_nx(lat_nx, alignment=32):
 def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='AA', visc=1.0 / 6.0,
                   periodic_fused=(0, 0, 0), fluid_only=True, accel=None, incompressible=False,
                   relaxation_enabled=True, type_kind=None, node_params=None, nt_bits=None, use_link_tags=True,
-                  alignment=32, dist_pad=None):
+                  alignment=32, dist_pad=None, regularized=False, subgrid=None, smagorinsky_const=0.1):
     """size = (nx, ny[, nz]) real nodes; a ghost envelope of 1 is added."""
     dim = grid.dim
     assert len(size) == dim
@@ -50,6 +50,9 @@ def make_box_desc(grid, size, model='bgk', precision='single', access_pattern='A
         kw.update(nt_type_mask=(1 << misc) - 1, nt_misc_shift=misc, nt_param_shift=param, nt_scratch_shift=scratch)
     if dist_pad:
         kw['dist_stride'] = kw['arr_nx'] * kw['arr_ny'] * kw['arr_nz'] + int(dist_pad)
+    if regularized or subgrid:
+        kw.update(regularized=int(bool(regularized)), smagorinsky_const=float(smagorinsky_const),
+                  subgrid=hipabi.SLF_SUBGRID_LES_SMAGORINSKY if subgrid else hipabi.SLF_SUBGRID_NONE)
     return hipabi.make_desc(**kw)
 
 

@@ -126,6 +126,8 @@ class LocalGroup(object):
         chunk event; the receiver copies it on its data stream and records the event its next step's chunks wait for."""
         par = it & 1
         sh = r._data_stream
+        if self.single_calc_stream and r._xface.shared:
+            return          # nothing to move and nothing to order: the one calc stream runs the sweeps in the order they need
         for pos in range(len(r._xchunks.order)):
             if not r._xchunks.exchanges_at(pos):
                 continue
@@ -172,6 +174,31 @@ class LocalGroup(object):
                 r._xface._bound = nb._xface._bound = None
         if done:
             self.runners[0].config.logger.debug('x-face buffers shared between the subdomains of this process: %d' % done)
+        self._serialise_sweeps()
+
+    single_calc_stream = False
+
+    def _serialise_sweeps(self):
+        """Every subdomain of the group on ONE device, all connected through shared x-face buffers: their sweeps go to ONE
+        stream.  A sweep of a 128 .. 170-node slab fills the device by itself, so nothing is lost by running them one
+        after the other -- and the order of the stream IS the order the face buffers need (B's step it + 1 after A's and
+        C's step it), which otherwise takes an event recorded on one stream, waited for on a second and passed on to a
+        third: 74 us between dependent sweeps, a third of the step of a pipe cut into three slabs
+        (profiles/r06/trace_busy_pipe_3x.txt: 27.6 GMLUPS where the undivided pipe runs at 40).  SLF_GROUP_ONE_STREAM=0:
+        one calc stream per subdomain and the events, as in round 5."""
+        rs = self.runners
+        if os.environ.get('SLF_GROUP_ONE_STREAM', '1') == '0' or len(rs) < 2:
+            return
+        if any(r._xface is None or not r._xface.shared for r in rs) or len(set(r.backend.gpu_id for r in rs)) != 1:
+            return
+        if any(len(r._xchunks.order) != 1 or r._bnd_stream is not r._calc_stream for r in rs):
+            return
+        for r in rs:
+            r.backend.sync_stream(*r._all_streams())
+        shared = rs[0]._calc_stream
+        for r in rs[1:]:
+            r._calc_stream = r._bnd_stream = shared
+        self.single_calc_stream = True
 
     def step(self, reqs):
         from sailfish_amd.stepqueue import DirectQueue, NotPlannable

@@ -92,6 +92,8 @@ struct slf_module {
   void* xrecv[2];
   slf::RowClasses rows;   // slf_module_classify_rows; rows.map == NULL: nothing classified
   void* rows_mem;         // one device allocation behind the tables of `rows`
+  slf::SlotTable slots;   // indirect addressing: slot -> node, built from the `nodes` table of the first launch that names it
+  void* slots_mem;
 };
 struct slf_kernel {
   slf_module* mod;
@@ -105,6 +107,40 @@ struct slf_kernel {
 };
 
 static hipStream_t native(slf_stream* s) { return s ? s->s : (hipStream_t)0; }
+
+// Indirect addressing: the slot -> node table of `nodes` (SlotTable, slf_kernels.h), built on first use and whenever a
+// launch names another table.  SLF_INDIRECT_SLOTS=0: never (one thread per dense node, the round-3 kernels: A/B switch).
+static const slf::SlotTable* slot_table_for(slf_module* m, const void* nodes, hipStream_t s) {
+  static const bool enabled = [] { const char* v = getenv("SLF_INDIRECT_SLOTS"); return !(v && atoi(v) == 0); }();
+  if (!enabled || !nodes || !m->geo.indirect) return nullptr;
+  if (m->slots.nodes == nodes) return &m->slots;
+  if (m->geo.lat_ny > 65535 || m->geo.lat_nz > 65535) return nullptr;
+  if (m->slots_mem) {
+    hipFree(m->slots_mem);
+    m->slots_mem = nullptr;
+  }
+  m->slots = slf::SlotTable{};
+  const size_t n = m->geo.dist_size;
+  char* mem = nullptr;
+  if (hipMalloc((void**)&mem, 2 * n * sizeof(uint32_t) + 256) != hipSuccess) return nullptr;
+  uint32_t* max_slot = (uint32_t*)(mem + 2 * n * sizeof(uint32_t));
+  uint32_t h = 0;
+  hipError_t e = hipMemsetAsync(mem, 0xFF, 2 * n * sizeof(uint32_t), s);
+  if (e == hipSuccess) e = hipMemsetAsync(max_slot, 0, 256, s);
+  if (e == hipSuccess) e = slf::launch_build_slot_table(m->geo, nodes, (uint32_t*)mem, (uint32_t*)mem + n, max_slot, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, max_slot, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    hipFree(mem);
+    return nullptr;
+  }
+  m->slots_mem = mem;
+  m->slots.nodes = nodes;
+  m->slots.slot_gi = (const uint32_t*)mem;
+  m->slots.slot_yz = (const uint32_t*)mem + n;
+  m->slots.n_slots = h + 1;
+  return &m->slots;
+}
 
 extern "C" {
 
@@ -1015,6 +1051,28 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
     delete m;
     return fail(SLF_ERR_UNSUPPORTED, "the exact difference method (force_implementation = EDM) needs the BGK collision");
   }
+  ph.regularized = d->regularized != 0;
+  ph.subgrid = d->subgrid;
+  ph.smagorinsky_const = d->smagorinsky_const;
+  if (d->subgrid != SLF_SUBGRID_NONE && d->subgrid != SLF_SUBGRID_LES_SMAGORINSKY) {
+    delete m;
+    return fail(SLF_ERR_INVALID, "subgrid must be one of SLF_SUBGRID_*");
+  }
+  if (ph.regularized || ph.subgrid) {
+    // the options of the BGK relaxation preamble (relaxation_common.mako:166-237).  The reference's MRT relaxation does not
+    // call the preamble (its kernels would silently ignore both flags); here that is an error, as are the combinations the
+    // preamble's expressions were never written for
+    if (d->model != SLF_BGK || d->simtype != SLF_SIM_LBM || d->incompressible == SLF_DENSITY_ROUNDOFF || ph.force_edm) {
+      delete m;
+      return fail(SLF_ERR_UNSUPPORTED, "regularized / subgrid: single-fluid BGK modules, standard or incompressible density "
+                                       "model, Guo forcing or no body force");
+    }
+    if (ph.subgrid && !(d->smagorinsky_const > 0.0)) {
+      delete m;
+      return fail(SLF_ERR_INVALID, "subgrid = les-smagorinsky needs smagorinsky_const > 0");
+    }
+    g.variant = 0;       // per-node kernels: the tuned / whole-row ones implement the plain collision
+  }
   if (d->incompressible == SLF_DENSITY_ROUNDOFF) {
     // --minimize_roundoff: "BGK-like models" in the reference (lb_base.py:72-76); here BGK, single fluid, fluid and
     // bounce-back nodes, through the per-node kernels (slf_node.h: macro_roundoff, bgk_relax_roundoff)
@@ -1065,6 +1123,8 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   m->xsend[0] = m->xsend[1] = m->xrecv[0] = m->xrecv[1] = nullptr;
   m->rows = slf::RowClasses{};
   m->rows_mem = nullptr;
+  m->slots = slf::SlotTable{};
+  m->slots_mem = nullptr;
   const int np = d->n_node_params > 0 ? d->n_node_params : 1;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc(&m->node_params, (size_t)np * d->precision);
@@ -1103,6 +1163,7 @@ int slf_module_destroy(slf_module* m) {
     if (m->node_params) hipFree(m->node_params);
     if (m->status) hipFree(m->status);
     if (m->rows_mem) hipFree(m->rows_mem);
+    if (m->slots_mem) hipFree(m->slots_mem);
     delete m;
   }
   return SLF_OK;
@@ -1248,7 +1309,8 @@ int slf_kernel_get(slf_module* m, const char* name, slf_kernel** out) {
     // what the resident kernel serves (slf_resident.hip): 2-D single-fluid modules, direct addressing, the standard
     // density formulation, node kinds whose code touches nothing but the node's own populations
     const slf::Geometry& g = m->geo;
-    if (g.dim != 2 || m->sc.enabled || g.indirect || m->phys.incompressible == SLF_DENSITY_ROUNDOFF)
+    if (g.dim != 2 || m->sc.enabled || g.indirect || m->phys.incompressible == SLF_DENSITY_ROUNDOFF || m->phys.regularized ||
+        m->phys.subgrid)
       return fail(SLF_ERR_UNSUPPORTED, "CollideAndPropagateResident: 2-D single-fluid modules with direct addressing and the "
                                        "standard density formulation only");
     if (g.axis_mode[0] == 1 || g.axis_mode[1] == 1)
@@ -1378,6 +1440,13 @@ int slf_kernel_set_args(slf_kernel* k, const char* fmt, const void* const* argv,
     return fail(SLF_ERR_INVALID, "argument list does not match the kernel's signature");
   k->needs_iteration = needs_iteration;
   k->bound = true;
+  if (k->kind == KK_COLLIDE_AND_PROPAGATE && k->mod->geo.indirect && !k->ptrs.empty() &&
+      k->mod->phys.incompressible != SLF_DENSITY_ROUNDOFF && !k->mod->phys.regularized && !k->mod->phys.subgrid) {
+    // indirect addressing: the sweep is launched over the slots (slot_sweep_kernel); the slot -> node table of this
+    // `nodes` argument is built here, once (a launch may be recorded into a graph, where nothing can be allocated)
+    SLF_HIP(hipSetDevice(k->mod->ctx->device));
+    slot_table_for(k->mod, (const void*)k->ptrs[0], (hipStream_t)0);
+  }
   return SLF_OK;
 }
 
@@ -1419,6 +1488,8 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.rows = m->rows.map ? &m->rows : nullptr;
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       if (g.indirect && !a.nodes) return fail(SLF_ERR_INVALID, "indirect addressing: the nodes table is NULL");
+      // (the slot table is built when the arguments are bound, slf_kernel_set_args: a launch may be part of a graph capture)
+      if (g.indirect && k->kind == KK_COLLIDE_AND_PROPAGATE && m->slots.nodes == a.nodes) a.slots = &m->slots;
       slf::Prop prop = slf::PROP_AB;
       if (m->access_pattern == SLF_AA) {
         if (!k->needs_iteration) return fail(SLF_ERR_INVALID, "AA kernels need the iteration argument");

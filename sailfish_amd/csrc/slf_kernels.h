@@ -47,6 +47,9 @@ struct Physics {
   int has_force;
   int relaxation_enabled;
   int force_edm;   // body / Shan-Chen forces by the exact difference method instead of Guo's
+  // --regularized / --subgrid=les-smagorinsky (slf_module_desc; relaxation_common.mako:166-237): per-node kernels only
+  int regularized, subgrid;
+  double smagorinsky_const;
 };
 
 struct ShanChen {
@@ -58,6 +61,7 @@ struct ShanChen {
 };
 
 struct RowClasses;
+struct SlotTable;
 
 struct SweepArgs {
   const void* nodes;   // indirect addressing: dense index -> slot table (uint32), else NULL
@@ -79,6 +83,8 @@ struct SweepArgs {
   // x-face buffers (slf_module_set_xface_buffers): [0] low face (x = 1 side), [1] high face; NULL = not used
   void* xsend[2];
   const void* xrecv[2];
+  // indirect addressing: which node owns which slot (SlotTable), NULL = not built: one thread per DENSE node
+  const SlotTable* slots;
   // row classes of the node map `map` (slf_module_classify_rows), NULL = not classified; see RowClasses
   const RowClasses* rows;
 };
@@ -90,6 +96,16 @@ struct SweepArgs {
 // with boundary conditions.  Rows whose worst segment is class 2 are listed in bc_rows and swept by the kernel
 // instantiated for the module's Geometry::bc_level; all other rows by the level-0 instantiation with its 8
 // resident waves per SIMD -- a lid-driven cavity has boundary-condition nodes in 0.2 % of its rows.
+// Indirect addressing, the other way round: slot -> node.  Built once per `nodes` table (slf_api.hip), so that the sweep
+// can be launched over the SLOTS -- every lane of every wave an active node, and consecutive lanes consecutive slots of
+// every array -- instead of over the dense box, where a packed bed leaves 70 % of the lanes idle.
+struct SlotTable {
+  const void* nodes;          // the dense node -> slot table this was built from
+  const uint32_t* slot_gi;    // dense index of the node that owns slot s; INVALID_NODE: nobody does
+  const uint32_t* slot_yz;    // its y | z << 16
+  uint32_t n_slots;           // highest used slot + 1
+};
+
 struct RowClasses {
   const void* map;             // the device node map the tables were built from
   const uint32_t* seg_class;   // bytes [arr_nz * arr_ny][nseg], addressed as dwords (scalar loads)
@@ -129,6 +145,8 @@ hipError_t launch_macro(const KernelSelector& sel, Prop prop, const Geometry& g,
 
 // Builds the tables of RowClasses for `map` (device buffers seg_class, row_class, bc_rows and the counters
 // {class-2 rows, class-0 segments} are the caller's); the counts are read back by the caller.
+hipError_t launch_build_slot_table(const Geometry& g, const void* nodes, uint32_t* slot_gi, uint32_t* slot_yz,
+                                   uint32_t* max_slot, hipStream_t s);
 hipError_t launch_classify_rows(const Geometry& g, const void* map, uint32_t* seg_class, uint8_t* row_class,
                                 uint32_t* bc_rows, uint32_t* counters, int nseg, hipStream_t s);
 

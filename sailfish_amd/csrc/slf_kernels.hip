@@ -22,7 +22,7 @@
 
 namespace slf {
 
-template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool ROUNDOFF = false>
+template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool ROUNDOFF = false, bool TURB = false>
 __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
 
   R rho, v[3];
   bool wet = true;
-  node_update<L, R, MODEL, PROP, GENERAL, INDIRECT, FORCE_RUNTIME, 2, ROUNDOFF>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
+  node_update<L, R, MODEL, PROP, GENERAL, INDIRECT, FORCE_RUNTIME, 2, ROUNDOFF, TURB>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
 
   if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
   // ---- macroscopic output (save_macro_fields, kernel_common.mako:213-240)
@@ -92,6 +92,88 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
       if (!INDIRECT || t != INVALID_NODE) (p.dout + ds * (size_t)I)[t] = f[I];
     }
   });
+}
+
+// Indirect addressing (reference subdomain_runner.py:829-878, kernel_common.mako:140-167), one thread per SLOT: lane l of
+// a wave owns slot s0 + l of every array, so the own-slot accesses of the even in-place step are whole lines and every
+// lane works -- the per-node launch above walks the dense box, where a packed bed (30 % fluid) leaves 70 % of the lanes
+// of every wave idle and the active ones' accesses a third of a line (6.5 GMLUPS; profiles/r06/configs_indirect.jsonl).
+// The x-streaming steps translate every neighbour ONCE: node x - e_i (the pull) is node x + e_opp(i) (the push), so the
+// 18 entries of the dense table serve both; consecutive active nodes of a row have consecutive slots, so the gathers
+// through them are as good as dense.  Same node code (node_update<..., INDIRECT>), same results.
+template <class L, class R, int MODEL, int PROP>
+__global__ void __launch_bounds__(256, 4) slot_sweep_kernel(const SweepParams<L, R> p) {
+  const Geometry& g = p.g;
+  const uint32_t si = blockIdx.x * 256u + threadIdx.x;
+  if (si >= p.n_slots) return;
+  const uint32_t gi = p.slot_gi[si];
+  if (gi == INVALID_NODE) return;
+  const uint32_t yz = p.slot_yz[si];
+  const int gy = (int)(yz & 0xffffu), gz = (int)(yz >> 16);
+  if (gy < p.y0 || gy >= p.y1) return;                       // launches over a region of the subdomain (boundary / bulk)
+  if (L::dim == 3 && (gz < p.z0 || gz >= p.z1)) return;
+  const int gx = (int)(gi - ((uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz));
+  if (gx < 1 || gx > g.lat_nx - 2) return;                   // the layer of ghost nodes owns slots too
+  const uint32_t code = p.map[gi];
+  const int kind = (int)((g.type_lut >> (4u * (code & g.type_mask))) & 0xFull);
+  if (kind_is_excluded(kind)) return;
+  const AxisOff ox = axis_off(gx, g.lat_nx, 1, g.wrap[0]);
+  const AxisOff oy = axis_off(gy, g.lat_ny, g.arr_nx, g.wrap[1]);
+  const AxisOff oz = (L::dim == 3) ? axis_off(gz, g.lat_nz, g.arr_nxy, g.wrap[2]) : AxisOff{0, 0};
+  const size_t ds = g.dist_size;
+  uint32_t t[L::Q];            // slot of the node at x + e_i
+  t[0] = si;
+  if constexpr (PROP != PROP_AA_EVEN) {
+    static_for<1, L::Q>([&](auto I) { t[I] = p.nodes[(uint32_t)((int)gi + dir_offset<L, I>(ox, oy, oz, true))]; });
+  }
+  R f[L::Q];
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_ODD) {
+      const uint32_t sn = t[L::opp(I)];                      // x - e_i = x + e_opp(i)
+      f[I] = (sn != INVALID_NODE) ? (p.din + ds * (size_t)L::opp(I))[sn] : (R)0;
+    } else {
+      f[I] = (p.din + ds * (size_t)I)[si];
+    }
+  });
+  R rho, v[3];
+  bool wet = true;
+  node_update<L, R, MODEL, PROP, true, true, FORCE_RUNTIME, 2, false>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
+  if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
+  if ((p.options & 1u) && wet) {
+    p.rho[gi] = rho;
+    p.vx[gi] = v[0];
+    p.vy[gi] = v[1];
+    if constexpr (L::dim == 3) p.vz[gi] = v[2];
+  }
+  static_for<0, L::Q>([&](auto I) {
+    if constexpr (PROP == PROP_AA_EVEN) {
+      (p.dout + ds * (size_t)L::opp(I))[si] = f[I];
+    } else {
+      if (t[I] != INVALID_NODE) (p.dout + ds * (size_t)I)[t[I]] = f[I];
+    }
+  });
+}
+
+// slot -> node, from the dense node -> slot table: one thread per node of the padded box
+__global__ void __launch_bounds__(256) build_slot_table_kernel(const uint32_t* __restrict__ nodes, Geometry g, uint32_t* slot_gi,
+                                                               uint32_t* slot_yz, uint32_t* max_slot) {
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int gy = (int)blockIdx.y, gz = (int)blockIdx.z;
+  if (gx >= g.lat_nx) return;
+  const uint32_t gi = (uint32_t)gx + (uint32_t)g.arr_nx * (uint32_t)gy + (uint32_t)g.arr_nxy * (uint32_t)gz;
+  const uint32_t s = nodes[gi];
+  if (s == INVALID_NODE || s >= g.dist_size) return;
+  slot_gi[s] = gi;
+  slot_yz[s] = (uint32_t)gy | ((uint32_t)gz << 16);
+  atomicMax(max_slot, s);
+}
+
+hipError_t launch_build_slot_table(const Geometry& g, const void* nodes, uint32_t* slot_gi, uint32_t* slot_yz,
+                                   uint32_t* max_slot, hipStream_t s) {
+  dim3 block(256, 1, 1);
+  dim3 grid((g.lat_nx + 255) / 256, g.lat_ny, g.lat_nz);
+  hipLaunchKernelGGL(build_slot_table_kernel, grid, block, 0, s, (const uint32_t*)nodes, g, slot_gi, slot_yz, max_slot);
+  return hipGetLastError();
 }
 
 // SetInitialConditions: f_i = feq_i(rho, v) on *every* node of the lattice box,
@@ -363,6 +445,19 @@ static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& 
       else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false, false, true>), grid, block, 0, s, p);
       return hipGetLastError();
     }
+    if (ph.regularized || ph.subgrid) {       // --regularized / --subgrid=les-smagorinsky (BGK only; checked at module creation)
+      if (g.indirect) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, true, false, true>), grid, block, 0, s, p);
+      else if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, false, false, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false, false, false, true>), grid, block, 0, s, p);
+      return hipGetLastError();
+    }
+  }
+  if (g.indirect && p.slot_gi) {       // one thread per slot (slot_sweep_kernel)
+    SweepParams<L, R> q = p;
+    q.y1 = y1;
+    q.z1 = (L::dim == 3) ? z1 : 1;
+    hipLaunchKernelGGL((slot_sweep_kernel<L, R, MODEL, PROP>), dim3((q.n_slots + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, q);
+    return hipGetLastError();
   }
   if (g.indirect) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, true>), grid, block, 0, s, p);
   else if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true>), grid, block, 0, s, p);

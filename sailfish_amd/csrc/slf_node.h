@@ -564,6 +564,96 @@ SLF_D void regularized_bc(R (&f)[L::Q], R rho, R rho0, const R (&v)[3]) {
   });
 }
 
+SLF_D float slf_sqrt(float x) { return sqrtf(x); }
+SLF_D double slf_sqrt(double x) { return sqrt(x); }
+
+// --regularized / --subgrid=les-smagorinsky (reference lb_single.py:27-42; bgk_relaxation_preamble and
+// update_relaxation_time, relaxation_common.mako:166-237; BGK_relaxate, relaxation.mako:124-132).  Both work on the
+// non-equilibrium momentum flux of the populations as read, at the equilibrium's velocity (u + a/2 under Guo forcing):
+//   subgrid (flags bit 1): tau0 = 1/2 + 3 visc, tau0 += (sqrt(tau0^2 + 36 C^2 sqrt(Q)) - tau0) / 2 with Q = T_ab T_ab
+//     (off-diagonal components twice), omega = 1 / tau0, the Guo prefactor at that tau0 (sym_force.py:156-160);
+//   regularized (bit 0): f_i = feq_i + w_i / (2 cs^4) (e_ia e_ib - cs^2 delta_ab) T_ab (sym.reglb_flux_tensor) before the
+//     relaxation.
+// Operation for operation oracle/lbm_oracle.c: bgk_relax.  Guo forcing or none (the exact difference method is refused at
+// module creation); standard and incompressible density models.
+template <class L, class R>
+SLF_D void bgk_relax_turb(R (&f)[L::Q], R rho, R (&v)[3], const CollideParams<L, R>& cp, int flags, R visc, R c2x36) {
+  const R rho0 = cp.incompressible != 0 ? (R)1 : rho;
+  const bool has_force = cp.has_force != 0;
+  if (has_force) {
+    static_for<0, L::dim>([&](auto D) { v[D] = v[D] + (R)0.5 * cp.accel[D]; });
+  }
+  const R u15 = usq15<L, R>(v);
+  constexpr int NP = L::dim * (L::dim + 1) / 2;
+  R P[NP];
+  static_for<0, L::dim>([&](auto A) {
+    static_for<A, L::dim>([&](auto B) {
+      constexpr int idx = flux_index<L>(A, B);
+      R acc = (R)0;
+      static_for<1, L::Q>([&](auto I) {
+        constexpr int c = e_comp<L>(I, A) * e_comp<L>(I, B);
+        if constexpr (c > 0) acc = acc + f[I];
+        if constexpr (c < 0) acc = acc - f[I];
+      });
+      if constexpr (A == B) acc = acc - rho * (v[A] * v[A] + (R)(1.0 / 3.0));
+      else acc = acc - rho * (v[A] * v[B]);
+      P[idx] = acc;
+    });
+  });
+  R omega = cp.omega, guo_pref = cp.guo_pref;
+  if (flags & 2) {
+    R strain = (R)0;
+    static_for<0, L::dim>([&](auto A) {
+      static_for<A + 1, L::dim>([&](auto B) {
+        const R t = P[flux_index<L>(A, B)];
+        strain = strain + (R)2 * t * t;
+      });
+    });
+    static_for<0, L::dim>([&](auto A) {
+      const R t = P[flux_index<L>(A, A)];
+      strain = strain + t * t;
+    });
+    R tau0 = (R)0.5 + (R)3 * visc;
+    tau0 = tau0 + (R)0.5 * (slf_sqrt(tau0 * tau0 + c2x36 * slf_sqrt(strain)) - tau0);
+    omega = (R)1 / tau0;
+    guo_pref = (R)3 * ((R)1 - (R)0.5 / tau0);
+  }
+  if (flags & 1) {
+    static_for<0, L::Q>([&](auto I) {
+      R acc = (R)0;
+      static_for<0, L::dim>([&](auto A) {
+        static_for<A, L::dim>([&](auto B) {
+          constexpr int idx = flux_index<L>(A, B);
+          constexpr int ea = e_comp<L>(I, A), eb = e_comp<L>(I, B);
+          if constexpr (A == B) {
+            if constexpr (ea != 0) acc = acc + (R)(2.0 / 3.0) * P[idx];
+            else acc = acc + (R)(-1.0 / 3.0) * P[idx];
+          } else {
+            if constexpr (ea * eb > 0) acc = acc + (R)2 * P[idx];
+            if constexpr (ea * eb < 0) acc = acc - (R)2 * P[idx];
+          }
+        });
+      });
+      f[I] = feq<L, R, I>(rho, rho0, v, u15) + Weights<L, R>::w45(I) * acc;
+    });
+  }
+  static_for<0, L::Q>([&](auto I) {
+    const R fe = feq<L, R, I>(rho, rho0, v, u15);
+    f[I] = f[I] + omega * (fe - f[I]);
+  });
+  if (has_force) {
+    const R pref = rho * guo_pref;
+    R va = v[0] * cp.accel[0] + v[1] * cp.accel[1];
+    if constexpr (L::dim == 3) va = va + v[2] * cp.accel[2];
+    static_for<0, L::Q>([&](auto I) {
+      const R eu = edotv<L, R, I>(v);
+      const R ea = edotv<L, R, I>(cp.accel);
+      const R t = (ea - va) + (R)3 * eu * ea;
+      f[I] = f[I] + pref * Weights<L, R>::w(I) * t;
+    });
+  }
+}
+
 // Number of unknown populations, other than the one along the normal n, with a component along axis d.
 template <class L>
 constexpr int zouhe_count(int n, int d) {

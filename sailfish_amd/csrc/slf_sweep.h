@@ -39,7 +39,15 @@ struct SweepParams {
   const uint8_t* row_class;
   const uint32_t* bc_rows;
   int nseg, row_mode, y1, z1;
+  // indirect addressing, launches over the slots (SlotTable, slf_kernels.h)
+  const uint32_t* slot_gi;
+  const uint32_t* slot_yz;
+  uint32_t n_slots;
+  // --regularized (bit 0) / --subgrid=les-smagorinsky (bit 1): read by the TURB instantiations of the per-node kernels only
+  int turb_flags;
+  R turb_visc, turb_c2x36;      // viscosity and 36 C^2 of the subgrid model
 };
+
 
 // Which rows an XCD gets.  Workgroups are dealt out to the eight XCDs round-robin by their flat index; with one
 // workgroup per row every XCD sweeps every eighth row of a plane.  Where neighbouring rows share data through the L2 --
@@ -288,8 +296,10 @@ __device__ __forceinline__ void check_invalid(uint32_t* status, uint32_t options
 // exist at level 2 only, so that the level-1 kernels of the usual wall / inlet / outlet conditions do not carry their code).
 // ROUNDOFF: the --minimize_roundoff formulation (slf_node.h: macro_roundoff, bgk_relax_roundoff): BGK; fluid, full-way
 // and half-way bounce-back nodes (the module is refused otherwise); the per-node kernels only.
+// TURB: the BGK collision with the options of the reference's relaxation preamble (--regularized, --subgrid; which of
+// the two: SweepParams::turb_flags) -- slf_node.h bgk_relax_turb; the per-node kernels only, MODEL = BGK.
 template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, int FORCE = FORCE_RUNTIME, int BCL = 2,
-          bool ROUNDOFF = false>
+          bool ROUNDOFF = false, bool TURB = false>
 __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L::Q], uint32_t code, int kind,
                                             uint32_t gi, const AxisOff& ox, const AxisOff& oy, const AxisOff& oz,
                                             R& rho, R (&v)[3], bool& wet, uint32_t si = INVALID_NODE) {
@@ -470,7 +480,9 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
     }
     // ---- collision (relaxate, relaxation.mako:196-202: wet nodes only)
     if (wet && p.relaxation_enabled) {
-      if constexpr (MODEL == 0) {
+      if constexpr (MODEL == 0 && TURB) {
+        bgk_relax_turb<L, R>(f, rho, v, p.cp, p.turb_flags, p.turb_visc, p.turb_c2x36);
+      } else if constexpr (MODEL == 0) {
         bgk_relax<L, R, FORCE>(f, rho, v, p.cp);
       } else {
         mrt_relax<L, R, FORCE>(f, v, p.cp, kind == NK_EQUILIBRIUM_DENSITY || kind == NK_EQUILIBRIUM_VELOCITY);
@@ -504,7 +516,8 @@ __device__ __forceinline__ void node_update(const SweepParams<L, R>& p, R (&f)[L
   } else {
     macro_standard<L, R>(f, p.cp.incompressible != 0, rho, v);
     if (p.relaxation_enabled) {
-      if constexpr (MODEL == 0) bgk_relax<L, R, FORCE>(f, rho, v, p.cp);
+      if constexpr (MODEL == 0 && TURB) bgk_relax_turb<L, R>(f, rho, v, p.cp, p.turb_flags, p.turb_visc, p.turb_c2x36);
+      else if constexpr (MODEL == 0) bgk_relax<L, R, FORCE>(f, rho, v, p.cp);
       else mrt_relax<L, R, FORCE>(f, v, p.cp, false);
     }
   }
@@ -537,6 +550,13 @@ inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const
   p.bc_rows = nullptr;
   p.nseg = 0;
   p.row_mode = 0;
+  p.slot_gi = p.slot_yz = nullptr;
+  p.n_slots = 0;
+  if (a.slots && a.slots->nodes == a.nodes && a.nodes) {
+    p.slot_gi = a.slots->slot_gi;
+    p.slot_yz = a.slots->slot_yz;
+    p.n_slots = a.slots->n_slots;
+  }
   if (a.rows && a.rows->map == a.map && a.map) {
     p.seg_class = a.rows->seg_class;
     p.row_class = a.rows->row_class;
@@ -544,6 +564,9 @@ inline SweepParams<L, R> make_params(const Geometry& g, const Physics& ph, const
     p.nseg = a.rows->nseg;
   }
   p.relaxation_enabled = ph.relaxation_enabled;
+  p.turb_flags = (ph.regularized ? 1 : 0) | (ph.subgrid ? 2 : 0);
+  p.turb_visc = (R)ph.visc;
+  p.turb_c2x36 = (R)(36.0 * ph.smagorinsky_const * ph.smagorinsky_const);
   p.g = g;
   p.cp.omega = (R)(1.0 / ph.tau);
   for (int k = 0; k < L::Q; k++) p.cp.mrt_s[k] = (R)ph.mrt_rates[k];

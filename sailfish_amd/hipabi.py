@@ -56,6 +56,9 @@ class SlfModuleDesc(Structure):
         ('accel1', c_double * 3),
         ('force_implementation', c_int32),
         ('sparse_geometry', c_int32),
+        ('regularized', c_int32),
+        ('subgrid', c_int32),
+        ('smagorinsky_const', c_double),
     ]
 
 
@@ -172,6 +175,7 @@ SIGNATURES = {
 SLF_ADDR_DIRECT, SLF_ADDR_INDIRECT = 0, 1
 SLF_DENSITY_COMPRESSIBLE, SLF_DENSITY_INCOMPRESSIBLE, SLF_DENSITY_ROUNDOFF = 0, 1, 2
 SLF_FORCE_GUO, SLF_FORCE_EDM = 0, 1
+SLF_SUBGRID_NONE, SLF_SUBGRID_LES_SMAGORINSKY = 0, 1
 SLF_INVALID_NODE = 0xffffffff
 SLF_PEER_HANDLE_BYTES, SLF_PEER_CHANNELS = 64, 4
 

@@ -18,6 +18,12 @@ class LBFluidSim(LBSim):
                            help='use the incompressible model of Luo and He')
         group.add_argument('--model', help='LB collision model to use', type=str, choices=['bgk', 'mrt'],
                            default='bgk')
+        # the two options of the reference's BGK relaxation preamble (lb_single.py:27-30, 38-42; relaxation_common.mako:166-237)
+        group.add_argument('--regularized', action='store_true', default=False,
+                           help='Apply the regularization procedure prior to the collision step.')
+        group.add_argument('--subgrid', default='none', type=str, choices=['none', 'les-smagorinsky'],
+                           help='subgrid model to use')
+        group.add_argument('--smagorinsky_const', help='Smagorinsky constant', type=float, default=0.1)
 
     @classmethod
     def fields(cls):
@@ -33,6 +39,14 @@ class LBFluidSim(LBSim):
                   tau=sym.relaxation_time(cfg.visc), visc=cfg.visc,
                   mrt_rates=sym.mrt_rates(self.grid, cfg.visc),
                   incompressible=self.density_model(cfg))
+        if getattr(cfg, 'regularized', False) or getattr(cfg, 'subgrid', 'none') != 'none':
+            if cfg.model != 'bgk':
+                # the reference's MRT relaxation never calls the preamble that implements them: it would ignore both silently
+                raise ValueError('--regularized / --subgrid work with the BGK collision only')
+            kw.update(regularized=int(bool(getattr(cfg, 'regularized', False))),
+                      subgrid=hipabi.SLF_SUBGRID_LES_SMAGORINSKY if getattr(cfg, 'subgrid', 'none') == 'les-smagorinsky'
+                      else hipabi.SLF_SUBGRID_NONE,
+                      smagorinsky_const=float(getattr(cfg, 'smagorinsky_const', 0.1)))
 
     @staticmethod
     def density_model(cfg):

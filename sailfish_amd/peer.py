@@ -174,7 +174,7 @@ class PeerTransport(object):
         """Plain device memory of the ring neighbour written through its mapping (dense stores and one word per workgroup,
         the x-face pattern) and released by a signal is what the neighbour reads after its wait -- on the mappings and
         streams of this very run, with the reader holding the previous contents in its caches."""
-        self.set_timeout(float(os.environ.get('SLF_PEER_SELFTEST_TIMEOUT_S', '15')))
+        self.set_timeout(float(os.environ.get('SLF_PEER_SELFTEST_TIMEOUT_S', '60')))
         grp = PeerGroup(self)
         mine = grp.alloc(nwords * 4)
         self.backend.memset_buf(mine, 0, nwords * 4)
@@ -185,6 +185,14 @@ class PeerTransport(object):
         s = self.backend.make_stream()
         bad_total = 0
         out = ctypes.c_uint32()
+        # the first launch of a process loads the library's code objects (seconds when eight processes start on one device
+        # at once): do that outside the timed waits, then start the rounds together
+        _check(self.lib, self.lib.slf_peer_selftest_check(self.handle, ctypes.c_void_p(mine), 64, 0, s.handle, ctypes.byref(out)),
+               'slf_peer_selftest_check')
+        self.signal([self.rank], CH_ACK, s)
+        self.wait([self.rank], CH_ACK, s)
+        s.synchronize()
+        self.barrier()
         for sparse in (0, 1):
             for rnd in range(rounds):
                 pat = lambda r: (0x9e3779b9 * (1 + rnd + 100 * sparse) + 7919 * r) & 0xFFFFFFFF   # noqa: E731

@@ -850,7 +850,10 @@ class SubdomainRunner(object):
         ny = list(reversed(self._lat_size))[1] - 2
         streams = [self._calc_stream, self._bnd_stream]
         snd, rcv = x.send[par], x.recv[1 - par]
-        if group is not None:
+        # every sweep of the group on one stream (controller.LocalGroup._serialise_sweeps): its order is all the order
+        # the shared face buffers need -- no events
+        serial = group is not None and getattr(group, 'single_calc_stream', False) and x.shared
+        if group is not None and not serial:
             # the send set of this parity was last read by the neighbours' copies of step it - 2
             for e in self._neighbour_events(group, 'copied', par):
                 q.wait(streams[0], e)
@@ -872,6 +875,10 @@ class SubdomainRunner(object):
         waited = {}
         for pos, c in enumerate(plan.order):
             st = streams[pos & 1]
+            if serial:
+                for k in kernels:
+                    q.launch(k, plan.region(c, ny), st)
+                continue
             if need[c] > waited.get(id(st), -1):     # the streams are in order: a later transfer waited for covers the earlier ones
                 q.wait(st, pevb[need[c]])
                 waited[id(st)] = need[c]

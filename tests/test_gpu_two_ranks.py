@@ -74,6 +74,28 @@ def test_bench_launches_two_ranks_itself():
     assert all(v['undivided_box']['populations_bit_identical'] and v['undivided_box']['slabs'] == 2 for v in c['validation'].values())
 
 
+def test_results_of_the_peer_transport_that_fail_validation_are_not_reported():
+    """The peer transport has never run between two GPUs (single-GPU boxes): if the seam layers it produced did not match
+    the oracle, bench.py repeats the measurement over RCCL / torch.distributed and reports THAT, with the rejected figures
+    beside it (here the rejection is forced: SLF_BENCH_TEST_REJECT_PEER=1)."""
+    env = dict(os.environ, SLF_DIST_BACKEND='gloo', SLF_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               SLF_BENCH_TEST_REJECT_PEER='1', GPU_MAX_HW_QUEUES='2')
+    env.pop('SLF_HALO_TRANSPORT', None)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--scaling', 'strong',
+           '--domain', '256x48x40', '--axis', 'x', '--prewarm_steps', '2', '--repeats', '1', '--no_cpu_baseline', '--no_gpu_state',
+           '--access_pattern', 'AA']
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    out = res.stdout.decode(errors='replace')
+    assert res.returncode == 0, out[-3000:]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith('{"metric"')][-1])
+    c = d['config']
+    assert c['halo_transport'].startswith('torch.distributed') and c['validated'] is True
+    rej = c['peer_transport_rejected']
+    assert rej['halo_transport'] == 'peer' and rej['mlups']['AA'] > 0 and rej['validation']['AA']['test_forced_rejection']
+
+
 @pytest.mark.parametrize('how', ['stall', 'exit'])
 def test_a_rank_that_stops_ends_the_bench_with_an_error_line(how):
     """One of two ranks stops advancing (or leaves) after the rendezvous: instead of hanging until the launcher's limit,

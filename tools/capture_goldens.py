@@ -584,11 +584,79 @@ def roundoff_bc_goldens(grid, rng, n=12):
     return out
 
 
+def turbulence_goldens(grid, rng, n=24):
+    """--regularized and --subgrid=les-smagorinsky (reference lb_single.py:27-42), composed from the reference's own
+    objects in the order of bgk_relaxation_preamble (relaxation_common.mako:205-237): equilibrium at (rho, v0) ->
+    update_relaxation_time (:166-203: strain from ex_flux(d0) - ex_eq_flux, tau0 += (sqrt(tau0^2 + 36 C^2 sqrt(Q)) - tau0) / 2)
+    -> regularisation (:228-236: d0 = feq + reglb_flux_tensor . flux, the flux of the populations as read) -> BGK_relaxate
+    (relaxation.mako:124-132, omega = 1 / tau0 under the subgrid model) -> Guo term with the prefactor at tau0
+    (sym_force.py:140-160; relaxation_common.mako:110-135)."""
+    dim, Q = grid.dim, grid.Q
+    cfg = _Cfg()
+    rho = rng.uniform(0.9, 1.1, n)
+    f = np.array([[float(w) for w in grid.weights]] * n) * rho[:, None]
+    f = f * (1.0 + rng.uniform(-0.08, 0.08, (n, Q)))
+    accel = rng.uniform(-1e-4, 1e-4, (n, dim))
+    visc = np.array([0.001, 0.02])
+    csmag = np.array([0.1, 0.17])
+    eq = sym_equilibrium.bgk_equilibrium(grid, cfg)
+    reg = sym.reglb_flux_tensor(grid)
+    guo = sym_force.guo_external_force(grid, grid_num=0)
+    pref_e = sym_force.guo_external_force_pref(grid, cfg, grid_num=0)
+    pairs = [(a, b) for a in range(dim) for b in range(a, dim)]
+    out = {'f': f, 'accel': accel, 'visc': visc, 'smagorinsky_const': csmag}
+    shape = (len(visc), len(csmag), 2, n, Q)            # [viscosity][constant][without / with body force][sample]
+    for name in ('reg_post', 'les_post', 'reg_les_post'):
+        out[name] = np.zeros(shape)
+    out['les_tau'] = np.zeros(shape[:-1])
+    out['out_v'] = np.zeros((2, n, dim))
+    for k in range(n):
+        fs = _fi_subs(grid, f[k])
+        fs.update(_fi_subs(grid, f[k], ptr='d0'))
+        r = _evalf(sym.ex_rho(grid, 'fi', False), fs)
+        fs2 = dict(fs)
+        fs2.update({'g0m0': r, 'rho': r})
+        u = np.array([_evalf(sym.ex_velocity(grid, 'fi', d, cfg), fs2) for d in range(dim)])
+        for forced in (0, 1):
+            v0 = u + (0.5 * accel[k] if forced else 0.0)
+            out['out_v'][forced, k] = v0
+            ms = _macro_subs(grid, r, v0)
+            feq = np.array([_evalf(e, ms) for e in eq.expression])
+            sub = dict(fs)
+            sub.update(ms)
+            flux = np.array([_evalf(sym.ex_flux(grid, 'd0', a, b, cfg), sub) - _evalf(sym.ex_eq_flux(grid, a, b), ms)
+                             for a, b in pairs])
+            fl = {'flux[%d]' % j: flux[j] for j in range(len(pairs))}
+            d_reg = feq + np.array([_evalf(e, fl) for e in reg])
+            strain = sum((2.0 if a != b else 1.0) * flux[j] ** 2 for j, (a, b) in enumerate(pairs))
+            for vi, nu in enumerate(visc):
+                tau = sym.relaxation_time(nu)
+                for ci, c in enumerate(csmag):
+                    tau_les = tau + 0.5 * (np.sqrt(tau * tau + 36.0 * c * c * np.sqrt(strain)) - tau)
+                    out['les_tau'][vi, ci, forced, k] = tau_les
+                    for name, d0, t0 in (('reg_post', d_reg, tau), ('les_post', f[k], tau_les), ('reg_les_post', d_reg, tau_les)):
+                        post = d0 + (1.0 / t0) * (feq - d0)
+                        if forced:
+                            gs = dict(ms)
+                            gs.update({'g0ea' + ch: accel[k, j] for j, ch in enumerate('xyz'[:dim])})
+                            gs['tau0'] = t0
+                            gs['pref'] = _evalf(pref_e, gs)
+                            post = post + np.array([_evalf(g, gs) for g in guo])
+                        out[name][vi, ci, forced, k] = post
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'tables':      # the lattice tables only (the .npz files stay as they are)
         with open(os.path.join(OUT, 'lattices.json'), 'w') as fh:
             json.dump({g.__name__: lattice_tables(g) for g in (sym.D2Q9, sym.D3Q19)}, fh, indent=1, sort_keys=True)
         print('wrote lattices.json')
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'turbulence':     # --regularized / --subgrid=les-smagorinsky only
+        rng_t = np.random.RandomState(61)
+        for grid in (sym.D2Q9, sym.D3Q19):
+            np.savez_compressed(os.path.join(OUT, 'arith_reg_les_%s.npz' % grid.__name__), **turbulence_goldens(grid, rng_t))
+            print('wrote regularized / Smagorinsky goldens for', grid.__name__)
         return
     rng_sc = np.random.RandomState(777)
     for grid in (sym.D2Q9, sym.D3Q19):

@@ -313,5 +313,76 @@ c.run(ignore_cmdline=True)
     done
     grep -v "socket.cpp\|amdgpu.ids" $O/*.err | tail -n 30
     ;;
+  r6v6)   # the whole GPU suite after the peer transport + the rows of SURVEY 8(f) that had no number (indirect addressing,
+          # single-component Shan-Chen, obstacle examples) + the open ducts of round 5
+    export SLF_PEER_TIMEOUT_S=30
+    ( time timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > $O/pytest_gpu.log 2>&1; tail -22 $O/pytest_gpu.log
+    for c in 7a 7b 7c 7d 8a 8b 9a 9b 6xa 6xb; do
+      timeout 600 python tools/bench_configs.py --only $c 2> $O/cfg_$c.err | grep '^{' | tee -a $O/configs_new.jsonl | cut -c1-330
+    done
+    TRACE_CONFIGS="7a 8a 8b" bash tools/gpu.sh tracecfg pmccfg; rm -rf $O/trace_cfg*/ $O/pmc_cfg*/
+    grep -v "amdgpu.ids" $O/cfg_*.err | tail -n 30
+    ;;
+  r6v7)   # split rows: parity, then the open ducts with / without (alternating on this box); where several subdomains in
+          # one process lose their rate: kernel traces of the pipe in 3 x-slabs and of binary Shan-Chen in 4 x-slabs
+    ( time timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_runner.py -m gpu -q -x -k "split or row_classes or open_channel or do_nothing or duct or cylinder or sphere" --durations=5 ) > $O/pytest_split.log 2>&1; tail -8 $O/pytest_split.log
+    for rep in 1 2; do
+      for sp in 1 0; do
+        for c in 6xa 6xb; do
+          SLF_ROW_SPLIT=$sp timeout 600 python tools/bench_configs.py --only $c 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('split $sp', d['config'][:4], d['MLUPS_eff'], d['MLUPS_comp'])" | tee -a $O/split_rows_ab.txt
+        done
+      done
+    done
+    P="--lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA --mode=benchmark --max_iters=300 --benchmark_sample_from=100 --perf_stats_every=0"
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_pipe -o trace -- \
+        env SLF_PLACEMENT_TUNE=0 python $GRAFT_REPO_ROOT/examples/poiseuille_3d.py $P > $GRAFT_REPO_ROOT/$O/trace_pipe.log 2>&1 )
+    python tools/probe/trace_busy.py $O/trace_pipe | tee $O/trace_busy_pipe_3x.txt; rm -rf $O/trace_pipe; grep "Total MLUPS" $O/trace_pipe.log
+    cat > /tmp/sc4.py <<PYEOF
+import sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
+from examples.binary_fluid.sc_separation_3d import SeparationSim
+from sailfish.controller import LBSimulationController
+from sailfish.geo import EqualSubdomainsGeometry3D
+c = LBSimulationController(SeparationSim, EqualSubdomainsGeometry3D, default_config=dict(lat_nx=256, lat_ny=256, lat_nz=256, subdomains=4, conn_axis='x', access_pattern='AB', mode='benchmark', max_iters=300, benchmark_sample_from=100, perf_stats_every=0))
+c.run(ignore_cmdline=True)
+PYEOF
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_sc -o trace -- \
+        env SLF_PLACEMENT_TUNE=0 python /tmp/sc4.py > $GRAFT_REPO_ROOT/$O/trace_sc.log 2>&1 )
+    python tools/probe/trace_busy.py $O/trace_sc | tee $O/trace_busy_sc_4x.txt; rm -rf $O/trace_sc; grep "Total MLUPS" $O/trace_sc.log
+    timeout 300 python /tmp/sc4.py 2>&1 | grep "Total MLUPS" | tee $O/sc_4x_untraced.txt
+    timeout 300 python examples/poiseuille_3d.py $P 2>&1 | grep "Total MLUPS" | tee $O/pipe_3x_untraced.txt
+    ;;
+  r6v8)   # indirect addressing, one thread per slot: parity, then the packed bed and the wavy pipe with / without;
+          # subdomains of one process with their sweeps on one stream: parity, pipe in 3 x-slabs, config 4's slabs in one process
+    export SLF_PEER_TIMEOUT_S=30
+    ( time timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_runner.py tests/test_gpu_sc.py tests/test_gpu_kat.py tests/test_gpu_examples.py -m gpu -q -x --durations=5 ) > $O/pytest_indirect_groups.log 2>&1; tail -8 $O/pytest_indirect_groups.log
+    ( time timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -x -k "eight_subdomains and z-peer" ) > $O/pytest_zpeer.log 2>&1; tail -4 $O/pytest_zpeer.log
+    for sl in 1 0; do
+      for c in 7a 7c; do
+        SLF_INDIRECT_SLOTS=$sl timeout 600 python tools/bench_configs.py --only $c 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('slots $sl', d['config'][:3], d['MLUPS_eff'], d['MLUPS_comp'], d.get('frac_of_8TBps'))" | tee -a $O/indirect_slots_ab.txt
+      done
+    done
+    TRACE_CONFIGS="7a" bash tools/gpu.sh tracecfg pmccfg; rm -rf $O/trace_cfg*/ $O/pmc_cfg*/
+    P="--lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA --mode=benchmark --max_iters=600 --benchmark_sample_from=200 --perf_stats_every=0"
+    for one in 1 0 1 0; do
+      ( SLF_GROUP_ONE_STREAM=$one timeout 300 python examples/poiseuille_3d.py $P 2>&1 | grep "Total MLUPS" | sed "s/^/one stream $one: pipe 3 x-slabs /" ) | tee -a $O/group_one_stream_ab.txt
+    done
+    for one in 1 0; do
+      SLF_GROUP_ONE_STREAM=$one timeout 900 python tools/bench_configs.py --only 3,3b,3g8 2>/dev/null | grep '^{' | python -c "
+import sys,json
+for ln in sys.stdin:
+    d=json.loads(ln); print('one stream $one', d['config'][:4], d['MLUPS_eff'], d.get('frac_of_8TBps'))" | tee -a $O/group_one_stream_ab.txt
+    done
+    ;;
+  r6v9)   # indirect addressing over the slots (table built when the arguments are bound), --regularized / --subgrid
+    export SLF_PEER_TIMEOUT_S=30
+    ( time timeout 1800 python -m pytest tests/test_gpu_reg_les.py tests/test_gpu_parity.py tests/test_gpu_runner.py tests/test_gpu_sc.py tests/test_gpu_golden.py tests/test_gpu_resident.py -m gpu -q -x --durations=5 ) > $O/pytest_reg_les_indirect.log 2>&1; tail -8 $O/pytest_reg_les_indirect.log
+    for sl in 1 0 1 0; do
+      for c in 7a 7c; do
+        SLF_INDIRECT_SLOTS=$sl timeout 600 python tools/bench_configs.py --only $c 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('slots $sl', d['config'][:3], d['MLUPS_eff'], d['MLUPS_comp'], d.get('frac_of_8TBps'))" | tee -a $O/indirect_slots_ab.txt
+      done
+    done
+    TRACE_CONFIGS="7a" bash tools/gpu.sh tracecfg pmccfg; rm -rf $O/trace_cfg*/ $O/pmc_cfg*/
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
