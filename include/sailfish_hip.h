@@ -328,6 +328,15 @@ int slf_module_destroy(slf_module* m);
  * launched with bit 2 (value 4) of their `options` argument set flag wet nodes whose density is not finite.
  * Waits for `stream`, returns out = {flag, x, y, z} of the first such node and clears the flag. */
 int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]);
+/* Boundary-condition parameters that change with time (round 6).  The reference renders time- and space-dependent node
+ * parameters into device code (node_type.py:471-626 DynamicValue, LinearlyInterpolatedTimeSeries; boundary.mako:52-84
+ * timeseries_interpolate, get_time_from_iteration); the pre-built kernels read constants from the module's parameter
+ * table (slf_module_desc::node_params), so the host evaluates such values and rewrites their table entries before
+ * every step: entries first .. first + n - 1 take values[] (converted to the module's precision) ON `stream` -- the
+ * launches enqueued on that stream afterwards see the new values, those enqueued before it the old ones; the call
+ * returns at once (up to 256 values travel as arguments of a one-wave kernel, longer updates through pinned staging
+ * buffers the module owns).  first + n must not exceed n_node_params. */
+int slf_module_update_node_params(slf_module* m, int first, const double* values, int n, slf_stream* stream);
 /* Row classes of the node map at `map_dptr` (no counterpart in the reference, whose kernels decode the map in every
  * thread: geo_helpers.mako:146-161, kernel_common.mako:191-201).  Builds, on the device, one class per 64-node
  * x-segment of every row -- 0 = all plain fluid: the wavefront that owns the segment neither reads the map (4 of the

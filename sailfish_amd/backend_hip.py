@@ -596,6 +596,14 @@ class HIPBackend(placement.VmmMixin):
                'slf_module_classify_rows')
         return {'rows': out[0], 'bc_rows': out[1], 'segments': out[2], 'fluid_segments': out[3]}
 
+    def update_node_params(self, module, first, values, stream=None):
+        """Entries first .. of the module's boundary-condition parameter table take `values` for the launches enqueued on
+        `stream` from now on (time-dependent boundary values: C ABI slf_module_update_node_params)."""
+        vals = np.ascontiguousarray(values, dtype=np.float64)
+        _check(self._lib, self._lib.slf_module_update_node_params(module.handle, int(first), vals.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                                  int(vals.size), stream.handle if stream else None),
+               'slf_module_update_node_params')
+
     def set_x_ghost_unused(self, module, low, high):
         """Nothing reads the ghost column x = 0 (low) / x = nx + 1 (high): the sweeps stop storing into it."""
         _check(self._lib, self._lib.slf_module_set_x_ghost_unused(module.handle, int(bool(low)), int(bool(high))),

@@ -208,6 +208,8 @@ class LocalGroup(object):
         if self._plan_ok is None:
             self._plan_ok = all(r._plan_ok for r in rs)
         timed = any(r._profile.wants_gpu_events() for r in rs)
+        for r in rs:
+            r._update_dynamic_params(it)
         plan = None
         if self._plan_ok and not timed:
             key = (it & 1, tuple(bool(req[1]) for req in reqs))

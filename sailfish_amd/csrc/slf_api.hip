@@ -94,6 +94,12 @@ struct slf_module {
   void* rows_mem;         // one device allocation behind the tables of `rows`
   slf::SlotTable slots;   // indirect addressing: slot -> node, built from the `nodes` table of the first launch that names it
   void* slots_mem;
+  int n_node_params, precision;
+  // slf_module_update_node_params: pinned staging buffers for long updates, each with the event of its last copy
+  void* stage[4];
+  hipEvent_t stage_ev[4];
+  size_t stage_bytes[4];
+  int stage_next;
 };
 struct slf_kernel {
   slf_module* mod;
@@ -1125,6 +1131,10 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   m->rows_mem = nullptr;
   m->slots = slf::SlotTable{};
   m->slots_mem = nullptr;
+  m->n_node_params = d->n_node_params > 0 ? d->n_node_params : 0;
+  m->precision = d->precision;
+  for (int i = 0; i < 4; i++) { m->stage[i] = nullptr; m->stage_ev[i] = nullptr; m->stage_bytes[i] = 0; }
+  m->stage_next = 0;
   const int np = d->n_node_params > 0 ? d->n_node_params : 1;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc(&m->node_params, (size_t)np * d->precision);
@@ -1164,6 +1174,10 @@ int slf_module_destroy(slf_module* m) {
     if (m->status) hipFree(m->status);
     if (m->rows_mem) hipFree(m->rows_mem);
     if (m->slots_mem) hipFree(m->slots_mem);
+    for (int i = 0; i < 4; i++) {
+      if (m->stage[i]) hipHostFree(m->stage[i]);
+      if (m->stage_ev[i]) hipEventDestroy(m->stage_ev[i]);
+    }
     delete m;
   }
   return SLF_OK;
@@ -1224,6 +1238,66 @@ int slf_module_classify_rows(slf_module* m, const void* map_dptr, slf_stream* st
     out_counts[2] = (int32_t)(m->rows.n_segments > 0x7fffffff ? 0x7fffffff : m->rows.n_segments);
     out_counts[3] = (int32_t)(m->rows.n_fluid_segments > 0x7fffffff ? 0x7fffffff : m->rows.n_fluid_segments);
   }
+  return SLF_OK;
+}
+
+namespace {
+constexpr int PARAM_UPDATE_MAX = 256;
+struct ParamUpdateF {
+  float v[PARAM_UPDATE_MAX];
+  int n;
+};
+struct ParamUpdateD {
+  double v[PARAM_UPDATE_MAX];
+  int n;
+};
+__global__ void update_params_kernel_f(float* table, ParamUpdateF u) {
+  for (int i = threadIdx.x; i < u.n; i += blockDim.x) table[i] = u.v[i];
+}
+__global__ void update_params_kernel_d(double* table, ParamUpdateD u) {
+  for (int i = threadIdx.x; i < u.n; i += blockDim.x) table[i] = u.v[i];
+}
+}  // namespace
+
+int slf_module_update_node_params(slf_module* m, int first, const double* values, int n, slf_stream* stream) {
+  if (!m || (!values && n > 0)) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (n <= 0) return SLF_OK;
+  if (first < 0 || first + n > m->n_node_params) return fail(SLF_ERR_INVALID, "node parameter range outside the module's table");
+  SLF_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = native(stream);
+  char* dst = (char*)m->node_params + (size_t)first * m->precision;
+  if (n <= PARAM_UPDATE_MAX) {
+    // the values travel as kernel arguments: nothing the host must keep alive, nothing that could make the call wait
+    if (m->precision == 4) {
+      ParamUpdateF u;
+      u.n = n;
+      for (int i = 0; i < n; i++) u.v[i] = (float)values[i];
+      hipLaunchKernelGGL(update_params_kernel_f, dim3(1), dim3(64), 0, s, (float*)dst, u);
+    } else {
+      ParamUpdateD u;
+      u.n = n;
+      for (int i = 0; i < n; i++) u.v[i] = values[i];
+      hipLaunchKernelGGL(update_params_kernel_d, dim3(1), dim3(64), 0, s, (double*)dst, u);
+    }
+    SLF_HIP(hipGetLastError());
+    return SLF_OK;
+  }
+  // long updates (a value per node of an inlet): through one of four pinned staging buffers, reused once its last copy is done
+  const int k = m->stage_next;
+  m->stage_next = (k + 1) & 3;
+  const size_t bytes = (size_t)n * m->precision;
+  if (m->stage_ev[k]) SLF_HIP(hipEventSynchronize(m->stage_ev[k]));
+  else SLF_HIP(hipEventCreateWithFlags(&m->stage_ev[k], hipEventDisableTiming));
+  if (m->stage_bytes[k] < bytes) {
+    if (m->stage[k]) SLF_HIP(hipHostFree(m->stage[k]));
+    m->stage[k] = nullptr;
+    SLF_HIP(hipHostMalloc(&m->stage[k], bytes, hipHostMallocDefault));
+    m->stage_bytes[k] = bytes;
+  }
+  if (m->precision == 4) for (int i = 0; i < n; i++) ((float*)m->stage[k])[i] = (float)values[i];
+  else memcpy(m->stage[k], values, bytes);
+  SLF_HIP(hipMemcpyAsync(dst, m->stage[k], bytes, hipMemcpyHostToDevice, s));
+  SLF_HIP(hipEventRecord(m->stage_ev[k], s));
   return SLF_OK;
 }
 

@@ -33,6 +33,13 @@ class _ParamTable(object):
             self.values.extend(float(v) for v in (value if isinstance(value, tuple) else (value,)))
         return self._where[value]
 
+    def append(self, rows):
+        """Entries of their own for every row of `rows` [n, components] (values that change with time: equal values now
+        need not stay equal).  Returns the index of the first one."""
+        first = len(self.values)
+        self.values.extend(float(v) for v in np.asarray(rows, dtype=np.float64).ravel())
+        return first
+
 
 class GeoEncoderConst(object):
     """Node map -> one uint32 per node, parameters -> one flat table (the role of reference geo_encoder.py:76-382;
@@ -51,6 +58,7 @@ class GeoEncoderConst(object):
         self.scratch_space_size = 0
         self._unused_tag_bits = 0
         self._have_link_tags = False
+        self._dynamic = []        # (first table index, DynamicValue, node coordinates) of the time-dependent parameters
 
     def _type_id(self, node_type):
         return self._type_id_remap.get(node_type, 0xffffffff)
@@ -83,11 +91,51 @@ class GeoEncoderConst(object):
                         entry = tuple(v) if hasattr(v, '__len__') else (float(v),)
                         sel = where[value == v]
                         index_map[tuple(sel[:, k] for k in range(sel.shape[1]))] = table.index_of(entry)
+                elif isinstance(value, nt.DynamicValue):
+                    # expressions of position / time (reference: device code, node_type.py:471-570): evaluated here.
+                    # Constant in time: one table entry per distinct value, like a per-node array.  Time-dependent: an
+                    # entry of its own per node (per value, if it does not depend on position) that the runner rewrites
+                    # before every step (dynamic_updates()).
+                    where = np.argwhere(nodes)
+                    coords = self._global_coords(where)
+                    dt = getattr(self.config, 'dt_per_lattice_time_unit', 1.0)
+                    ncomp = len(value)
+                    if not value.time_dependent():
+                        vals = value.evaluate(coords, 0, dt)
+                        uniq, inv = np.unique(vals, axis=0, return_inverse=True)
+                        inv = np.asarray(inv).ravel()
+                        for u, row in enumerate(uniq):
+                            sel = where[inv == u]
+                            index_map[tuple(sel[:, k] for k in range(sel.shape[1]))] = table.index_of(tuple(float(x) for x in row))
+                    elif value.space_dependent():
+                        first = table.append(value.evaluate(coords, 0, dt))
+                        index_map[tuple(where[:, k] for k in range(where.shape[1]))] = first + ncomp * np.arange(len(where), dtype=np.uint32)
+                        self._dynamic.append((first, value, coords))
+                    else:
+                        one = tuple(c[:1] for c in coords)
+                        first = table.append(value.evaluate(one, 0, dt))
+                        index_map[nodes] = first
+                        self._dynamic.append((first, value, one))
                 else:
                     raise ValueError('unsupported node parameter type for the HIP backend: %r' % type(value))
         self._geo_params = table.values
         self._bits_param = util.bit_len(len(table.values))
         return index_map
+
+    def _global_coords(self, where):
+        """(gx, gy[, gz]) of the nodes at the array indices `where` ([n, dim], C order, ghost layers included)."""
+        spec = self.subdomain.spec
+        env = spec.envelope_size
+        return tuple(where[:, self.dim - 1 - axis].astype(np.float64) + (spec.location[axis] - env) for axis in range(self.dim))
+
+    def dynamic_updates(self, iteration):
+        """[(first table index, values)] of the parameters that depend on time, at LB iteration `iteration`."""
+        dt = getattr(self.config, 'dt_per_lattice_time_unit', 1.0)
+        return [(first, value.evaluate(coords, iteration, dt).ravel()) for first, value, coords in self._dynamic]
+
+    @property
+    def time_dependent(self):
+        return bool(self._dynamic)
 
     def prepare_encode(self, type_map, param_map, param_dict, orientation, have_link_tags):
         """type_map: node type ids (overwritten by encode()); param_map: per-node keys into param_dict

@@ -154,9 +154,143 @@ def multifield(values, where=None):
     return rec.flatten() if where is None else rec[where]
 
 
-class DynamicValue(object):
-    """Time / space dependent BC values are generated as device code by the reference
-    (node_type.py:471-570); the pre-built gfx950 kernels take constant parameters only."""
+def timeseries_interpolate(data, step_size, iteration):
+    """Value of a wrapped, linearly interpolated time series at LB iteration `iteration` (reference boundary.mako:52-76:
+    position = iteration mod (step * size); neighbours idx, idx + 1 wrapped; pos * d1 + d0 * (1 - pos))."""
+    data = np.asarray(data, dtype=np.float64)
+    size = data.size
+    pos = np.fmod(float(iteration), float(step_size) * size) / float(step_size)
+    idx = int(np.floor(pos))
+    w = pos - idx
+    idx2 = idx + 1
+    if idx2 >= size:
+        idx2 -= size
+    return w * data[idx2] + data[idx] * (1.0 - w)
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('DynamicValue boundary parameters are not supported by the HIP backend')
+
+_lits_class = None
+
+
+def _lits():
+    """LinearlyInterpolatedTimeSeries is a sympy Symbol (it takes part in expressions): defined on first use so that
+    importing this module does not import sympy."""
+    global _lits_class
+    if _lits_class is not None:
+        return _lits_class
+    import hashlib
+    from sympy import Symbol
+
+    class LinearlyInterpolatedTimeSeries(Symbol):
+        """A time-dependent scalar data source based on a discrete time series (reference node_type.py:572-626): the data
+        points are `step_size` LB iterations apart, values in between are interpolated linearly, the series is wrapped.
+        Two series are equal iff their data and step sizes are."""
+
+        def __new__(cls, data, step_size=1.0):
+            arr = np.ascontiguousarray(np.float64(data))
+            return Symbol.__new__(cls, 'lits%s_%s' % (hashlib.sha1(arr).hexdigest(), step_size))
+
+        def __init__(self, data, step_size=1.0):
+            self._data = np.ascontiguousarray(np.float64(data)).copy()
+            self._step_size = step_size
+
+        def __hash__(self):
+            return hash((hashlib.sha1(self._data).digest(), str(self._step_size)))
+
+        def __eq__(self, other):
+            return isinstance(other, LinearlyInterpolatedTimeSeries) and self._step_size == other._step_size and \
+                self._data.shape == other._data.shape and bool(np.all(other._data == self._data))
+
+        def __ne__(self, other):
+            return not self.__eq__(other)
+
+        def __str__(self):
+            return 'LinearlyInterpolatedTimeSeries([%d items], %f)' % (self._data.size, self._step_size)
+
+        def data_hash(self):
+            return hashlib.sha1(self._data).digest()
+
+        def at(self, iteration):
+            return timeseries_interpolate(self._data, self._step_size, iteration)
+
+    _lits_class = LinearlyInterpolatedTimeSeries
+    return _lits_class
+
+
+def __getattr__(name):          # PEP 562: `from sailfish.node_type import LinearlyInterpolatedTimeSeries`
+    if name == 'LinearlyInterpolatedTimeSeries':
+        return _lits()
+    raise AttributeError(name)
+
+
+class DynamicValue(object):
+    """A node parameter given as expressions of the node location (sym.S.gx, S.gy, S.gz), the time (S.time = iteration x
+    --dt_per_lattice_time_unit) and time series (LinearlyInterpolatedTimeSeries) -- reference node_type.py:471-570, where
+    the expressions become device code.  Here they are evaluated on the host (numpy, through sympy.lambdify): once per
+    node when the geometry is encoded, and once per step for the values that depend on time, which the runner writes
+    into the kernels' node-parameter table before the step (SubdomainRunner._update_dynamic_params).  One expression per
+    component (a density: one; a velocity: one per axis)."""
+
+    def __init__(self, *params):
+        self.params = tuple(params)
+        self._fn = None
+
+    def __hash__(self):
+        return hash(self.params)
+
+    def __eq__(self, other):
+        return isinstance(other, DynamicValue) and self.params == other.params
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __iter__(self):
+        return iter(self.params)
+
+    def __len__(self):
+        return len(self.params)
+
+    def __getitem__(self, i):
+        return self.params[i]
+
+    def __str__(self):
+        return 'DynamicValue(' + ', '.join(str(x) for x in self.params) + ')'
+
+    def _symbols(self):
+        out = set()
+        for p in self.params:
+            out |= getattr(p, 'free_symbols', set())
+        return out
+
+    def has_symbols(self, *args):
+        """True if any expression depends on at least one of the given symbols."""
+        mine = self._symbols()
+        return any(a in mine for a in args)
+
+    def get_timeseries(self):
+        lits = _lits()
+        return [x for x in self._symbols() if isinstance(x, lits)]
+
+    def time_dependent(self):
+        from sailfish_amd import sym
+        return self.has_symbols(sym.S.time) or bool(self.get_timeseries())
+
+    def space_dependent(self):
+        from sailfish_amd import sym
+        return self.has_symbols(sym.S.gx, sym.S.gy, sym.S.gz)
+
+    def evaluate(self, coords, iteration, dt):
+        """[nodes, components] values at the nodes with global coordinates coords = (gx, gy[, gz]) (equal-length 1-D arrays)
+        at LB iteration `iteration`."""
+        import sympy
+        from sailfish_amd import sym
+        series = self.get_timeseries()
+        if self._fn is None:
+            args = [sym.S.gx, sym.S.gy, sym.S.gz, sym.S.time] + series
+            self._fn = [sympy.lambdify(args, sympy.sympify(p), 'numpy') for p in self.params]
+        n = len(coords[0])
+        g = [np.asarray(c, dtype=np.float64) for c in coords] + [np.zeros(n)] * (3 - len(coords))
+        vals = [s_.at(iteration) for s_ in series]
+        out = np.empty((n, len(self.params)), dtype=np.float64)
+        for k, fn in enumerate(self._fn):
+            out[:, k] = np.broadcast_to(np.asarray(fn(g[0], g[1], g[2], float(iteration) * float(dt), *vals), dtype=np.float64), (n,))
+        return out

@@ -258,6 +258,8 @@ class Subdomain(object):
             if all(util.is_number(el) for el in value):
                 return
             raise ValueError('Tuple elements have to be numbers.')
+        if isinstance(value, nt.DynamicValue):      # expressions of position / time, evaluated on the host (node_type.py)
+            return
         raise ValueError('Unrecognized node param: {0} (type {1})'.format(name, type(value)))
 
     @staticmethod
@@ -282,6 +284,11 @@ class Subdomain(object):
         n_selected = int(np.count_nonzero(mask))
         for name, value in node_type.params.items():
             self._check_param(name, value, n_selected)
+            if isinstance(value, nt.DynamicValue):          # reference subdomain.py:509-515
+                if value.time_dependent():
+                    self.config.time_dependence = True
+                if value.space_dependent():
+                    self.config.space_dependence = True
         if np.any(self._param_map_base[selected]):
             raise AssertionError('Overriding previously set nodes is not allowed.')
         key = self._param_key(node_type)

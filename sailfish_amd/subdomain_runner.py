@@ -645,6 +645,7 @@ class SubdomainRunner(object):
         on the steps that record timing events."""
         b = self.backend
         it = self._sim.iteration
+        self._update_dynamic_params(it)
         if self._plan_ok and not self._profile.wants_gpu_events():
             key = (it & 1, bool(sync_req))
             plan = self._plans.get(key)
@@ -670,6 +671,19 @@ class SubdomainRunner(object):
         self._sim.iteration += 1
         b.set_iteration(self._sim.iteration)
 
+    def _time_dependent(self):
+        enc = getattr(self._subdomain, '_encoder', None)
+        return enc is not None and getattr(enc, 'time_dependent', False)
+
+    def _update_dynamic_params(self, it):
+        """Boundary values that depend on time (node_type.DynamicValue with sym.S.time / time series; reference: device
+        code, boundary.mako:52-84): evaluated on the host for LB iteration `it` and written into the kernels' parameter
+        table on the calc stream, in front of the step's launches (C ABI slf_module_update_node_params; a one-wave kernel
+        whose arguments ARE the values: the host does not wait)."""
+        if self._time_dependent():
+            for first, values in self._subdomain._encoder.dynamic_updates(it):
+                self.backend.update_node_params(self.module, first, values, self._calc_stream)
+
     # ------------------------------------------------------------------ the step as a program (stepqueue.py)
     _plan_ok = False
 
@@ -688,7 +702,8 @@ class SubdomainRunner(object):
         # one before it drains.  Ghost-layer PBC kernels and the macro pass of the non-local models work on whole
         # arrays: one stream there.
         two = os.environ.get('SLF_CALC_STREAMS', '2') != '1' and not self._pbc_axes and not self.has_macro_exchange and \
-            bool(self._links) and hasattr(b, 'supports_step_plans')
+            bool(self._links) and hasattr(b, 'supports_step_plans') and not self._time_dependent()
+        # (time-dependent boundary values are rewritten on the calc stream before every step: every sweep launch on it)
         if self._xface is not None:
             # z-chunks on alternating streams only on request: measured slower than the drain at the chunk boundaries
             # it avoids (profiles/r04/NOTES.md)
@@ -1244,8 +1259,8 @@ class SubdomainRunner(object):
         subdomains: one runtime call per 2 / 16 steps instead of a Python-level launch per kernel); small 2-D subdomains
         go through launches that perform several steps each (_fast_forward_resident) first.
         Returns the number of steps done (0: take a normal step)."""
-        if not getattr(self.config, 'hip_graphs', True) or self._links or self._quit_requested():
-            return 0
+        if not getattr(self.config, 'hip_graphs', True) or self._links or self._quit_requested() or self._time_dependent():
+            return 0         # (time-dependent boundary values: the host writes them before every step)
         n = self._steps_without_host()
         if n < 2:
             return 0

@@ -208,3 +208,23 @@ def lookup_grid(name):
         if g.__name__ == name:
             return g
     raise ValueError('unsupported grid %s (the HIP backend implements D2Q9 and D3Q19)' % name)
+
+
+class _Symbols(object):
+    """`sym.S`: the symbols user code writes time- and space-dependent values with (reference sym.py:1049-1149:
+    S.gx / S.gy / S.gz -- node location in the global coordinate system, S.time -- time in physical units).  sympy objects,
+    created on first use: nothing else on the host side needs sympy.  Values built from them (node_type.DynamicValue) are
+    evaluated on the HOST -- per node when the geometry is encoded, per step where they depend on time -- and reach the
+    kernels as ordinary entries of the node-parameter table (the reference renders them into device code)."""
+    _names = {'gx': 'gx', 'gy': 'gy', 'gz': 'gz', 'time': 'phys_time'}
+
+    def __getattr__(self, name):
+        if name not in self._names:
+            raise AttributeError(name)
+        import sympy
+        sym = sympy.Symbol(self._names[name], real=True)
+        setattr(self, name, sym)
+        return sym
+
+
+S = _Symbols()

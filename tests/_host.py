@@ -67,6 +67,7 @@ EXAMPLE_MAP = {
     ('external_geometry', 'ExternalSimulation'): ('examples.external_geometry', 'GeometrySim'),
     ('cylinder', 'CylinderSimulation'): ('examples.cylinder', 'CylinderSim'),
     ('sphere_3d', 'SphereSimulation'): ('examples.sphere_3d', 'SphereSim'),
+    ('womersley', 'WomersleySim'): ('examples.womersley', 'WomersleySim'),
 }
 
 

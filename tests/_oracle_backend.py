@@ -132,6 +132,10 @@ class OracleBackend(object):
         for k in self._kernels:
             k.iteration = int(it)
 
+    def update_node_params(self, module, first, values, stream=None):
+        for i, v in enumerate(np.asarray(values, dtype=np.float64).ravel()):
+            module.desc.node_params[int(first) + i] = float(v)
+
     def run_kernel(self, k, grid_size=None, stream=None):
         m, d, L = k.module, k.module.desc, k.module.sim.L
         dim = 2 if d.lattice == hipabi.SLF_D2Q9 else 3

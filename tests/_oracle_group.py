@@ -71,6 +71,11 @@ class OracleSubdomain(object):
         it = self.iteration
         opts = 1 if save else 0
         m = self.node_map
+        enc = self.runner._subdomain._encoder
+        if getattr(enc, 'time_dependent', False):       # boundary values that depend on time: the table entries of this step
+            for first, values in enc.dynamic_updates(it):
+                for i, v in enumerate(values):
+                    self.desc.node_params[first + i] = float(v)
         if self.aa:
             prop = 2 if (it & 1) else 1
             self.o.step(prop, m, self.dist[0], self.dist[0], self.rho, *self.v, options=opts)

@@ -75,3 +75,37 @@ def test_minimize_roundoff_is_a_density_model_and_refused_where_it_does_not_appl
                                                                   max_iters=1, quiet=True))
     with pytest.raises(NotImplementedError):
         ctrl.run(ignore_cmdline=True)
+
+
+def test_regularized_and_subgrid_options_reach_the_module_descriptor():
+    """--regularized / --subgrid=les-smagorinsky / --smagorinsky_const (reference lb_single.py:27-42): same names and
+    defaults, carried into slf_module_desc; MRT is refused on the host (the reference's MRT relaxation never calls the
+    preamble that implements them and would ignore the flags)."""
+    import pytest
+    from sailfish_amd import hipabi
+    from sailfish_amd.geo import LBGeometry2D
+    from tests import _host
+    sim_cls = _host.load_sim_class('ldc_2d', 'LDCSim')
+    for opts, want in ((dict(), (0, hipabi.SLF_SUBGRID_NONE)),
+                       (dict(regularized=True), (1, hipabi.SLF_SUBGRID_NONE)),
+                       (dict(subgrid='les-smagorinsky', smagorinsky_const=0.17), (0, hipabi.SLF_SUBGRID_LES_SMAGORINSKY))):
+        _, _, runners = _host.build_runners(sim_cls, 2, LBGeometry2D, dict(lat_nx=32, lat_ny=32, **opts))
+        r = runners[0]
+        r._init_geometry()
+        r._sim.init_fields(r)
+        d = r._module_desc()
+        assert (int(d.regularized), int(d.subgrid)) == want
+        if opts.get('subgrid'):
+            assert d.smagorinsky_const == 0.17
+    import argparse
+    from sailfish_amd.lb_single import LBFluidSim
+    ap = argparse.ArgumentParser()
+    LBFluidSim.add_options(ap, 2)
+    cfg = ap.parse_args([])
+    assert cfg.regularized is False and cfg.subgrid == 'none' and cfg.smagorinsky_const == 0.1       # the reference's defaults
+    _, _, runners = _host.build_runners(sim_cls, 2, LBGeometry2D, dict(lat_nx=32, lat_ny=32, regularized=True, model='mrt'))
+    r = runners[0]
+    r._init_geometry()
+    r._sim.init_fields(r)
+    with pytest.raises(ValueError, match='BGK'):
+        r._module_desc()

@@ -655,3 +655,78 @@ def test_slip_walls_through_the_runner(pattern, case):
                    access_pattern=pattern, subdomains=nsub, conn_axis=axis)
         _, exact = check_against_oracle(S.SlipDuctSim, None, 3, cfg, 60, 1e-3)
     assert exact
+
+
+def _pulsating_channel(dim):
+    """An open channel whose inlet / outlet densities oscillate in time and whose inlet ... (node_type.DynamicValue)."""
+    import sympy
+    from sailfish_amd import node_type as nt
+    from sailfish_amd import sym
+    from sailfish_amd.lb_single import LBFluidSim
+    from sailfish_amd.subdomain import Subdomain2D, Subdomain3D
+    S = sym.S
+    amp, om = 0.004, 2 * np.pi / 60.0
+
+    class Channel(Subdomain2D if dim == 2 else Subdomain3D):
+        def boundary_conditions(self, hx, hy, *hz):
+            wall = (hy == 0) | (hy == self.gy - 1)
+            self.set_node(wall, nt.NTFullBBWall)
+            # a density that depends on time at the inlet, on time AND position at the outlet (an entry per node)
+            self.set_node((hx == 0) & ~wall, nt.NTEquilibriumDensity(nt.DynamicValue(1.0 + amp * sympy.sin(S.time * om))))
+            self.set_node((hx == self.gx - 1) & ~wall,
+                          nt.NTEquilibriumDensity(nt.DynamicValue(1.0 - amp * sympy.sin(S.time * om) * (1 + 0.01 * S.gy))))
+
+        def initial_conditions(self, sim, hx, hy, *hz):
+            sim.rho[:] = 1.0
+
+    class ChannelSim(LBFluidSim):
+        subdomain = Channel
+
+        @classmethod
+        def modify_config(cls, config):
+            if dim == 3:
+                config.periodic_z = True
+    return ChannelSim
+
+
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('dim,nsub,axis', [(2, 1, 'x'), (2, 2, 'y'), (3, 1, 'x'), (3, 2, 'x')])
+def test_time_dependent_boundary_values(pattern, dim, nsub, axis):
+    """Boundary values that depend on time (and position): evaluated on the host before every step and written into the
+    kernels' parameter table on the calc stream (slf_module_update_node_params) -- the HIP run equals the oracle twin,
+    which takes the same values, bit for bit; one and two subdomains, both access patterns, step plans in use."""
+    size = dict(lat_nx=24, lat_ny=11) if dim == 2 else dict(lat_nx=70, lat_ny=9, lat_nz=6)
+    cfg = dict(size, visc=0.08, access_pattern=pattern, subdomains=nsub, conn_axis=axis)
+    ctrl, exact = check_against_oracle(_pulsating_channel(dim), None, dim, cfg, 37, 0.01)
+    assert exact
+    assert all(r._time_dependent() for r in ctrl.runners)
+
+
+def test_womersley_flow_follows_the_analytical_profile():
+    """examples/womersley.py: a pipe driven by dP(t) = dP0 sin(omega t) through time-dependent equilibrium-density
+    nodes.  After seven periods (the start-up transient decays with the slowest viscous mode, nu 2.405^2 / R^2 = 1 / 4400
+    steps) the axial velocity across the middle of the pipe, sampled at four phases of the eighth period, follows the classical Womersley solution (amplitude and phase lag; staircase walls, weak compressibility and
+    the finite pipe leave under one per cent of the peak amplitude)."""
+    sim_cls = _host.load_sim_class('womersley', 'WomersleySim')
+    omega, nx, d = 0.002, 96, 34
+    period = 2 * np.pi / omega
+    errs = []
+    for phase in (0.0, 0.25, 0.5, 0.75):
+        steps = int(round((7 + phase) * period))
+        ctrl = run_gpu(sim_cls, None, 3, dict(lat_nx=nx, lat_ny=d, lat_nz=d, visc=0.01, omega=omega, access_pattern='AA',
+                                              drive='pressure', subdomains=1), steps)
+        r = ctrl.runners[0]
+        vx = np.asarray(r._sim.vx)[d // 2, :, nx // 2]                 # across the pipe, through its axis
+        sd = r._subdomain
+        width = sd.channel_width(r.config)
+        y = np.arange(d, dtype=np.float64)
+        rad = np.abs(y - (d / 2 - 0.5)) / (width / 2.0)
+        inside = rad < 0.95
+        want = sd.womersley_profile(rad[inside], steps)
+        got = vx[inside]
+        scale = np.max(np.abs(sd.womersley_profile(np.linspace(0, 0.95, 20)[:, None], np.linspace(0, period, 40)[None, :])))
+        errs.append(float(np.max(np.abs(got - want)) / scale))
+        for rr in ctrl.runners:
+            rr.release()
+    print('Womersley profile, max deviation / peak amplitude at four phases:', ['%.3f' % e for e in errs])
+    assert max(errs) < 0.03, errs          # measured: 0.005 - 0.009
