@@ -337,6 +337,12 @@ int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]);
  * returns at once (up to 256 values travel as arguments of a one-wave kernel, longer updates through pinned staging
  * buffers the module owns).  first + n must not exceed n_node_params. */
 int slf_module_update_node_params(slf_module* m, int first, const double* values, int n, slf_stream* stream);
+/* A body force that changes with time (add_body_force(DynamicValue(...)) of sym.S.time, reference lb_base.py:335-353 +
+ * the rendered expression in relaxation_common.mako:body_force): the acceleration is an argument of every sweep launch,
+ * so the host sets the value the NEXT launches take -- accel[3] for lattice 0, or lattice 1 of a binary model.  The
+ * module must have been created with a body force (has_force, resp. accel1): which instantiation runs was decided
+ * there.  Forces that depend on position are not served (they would need a field). */
+int slf_module_set_body_force(slf_module* m, int lattice, const double accel[3]);
 /* Row classes of the node map at `map_dptr` (no counterpart in the reference, whose kernels decode the map in every
  * thread: geo_helpers.mako:146-161, kernel_common.mako:191-201).  Builds, on the device, one class per 64-node
  * x-segment of every row -- 0 = all plain fluid: the wavefront that owns the segment neither reads the map (4 of the

@@ -604,6 +604,11 @@ class HIPBackend(placement.VmmMixin):
                                                                   int(vals.size), stream.handle if stream else None),
                'slf_module_update_node_params')
 
+    def set_body_force(self, module, accel, lattice=0):
+        """The acceleration the sweeps launched from now on apply (time-dependent body forces)."""
+        a = (ctypes.c_double * 3)(*([float(x) for x in accel] + [0.0] * (3 - len(accel))))
+        _check(self._lib, self._lib.slf_module_set_body_force(module.handle, int(lattice), a), 'slf_module_set_body_force')
+
     def set_x_ghost_unused(self, module, low, high):
         """Nothing reads the ghost column x = 0 (low) / x = nx + 1 (high): the sweeps stop storing into it."""
         _check(self._lib, self._lib.slf_module_set_x_ghost_unused(module.handle, int(bool(low)), int(bool(high))),

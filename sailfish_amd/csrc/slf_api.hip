@@ -1301,6 +1301,20 @@ int slf_module_update_node_params(slf_module* m, int first, const double* values
   return SLF_OK;
 }
 
+int slf_module_set_body_force(slf_module* m, int lattice, const double accel[3]) {
+  if (!m || !accel) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (lattice == 0) {
+    if (!m->phys.has_force) return fail(SLF_ERR_INVALID, "the module was created without a body force (has_force)");
+    for (int i = 0; i < 3; i++) m->phys.accel[i] = accel[i];
+  } else if (lattice == 1) {
+    if (m->sc.enabled != 1) return fail(SLF_ERR_INVALID, "lattice 1 exists in binary models only");
+    for (int i = 0; i < 3; i++) m->sc.accel1[i] = accel[i];
+  } else {
+    return fail(SLF_ERR_INVALID, "lattice must be 0 or 1");
+  }
+  return SLF_OK;
+}
+
 int slf_module_poll_invalid(slf_module* m, slf_stream* stream, int32_t out[4]) {
   if (!m || !out) return fail(SLF_ERR_INVALID, "NULL argument");
   uint32_t h[4] = {0, 0, 0, 0};

@@ -137,6 +137,7 @@ SIGNATURES = {
     'slf_module_poll_invalid': (c_int, [c_void_p, c_void_p, POINTER(c_int32 * 4)]),
     'slf_module_classify_rows': (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int32 * 4)]),
     'slf_module_update_node_params': (c_int, [c_void_p, c_int, POINTER(c_double), c_int, c_void_p]),
+    'slf_module_set_body_force': (c_int, [c_void_p, c_int, POINTER(c_double)]),
     'slf_graph_capture_begin': (c_int, [c_void_p]),
     'slf_graph_capture_end': (c_int, [c_void_p, POINTER(c_void_p)]),
     'slf_graph_launch': (c_int, [c_void_p, c_void_p]),

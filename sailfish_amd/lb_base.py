@@ -185,6 +185,7 @@ class LBForcedSim(LBSim):
     def __init__(self, config):
         super(LBForcedSim, self).__init__(config)
         self._forces = {}
+        self._symbolic_forces = []      # DynamicValue accelerations (lattice 0) that depend on time
 
     @classmethod
     def add_options(cls, group, dim):
@@ -197,7 +198,18 @@ class LBForcedSim(LBSim):
         dim = self.grids[0].dim
         assert len(force) == dim
         if isinstance(force, nt.DynamicValue):
-            raise NotImplementedError('time / space dependent forces are not supported by the HIP backend')
+            # reference lb_base.py:346-353.  An acceleration that depends on TIME is evaluated on the host before every
+            # step (it is an argument of the sweep launches: SubdomainRunner._update_dynamic_params); one that depends on
+            # position would need a force field per node, which the kernels do not read
+            if force.space_dependent():
+                self.config.space_dependence = True
+                raise NotImplementedError('body forces that depend on position are not supported by the HIP backend')
+            if not accel or grid != 0:
+                raise NotImplementedError('time-dependent body forces: accelerations on lattice 0')
+            if force.time_dependent():
+                self.config.time_dependence = True
+            self._symbolic_forces.append(force)
+            return
         if not accel:
             raise NotImplementedError('force (rather than acceleration) fields are not supported by the HIP backend')
         if grid not in (0, 1):
@@ -205,10 +217,28 @@ class LBForcedSim(LBSim):
         self._forces.setdefault(grid, {}).setdefault(accel, np.zeros(dim, np.float64))
         self._forces[grid][accel] = self._forces[grid][accel] + np.float64(force)
 
+    def body_force_at(self, iteration):
+        """Acceleration on lattice 0 at LB iteration `iteration`: the constant part + the DynamicValue parts, or None when
+        the simulation has no body force at all."""
+        f = self._forces.get(0, {}).get(True)
+        if not self._symbolic_forces:
+            return f if (f is not None and np.any(f != 0.0)) else None
+        dim = self.grids[0].dim
+        total = np.zeros(dim) if f is None else np.array(f, dtype=np.float64)
+        dt = getattr(self.config, 'dt_per_lattice_time_unit', 1.0)
+        zero = tuple(np.zeros(1) for _ in range(dim))
+        for dv in self._symbolic_forces:
+            total = total + dv.evaluate(zero, iteration, dt)[0]
+        return total
+
+    @property
+    def time_dependent_force(self):
+        return any(dv.time_dependent() for dv in self._symbolic_forces)
+
     def fill_module_desc(self, kw):
         super(LBForcedSim, self).fill_module_desc(kw)
-        f = self._forces.get(0, {}).get(True)
-        if f is not None and np.any(f != 0.0):
+        f = self.body_force_at(0)
+        if f is not None and (np.any(f != 0.0) or self._symbolic_forces):
             kw['has_force'] = 1
             kw['accel'] = list(f) + [0.0] * (3 - len(f))
         impl = getattr(self.config, 'force_implementation', 'guo')

@@ -673,7 +673,7 @@ class SubdomainRunner(object):
 
     def _time_dependent(self):
         enc = getattr(self._subdomain, '_encoder', None)
-        return enc is not None and getattr(enc, 'time_dependent', False)
+        return (enc is not None and getattr(enc, 'time_dependent', False)) or getattr(self._sim, 'time_dependent_force', False)
 
     def _update_dynamic_params(self, it):
         """Boundary values that depend on time (node_type.DynamicValue with sym.S.time / time series; reference: device
@@ -683,6 +683,9 @@ class SubdomainRunner(object):
         if self._time_dependent():
             for first, values in self._subdomain._encoder.dynamic_updates(it):
                 self.backend.update_node_params(self.module, first, values, self._calc_stream)
+            if getattr(self._sim, 'time_dependent_force', False):
+                # the acceleration is an argument of the sweep launches: the ones enqueued from here on take this value
+                self.backend.set_body_force(self.module, self._sim.body_force_at(it))
 
     # ------------------------------------------------------------------ the step as a program (stepqueue.py)
     _plan_ok = False

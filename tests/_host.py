@@ -68,6 +68,7 @@ EXAMPLE_MAP = {
     ('cylinder', 'CylinderSimulation'): ('examples.cylinder', 'CylinderSim'),
     ('sphere_3d', 'SphereSimulation'): ('examples.sphere_3d', 'SphereSim'),
     ('womersley', 'WomersleySim'): ('examples.womersley', 'WomersleySim'),
+    ('poiseuille_pulsatile', 'PulsatileSim'): ('examples.poiseuille_pulsatile', 'PulsatileSim'),
 }
 
 

@@ -132,6 +132,10 @@ class OracleBackend(object):
         for k in self._kernels:
             k.iteration = int(it)
 
+    def set_body_force(self, module, accel, lattice=0):
+        for i, a in enumerate(accel):
+            module.desc.accel[i] = float(a)
+
     def update_node_params(self, module, first, values, stream=None):
         for i, v in enumerate(np.asarray(values, dtype=np.float64).ravel()):
             module.desc.node_params[int(first) + i] = float(v)

@@ -76,6 +76,9 @@ class OracleSubdomain(object):
             for first, values in enc.dynamic_updates(it):
                 for i, v in enumerate(values):
                     self.desc.node_params[first + i] = float(v)
+        if getattr(self.runner._sim, 'time_dependent_force', False):
+            for i, a in enumerate(self.runner._sim.body_force_at(it)):
+                self.desc.accel[i] = float(a)
         if self.aa:
             prop = 2 if (it & 1) else 1
             self.o.step(prop, m, self.dist[0], self.dist[0], self.rho, *self.v, options=opts)

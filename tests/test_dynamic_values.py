@@ -127,3 +127,49 @@ def test_pulsating_channel_through_the_runner_equals_the_oracle_twin(pattern):
         assert np.array_equal(f[m], fo[m])
         means.append(float(np.nanmean(r._sim.vx[1:-1, 2:-2])))
     assert means[0] > 5e-4 and means[1] < 0.6 * means[0], means       # the flow follows the pressure: it slows down again
+
+
+@pytest.mark.parametrize('drive', ['force', 'pressure'])
+def test_pulsatile_example_through_the_runner_equals_the_oracle_twin(drive):
+    """examples/poiseuille_pulsatile.py: a body force resp. a pressure difference a0 sin(t).  The product's runner with the
+    CPU test backend (set_body_force / update_node_params before every step) == the oracle twin, bit for bit; and the force
+    the module sees really is the expression's value at the step's time."""
+    from tests._oracle_backend import OracleBackend
+    from tests._oracle_group import OracleGroup
+    from sailfish_amd import util
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls = _host.load_sim_class('poiseuille_pulsatile', 'PulsatileSim')
+    cfg = dict(lat_nx=16, lat_ny=12, visc=0.05, drive=drive, horizontal=True, access_pattern='AA', dt_per_lattice_time_unit=0.05,
+               wall='fullbb', stationary=False)
+    steps = 33
+    og = OracleGroup(sim_cls, 2, 'EqualSubdomainsGeometry2D', cfg)
+    og.run(steps, save_last=True)
+    old = util.get_backends
+    util.get_backends = lambda backends=('hip',): iter([OracleBackend])
+    try:
+        ctrl = LBSimulationController(sim_cls, LBGeometry2D, default_config=dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0,
+                                                                                  backends='oracle_test'))
+        ctrl.run(ignore_cmdline=True)
+    finally:
+        util.get_backends = old
+    r = ctrl.runners[0]
+    assert r._time_dependent()
+    f = r._debug_get_dist()[(slice(None),) + tuple(r._spec._nonghost_slice)]
+    fo = og.merged('dist')
+    m = np.isfinite(fo)
+    assert np.array_equal(f[m], fo[m])
+    if drive == 'force':
+        a0 = r._subdomain.max_v * 8.0 * 0.05 / r._subdomain.channel_width(r.config) ** 2
+        assert abs(r._sim.body_force_at(10)[0] - a0 * np.sin(10 * 0.05)) < 1e-18 and r._sim.body_force_at(10)[1] == 0.0
+        assert abs(r.module.desc.accel[0] - a0 * np.sin((steps - 1) * 0.05)) < 1e-18       # what the last step's launch took
+
+
+def test_forces_that_depend_on_position_are_refused():
+    from sailfish_amd.lb_base import LBForcedSim
+    from sailfish_amd.lb_single import LBFluidSim
+
+    class Sim(LBFluidSim, LBForcedSim):
+        pass
+    s = Sim(_host.make_config(2))
+    with pytest.raises(NotImplementedError):
+        s.add_body_force(nt.DynamicValue(1e-5 * sym.S.gy, 0.0))

@@ -730,3 +730,14 @@ def test_womersley_flow_follows_the_analytical_profile():
             rr.release()
     print('Womersley profile, max deviation / peak amplitude at four phases:', ['%.3f' % e for e in errs])
     assert max(errs) < 0.03, errs          # measured: 0.005 - 0.009
+
+
+@pytest.mark.parametrize('drive,pattern,nsub', [('force', 'AA', 1), ('force', 'AB', 2), ('pressure', 'AA', 2), ('pressure', 'AB', 1)])
+def test_pulsatile_example_equals_the_oracle(drive, pattern, nsub):
+    """examples/poiseuille_pulsatile.py (cf. the reference's example of the same name): a body force resp. a pressure
+    difference a0 sin(t), t = iteration x dt_per_lattice_time_unit -- the force as an argument of the sweep launches
+    (slf_module_set_body_force before every step), the densities through the parameter table."""
+    cfg = dict(lat_nx=40, lat_ny=18, visc=0.05, drive=drive, horizontal=True, access_pattern=pattern, dt_per_lattice_time_unit=0.05,
+               wall='fullbb', stationary=False, subdomains=nsub, conn_axis='x')
+    ctrl, exact = check_against_oracle('poiseuille_pulsatile', 'PulsatileSim', 2, cfg, 41, 0.02)
+    assert exact and all(r._time_dependent() for r in ctrl.runners)

@@ -384,5 +384,29 @@ for ln in sys.stdin:
     done
     TRACE_CONFIGS="7a" bash tools/gpu.sh tracecfg pmccfg; rm -rf $O/trace_cfg*/ $O/pmc_cfg*/
     ;;
+  r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
+    export SLF_PEER_TIMEOUT_S=60
+    bash tools/gpu.sh host smoke
+    for pat in AA AB; do
+      PMC_SIZES_ONLY=1 BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh pmc; cp $O/pmc_summary.txt $O/pmc_sizes_${pat}_512_final.txt
+      [ $pat = AA ] && kern="slf::fast_" || kern="slf::fast_row_kernel"
+      python tools/traffic_update.py --from-pmc $O/pmc --kernel "$kern" --key D3Q19_bgk_f32_${pat}_512_fused
+      rm -rf $O/pmc
+    done
+    cp profiles/traffic.json $O/traffic.json
+    timeout 900 python bench.py 2>&1 | tail -1 > $O/bench_final.json; cut -c1-400 $O/bench_final.json
+    timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
+    for pat in AA AB; do
+      BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh trace; cp $O/kernel_stats.csv $O/kernel_stats_${pat}_final.csv; rm -rf $O/trace
+    done
+    # the same box, back to back: the 256^3 box of BASELINE config 2 through bench.py and through the host stack, and the headline again
+    timeout 600 python bench.py --size 256 --no_cpu_baseline --no_gpu_state 2>&1 | tail -1 > $O/bench_256.json; cut -c1-200 $O/bench_256.json
+    timeout 1500 python tools/bench_configs.py 2>/dev/null | grep '^{' > $O/configs_final.jsonl; cut -c1-150 $O/configs_final.jsonl
+    timeout 900 python tools/bench_configs.py --only 6xa,6xb,7a,7b,7c,7d,8a,8b,9a,9b 2>/dev/null | grep '^{' >> $O/configs_final.jsonl; tail -10 $O/configs_final.jsonl | cut -c1-150
+    timeout 600 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>&1 | tail -1 > $O/bench_driver_cmd_after_configs.json; cut -c1-200 $O/bench_driver_cmd_after_configs.json
+    bash tools/gpu.sh torchrun; mv $O/torchrun.jsonl $O/torchrun_final_peer.jsonl
+    SLF_HALO_TRANSPORT=rccl bash tools/gpu.sh torchrun; mv $O/torchrun.jsonl $O/torchrun_final_rccl.jsonl
+    ( time timeout 2700 python -m pytest tests -m gpu -q --durations=12 ) > $O/pytest_gpu_final.log 2>&1; tail -22 $O/pytest_gpu_final.log
+    ;;
   *) echo "unknown visit $NAME" ;;
 esac
