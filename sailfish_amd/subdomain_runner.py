@@ -271,7 +271,10 @@ class SubdomainRunner(object):
             self.backend.set_x_ghost_unused(self.module, low, high)
         self._calc_stream = self.backend.make_stream()
         # the halo stream: ahead of the bulk sweep's queued workgroups where the backend can say so
-        prio = getattr(self.backend, 'supports_stream_priority', False) and os.environ.get('SLF_HALO_PRIORITY', '1') != '0'
+        # (not with the peer transport: its waits are kernels that spin on this stream until the neighbours have signalled,
+        # and a spinning kernel in a high-priority queue holds the sweeps back -- DESIGN.md §7)
+        prio = getattr(self.backend, 'supports_stream_priority', False) and os.environ.get('SLF_HALO_PRIORITY', '1') != '0' and \
+            not getattr(self._connector, 'zero_copy', False)
         self._data_stream = self.backend.make_stream(high_priority=True) if prio else self.backend.make_stream()
         self._dist_stride = hipabi.dist_stride(self._desc)
 

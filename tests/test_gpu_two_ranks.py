@@ -202,6 +202,33 @@ def test_example_starts_its_own_ranks(pattern, axis, nsub, tmp_path):
         assert np.array_equal(got[name], ref[name], equal_nan=True), name
 
 
+@pytest.mark.parametrize('axis,nsub', [('x', 2), ('z', 2), ('y', 4)])
+def test_shan_chen_mixture_one_process_per_subdomain(axis, nsub, tmp_path):
+    """The binary Shan-Chen model with one PROCESS per subdomain on the one GPU of the box: the density planes that the
+    force kernel reads across the seam and the distributions both travel through the device-side peer transport
+    (connector.PeerConnector, receive buffers by step parity), and the merged fields equal the single-subdomain run of
+    the same script bit for bit (reference lb_binary.py:393-433 macro exchange + lb_base.py:232-256)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from utils.merge_subdomains import merge_subdomains
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'SLF_DIST_BACKEND', 'SLF_FORCE_DEVICE'):
+        env.pop(k, None)
+    steps = 10
+    common = ['--max_iters=%d' % steps, '--every=%d' % steps, '--conn_axis=' + axis, '--quiet', '--nooutput_compress',
+              '--perf_stats_every=0']
+    for name, extra in (('many', ['--subdomains=%d' % nsub, '--gpus'] + ['0'] * nsub), ('one', ['--subdomains=1', '--gpus', '0'])):
+        cmd = [sys.executable, os.path.join(ROOT, 'tests', '_sc_ranks_script.py'), '--output=' + str(tmp_path / name)] + common + extra
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+        assert res.returncode == 0, res.stdout.decode(errors='replace')[-3000:]
+    got = merge_subdomains(str(tmp_path / 'many'), 1, steps, save=False)
+    ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
+    assert set(got) == set(ref) and 'rho' in ref and 'phi' in ref
+    for name in ref:
+        assert np.array_equal(got[name], ref[name], equal_nan=True), name
+    assert np.ptp(ref['phi']) > 1e-3
+
+
 # ---- the same paths over RCCL: run by themselves on any box with at least two GPUs (an 8-GPU node exercises the real
 # ---- transport -- DirectRccl communicator of two ranks, step plans with RCCL batches to another device -- without anyone
 # ---- asking); skipped on the 1-GPU boxes of the build pool.
