@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r05', 'bench_driver_cmd_final.json')))    # the driver's command line
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r06', 'bench_driver_cmd_final.json')))    # the driver's command line
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -22,7 +22,9 @@ def test_committed_bench_line_has_every_contract_field():
     assert c['value_is'].startswith('median block of exactly K steps') and c['timed_blocks'] >= c['repeats']
     assert c['timed_seconds'] >= 0.5 and abs(c['timed_seconds'] / c['timed_blocks'] - d['ms_per_step'] * d['steps'] * 1e-3) < 0.2 * c['timed_seconds'] / c['timed_blocks']
     assert min(c['runs_mlups']) <= c['median_mlups'] <= max(c['runs_mlups']) and abs(max(c['runs_mlups']) - d['best_value']) < 1.0
-    assert d['value'] == d['median_value'] == c['median_mlups'] and d['value'] <= d['best_value'] < 1.01 * d['value']
+    # round 6: `value_kind` says in words what `value` is (the duplicate key median_value is gone)
+    assert d['value'] == c['median_mlups'] and d['value'] <= d['best_value'] < 1.01 * d['value'] and 'median_value' not in d
+    assert d['value_kind'].startswith('median block')
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
