@@ -439,6 +439,20 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
  * switch a face back to ghost columns.  D3Q19 single-fluid modules, direct addressing, x not wrapped in-sweep. */
 int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high, void* recv_low, void* recv_high);
 
+/* The same for the binary Shan-Chen model (two lattices coupled through the densities their force stencil reads at the
+ * neighbouring nodes; reference lb_binary.py:393-517 with subdomain_runner.py:1907-2197 _send_macro / _recv_macro and
+ * the ghost-column blocks of both lattices).  Three sets of planes per connected face, chosen by `which`:
+ *   0, 1  the populations of lattice 0 / 1: layout, markers and ownership rules of slf_module_set_xface_buffers;
+ *   2     the densities: [z][field][y] over the padded plane, arr_nz * 2 * arr_ny reals per face (field 0 = rho,
+ *         1 = phi).  "ShanChenPrepareDensities" stores rho and phi of the subdomain's first / last column into
+ *         send_low / send_high; the edge lanes of "ShanChenCollideAndPropagateFusedV" take the five stencil values per
+ *         field that lie across the face from recv_low / recv_high (the neighbour's send_high / send_low of the SAME
+ *         step) and never touch the ghost columns.  No markers: every entry that is read has been written in the step.
+ * A connected face needs all three sets.  For fluid-only D3Q19 modules, two-copy access pattern, direct addressing,
+ * y and z wrapped inside the sweep, x not; only the two kernels named above run with planes set (the others refuse). */
+int slf_module_set_xface_planes(slf_module* m, int32_t which, void* send_low, void* send_high, void* recv_low,
+                                void* recv_high);
+
 /* The ghost columns x = 0 (low) / x = nx + 1 (high) of this subdomain carry nothing the simulation uses -- the face is
  * a wall or open, neither periodic through the ghost-layer kernels nor connected to another subdomain through ghost
  * columns, and (in-place pattern) the first / last real column holds no wet node: the odd in-place step of a WET node
@@ -478,6 +492,8 @@ int slf_plan_add_memset(slf_plan* plan, void* dptr, int value, size_t bytes, slf
 int slf_plan_add_copy(slf_plan* plan, void* dst, const void* src, size_t bytes, slf_stream* stream);    /* same device */
 int slf_plan_add_xface_buffers(slf_plan* plan, slf_module* m, void* send_low, void* send_high, void* recv_low,
                                void* recv_high);                                /* slf_module_set_xface_buffers */
+int slf_plan_add_xface_planes(slf_plan* plan, slf_module* m, int32_t which, void* send_low, void* send_high,
+                              void* recv_low, void* recv_high);                 /* slf_module_set_xface_planes */
 int slf_plan_add_peer_signal(slf_plan* plan, slf_peer* peer, const int32_t* ranks, int n, int channel, slf_stream* stream);
 int slf_plan_add_peer_wait(slf_plan* plan, slf_peer* peer, const int32_t* ranks, int n, int channel, int count,
                            slf_stream* stream);

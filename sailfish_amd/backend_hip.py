@@ -246,6 +246,13 @@ class HIPPlan(object):
                'slf_plan_add_xface_buffers')
         self._keep.append(module)
 
+    def xface_planes(self, module, which, send_low, send_high, recv_low, recv_high):
+        _check(self._lib, self._lib.slf_plan_add_xface_planes(self.handle, module.handle, int(which),
+                                                              *[ctypes.c_void_p(a or None) for a in
+                                                                (send_low, send_high, recv_low, recv_high)]),
+               'slf_plan_add_xface_planes')
+        self._keep.append(module)
+
     def call(self, fn):
         raise NotPlannable('this step needs Python between its launches')
 
@@ -658,6 +665,15 @@ class HIPBackend(placement.VmmMixin):
         _check(self._lib, self._lib.slf_module_set_xface_buffers(module.handle, *[ctypes.c_void_p(a or None) for a in
                                                                                    (send_low, send_high, recv_low, recv_high)]),
                'slf_module_set_xface_buffers')
+
+    supports_xface_planes = True      # slf_module_set_xface_planes: binary Shan-Chen over connected x faces
+
+    def set_xface_planes(self, module, which, send_low, send_high, recv_low, recv_high):
+        """x-face planes of a binary Shan-Chen module: which = 0 / 1 populations of lattice 0 / 1, 2 = densities."""
+        _check(self._lib, self._lib.slf_module_set_xface_planes(module.handle, int(which),
+                                                                *[ctypes.c_void_p(a or None) for a in
+                                                                  (send_low, send_high, recv_low, recv_high)]),
+               'slf_module_set_xface_planes')
 
     supports_step_plans = True
 

@@ -69,6 +69,8 @@ class LocalGroup(object):
     def __init__(self, runners):
         self.runners = runners
         self.by_id = dict((r._spec.id, r) for r in runners)
+        for r in runners:
+            r._group = self
         self._plans = {}
         self._plan_ok = None
 
@@ -110,6 +112,8 @@ class LocalGroup(object):
             mine = msgs[r._spec.id]
             if not mine:
                 continue
+            if getattr(r, '_nnx', None) is not None and r._nnx_serial(self):
+                continue        # shared planes, one calc stream: nothing to move and nothing to order
             sh = r._data_stream
             for nid, (_, _, _, recv_buf, n_recv) in sorted(mine.items()):
                 src = self.by_id[nid]
@@ -118,7 +122,8 @@ class LocalGroup(object):
                 if n_recv == 0:
                     continue
                 q.wait(sh, src._pev[par][pre + 'packed'])
-                self._copy(q, r, src, recv_buf, send_buf, n_recv * r.float().itemsize)
+                if recv_buf != send_buf:        # shared planes (_share_xface_buffers): the order is all that is needed
+                    self._copy(q, r, src, recv_buf, send_buf, n_recv * r.float().itemsize)
             q.record(r._pev[par][pre + 'copied'], sh)
 
     def _program_copies_xface(self, q, it, r):
@@ -156,6 +161,23 @@ class LocalGroup(object):
             return
         done = 0
         for r in self.runners:
+            # the binary Shan-Chen model's planes (xface.NNPlanes): the neighbour's send buffer of a link BECOMES my receive
+            # buffer of the same link, per kind and step parity (a link's buffer holds its faces in the order both sides use)
+            if getattr(r, '_nnx', None) is None:
+                continue
+            for kind, links in (('dist', r._links), ('macro', r._macro_links)):
+                for nid, link in links.items():
+                    nb = self.by_id.get(nid)
+                    if nb is None or getattr(nb, '_nnx', None) is None or nb.backend.gpu_id != r.backend.gpu_id:
+                        continue
+                    nlink = (nb._links if kind == 'dist' else nb._macro_links)[r._spec.id]
+                    for par in (0, 1):
+                        nlink.send_bufs[par] = link.recv_bufs[par]
+                        done += 1
+                    nlink.send_buf = nlink.send_bufs[0]
+                    nb._nnx_place(kind, r._spec.id)
+                    r._nnx.shared = nb._nnx.shared = True
+        for r in self.runners:
             if r._xface is None:
                 continue
             sp = r._spec
@@ -189,9 +211,14 @@ class LocalGroup(object):
         rs = self.runners
         if os.environ.get('SLF_GROUP_ONE_STREAM', '1') == '0' or len(rs) < 2:
             return
-        if any(r._xface is None or not r._xface.shared for r in rs) or len(set(r.backend.gpu_id for r in rs)) != 1:
+        def shared_planes(r):
+            if getattr(r, '_nnx', None) is not None:
+                return r._nnx.shared
+            return r._xface is not None and r._xface.shared and len(r._xchunks.order) == 1
+
+        if not all(shared_planes(r) for r in rs) or len(set(r.backend.gpu_id for r in rs)) != 1:
             return
-        if any(len(r._xchunks.order) != 1 or r._bnd_stream is not r._calc_stream for r in rs):
+        if any(r._bnd_stream is not r._calc_stream for r in rs):
             return
         for r in rs:
             r.backend.sync_stream(*r._all_streams())

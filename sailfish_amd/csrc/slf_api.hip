@@ -90,6 +90,8 @@ struct slf_module {
   uint32_t* status;   // device {flag, x, y, z} of the on-GPU invalid value check
   void* xsend[2];     // x-face buffers (slf_module_set_xface_buffers), NULL = unused
   void* xrecv[2];
+  void* sc_send[3][2];  // binary Shan-Chen over connected x faces (slf_module_set_xface_planes): [lattice 0, lattice 1,
+  void* sc_recv[3][2];  // densities][low / high face], NULL = unused
   slf::RowClasses rows;   // slf_module_classify_rows; rows.map == NULL: nothing classified
   void* rows_mem;         // one device allocation behind the tables of `rows`
   slf::SlotTable slots;   // indirect addressing: slot -> node, built from the `nodes` table of the first launch that names it
@@ -1127,6 +1129,7 @@ int slf_module_create(slf_ctx* ctx, const slf_module_desc* d, slf_module** out) 
   m->node_params = nullptr;
   m->status = nullptr;
   m->xsend[0] = m->xsend[1] = m->xrecv[0] = m->xrecv[1] = nullptr;
+  for (int w = 0; w < 3; w++) m->sc_send[w][0] = m->sc_send[w][1] = m->sc_recv[w][0] = m->sc_recv[w][1] = nullptr;
   m->rows = slf::RowClasses{};
   m->rows_mem = nullptr;
   m->slots = slf::SlotTable{};
@@ -1346,6 +1349,45 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
   m->xsend[1] = send_high;
   m->xrecv[0] = recv_low;
   m->xrecv[1] = recv_high;
+  return SLF_OK;
+}
+
+// x-face planes of the binary model into the launch arguments; all six faces' worth or none (a sweep without the density
+// planes would read ghost columns nobody fills)
+static void sc_planes_of(const slf_module* m, slf::SweepArgs& a) {
+  for (int f = 0; f < 2; f++) {
+    a.xsend[f] = m->sc_send[0][f];   a.xrecv[f] = m->sc_recv[0][f];
+    a.xsend2[f] = m->sc_send[1][f];  a.xrecv2[f] = m->sc_recv[1][f];
+    a.msend[f] = m->sc_send[2][f];   a.mrecv[f] = m->sc_recv[2][f];
+  }
+}
+
+static int check_xface_planes(const slf_module* m, int32_t which, void* send_low, void* send_high, void* recv_low,
+                              void* recv_high) {
+  if (!m) return fail(SLF_ERR_INVALID, "module is NULL");
+  if (which < 0 || which > 2) return fail(SLF_ERR_INVALID, "x-face planes: 0 / 1 = populations of lattice 0 / 1, 2 = densities");
+  if (send_low || send_high || recv_low || recv_high) {
+    const slf::Geometry& g = m->geo;
+    if (m->sel.lattice != 1 || g.indirect || m->sc.enabled != 1 || !(g.variant & 8) || m->sel.general)
+      return fail(SLF_ERR_UNSUPPORTED, "x-face planes: fluid-only D3Q19 binary Shan-Chen modules with direct addressing (whole-row kernels)");
+    if (m->access_pattern != SLF_AB) return fail(SLF_ERR_UNSUPPORTED, "x-face planes: two-copy access pattern only");
+    if (g.wrap[0]) return fail(SLF_ERR_INVALID, "x-face planes make no sense with x wrapped inside the sweep");
+    if (!g.wrap[1] || !g.wrap[2])
+      return fail(SLF_ERR_UNSUPPORTED, "x-face planes: y and z must be wrapped inside the sweep (every entry an edge node reads is written each step)");
+    if (g.lat_nx - 2 > 1024 || g.lat_nx - 2 < 2) return fail(SLF_ERR_UNSUPPORTED, "x-face planes: rows of 2 .. 1024 nodes");
+    if ((send_low == nullptr) != (recv_low == nullptr) || (send_high == nullptr) != (recv_high == nullptr))
+      return fail(SLF_ERR_INVALID, "a connected face needs both its send and its receive plane");
+  }
+  return SLF_OK;
+}
+
+int slf_module_set_xface_planes(slf_module* m, int32_t which, void* send_low, void* send_high, void* recv_low,
+                                void* recv_high) {
+  if (int e = check_xface_planes(m, which, send_low, send_high, recv_low, recv_high)) return e;
+  m->sc_send[which][0] = send_low;
+  m->sc_send[which][1] = send_high;
+  m->sc_recv[which][0] = recv_low;
+  m->sc_recv[which][1] = recv_high;
   return SLF_OK;
 }
 
@@ -1617,6 +1659,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.status = m->status;
       a.options = (uint32_t)k->ints[0];
       a.sc_local_velocity = k->sc_local_velocity;
+      sc_planes_of(m, a);
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       slf::Prop prop = slf::PROP_AB;
       if (m->access_pattern == SLF_AA) {
@@ -1652,6 +1695,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
       a.status = m->status;
       a.options = (uint32_t)k->ints[0];
       a.sc_local_velocity = k->sc_local_velocity;
+      sc_planes_of(m, a);
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       slf::Prop prop = slf::PROP_AB;
       if (m->access_pattern == SLF_AA) {
@@ -1975,6 +2019,19 @@ int slf_plan_add_xface_buffers(slf_plan* p, slf_module* m, void* send_low, void*
   return SLF_OK;
 }
 
+int slf_plan_add_xface_planes(slf_plan* p, slf_module* m, int32_t which, void* send_low, void* send_high, void* recv_low,
+                              void* recv_high) {
+  if (!p || !m) return fail(SLF_ERR_INVALID, "NULL argument");
+  if (int e = check_xface_planes(m, which, send_low, send_high, recv_low, recv_high)) return e;
+  PlanOp o;
+  o.kind = PL_XFACE;
+  o.mod = m;
+  o.value = which + 1;        // 0: the single-fluid buffers
+  o.xf[0] = send_low; o.xf[1] = send_high; o.xf[2] = recv_low; o.xf[3] = recv_high;
+  p->ops.push_back(o);
+  return SLF_OK;
+}
+
 static int plan_add_peer(slf_plan* p, PlanKind kind, slf_peer* peer, const int32_t* ranks, int n, int channel, int count,
                          slf_stream* stream) {
   if (!p) return fail(SLF_ERR_INVALID, "NULL argument");
@@ -2016,6 +2073,11 @@ int slf_plan_run(slf_plan* p, uint32_t iteration) {
       case PL_MEMSET: e = slf_memset(p->ctx, o.dst, o.value, o.bytes, o.stream); break;
       case PL_COPY: e = slf_memcpy_d2d_async(p->ctx, o.dst, o.src, o.bytes, o.stream); break;
       case PL_XFACE:
+        if (o.value > 0) {
+          o.mod->sc_send[o.value - 1][0] = o.xf[0]; o.mod->sc_send[o.value - 1][1] = o.xf[1];
+          o.mod->sc_recv[o.value - 1][0] = o.xf[2]; o.mod->sc_recv[o.value - 1][1] = o.xf[3];
+          break;
+        }
         o.mod->xsend[0] = o.xf[0]; o.mod->xsend[1] = o.xf[1];
         o.mod->xrecv[0] = o.xf[2]; o.mod->xrecv[1] = o.xf[3];
         break;

@@ -87,6 +87,12 @@ struct SweepArgs {
   const SlotTable* slots;
   // row classes of the node map `map` (slf_module_classify_rows), NULL = not classified; see RowClasses
   const RowClasses* rows;
+  // binary Shan-Chen over connected x faces (slf_module_set_xface_planes): xsend / xrecv above serve lattice 0, these
+  // lattice 1 and the densities rho, phi ([z][field][y] planes); NULL = not used
+  void* xsend2[2];
+  const void* xrecv2[2];
+  void* msend[2];
+  const void* mrecv[2];
 };
 
 // What slf_module_classify_rows() found in a node map, per 64-node x-segment (= one wavefront of a whole-row

@@ -46,6 +46,11 @@ struct ScParams {
   int potential;
   int force_edm;
   int xcd_shift;     // xcd_row(): rows per XCD and block of rows = 1 << this
+  // connected x faces (XF instantiations; slf_module_set_xface_planes): dense planes instead of ghost columns
+  R* xsend[2][2];          // [lattice][low / high face]: populations that leave, [z][k][y] as slf_sweep.h
+  const R* xrecv[2][2];    //                             populations that enter
+  R* msend[2];             // [face]: densities of my first / last column, [z][field][y]
+  const R* mrecv[2];       //         densities of the neighbour's last / first column
 };
 
 template <class R, int POT>
@@ -249,11 +254,61 @@ __device__ __forceinline__ void sc_store(const Geometry& g, R (&f)[L::Q], R* dou
   }
 }
 
+// ---- connected x faces (XF): the binary model over the x-face planes of a 1-D decomposition along x ----
+// Populations: per lattice the single-fluid scheme (slf_sweep.h x_face_receive, row_push's xsend) -- two-copy steps only.
+// Densities: the force stencil of an edge node reads the neighbour subdomain's first / last column; the pass in front
+// (sc_macro_kernel) stores rho and phi of ITS edge nodes into a send plane [z][field][y] over the padded (arr_ny x arr_nz)
+// plane, and the sweep's edge lanes take the five values per field that sit across the face from the receive plane.  For
+// fluid-only subdomains whose y and z axes are wrapped inside the kernels: every entry that is read has been written in
+// the same step, so the density planes need no "nothing crossed here" marker.
+template <class L, class R>
+__device__ __forceinline__ void sc_face_receive(const R* const (&xrecv)[2], R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
+  if (xrecv[0] && x == 1) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) > 0) {
+        const R val = xrecv[0][face_elem<L, I>(fr, 0)];
+        if (face_value_present(val)) f[I] = val;
+      }
+    });
+  }
+  if (xrecv[1] && x == nx) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) < 0) {
+        const R val = xrecv[1][face_elem<L, I>(fr, 0)];
+        if (face_value_present(val)) f[I] = val;
+      }
+    });
+  }
+}
+// row of (y, z) in a density plane, and the offsets to its y / z neighbours (wrapped like the arrays)
+struct ScMacroRows {
+  int row;
+  AxisOff oy, oz;
+  int fstride;      // field 1 sits this far behind field 0
+};
+__device__ __forceinline__ ScMacroRows sc_macro_rows(const Geometry& g, int gy, int gz) {
+  ScMacroRows mr;
+  mr.row = gy + 2 * g.arr_ny * gz;
+  mr.oy = axis_off(gy, g.lat_ny, 1, g.wrap[1]);
+  mr.oz = axis_off(gz, g.lat_nz, 2 * g.arr_ny, g.wrap[2]);
+  mr.fstride = g.arr_ny;
+  return mr;
+}
+// offset (in a density plane) of the k-th direction with e_x > 0 (PLUS) resp. < 0 from the row of (y, z): wave-uniform
+template <class L, bool PLUS>
+__device__ __forceinline__ void sc_macro_offsets(const ScMacroRows& mr, int (&off)[count_x_dirs<L>()]) {
+  const AxisOff ox0 = {0, 0};
+  static_for<1, L::Q>([&](auto I) {
+    if constexpr (L::ex(I) != 0 && (L::ex(I) > 0) == PLUS) off[x_dir_rank<L, I>()] = dir_offset<L, I>(ox0, mr.oy, mr.oz, true);
+  });
+}
+
 // VOUT = false ("ShanChenPrepareDensities", the partner of the fused sweep that forms the velocity itself): only the
 // two densities are stored -- three of the five written streams gone; the velocity arrays are brought up to date by
 // the launches whose options ask for output (bit 0), which run the VOUT = true instantiation.
-template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool VOUT = true>
+template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool VOUT = true, bool XF = false>
 __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
+  static_assert(!XF || (PROP == PROP_AB && !GENERAL && !INDIRECT), "x-face planes: two-copy steps of fluid-only subdomains");
   const Geometry& g = p.g;
   bool live;
   const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live, p.xcd_shift);
@@ -273,6 +328,7 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   R f[L::Q];
   // lattice 0
   sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
+  if constexpr (XF) sc_face_receive<L, R>(p.xrecv[0], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
   const R rho0 = density<L, R>(f);
   R v[3] = {(R)0, (R)0, (R)0};
   if constexpr (VOUT) {
@@ -282,9 +338,16 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   }
   // lattice 1
   sc_load<L, R, PROP, INDIRECT>(f, (const R*)p.d_out, ds, n, p.nodes, si);
+  if constexpr (XF) sc_face_receive<L, R>(p.xrecv[1], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
   const R rho1 = density<L, R>(f);
   p.rho0[gi] = rho0;
   p.rho1[gi] = rho1;
+  if constexpr (XF) {
+    // what the neighbours' sweeps read across the faces
+    const int mrow = n.gy + 2 * g.arr_ny * n.gz;
+    if (p.msend[0] && n.gx == 1) { p.msend[0][mrow] = rho0; p.msend[0][mrow + g.arr_ny] = rho1; }
+    if (p.msend[1] && n.gx == g.lat_nx - 2) { p.msend[1][mrow] = rho0; p.msend[1][mrow + g.arr_ny] = rho1; }
+  }
   if constexpr (VOUT) {
     v[0] = v[0] + p.omega[1] * momentum<L, R, 0>(f);
     v[1] = v[1] + p.omega[1] * momentum<L, R, 1>(f);
@@ -390,9 +453,10 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 // the neighbours only, the velocity arrays not at all (the pass in front of it then stores two streams instead of five).
 // Both sets of populations are in registers from the start.
 // PULL (with OWNV, ROW, the odd in-place step): the populations come through sc_pull_rows() -- aligned loads.
-template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool OWNV = false, bool PULL = false>
+template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool OWNV = false, bool PULL = false, bool XF = false>
 __global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? (OWNV ? SLF_SC_FUSEDV_WAVES : SLF_SC_FUSED_WAVES) : 4)
 sc_fused_kernel(const ScParams<L, R> p) {
+  static_assert(!XF || (PROP == PROP_AB && !GENERAL && ROW && OWNV && !PULL), "x-face planes: the whole-row two-copy sweep of fluid-only subdomains");
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
@@ -432,13 +496,41 @@ sc_fused_kernel(const ScParams<L, R> p) {
   }
   // stencil sums of the fields some lattice is coupled to
   R S[2][3] = {{(R)0, (R)0, (R)0}, {(R)0, (R)0, (R)0}};
+  // XF: the stencil of an edge node reaches into the neighbour subdomain -- those five values per field come from the
+  // receive plane; the lane's own loads stay inside the row (the ghost column's line is never fetched)
+  [[maybe_unused]] bool is_lo = false, is_hi = false;
+  [[maybe_unused]] const R* mplane = nullptr;
+  [[maybe_unused]] int moff[count_x_dirs<L>()];
+  ScNode ns = n;
+  if constexpr (XF) {
+    is_lo = live && p.mrecv[0] && n.gx == 1;
+    is_hi = live && p.mrecv[1] && n.gx == nx;
+    if (is_lo) ns.ox.m = 0;
+    if (is_hi) ns.ox.p = 0;
+    const ScMacroRows mr = sc_macro_rows(g, n.gy, n.gz);
+    int offp[count_x_dirs<L>()], offm[count_x_dirs<L>()];
+    sc_macro_offsets<L, true>(mr, offp);
+    sc_macro_offsets<L, false>(mr, offm);
+    static_for<0, count_x_dirs<L>()>([&](auto K) { moff[K] = mr.row + (is_lo ? offm[K] : offp[K]); });
+    mplane = is_lo ? p.mrecv[0] : p.mrecv[1];
+  }
   if (wet) {
     const R* const fields[2] = {p.rho0, p.rho1};
     sc_with_potential(p.potential, [&](auto POT) {
       static_for<0, 2>([&](auto J) {
         if (p.G[J] != (R)0 || p.G2[J] != (R)0) {
+          [[maybe_unused]] R ev[count_x_dirs<L>()];
+          if constexpr (XF) {
+            static_for<0, count_x_dirs<L>()>([&](auto K) { ev[K] = (R)0; });
+            if (is_lo || is_hi) {
+              static_for<0, count_x_dirs<L>()>([&](auto K) { ev[K] = mplane[moff[K] + (int)J * g.arr_ny]; });
+            }
+          }
           static_for<1, L::Q>([&](auto I) {
-            const R psi = sc_psi<R, POT>(*sc_neighbour<L, I>(fields[J], n, true));
+            R nb = *sc_neighbour<L, I>(fields[J], ns, true);
+            if constexpr (XF && L::ex(I) > 0) nb = is_hi ? ev[x_dir_rank<L, I>()] : nb;
+            if constexpr (XF && L::ex(I) < 0) nb = is_lo ? ev[x_dir_rank<L, I>()] : nb;
+            const R psi = sc_psi<R, POT>(nb);
             static_for<0, L::dim>([&](auto D) {
               constexpr int e = e_comp<L>(I, D);
               if constexpr (e > 0) S[J][D] = S[J][D] + psi * Weights<L, R>::w(I);
@@ -459,6 +551,13 @@ sc_fused_kernel(const ScParams<L, R> p) {
     } else {
       sc_load<L, R, PROP>(fa, p.d_in, ds, n);
       sc_load<L, R, PROP>(fb, p.d_in2, ds, n);
+    }
+    if constexpr (XF) {
+      if (live) {
+        const FaceRows fr = face_rows<L>(g, n.gy, n.gz);
+        sc_face_receive<L, R>(p.xrecv[0], fa, n.gx, nx, fr);
+        sc_face_receive<L, R>(p.xrecv[1], fb, n.gx, nx, fr);
+      }
     }
     rho[0] = density<L, R>(fa);
     vc[0] = p.omega[0] * momentum<L, R, 0>(fa);
@@ -499,7 +598,13 @@ sc_fused_kernel(const ScParams<L, R> p) {
     }
     if (wet) bgk_relax_accel<L, R>(f, rho[K], v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
     if constexpr (ROW && PROP != PROP_AA_EVEN && K == 1) __syncthreads();     // row_push's LDS words are still being read
-    sc_store<L, R, PROP, GENERAL, ROW>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n, nx, live, active);
+    if constexpr (XF) {
+      const FaceRows fr = face_rows<L>(g, n.gy, n.gz);
+      row_push<L, R, GENERAL, sc_nt<L>()>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n.row, n.xi, n.gx, nx, live, active, n.oy,
+                                          n.oz, p.xsend[K], &fr);
+    } else {
+      sc_store<L, R, PROP, GENERAL, ROW>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n, nx, live, active);
+    }
   };
   if constexpr (OWNV) {
     // single precision D3Q19: lattice 1 waits in LDS while lattice 0 collides and streams -- registers as for one
@@ -681,12 +786,27 @@ static ScParams<L, R> make_sc(const Geometry& g, const Physics& ph, const ShanCh
   p.G2[0] = (R)sc.G[2];
   p.G2[1] = (R)sc.G[3];
   p.xcd_shift = 0;
+  for (int f = 0; f < 2; f++) {
+    p.xsend[0][f] = (R*)a.xsend[f];
+    p.xsend[1][f] = (R*)a.xsend2[f];
+    p.xrecv[0][f] = (const R*)a.xrecv[f];
+    p.xrecv[1][f] = (const R*)a.xrecv2[f];
+    p.msend[f] = (R*)a.msend[f];
+    p.mrecv[f] = (const R*)a.mrecv[f];
+  }
   p.has_body_force2 = 0;
   for (int d = 0; d < 3; d++) {
     p.accel2[d] = (R)sc.accel1[d];
     if (p.accel2[d] != (R)0) p.has_body_force2 = 1;
   }
   return p;
+}
+
+static inline bool sc_xface_in_use(const SweepArgs& a) {
+  for (int f = 0; f < 2; f++) {
+    if (a.xsend[f] || a.xrecv[f] || a.xsend2[f] || a.xrecv2[f] || a.msend[f] || a.mrecv[f]) return true;
+  }
+  return false;
 }
 
 // rows sc_pull_rows() serves: wrapped along x inside the kernel, the whole row in one workgroup, whole-row kernels on
@@ -706,6 +826,18 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
   // the densities-only form: indirect addressing keeps the reference's pass
   const bool vout = !a.sc_local_velocity || (a.options & 1u) || g.indirect;
+  if (sc_xface_in_use(a)) {
+    // connected x faces through planes: edge lanes take the entering populations from the receive planes and store their
+    // densities for the neighbours (the module was checked when the planes were set: slf_module_set_xface_planes)
+    if constexpr (L::dim == 3) {
+      if (prop != PROP_AB || general || g.indirect) return hipErrorInvalidValue;
+      p.xcd_shift = xcd_shift_for(grid.y, grid.x);        // 32 consecutive rows write one line of a plane: one XCD
+      if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, true, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, false, true>), grid, block, 0, s, p);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  }
   if constexpr (L::dim == 3) {
     if (!vout && !general && prop == PROP_AA_ODD && sc_row_pull_ok(g)) {
       hipLaunchKernelGGL((sc_density_pull_kernel<L, R>), grid, block, 0, s, p);
@@ -761,6 +893,7 @@ template <class L, class R>
 static hipError_t sc_sweep2(int grid_idx, Prop prop, bool general, const Geometry& g, const Physics& ph,
                             const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                             hipStream_t s) {
+  if (sc_xface_in_use(a)) return hipErrorInvalidValue;       // planes: the fused sweep only
   ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, grid_idx, y0, z0);
   const int nx = g.lat_nx - 2;
   // whole-row workgroups + aligned stores for the x-streaming steps in 3-D (as slf_row.hip)
@@ -820,6 +953,14 @@ static hipError_t sc_fused2(Prop prop, bool general, const Geometry& g, const Ph
       else hipLaunchKernelGGL((sc_fused_kernel<L, R, P, false, ROW>), grid, block, 0, s, p);          \
     }                                                                                              \
   } while (0)
+  if (sc_xface_in_use(a)) {
+    if constexpr (L::dim == 3) {
+      if (!row || prop != PROP_AB || general || !a.sc_local_velocity || grid.x != 1) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AB, false, true, true, false, true>), grid, block, park, s, p);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  }
   if constexpr (L::dim == 3) {
     if (row && prop == PROP_AB) { SLF_SCF(PROP_AB, true); return hipGetLastError(); }
     if (row && prop == PROP_AA_ODD && a.sc_local_velocity && sc_row_pull_ok(g) && grid.x == 1) {
@@ -846,6 +987,7 @@ template <class L, class R>
 static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometry& g, const Physics& ph,
                               const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                               hipStream_t s) {
+  if (sc_xface_in_use(a)) return hipErrorInvalidValue;       // planes: the binary model only
   ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
   p.G[0] = (R)sc.G[0];
   p.G[1] = (R)0;

@@ -127,6 +127,7 @@ SIGNATURES = {
     'slf_module_create': (c_int, [c_void_p, POINTER(SlfModuleDesc), POINTER(c_void_p)]),
     'slf_module_destroy': (c_int, [c_void_p]),
     'slf_module_set_xface_buffers': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'slf_module_set_xface_planes': (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'slf_module_set_x_ghost_unused': (c_int, [c_void_p, c_int, c_int]),
     'slf_module_block_size': (c_int, [c_void_p, POINTER(c_int)]),
     'slf_kernel_get': (c_int, [c_void_p, c_char_p, POINTER(c_void_p)]),
@@ -152,6 +153,7 @@ SIGNATURES = {
     'slf_plan_add_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     'slf_plan_add_copy': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'slf_plan_add_xface_buffers': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'slf_plan_add_xface_planes': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'slf_plan_add_peer_signal': (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_void_p]),
     'slf_plan_add_peer_wait': (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_int, c_void_p]),
     'slf_plan_run': (c_int, [c_void_p, c_uint32]),

@@ -57,6 +57,9 @@ class DirectQueue(object):
     def xface(self, module, send_low, send_high, recv_low, recv_high):
         self.backend.set_xface_buffers(module, send_low, send_high, recv_low, recv_high)
 
+    def xface_planes(self, module, which, send_low, send_high, recv_low, recv_high):
+        self.backend.set_xface_planes(module, which, send_low, send_high, recv_low, recv_high)
+
     def call(self, fn):
         """Arbitrary host code between the entries (what a plan cannot hold)."""
         fn()

@@ -458,6 +458,10 @@ class SubdomainRunner(object):
             return False
         if not xface.supported(self._sim.grid, self._desc, self.indirect) or len(self._sim.grids) != 1:
             return False
+        return self._x_slabs_line_up()
+
+    def _x_slabs_line_up(self):
+        """A 1-D decomposition along x whose slabs share their y / z extent (same answer in every runner)."""
         local = self._local_periodic()
         if any(local[a] and not self._fused[a] for a in range(self.dim)):
             # periodic images made by the ghost-layer kernels live in the arrays, not in the face buffers
@@ -469,7 +473,7 @@ class SubdomainRunner(object):
             faces = set(face for face, _ in spec.connecting_subdomains())
             if not faces or not faces <= set((spec.X_LOW, spec.X_HIGH)):
                 return False
-            if not xface.supported(self._sim.grid, self._desc) or spec.size[0] > 1024:
+            if spec.size[0] > 1024 or spec.size[0] < 2:
                 return False
         return True
 
@@ -1380,10 +1384,119 @@ class NNSubdomainRunner(SubdomainRunner):
 
     has_macro_exchange = True
 
+    # -- 1-D decompositions along x of the binary model: the populations of both lattices and the densities cross the
+    # -- faces through dense planes the two kernels of a step write / read themselves (xface.NNPlanes)
+    _nnx = None
+
+    def _nn_x_faces_only(self):
+        if not getattr(self.config, 'hip_xface', True) or self.dim != 3 or len(self._sim.grids) != 2 or \
+                not getattr(self.backend, 'supports_xface_planes', False):
+            return False
+        if not xface.supported_nn(self._sim.grid, self._desc, self.indirect):
+            return False
+        return self._x_slabs_line_up()
+
+    def _init_nn_planes(self):
+        """Per neighbour, kind ('dist': both lattices, 'macro': rho and phi) and step parity one send and one receive
+        buffer, [through my low face | through my high face] as in _init_xface_halo.  The links carry no pack / unpack
+        kernels -- the sweeps fill and read the planes -- so the step program of the general case (pack -> exchange ->
+        unpack, per kind) moves them as it stands."""
+        spec = self._spec
+        nnx = xface.NNPlanes(self.backend, self.module, self._sim.grid, self._desc)
+        by_neighbour = {}
+        for face, nid in sorted(spec.connecting_subdomains()):
+            by_neighbour.setdefault(nid, []).append(xface.LOW if face == spec.X_LOW else xface.HIGH)
+        zc = getattr(self._connector, 'zero_copy', False)
+        all_links = {'dist': self._links, 'macro': self._macro_links}
+        for kind in ('dist', 'macro'):
+            n, links = nnx.count[kind], all_links[kind]
+            for nid in sorted(by_neighbour):
+                link = subdomain_connection.HaloLink(nid)
+                link.faces = sorted(by_neighbour[nid])
+                link.n_send = link.n_recv = n * len(link.faces)
+                if zc:
+                    link.recv_bufs = [self._connector.alloc_recv(self, kind, nid, par, link.n_recv, self.float) for par in (0, 1)]
+                else:
+                    link.send_bufs = [self._connector.alloc_buffer(self, link.n_send, self.float) for _ in (0, 1)]
+                    link.recv_bufs = [self._connector.alloc_buffer(self, link.n_recv, self.float) for _ in (0, 1)]
+                links[nid] = link
+            if zc:
+                self._connector.resolve(self)        # collective: once per kind, in this order, on every rank
+                for nid, link in links.items():
+                    link.send_bufs = [self._connector.send_addr(self, kind, nid, par) for par in (0, 1)]
+            for nid, link in links.items():
+                link.send_buf, link.recv_buf = link.send_bufs[0], link.recv_bufs[0]
+                if kind == 'dist':
+                    link.kernels = dict(((mode, copy), ([], [], link.n_send, link.n_recv))
+                                        for mode in ('push', 'pull') for copy in (0, 1))
+                else:
+                    link.packs, link.unpacks = [[], []], [[], []]
+        self._nnx = nnx
+        nnx.shared = bool(zc)
+        self.config.logger.debug('subdomain %d: binary model over x-face planes (%s)' % (
+            spec.id, 'the neighbours\' memory mapped here' if zc else type(self._connector).__name__))
+        for kind in all_links:
+            for nid in all_links[kind]:
+                self._nnx_place(kind, nid)
+        nnx.reset()
+
+    def _nnx_place(self, kind, nid):
+        """The face addresses inside the buffers of the link to `nid` (again after a buffer of the link was replaced)."""
+        nnx = self._nnx
+        link = (self._links if kind == 'dist' else self._macro_links)[nid]
+        step = nnx.count[kind] * nnx.isz
+        for par in (0, 1):
+            for k, face in enumerate(link.faces):                     # my send order: low, high
+                nnx.send[kind][par][face] = link.send_bufs[par] + k * step
+            for k, face in enumerate(reversed(link.faces)):           # the neighbour's send order seen from here
+                nnx.recv[kind][par][face] = link.recv_bufs[par] + k * step
+
+    def _nnx_serial(self, group):
+        """Stepped by a group that runs every sweep of its subdomains on ONE stream, planes shared with the neighbours: the
+        order of that stream is all the order the planes need (controller.LocalGroup._serialise_sweeps)."""
+        return self._nnx is not None and group is not None and getattr(group, 'single_calc_stream', False) and self._nnx.shared
+
+    def halo_messages(self, kind='dist'):
+        if self._nnx is None:
+            return SubdomainRunner.halo_messages(self, kind)
+        par = self._nnx_parity
+        links = self._links if kind == 'dist' else self._macro_links
+        return [(nid, links[nid].send_bufs[par], links[nid].n_send, links[nid].recv_bufs[par], links[nid].n_recv)
+                for nid in sorted(links)]
+
+    def _set_step_state(self, it):
+        SubdomainRunner._set_step_state(self, it)
+        self._nnx_parity = it & 1
+
+    def _reset_xface(self):
+        if self._nnx is None:
+            return SubdomainRunner._reset_xface(self)
+        self.backend.sync_stream(*self._all_streams())
+        self._connector.quiesce(self)       # zero-copy transports: the neighbours write into these planes themselves
+        self._nnx.reset(self._calc_stream)
+        self.backend.sync_stream(self._calc_stream)
+        self._connector.quiesce(self)
+        self.__dict__.pop('_halo_mode', None)
+
+    def _materialise_halo(self):
+        if self._nnx is None:
+            return SubdomainRunner._materialise_halo(self)
+        if not hasattr(self, '_halo_mode'):
+            return
+        self.backend.sync_stream(*self._all_streams())
+        self._nnx.materialise([self.gpu_dist(g, self._halo_copy) for g in (0, 1)], self._calc_stream, self._nnx_parity)
+        self.backend.sync_stream(self._calc_stream)
+
     def _init_halo(self):
         """Population halo as in the base class (all lattices), plus the exchange of the macroscopic
         fields the non-local force reads at neighbouring nodes (reference _init_interblock_kernels /
         _send_macro / _recv_macro, subdomain_runner.py:1907-2100)."""
+        if self._all_specs is not None and len(self._all_specs) >= 2 and self._nn_x_faces_only():
+            self._links, self._macro_links, self._ev_halo = {}, {}, None
+            if self._connector is None:
+                from sailfish_amd.connector import LocalConnector
+                self._connector = LocalConnector()
+            return self._init_nn_planes()
         SubdomainRunner._init_halo(self)
         if self._all_specs is None or len(self._all_specs) < 2:
             return
@@ -1468,6 +1581,11 @@ class NNSubdomainRunner(SubdomainRunner):
         # which the other steps' pass leaves to the sweep -- lb_binary.get_compute_kernels)
         macro_kernel = (self._kernels_full if sync_req else self._kernels_none)[it & 1][0]
         base = 1 - (it & 1)
+        if self._nnx is not None:
+            self._nnx.program_bind(q, it)
+            if self._nnx_serial(group):
+                q.launch(macro_kernel, None, sk)
+                return
         if self._links:
             q.wait(sk, pev['halo'])                          # populations received after the last step
         if timed:
@@ -1486,7 +1604,7 @@ class NNSubdomainRunner(SubdomainRunner):
 
     def _program_macro_back(self, q, it):
         """Unpack the neighbours' values into the ghost nodes; the sweep waits for it."""
-        if not self._macro_links:
+        if not self._macro_links or self._nnx_serial(getattr(self, '_group', None)):
             return
         prof, timed = self._profile, not q.planned
         ev, sh = self._pev[it & 1], self._data_stream
@@ -1503,7 +1621,16 @@ class NNSubdomainRunner(SubdomainRunner):
     def _program_front(self, q, it, sync_req, group=None):
         """The sweeps of every lattice over the whole subdomain (no face layers split off: the force reads the fields of
         the step, which the macro pass has just written) -> ghost-layer PBC kernels -> pack."""
+        if self._nnx_serial(group):
+            for k in self._sweep_kernels(it, sync_req):
+                q.launch(k, None, self._calc_stream)
+            return
         self._program_sweep_rest(q, it, self._sweep_kernels(it, sync_req), None, None, group)
+
+    def _program_back(self, q, it):
+        if self._nnx_serial(getattr(self, '_group', None)):
+            return
+        SubdomainRunner._program_back(self, q, it)
 
     def _debug_get_dist(self, output=True, grid_num=0, copy=None):
         return SubdomainRunner._debug_get_dist(self, output, grid_num, copy)

@@ -336,3 +336,113 @@ class XFaceHalo(object):
                                                        d.arr_nx * d.arr_ny, d.arr_nz, d.arr_ny, NXD * d.arr_ny],
                                                       'PPiiiiiiii')
                 b.run_kernel(self._kernels[key], None, stream)
+
+
+# ---- binary Shan-Chen over connected x faces (C ABI: slf_module_set_xface_planes) ---------------------------------------
+NN_FIELDS = 2    # rho, phi
+
+
+def supported_nn(grid, desc, indirect=False):
+    """Can a binary Shan-Chen module built from `desc` take x-face planes?  What slf_module_set_xface_planes checks:
+    fluid-only D3Q19, two-copy pattern, direct addressing, y and z wrapped inside the kernels (every plane entry an edge
+    node reads is then written in the same step), rows of 2 .. 1024 nodes, whole-row kernels."""
+    from sailfish_amd import hipabi
+    if int(desc.simtype) != hipabi.SLF_SIM_SHAN_CHEN_BINARY or int(desc.access_pattern) != hipabi.SLF_AB:
+        return False
+    variant = os.environ.get('SLF_VARIANT')
+    if variant is not None and not (int(variant) & 8):
+        return False
+    if os.environ.get('SLF_SC_FUSED', '2') != '2' or os.environ.get('SLF_SC_XFACE', '1') == '0':
+        return False        # the planes are served by ShanChenPrepareDensities / ShanChenCollideAndPropagateFusedV only
+    nx = desc.lat_nx - 2
+    return grid.dim == 3 and grid.Q == 19 and not indirect and bool(desc.fluid_only) and 2 <= nx <= 1024 and \
+        bool(desc.periodic_fused[1]) and bool(desc.periodic_fused[2]) and not desc.periodic_fused[0]
+
+
+class NNPlanes(object):
+    """The three sets of planes of one subdomain: populations of lattice 0 and 1 (face_count(desc) reals per face each) and
+    the densities (NN_FIELDS * arr_ny * arr_nz).  A neighbour link moves ONE buffer per kind and step parity:
+    'dist' = [face][lattice][planes], 'macro' = [face][planes]; send[kind][parity][face] / recv[...] are the addresses of a
+    face's part.  Set p of the population planes is written by the sweep of the steps of parity p and read by the two
+    kernels of the following step; set p of the density planes is written and read within the steps of parity p."""
+
+    def __init__(self, backend, module, grid, desc):
+        self.backend, self.module, self.grid, self.desc = backend, module, grid, desc
+        self.dtype = np.float32 if desc.precision == 4 else np.float64
+        self.isz = self.dtype().itemsize
+        self.n_dist = face_count(desc)                       # one lattice, one face
+        self.n_macro = NN_FIELDS * desc.arr_ny * desc.arr_nz
+        self.count = {'dist': 2 * self.n_dist, 'macro': self.n_macro}      # elements per face and kind
+        self.send = dict((k, [[0, 0], [0, 0]]) for k in self.count)
+        self.recv = dict((k, [[0, 0], [0, 0]]) for k in self.count)
+        self.shared = False
+        self.enter = [sym.get_prop_dists(grid, 1, 0), sym.get_prop_dists(grid, -1, 0)]
+        self._kernels = {}
+
+    def program_bind(self, q, it):
+        """The kernels launched from here on serve step `it`: they write the population planes of its parity, read those
+        of the other one, and exchange densities through the planes of its parity."""
+        par = it & 1
+        ds, dr = self.send['dist'][par], self.recv['dist'][1 - par]
+        off = self.n_dist * self.isz
+        for lat in (0, 1):
+            q.xface_planes(self.module, lat, *[a + lat * off if a else 0 for a in (ds[LOW], ds[HIGH], dr[LOW], dr[HIGH])])
+        ms, mr = self.send['macro'][par], self.recv['macro'][par]
+        q.xface_planes(self.module, 2, ms[LOW], ms[HIGH], mr[LOW], mr[HIGH])
+
+    def unbind(self):
+        for which in (0, 1, 2):
+            self.backend.set_xface_planes(self.module, which, 0, 0, 0, 0)
+
+    def own_buffers(self):
+        """Addresses and byte counts of what this subdomain RECEIVES into (its own memory in every transport)."""
+        out = []
+        for kind in ('dist', 'macro'):
+            for par in (0, 1):
+                for f in (LOW, HIGH):
+                    a = self.recv[kind][par][f]
+                    if a and (a, self.count[kind] * self.isz) not in out:
+                        out.append((a, self.count[kind] * self.isz))
+        return out
+
+    def send_buffers(self):
+        out = []
+        for kind in ('dist', 'macro'):
+            for par in (0, 1):
+                for f in (LOW, HIGH):
+                    a = self.send[kind][par][f]
+                    if a and (a, self.count[kind] * self.isz) not in out:
+                        out.append((a, self.count[kind] * self.isz))
+        return out
+
+    def reset(self, stream=None):
+        """All bits set: nothing has crossed the faces, the arrays count (state written from the host).  Shared planes: only
+        what this subdomain receives (its send planes are a neighbour's input and are cleared by that neighbour)."""
+        bufs = self.own_buffers()
+        if not self.shared:
+            bufs = bufs + [b for b in self.send_buffers() if b not in bufs]
+        for a, nbytes in bufs:
+            self.backend.memset_buf(a, 0xFF, nbytes, stream)
+
+    def materialise(self, dists, stream, parity):
+        """Writes the population planes received in the steps of `parity` into the first / last real column of the arrays
+        `dists` = (lattice 0, lattice 1) those steps wrote (a push: same slots) -- before anything reads the arrays on the
+        host (checkpoint, debug dump)."""
+        b, d = self.backend, self.desc
+        nx = d.lat_nx - 2
+        recv = self.recv['dist'][parity]
+        for face in (LOW, HIGH):
+            if not recv[face]:
+                continue
+            x = 1 if face == LOW else nx
+            mask = 0
+            for q in self.enter[face]:
+                mask |= 1 << q
+            for lat, dist in enumerate(dists):
+                src = recv[face] + lat * self.n_dist * self.isz
+                key = (dist, src, mask)
+                if key not in self._kernels:
+                    self._kernels[key] = b.get_kernel(self.module, 'DistributeContinuousData', (64,),
+                                                      [dist, src, mask, x, d.arr_nx, d.arr_ny, d.arr_nx * d.arr_ny, d.arr_nz,
+                                                       d.arr_ny, NXD * d.arr_ny], 'PPiiiiiiii')
+                b.run_kernel(self._kernels[key], None, stream)

@@ -227,6 +227,66 @@ def test_sc_multi_subdomain(single, dim, size, nsub, axis, pattern, fused):
             assert np.array_equal(gd, o.real(od)), 'subdomain %d lattice %d' % (r._spec.id, grid_num)
 
 
+@pytest.mark.parametrize('mode', ['one stream', 'events', 'copies'])
+@pytest.mark.parametrize('size,nsub,precision,potential', [((40, 9, 8), 2, 'single', 'linear'), ((48, 12, 8), 3, 'single', 'classic'),
+                                                           ((130, 16, 6), 2, 'double', 'linear'), ((264, 34, 5), 4, 'single', 'linear')])
+def test_sc_x_slabs_through_planes(size, nsub, precision, potential, mode, monkeypatch):
+    """1-D decomposition along x of the binary model: the populations of both lattices and the densities cross the faces
+    through the dense planes the two kernels of a step write and read themselves (slf_module_set_xface_planes,
+    xface.NNPlanes) -- no ghost columns, no pack / unpack launches.  Equal to the oracle group bit for bit (populations of
+    both lattices after materialise(), rho, phi); the subdomains of one process share the planes and run on one stream
+    ('one stream'), order them with events (SLF_GROUP_ONE_STREAM=0) or copy them (SLF_XFACE_SHARE=0)."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from tests._oracle_group import OracleNNGroup
+    if mode == 'events':
+        monkeypatch.setenv('SLF_GROUP_ONE_STREAM', '0')
+    elif mode == 'copies':
+        monkeypatch.setenv('SLF_XFACE_SHARE', '0')
+    steps = 11
+    sim_cls, _ = _sc.make_sim(3)
+    cfg = _sc.config(3, size, pattern='AB', fused=True, precision=precision, potential=potential)
+    cfg.update(subdomains=nsub, conn_axis='x')
+    og = OracleNNGroup(sim_cls, 3, 'EqualSubdomainsGeometry3D', dict(cfg))
+    og.run(steps)
+    gcfg = dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0)
+    ctrl = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D, default_config=gcfg)
+    ctrl.run(ignore_cmdline=True)
+    assert len(ctrl.runners) == nsub
+    tol = dict(rtol=0, atol=0) if potential == 'linear' else dict(rtol=2e-6, atol=1e-7)      # expf: the device's own
+    for r, o in zip(ctrl.runners, og.subs):
+        assert r._nnx is not None and r._nnx.shared == (mode != 'copies')
+        assert not r._links[sorted(r._links)[0]].kernels[('push', 0)][0]        # nothing is packed
+        if potential == 'linear':
+            assert np.array_equal(r._sim.rho, o.real(o.rho)) and np.array_equal(r._sim.phi, o.real(o.phi))
+        else:
+            np.testing.assert_allclose(r._sim.rho, o.real(o.rho), **tol)
+        for grid_num, od in enumerate(o.current()):
+            gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+            if potential == 'linear':
+                assert np.array_equal(gd, o.real(od)), 'subdomain %d lattice %d' % (r._spec.id, grid_num)
+            else:
+                np.testing.assert_allclose(gd, o.real(od), **tol)
+
+
+def test_sc_x_slab_planes_refuse_what_they_do_not_serve():
+    """The planes are for the two kernels that know them: a module that is not a fluid-only two-copy binary model, or whose
+    y / z axes are not wrapped inside the kernels, does not take them (and the runner keeps the ghost columns)."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls, _ = _sc.make_sim(3)
+    for extra in (dict(access_pattern='AA'), dict(hip_fused_periodic=False)):
+        cfg = _sc.config(3, (40, 9, 8))
+        cfg.update(subdomains=2, conn_axis='x', max_iters=3, quiet=True, perf_stats_every=0)
+        cfg.update(extra)
+        ctrl = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D, default_config=cfg)
+        ctrl.run(ignore_cmdline=True)
+        for r in ctrl.runners:
+            assert r._nnx is None
+            with pytest.raises(Exception):
+                r.backend.set_xface_planes(r.module, 2, 1 << 20, 0, 1 << 21, 0)
+
+
 def test_sc_checkpoint_roundtrip(tmp_path):
     """Both lattices of the binary model are checkpointed (dist0a, dist1a [, dist0b, dist1b], reference
     subdomain_runner.py:1414-1449): 8 steps + restore + 7 steps == 15 steps, bit for bit."""

@@ -215,12 +215,15 @@ def test_shan_chen_mixture_one_process_per_subdomain(axis, nsub, tmp_path):
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'SLF_DIST_BACKEND', 'SLF_FORCE_DEVICE'):
         env.pop(k, None)
     steps = 10
-    common = ['--max_iters=%d' % steps, '--every=%d' % steps, '--conn_axis=' + axis, '--quiet', '--nooutput_compress',
+    common = ['--max_iters=%d' % steps, '--every=%d' % steps, '--conn_axis=' + axis, '--verbose', '--nooutput_compress',
               '--perf_stats_every=0']
     for name, extra in (('many', ['--subdomains=%d' % nsub, '--gpus'] + ['0'] * nsub), ('one', ['--subdomains=1', '--gpus', '0'])):
         cmd = [sys.executable, os.path.join(ROOT, 'tests', '_sc_ranks_script.py'), '--output=' + str(tmp_path / name)] + common + extra
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
-        assert res.returncode == 0, res.stdout.decode(errors='replace')[-3000:]
+        text = res.stdout.decode(errors='replace')
+        assert res.returncode == 0, text[-3000:]
+        # slabs along x: no ghost columns, the kernels write / read dense planes in the neighbour's memory (xface.NNPlanes)
+        assert ('binary model over x-face planes' in text) == (axis == 'x' and name == 'many'), text[-3000:]
     got = merge_subdomains(str(tmp_path / 'many'), 1, steps, save=False)
     ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
     assert set(got) == set(ref) and 'rho' in ref and 'phi' in ref

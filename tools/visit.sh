@@ -384,6 +384,31 @@ for ln in sys.stdin:
     done
     TRACE_CONFIGS="7a" bash tools/gpu.sh tracecfg pmccfg; rm -rf $O/trace_cfg*/ $O/pmc_cfg*/
     ;;
+  r6s1)   # binary Shan-Chen over x-face planes: parity, processes, then 256^3 in 4 x-slabs / 2 x-slabs / undivided
+    ( time timeout 1500 python -m pytest tests/test_gpu_sc.py -m gpu -q -x -k "planes or multi_subdomain or checkpoint" --durations=5 ) > $O/pytest_sc_planes.log 2>&1; tail -15 $O/pytest_sc_planes.log
+    ( time timeout 900 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q -x -k "shan_chen" --durations=5 ) > $O/pytest_sc_ranks.log 2>&1; tail -8 $O/pytest_sc_ranks.log
+    cat > /tmp/sc4.py <<PYEOF
+import sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
+from examples.binary_fluid.sc_separation_3d import SeparationSim
+from sailfish.controller import LBSimulationController
+from sailfish.geo import EqualSubdomainsGeometry3D
+n = int(sys.argv[1])
+c = LBSimulationController(SeparationSim, EqualSubdomainsGeometry3D, default_config=dict(lat_nx=256, lat_ny=256, lat_nz=256, subdomains=n, conn_axis='x', access_pattern='AB', mode='benchmark', max_iters=300, benchmark_sample_from=100, perf_stats_every=0))
+c.run(ignore_cmdline=True)
+PYEOF
+    for rep in 1 2; do
+      for n in 4 2 1; do
+        for xf in 1 0; do
+          echo "planes $xf subdomains $n: $(SLF_SC_XFACE=$xf timeout 300 python /tmp/sc4.py $n 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_x_slabs_ab.txt
+        done
+      done
+    done
+    echo "planes 1 subdomains 4, one stream 0: $(SLF_GROUP_ONE_STREAM=0 timeout 300 python /tmp/sc4.py 4 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_x_slabs_ab.txt
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_sc -o trace -- \
+        env SLF_PLACEMENT_TUNE=0 python /tmp/sc4.py 4 > $GRAFT_REPO_ROOT/$O/trace_sc.log 2>&1 )
+    python tools/probe/trace_busy.py $O/trace_sc | tee $O/trace_busy_sc_4x_planes.txt; rm -rf $O/trace_sc
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
