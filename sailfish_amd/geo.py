@@ -47,20 +47,44 @@ def _split(total, parts):
     return [(i * base, base if i < parts - 1 else base + rest) for i in range(parts)]
 
 
+def _split_rows(total, parts, align, tolerance=0.15):
+    """Pieces along x -- the axis the rows of the arrays run along.  A whole-row workgroup stores whole 128-byte lines
+    (32 single-precision values; x = 1 of every row sits on a line boundary), except for the last line of a row whose
+    length is no multiple of 32: that one is a partial-line store, a read-modify-write per direction and row.  Rows of
+    171 nodes (512 / 3) sweep at 29 GMLUPS where rows of 160 and 192 reach 37-38 (profiles/r06/slab_align_ab.txt), so
+    the cuts go to multiples of `align` nodes wherever every piece stays within `tolerance` of the equal share (a GPU per
+    slab must not wait for the widest one longer than the better rows save); otherwise, and with align = 0, the
+    reference's equal pieces."""
+    mean = total / float(parts)
+    if align and align > 1 and parts > 1 and mean >= 2 * align:
+        cuts = [0] + [int(round(i * mean / align)) * align for i in range(1, parts)] + [total]
+        sizes = [b - a for a, b in zip(cuts, cuts[1:])]
+        if min(sizes) > 0 and max(abs(n - mean) for n in sizes) <= tolerance * mean:
+            return list(zip(cuts, sizes))
+    return _split(total, parts)
+
+
+def _add_split_options(group, axes):
+    group.add_argument('--subdomains', help='number of subdomains', type=int, default=1)
+    group.add_argument('--conn_axis', type=str, default='x', choices=axes,
+                       help='axis along which the subdomains will be connected')
+    group.add_argument('--slab_align', type=int, default=32,
+                       help='cut along x at multiples of this many nodes where every slab stays within 15 %% of the '
+                            'equal share: rows then end on a 128-byte line (0: equal pieces, as the reference)')
+
+
 class EqualSubdomainsGeometry2D(LBGeometry2D):
     """--subdomains equal pieces along --conn_axis."""
 
     @classmethod
     def add_options(cls, group):
         LBGeometry2D.add_options(group)
-        group.add_argument('--subdomains', help='number of subdomains', type=int, default=1)
-        group.add_argument('--conn_axis', type=str, default='x', choices=['x', 'y'],
-                           help='axis along which the subdomains will be connected')
+        _add_split_options(group, ['x', 'y'])
 
     def subdomains(self):
         s = self.config.subdomains
         if self.config.conn_axis == 'x':
-            return [SubdomainSpec2D((o, 0), (n, self.gy)) for o, n in _split(self.gx, s)]
+            return [SubdomainSpec2D((o, 0), (n, self.gy)) for o, n in _split_rows(self.gx, s, getattr(self.config, 'slab_align', 32))]
         return [SubdomainSpec2D((0, o), (self.gx, n)) for o, n in _split(self.gy, s)]
 
 
@@ -68,14 +92,13 @@ class EqualSubdomainsGeometry3D(LBGeometry3D):
     @classmethod
     def add_options(cls, group):
         LBGeometry3D.add_options(group)
-        group.add_argument('--subdomains', help='number of subdomains', type=int, default=1)
-        group.add_argument('--conn_axis', type=str, default='x', choices=['x', 'y', 'z'],
-                           help='axis along which the subdomains will be connected')
+        _add_split_options(group, ['x', 'y', 'z'])
 
     def subdomains(self):
         s = self.config.subdomains
         if self.config.conn_axis == 'x':
-            return [SubdomainSpec3D((o, 0, 0), (n, self.gy, self.gz)) for o, n in _split(self.gx, s)]
+            return [SubdomainSpec3D((o, 0, 0), (n, self.gy, self.gz))
+                    for o, n in _split_rows(self.gx, s, getattr(self.config, 'slab_align', 32))]
         elif self.config.conn_axis == 'y':
             return [SubdomainSpec3D((0, o, 0), (self.gx, n, self.gz)) for o, n in _split(self.gy, s)]
         return [SubdomainSpec3D((0, 0, o), (self.gx, self.gy, n)) for o, n in _split(self.gz, s)]

@@ -184,3 +184,27 @@ def test_more_reference_examples_load_unchanged(module, sim, dim, extra):
         assert r._subdomain.active_nodes < 0.8 * np.prod(r._subdomain.full_lat_shape)
     if 'sc_' in module and 'binary_fluid' not in module or sim in ('SeparationSCSim',):
         assert desc.simtype in (hipabi.SLF_SIM_SHAN_CHEN_BINARY, hipabi.SLF_SIM_SHAN_CHEN_SINGLE)
+
+
+def test_x_slabs_are_cut_on_line_boundaries_where_the_balance_allows():
+    """geo._split_rows: cuts along x at multiples of 32 nodes (a 128-byte line of single-precision values) when every
+    slab stays within 15 % of the equal share; the reference's equal pieces otherwise, always for --slab_align=0, and along
+    y / z (reference geo.py:113-135)."""
+    from sailfish_amd import geo
+    assert geo._split_rows(512, 3, 32) == [(0, 160), (160, 192), (352, 160)]
+    assert geo._split_rows(512, 3, 0) == geo._split(512, 3) == [(0, 170), (170, 170), (340, 172)]
+    assert geo._split_rows(1024, 8, 32) == geo._split(1024, 8)                 # already on lines
+    assert geo._split_rows(512, 5, 32) == geo._split(512, 5)                   # 96 / 128 would be 25 % off the share
+    assert geo._split_rows(100, 3, 32) == geo._split(100, 3)                   # slabs narrower than two lines
+    assert geo._split_rows(1000, 3, 32) == [(0, 320), (320, 352), (672, 328)]  # the last slab takes the odd end
+    for total, parts in ((512, 3), (1000, 3), (2048, 3), (777, 2), (4096, 7)):
+        pieces = geo._split_rows(total, parts, 32)
+        assert pieces[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(pieces, pieces[1:]))
+        assert sum(n for _, n in pieces) == total and all(abs(n - total / parts) <= 0.15 * total / parts for _, n in pieces)
+
+    class Cfg(object):
+        lat_nx, lat_ny, lat_nz, subdomains = 512, 64, 48, 3
+    for axis, align, want in (('x', 32, [160, 192, 160]), ('x', 0, [170, 170, 172]), ('y', 32, [21, 21, 22]), ('z', 32, [16, 16, 16])):
+        Cfg.conn_axis, Cfg.slab_align = axis, align
+        specs = geo.EqualSubdomainsGeometry3D(Cfg).subdomains()
+        assert [s.size['xyz'.index(axis)] for s in specs] == want

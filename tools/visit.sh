@@ -409,6 +409,19 @@ PYEOF
         env SLF_PLACEMENT_TUNE=0 python /tmp/sc4.py 4 > $GRAFT_REPO_ROOT/$O/trace_sc.log 2>&1 )
     python tools/probe/trace_busy.py $O/trace_sc | tee $O/trace_busy_sc_4x_planes.txt; rm -rf $O/trace_sc
     ;;
+  r6s2)   # x-slab cuts on 128-byte lines: the force-driven pipe 512x256x256 in 3 x-slabs, 170/170/172 against 160/192/160
+    P="--lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA --mode=benchmark --max_iters=600 --benchmark_sample_from=200 --perf_stats_every=0"
+    for rep in 1 2; do
+      for al in 0 32; do
+        echo "pipe AA slab_align $al: $(timeout 300 python examples/poiseuille_3d.py $P --slab_align=$al 2>&1 | grep 'Total MLUPS')" | tee -a $O/slab_align_ab.txt
+      done
+    done
+    for al in 0 32; do
+      echo "pipe AB slab_align $al: $(timeout 300 python examples/poiseuille_3d.py ${P/=AA/=AB} --slab_align=$al 2>&1 | grep 'Total MLUPS')" | tee -a $O/slab_align_ab.txt
+    done
+    echo "pipe AA undivided: $(timeout 300 python examples/poiseuille_3d.py ${P/subdomains=3/subdomains=1} 2>&1 | grep 'Total MLUPS')" | tee -a $O/slab_align_ab.txt
+    ( time timeout 1200 python -m pytest tests/test_gpu_runner.py tests/test_gpu_slab.py -m gpu -q -x -k "subdomain or slab or group" --durations=5 ) > $O/pytest_slabs.log 2>&1; tail -6 $O/pytest_slabs.log
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
