@@ -315,6 +315,39 @@ def test_sc_checkpoint_roundtrip(tmp_path):
             assert np.array_equal(cont._debug_get_dist(grid_num=g), ref._debug_get_dist(grid_num=g), equal_nan=True)
 
 
+@pytest.mark.parametrize('steps_before', [8, 7])
+def test_sc_x_slab_planes_checkpoint_roundtrip(tmp_path, steps_before):
+    """Three x-slabs of the binary model exchanging through planes: a checkpoint holds what has CROSSED the faces too (the
+    arrays are stale there until NNPlanes.materialise() writes the received planes into them), and a restored run starts
+    from the arrays alone (planes reset to 'nothing crossed') -- steps + restore + the rest == a straight run of 15, every
+    population of both lattices of every subdomain bit for bit; after an even and after an odd number of steps (the two
+    copies of the two-copy pattern, the two parities of the planes)."""
+    import os
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    sim_cls, _ = _sc.make_sim(3)
+
+    def run(steps, **extra):
+        cfg = _sc.config(3, (48, 10, 8), pattern='AB')
+        cfg.update(max_iters=steps, quiet=True, perf_stats_every=0, subdomains=3, conn_axis='x', **extra)
+        ctrl = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D, default_config=cfg)
+        ctrl.run(ignore_cmdline=True)
+        assert all(r._nnx is not None for r in ctrl.runners)
+        return ctrl.runners
+
+    ck = str(tmp_path / 'ck')
+    run(steps_before, checkpoint_file=ck, final_checkpoint=True)
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.cpoint.npz'))
+    assert len(files) == 3
+    cont = run(15, restore_from=ck)
+    ref = run(15)
+    for a, b in zip(cont, ref):
+        assert a._sim.iteration == 15
+        for g in (0, 1):
+            assert np.array_equal(a._debug_get_dist(grid_num=g), b._debug_get_dist(grid_num=g), equal_nan=True)
+        assert np.array_equal(a._sim.rho, b._sim.rho) and np.array_equal(a._sim.phi, b._sim.phi)
+
+
 @pytest.mark.parametrize('dim,size', [(2, (70, 20)), (3, (40, 9, 8))])
 @pytest.mark.parametrize('pattern', ['AB', 'AA'])
 def test_sc_per_lattice_body_force(dim, size, pattern):

@@ -422,6 +422,17 @@ PYEOF
     echo "pipe AA undivided: $(timeout 300 python examples/poiseuille_3d.py ${P/subdomains=3/subdomains=1} 2>&1 | grep 'Total MLUPS')" | tee -a $O/slab_align_ab.txt
     ( time timeout 1200 python -m pytest tests/test_gpu_runner.py tests/test_gpu_slab.py -m gpu -q -x -k "subdomain or slab or group" --durations=5 ) > $O/pytest_slabs.log 2>&1; tail -6 $O/pytest_slabs.log
     ;;
+  r6pmc)   # the PMC passes of the headline kernels + bench lines for the sources as they are (after a kernel-source change)
+    for pat in AA AB; do
+      PMC_SIZES_ONLY=1 BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh pmc; cp $O/pmc_summary.txt $O/pmc_sizes_${pat}_512_final.txt
+      [ $pat = AA ] && kern="slf::fast_" || kern="slf::fast_row_kernel"
+      python tools/traffic_update.py --from-pmc $O/pmc --kernel "$kern" --key D3Q19_bgk_f32_${pat}_512_fused
+      rm -rf $O/pmc
+    done
+    cp profiles/traffic.json $O/traffic.json
+    timeout 900 python bench.py 2>&1 | tail -1 > $O/bench_final.json; cut -c1-400 $O/bench_final.json
+    timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
