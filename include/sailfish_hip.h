@@ -448,8 +448,10 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
  *         send_low / send_high; the edge lanes of "ShanChenCollideAndPropagateFusedV" take the five stencil values per
  *         field that lie across the face from recv_low / recv_high (the neighbour's send_high / send_low of the SAME
  *         step) and never touch the ghost columns.  No markers: every entry that is read has been written in the step.
- * A connected face needs all three sets.  For fluid-only D3Q19 modules, two-copy access pattern, direct addressing,
- * y and z wrapped inside the sweep, x not; only the two kernels named above run with planes set (the others refuse). */
+ * A connected face needs all three sets.  For fluid-only D3Q19 modules, direct addressing, y and z wrapped inside the
+ * sweep, x not; both access patterns (in place: the even step stores what the neighbour's odd step pulls into the own
+ * row of the plane, as the single-fluid kernels do); only the two kernels named above run with planes set (the others
+ * refuse). */
 int slf_module_set_xface_planes(slf_module* m, int32_t which, void* send_low, void* send_high, void* recv_low,
                                 void* recv_high);
 

@@ -1370,7 +1370,6 @@ static int check_xface_planes(const slf_module* m, int32_t which, void* send_low
     const slf::Geometry& g = m->geo;
     if (m->sel.lattice != 1 || g.indirect || m->sc.enabled != 1 || !(g.variant & 8) || m->sel.general)
       return fail(SLF_ERR_UNSUPPORTED, "x-face planes: fluid-only D3Q19 binary Shan-Chen modules with direct addressing (whole-row kernels)");
-    if (m->access_pattern != SLF_AB) return fail(SLF_ERR_UNSUPPORTED, "x-face planes: two-copy access pattern only");
     if (g.wrap[0]) return fail(SLF_ERR_INVALID, "x-face planes make no sense with x wrapped inside the sweep");
     if (!g.wrap[1] || !g.wrap[2])
       return fail(SLF_ERR_UNSUPPORTED, "x-face planes: y and z must be wrapped inside the sweep (every entry an edge node reads is written each step)");

@@ -255,18 +255,19 @@ __device__ __forceinline__ void sc_store(const Geometry& g, R (&f)[L::Q], R* dou
 }
 
 // ---- connected x faces (XF): the binary model over the x-face planes of a 1-D decomposition along x ----
-// Populations: per lattice the single-fluid scheme (slf_sweep.h x_face_receive, row_push's xsend) -- two-copy steps only.
+// Populations: per lattice the single-fluid scheme (slf_sweep.h x_face_receive / x_face_send_own_row, row_push's xsend).
 // Densities: the force stencil of an edge node reads the neighbour subdomain's first / last column; the pass in front
 // (sc_macro_kernel) stores rho and phi of ITS edge nodes into a send plane [z][field][y] over the padded (arr_ny x arr_nz)
 // plane, and the sweep's edge lanes take the five values per field that sit across the face from the receive plane.  For
 // fluid-only subdomains whose y and z axes are wrapped inside the kernels: every entry that is read has been written in
 // the same step, so the density planes need no "nothing crossed here" marker.
-template <class L, class R>
+template <class L, class R, bool PULL>
 __device__ __forceinline__ void sc_face_receive(const R* const (&xrecv)[2], R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
+  // PULL (the odd in-place step): the value sits in the row the pull reads from, (y, z) - e_I; else in the node's own row
   if (xrecv[0] && x == 1) {
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) > 0) {
-        const R val = xrecv[0][face_elem<L, I>(fr, 0)];
+        const R val = xrecv[0][face_elem<L, I>(fr, PULL ? -1 : 0)];
         if (face_value_present(val)) f[I] = val;
       }
     });
@@ -274,9 +275,23 @@ __device__ __forceinline__ void sc_face_receive(const R* const (&xrecv)[2], R (&
   if (xrecv[1] && x == nx) {
     static_for<1, L::Q>([&](auto I) {
       if constexpr (L::ex(I) < 0) {
-        const R val = xrecv[1][face_elem<L, I>(fr, 0)];
+        const R val = xrecv[1][face_elem<L, I>(fr, PULL ? -1 : 0)];
         if (face_value_present(val)) f[I] = val;
       }
+    });
+  }
+}
+// the even in-place step: the post-collision values the neighbour's next (odd) step pulls across the face, own row
+template <class L, class R>
+__device__ __forceinline__ void sc_face_send_own_row(R* const (&xsend)[2], const R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
+  if (xsend[1] && x == nx) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) > 0) xsend[1][face_elem<L, I>(fr, 0)] = f[I];
+    });
+  }
+  if (xsend[0] && x == 1) {
+    static_for<1, L::Q>([&](auto I) {
+      if constexpr (L::ex(I) < 0) xsend[0][face_elem<L, I>(fr, 0)] = f[I];
     });
   }
 }
@@ -308,7 +323,7 @@ __device__ __forceinline__ void sc_macro_offsets(const ScMacroRows& mr, int (&of
 // the launches whose options ask for output (bit 0), which run the VOUT = true instantiation.
 template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool VOUT = true, bool XF = false>
 __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
-  static_assert(!XF || (PROP == PROP_AB && !GENERAL && !INDIRECT), "x-face planes: two-copy steps of fluid-only subdomains");
+  static_assert(!XF || (!GENERAL && !INDIRECT), "x-face planes: fluid-only subdomains, direct addressing");
   const Geometry& g = p.g;
   bool live;
   const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live, p.xcd_shift);
@@ -328,7 +343,7 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   R f[L::Q];
   // lattice 0
   sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
-  if constexpr (XF) sc_face_receive<L, R>(p.xrecv[0], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
+  if constexpr (XF) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[0], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
   const R rho0 = density<L, R>(f);
   R v[3] = {(R)0, (R)0, (R)0};
   if constexpr (VOUT) {
@@ -338,7 +353,7 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   }
   // lattice 1
   sc_load<L, R, PROP, INDIRECT>(f, (const R*)p.d_out, ds, n, p.nodes, si);
-  if constexpr (XF) sc_face_receive<L, R>(p.xrecv[1], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
+  if constexpr (XF) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[1], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
   const R rho1 = density<L, R>(f);
   p.rho0[gi] = rho0;
   p.rho1[gi] = rho1;
@@ -456,7 +471,8 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool OWNV = false, bool PULL = false, bool XF = false>
 __global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? (OWNV ? SLF_SC_FUSEDV_WAVES : SLF_SC_FUSED_WAVES) : 4)
 sc_fused_kernel(const ScParams<L, R> p) {
-  static_assert(!XF || (PROP == PROP_AB && !GENERAL && ROW && OWNV && !PULL), "x-face planes: the whole-row two-copy sweep of fluid-only subdomains");
+  static_assert(!XF || (!GENERAL && OWNV && !PULL && ROW == (PROP != PROP_AA_EVEN)),
+                "x-face planes: fluid-only subdomains, whole-row kernels for the x-streaming steps");
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
@@ -555,8 +571,8 @@ sc_fused_kernel(const ScParams<L, R> p) {
     if constexpr (XF) {
       if (live) {
         const FaceRows fr = face_rows<L>(g, n.gy, n.gz);
-        sc_face_receive<L, R>(p.xrecv[0], fa, n.gx, nx, fr);
-        sc_face_receive<L, R>(p.xrecv[1], fb, n.gx, nx, fr);
+        sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[0], fa, n.gx, nx, fr);
+        sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[1], fb, n.gx, nx, fr);
       }
     }
     rho[0] = density<L, R>(fa);
@@ -598,10 +614,13 @@ sc_fused_kernel(const ScParams<L, R> p) {
     }
     if (wet) bgk_relax_accel<L, R>(f, rho[K], v, p.omega[K], p.guo_pref[K], false, true, a, p.force_edm != 0);
     if constexpr (ROW && PROP != PROP_AA_EVEN && K == 1) __syncthreads();     // row_push's LDS words are still being read
-    if constexpr (XF) {
+    if constexpr (XF && ROW) {
       const FaceRows fr = face_rows<L>(g, n.gy, n.gz);
       row_push<L, R, GENERAL, sc_nt<L>()>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n.row, n.xi, n.gx, nx, live, active, n.oy,
                                           n.oz, p.xsend[K], &fr);
+    } else if constexpr (XF) {
+      sc_store<L, R, PROP, GENERAL, ROW>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n, nx, live, active);
+      sc_face_send_own_row<L, R>(p.xsend[K], f, n.gx, nx, face_rows<L>(g, n.gy, n.gz));
     } else {
       sc_store<L, R, PROP, GENERAL, ROW>(g, f, K == 0 ? p.d_out : p.d_out2, ds, n, nx, live, active);
     }
@@ -830,10 +849,15 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
     // connected x faces through planes: edge lanes take the entering populations from the receive planes and store their
     // densities for the neighbours (the module was checked when the planes were set: slf_module_set_xface_planes)
     if constexpr (L::dim == 3) {
-      if (prop != PROP_AB || general || g.indirect) return hipErrorInvalidValue;
+      if (general || g.indirect) return hipErrorInvalidValue;
       p.xcd_shift = xcd_shift_for(grid.y, grid.x);        // 32 consecutive rows write one line of a plane: one XCD
-      if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, true, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, false, true>), grid, block, 0, s, p);
+      if (prop == PROP_AA_ODD) {
+        if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AA_ODD, false, false, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AA_ODD, false, false, false, true>), grid, block, 0, s, p);
+      } else {          // two-copy and the even in-place step: the node's own slots
+        if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, false, true>), grid, block, 0, s, p);
+      }
       return hipGetLastError();
     }
     return hipErrorInvalidValue;
@@ -955,8 +979,14 @@ static hipError_t sc_fused2(Prop prop, bool general, const Geometry& g, const Ph
   } while (0)
   if (sc_xface_in_use(a)) {
     if constexpr (L::dim == 3) {
-      if (!row || prop != PROP_AB || general || !a.sc_local_velocity || grid.x != 1) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AB, false, true, true, false, true>), grid, block, park, s, p);
+      if (general || !a.sc_local_velocity) return hipErrorInvalidValue;
+      if (prop == PROP_AA_EVEN) {
+        hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AA_EVEN, false, false, true, false, true>), grid, block, park, s, p);
+        return hipGetLastError();
+      }
+      if (!row || grid.x != 1) return hipErrorInvalidValue;
+      if (prop == PROP_AB) hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AB, false, true, true, false, true>), grid, block, park, s, p);
+      else hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AA_ODD, false, true, true, false, true>), grid, block, park, s, p);
       return hipGetLastError();
     }
     return hipErrorInvalidValue;

@@ -1484,7 +1484,8 @@ class NNSubdomainRunner(SubdomainRunner):
         if not hasattr(self, '_halo_mode'):
             return
         self.backend.sync_stream(*self._all_streams())
-        self._nnx.materialise([self.gpu_dist(g, self._halo_copy) for g in (0, 1)], self._calc_stream, self._nnx_parity)
+        self._nnx.materialise([self.gpu_dist(g, self._halo_copy) for g in (0, 1)], self._halo_mode == 'push', self._calc_stream,
+                              self._nnx_parity)
         self.backend.sync_stream(self._calc_stream)
 
     def _init_halo(self):

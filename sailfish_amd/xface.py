@@ -344,10 +344,10 @@ NN_FIELDS = 2    # rho, phi
 
 def supported_nn(grid, desc, indirect=False):
     """Can a binary Shan-Chen module built from `desc` take x-face planes?  What slf_module_set_xface_planes checks:
-    fluid-only D3Q19, two-copy pattern, direct addressing, y and z wrapped inside the kernels (every plane entry an edge
-    node reads is then written in the same step), rows of 2 .. 1024 nodes, whole-row kernels."""
+    fluid-only D3Q19, direct addressing, y and z wrapped inside the kernels (every plane entry an edge node reads is then
+    written in the same step), rows of 2 .. 1024 nodes, whole-row kernels; both access patterns."""
     from sailfish_amd import hipabi
-    if int(desc.simtype) != hipabi.SLF_SIM_SHAN_CHEN_BINARY or int(desc.access_pattern) != hipabi.SLF_AB:
+    if int(desc.simtype) != hipabi.SLF_SIM_SHAN_CHEN_BINARY:
         return False
     variant = os.environ.get('SLF_VARIANT')
     if variant is not None and not (int(variant) & 8):
@@ -424,25 +424,33 @@ class NNPlanes(object):
         for a, nbytes in bufs:
             self.backend.memset_buf(a, 0xFF, nbytes, stream)
 
-    def materialise(self, dists, stream, parity):
-        """Writes the population planes received in the steps of `parity` into the first / last real column of the arrays
-        `dists` = (lattice 0, lattice 1) those steps wrote (a push: same slots) -- before anything reads the arrays on the
-        host (checkpoint, debug dump)."""
+    def materialise(self, dists, pushed, stream, parity):
+        """Writes the population planes received in the steps of `parity` into the arrays `dists` = (lattice 0, lattice 1)
+        those steps wrote -- before anything reads the arrays on the host (checkpoint, debug dump).  pushed = True after a
+        push step (two-copy, odd in-place): the values belong into the first / last real column, same slots; False after
+        the even in-place step: into the ghost column, opposite slots, where the next pull looks for them (the kernels pull
+        from the ghost columns wherever a plane says 'nothing crossed here', i.e. after the reset that follows a restore)."""
         b, d = self.backend, self.desc
         nx = d.lat_nx - 2
         recv = self.recv['dist'][parity]
         for face in (LOW, HIGH):
             if not recv[face]:
                 continue
-            x = 1 if face == LOW else nx
-            mask = 0
-            for q in self.enter[face]:
-                mask |= 1 << q
+            if pushed:
+                x = 1 if face == LOW else nx
+                mask = 0
+                for q in self.enter[face]:
+                    mask |= 1 << q
+                jobs = [(mask, x, 0)]
+            else:
+                x = 0 if face == LOW else nx + 1
+                jobs = [(1 << self.grid.idx_opposite[q], x, k * d.arr_ny * self.isz) for k, q in enumerate(self.enter[face])]
             for lat, dist in enumerate(dists):
-                src = recv[face] + lat * self.n_dist * self.isz
-                key = (dist, src, mask)
-                if key not in self._kernels:
-                    self._kernels[key] = b.get_kernel(self.module, 'DistributeContinuousData', (64,),
-                                                      [dist, src, mask, x, d.arr_nx, d.arr_ny, d.arr_nx * d.arr_ny, d.arr_nz,
-                                                       d.arr_ny, NXD * d.arr_ny], 'PPiiiiiiii')
-                b.run_kernel(self._kernels[key], None, stream)
+                for mask, col, off in jobs:
+                    src = recv[face] + lat * self.n_dist * self.isz + off
+                    key = (dist, src, mask, col)
+                    if key not in self._kernels:
+                        self._kernels[key] = b.get_kernel(self.module, 'DistributeContinuousData', (64,),
+                                                          [dist, src, mask, col, d.arr_nx, d.arr_ny, d.arr_nx * d.arr_ny,
+                                                           d.arr_nz, d.arr_ny, NXD * d.arr_ny], 'PPiiiiiiii')
+                    b.run_kernel(self._kernels[key], None, stream)

@@ -228,14 +228,16 @@ def test_sc_multi_subdomain(single, dim, size, nsub, axis, pattern, fused):
 
 
 @pytest.mark.parametrize('mode', ['one stream', 'events', 'copies'])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
 @pytest.mark.parametrize('size,nsub,precision,potential', [((40, 9, 8), 2, 'single', 'linear'), ((48, 12, 8), 3, 'single', 'classic'),
                                                            ((130, 16, 6), 2, 'double', 'linear'), ((264, 34, 5), 4, 'single', 'linear')])
-def test_sc_x_slabs_through_planes(size, nsub, precision, potential, mode, monkeypatch):
+def test_sc_x_slabs_through_planes(size, nsub, precision, potential, pattern, mode, monkeypatch):
     """1-D decomposition along x of the binary model: the populations of both lattices and the densities cross the faces
     through the dense planes the two kernels of a step write and read themselves (slf_module_set_xface_planes,
     xface.NNPlanes) -- no ghost columns, no pack / unpack launches.  Equal to the oracle group bit for bit (populations of
     both lattices after materialise(), rho, phi); the subdomains of one process share the planes and run on one stream
-    ('one stream'), order them with events (SLF_GROUP_ONE_STREAM=0) or copy them (SLF_XFACE_SHARE=0)."""
+    ('one stream'), order them with events (SLF_GROUP_ONE_STREAM=0) or copy them (SLF_XFACE_SHARE=0).  Both access
+    patterns; 11 steps: the in-place run ends after an even step, whose crossings belong into the ghost columns."""
     from sailfish_amd import geo as geo_mod
     from sailfish_amd.controller import LBSimulationController
     from tests._oracle_group import OracleNNGroup
@@ -243,9 +245,9 @@ def test_sc_x_slabs_through_planes(size, nsub, precision, potential, mode, monke
         monkeypatch.setenv('SLF_GROUP_ONE_STREAM', '0')
     elif mode == 'copies':
         monkeypatch.setenv('SLF_XFACE_SHARE', '0')
-    steps = 11
+    steps = 12 if nsub == 3 else 11          # in place: once ending after an odd (push) step, else after an even one
     sim_cls, _ = _sc.make_sim(3)
-    cfg = _sc.config(3, size, pattern='AB', fused=True, precision=precision, potential=potential)
+    cfg = _sc.config(3, size, pattern=pattern, fused=True, precision=precision, potential=potential)
     cfg.update(subdomains=nsub, conn_axis='x')
     og = OracleNNGroup(sim_cls, 3, 'EqualSubdomainsGeometry3D', dict(cfg))
     og.run(steps)
@@ -270,12 +272,12 @@ def test_sc_x_slabs_through_planes(size, nsub, precision, potential, mode, monke
 
 
 def test_sc_x_slab_planes_refuse_what_they_do_not_serve():
-    """The planes are for the two kernels that know them: a module that is not a fluid-only two-copy binary model, or whose
-    y / z axes are not wrapped inside the kernels, does not take them (and the runner keeps the ghost columns)."""
+    """The planes are for the two kernels that know them: a module with indirect addressing, or whose y / z axes are not
+    wrapped inside the kernels, does not take them (and the runner keeps the ghost columns)."""
     from sailfish_amd import geo as geo_mod
     from sailfish_amd.controller import LBSimulationController
     sim_cls, _ = _sc.make_sim(3)
-    for extra in (dict(access_pattern='AA'), dict(hip_fused_periodic=False)):
+    for extra in (dict(node_addressing='indirect'), dict(hip_fused_periodic=False)):
         cfg = _sc.config(3, (40, 9, 8))
         cfg.update(subdomains=2, conn_axis='x', max_iters=3, quiet=True, perf_stats_every=0)
         cfg.update(extra)
@@ -315,20 +317,22 @@ def test_sc_checkpoint_roundtrip(tmp_path):
             assert np.array_equal(cont._debug_get_dist(grid_num=g), ref._debug_get_dist(grid_num=g), equal_nan=True)
 
 
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
 @pytest.mark.parametrize('steps_before', [8, 7])
-def test_sc_x_slab_planes_checkpoint_roundtrip(tmp_path, steps_before):
+def test_sc_x_slab_planes_checkpoint_roundtrip(tmp_path, steps_before, pattern):
     """Three x-slabs of the binary model exchanging through planes: a checkpoint holds what has CROSSED the faces too (the
     arrays are stale there until NNPlanes.materialise() writes the received planes into them), and a restored run starts
     from the arrays alone (planes reset to 'nothing crossed') -- steps + restore + the rest == a straight run of 15, every
     population of both lattices of every subdomain bit for bit; after an even and after an odd number of steps (the two
-    copies of the two-copy pattern, the two parities of the planes)."""
+    copies of the two-copy pattern, the two parities of the planes; in place: a restart before an even step, which reads
+    the first columns, and before an odd one, which pulls out of the ghost columns)."""
     import os
     from sailfish_amd import geo as geo_mod
     from sailfish_amd.controller import LBSimulationController
     sim_cls, _ = _sc.make_sim(3)
 
     def run(steps, **extra):
-        cfg = _sc.config(3, (48, 10, 8), pattern='AB')
+        cfg = _sc.config(3, (48, 10, 8), pattern=pattern)
         cfg.update(max_iters=steps, quiet=True, perf_stats_every=0, subdomains=3, conn_axis='x', **extra)
         ctrl = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D, default_config=cfg)
         ctrl.run(ignore_cmdline=True)
@@ -339,7 +343,7 @@ def test_sc_x_slab_planes_checkpoint_roundtrip(tmp_path, steps_before):
     run(steps_before, checkpoint_file=ck, final_checkpoint=True)
     files = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.cpoint.npz'))
     assert len(files) == 3
-    cont = run(15, restore_from=ck)
+    cont = run(15, restore_from=ck + '.last')
     ref = run(15)
     for a, b in zip(cont, ref):
         assert a._sim.iteration == 15

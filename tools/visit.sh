@@ -433,6 +433,27 @@ PYEOF
     timeout 900 python bench.py 2>&1 | tail -1 > $O/bench_final.json; cut -c1-400 $O/bench_final.json
     timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
     ;;
+  r6s3)   # the planes in the in-place pattern: parity, checkpoints, then 256^3 in 4 x-slabs AA with / without
+    ( time timeout 1500 python -m pytest tests/test_gpu_sc.py -m gpu -q -x --durations=5 ) > $O/pytest_sc_all.log 2>&1; tail -12 $O/pytest_sc_all.log
+    ( time timeout 900 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q -x -k "shan_chen" --durations=5 ) > $O/pytest_sc_ranks.log 2>&1; tail -5 $O/pytest_sc_ranks.log
+    cat > /tmp/sc4.py <<PYEOF
+import sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
+from examples.binary_fluid.sc_separation_3d import SeparationSim
+from sailfish.controller import LBSimulationController
+from sailfish.geo import EqualSubdomainsGeometry3D
+n = int(sys.argv[1])
+c = LBSimulationController(SeparationSim, EqualSubdomainsGeometry3D, default_config=dict(lat_nx=256, lat_ny=256, lat_nz=256, subdomains=n, conn_axis='x', access_pattern=sys.argv[2], mode='benchmark', max_iters=300, benchmark_sample_from=100, perf_stats_every=0))
+c.run(ignore_cmdline=True)
+PYEOF
+    for rep in 1 2; do
+      for n in 4 1; do
+        for xf in 1 0; do
+          echo "AA planes $xf subdomains $n: $(SLF_SC_XFACE=$xf timeout 300 python /tmp/sc4.py $n AA 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_x_slabs_aa.txt
+        done
+      done
+    done
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
