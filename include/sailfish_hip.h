@@ -448,7 +448,9 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
  *         send_low / send_high; the edge lanes of "ShanChenCollideAndPropagateFusedV" take the five stencil values per
  *         field that lie across the face from recv_low / recv_high (the neighbour's send_high / send_low of the SAME
  *         step) and never touch the ghost columns.  No markers: every entry that is read has been written in the step.
- * A connected face needs all three sets.  For fluid-only D3Q19 modules, direct addressing, y and z wrapped inside the
+ * The single-component model (`PrepareMacroFields` / `CollideAndPropagate`, reference lb_single.py:242-347) takes sets 0
+ * and 2 (field 0 of the density planes; same size).
+ * A connected face needs all of its sets.  For fluid-only D3Q19 modules, direct addressing, y and z wrapped inside the
  * sweep, x not; both access patterns (in place: the even step stores what the neighbour's odd step pulls into the own
  * row of the plane, as the single-fluid kernels do); only the two kernels named above run with planes set (the others
  * refuse). */

@@ -1368,8 +1368,9 @@ static int check_xface_planes(const slf_module* m, int32_t which, void* send_low
   if (which < 0 || which > 2) return fail(SLF_ERR_INVALID, "x-face planes: 0 / 1 = populations of lattice 0 / 1, 2 = densities");
   if (send_low || send_high || recv_low || recv_high) {
     const slf::Geometry& g = m->geo;
-    if (m->sel.lattice != 1 || g.indirect || m->sc.enabled != 1 || !(g.variant & 8) || m->sel.general)
-      return fail(SLF_ERR_UNSUPPORTED, "x-face planes: fluid-only D3Q19 binary Shan-Chen modules with direct addressing (whole-row kernels)");
+    if (m->sel.lattice != 1 || g.indirect || !m->sc.enabled || !(g.variant & 8) || m->sel.general)
+      return fail(SLF_ERR_UNSUPPORTED, "x-face planes: fluid-only D3Q19 Shan-Chen modules with direct addressing (whole-row kernels)");
+    if (m->sc.enabled == 2 && which == 1) return fail(SLF_ERR_INVALID, "x-face planes: the single-component model has one lattice");
     if (g.wrap[0]) return fail(SLF_ERR_INVALID, "x-face planes make no sense with x wrapped inside the sweep");
     if (!g.wrap[1] || !g.wrap[2])
       return fail(SLF_ERR_UNSUPPORTED, "x-face planes: y and z must be wrapped inside the sweep (every entry an edge node reads is written each step)");
@@ -1748,6 +1749,7 @@ int slf_kernel_launch(slf_kernel* k, const slf_region* region, slf_stream* strea
         a.v[1] = (void*)k->ptrs[b0 + 5];
         a.v[2] = g.dim == 3 ? (void*)k->ptrs[b0 + 6] : nullptr;
       }
+      sc_planes_of(m, a);
       if (m->sel.general && !a.map) return fail(SLF_ERR_INVALID, "node map is NULL but the module is not fluid_only");
       slf::Prop prop = slf::PROP_AB;
       if (m->access_pattern == SLF_AA) {

@@ -318,6 +318,65 @@ __device__ __forceinline__ void sc_macro_offsets(const ScMacroRows& mr, int (&of
   });
 }
 
+// What an edge lane knows about its face: which face, its receive plane, and where the five stencil values per field lie.
+template <class L, class R>
+struct ScEdge {
+  bool lo, hi;
+  const R* plane;
+  int off[count_x_dirs<L>()];
+  int fstride;
+};
+template <class L, class R>
+__device__ __forceinline__ ScEdge<L, R> sc_edge(const ScParams<L, R>& p, const ScNode& n, int nx, bool live, ScNode& ns) {
+  const Geometry& g = p.g;
+  ScEdge<L, R> e;
+  e.lo = live && p.mrecv[0] && n.gx == 1;
+  e.hi = live && p.mrecv[1] && n.gx == nx;
+  ns = n;
+  if (e.lo) ns.ox.m = 0;          // the lane's own loads stay inside the row
+  if (e.hi) ns.ox.p = 0;
+  const ScMacroRows mr = sc_macro_rows(g, n.gy, n.gz);
+  int offp[count_x_dirs<L>()], offm[count_x_dirs<L>()];
+  sc_macro_offsets<L, true>(mr, offp);
+  sc_macro_offsets<L, false>(mr, offm);
+  static_for<0, count_x_dirs<L>()>([&](auto K) { e.off[K] = mr.row + (e.lo ? offm[K] : offp[K]); });
+  e.plane = e.lo ? p.mrecv[0] : p.mrecv[1];
+  e.fstride = mr.fstride;
+  return e;
+}
+// sc_accel() of one field for a node that may sit on a connected x face (single-component model): the same sum in the
+// same order, the values across the face from the receive plane
+template <class L, class R>
+__device__ __forceinline__ void sc_accel_edge(const R* field, R G, R rho, int potential, const ScNode& ns,
+                                              const ScEdge<L, R>& e, R (&a)[3]) {
+  sc_with_potential(potential, [&](auto POT) {
+    if (G != (R)0) {
+      R ev[count_x_dirs<L>()];
+      static_for<0, count_x_dirs<L>()>([&](auto K) { ev[K] = (R)0; });
+      if (e.lo || e.hi) {
+        static_for<0, count_x_dirs<L>()>([&](auto K) { ev[K] = e.plane[e.off[K]]; });
+      }
+      R force[3] = {(R)0, (R)0, (R)0};
+      static_for<1, L::Q>([&](auto I) {
+        R nb = *sc_neighbour<L, I>(field, ns, true);
+        if constexpr (L::ex(I) > 0) nb = e.hi ? ev[x_dir_rank<L, I>()] : nb;
+        if constexpr (L::ex(I) < 0) nb = e.lo ? ev[x_dir_rank<L, I>()] : nb;
+        const R psi = sc_psi<R, POT>(nb);
+        static_for<0, L::dim>([&](auto D) {
+          constexpr int ec = e_comp<L>(I, D);
+          if constexpr (ec > 0) force[D] = force[D] + psi * Weights<L, R>::w(I);
+          if constexpr (ec < 0) force[D] = force[D] + psi * ((R)0 - Weights<L, R>::w(I));
+        });
+      });
+      const R psi_loc = sc_psi<R, POT>(rho);
+      static_for<0, L::dim>([&](auto D) {
+        force[D] = force[D] * (((R)0 - psi_loc) * G);
+        a[D] = a[D] + force[D];
+      });
+    }
+  });
+}
+
 // VOUT = false ("ShanChenPrepareDensities", the partner of the fused sweep that forms the velocity itself): only the
 // two densities are stored -- three of the five written streams gone; the velocity arrays are brought up to date by
 // the launches whose options ask for output (bit 0), which run the VOUT = true instantiation.
@@ -663,8 +722,9 @@ sc_fused_kernel(const ScParams<L, R> p) {
 
 // ---- single-component Shan-Chen (reference lb_single.py:242-347, lb_single_fluid.mako:129-229) ----
 // PrepareMacroFields: density of every wet node
-template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false>
+template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool XF = false>
 __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p) {
+  static_assert(!XF || (!GENERAL && !INDIRECT), "x-face planes: fluid-only subdomains, direct addressing");
   const Geometry& g = p.g;
   bool live;
   const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live, p.xcd_shift);
@@ -681,13 +741,22 @@ __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p)
   }
   R f[L::Q];
   sc_load<L, R, PROP, INDIRECT>(f, p.d_in, g.dist_size, n, p.nodes, si);
-  p.rho0[n.gi] = density<L, R>(f);
+  if constexpr (XF) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[0], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
+  const R rho = density<L, R>(f);
+  p.rho0[n.gi] = rho;
+  if constexpr (XF) {
+    const int mrow = n.gy + 2 * g.arr_ny * n.gz;      // the binary model's plane layout, field 0 only
+    if (p.msend[0] && n.gx == 1) p.msend[0][mrow] = rho;
+    if (p.msend[1] && n.gx == g.lat_nx - 2) p.msend[1][mrow] = rho;
+  }
 }
 
 // CollideAndPropagate with the self-interaction force F = -G psi(rho(x)) sum_i w_i e_i psi(rho(x + e_i))
-template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool INDIRECT = false>
+template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool INDIRECT = false, bool XF = false>
 __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p) {
   static_assert(!(ROW && INDIRECT), "indirect addressing: per-node kernels only");
+  static_assert(!XF || (!GENERAL && !INDIRECT && ROW == (PROP != PROP_AA_EVEN)),
+                "x-face planes: fluid-only subdomains, whole-row kernels for the x-streaming steps");
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
@@ -716,12 +785,21 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
   const size_t ds = g.dist_size;
   R f[L::Q];
   sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
+  if constexpr (XF) {
+    if (live) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[0], f, n.gx, nx, face_rows<L>(g, n.gy, n.gz));
+  }
   R rho, v[3];
   macro_standard<L, R>(f, false, rho, v);
   R a[3] = {(R)0, (R)0, (R)0};
   if (wet) {
     const R* const fields[2] = {p.rho0, p.rho0};
-    sc_accel<L, R, 1>(fields, p.G, rho, p.potential, n, a);
+    if constexpr (XF) {
+      ScNode ns;
+      const ScEdge<L, R> edge = sc_edge<L, R>(p, n, nx, live, ns);
+      sc_accel_edge<L, R>(p.rho0, p.G[0], rho, p.potential, ns, edge, a);
+    } else {
+      sc_accel<L, R, 1>(fields, p.G, rho, p.potential, n, a);
+    }
     static_for<0, L::dim>([&](auto D) { a[D] = a[D] / rho; });
     if (p.has_body_force) {
       static_for<0, L::dim>([&](auto D) { a[D] = a[D] + p.accel[D]; });
@@ -737,7 +815,13 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
     p.vy[gi] = v[1];
     if constexpr (L::dim == 3) p.vz[gi] = v[2];
   }
-  sc_store<L, R, PROP, GENERAL, ROW, INDIRECT>(g, f, p.d_out, ds, n, nx, live, active, p.nodes, si);
+  if constexpr (XF && ROW) {
+    const FaceRows fr = face_rows<L>(g, n.gy, n.gz);
+    row_push<L, R, GENERAL, sc_nt<L>()>(g, f, p.d_out, ds, n.row, n.xi, n.gx, nx, live, active, n.oy, n.oz, p.xsend[0], &fr);
+  } else {
+    sc_store<L, R, PROP, GENERAL, ROW, INDIRECT>(g, f, p.d_out, ds, n, nx, live, active, p.nodes, si);
+    if constexpr (XF) sc_face_send_own_row<L, R>(p.xsend[0], f, n.gx, nx, face_rows<L>(g, n.gy, n.gz));
+  }
 }
 
 // f1 = feq(rho, v), f2 = feq(phi, v) on every node (no type test)
@@ -1017,7 +1101,6 @@ template <class L, class R>
 static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometry& g, const Physics& ph,
                               const ShanChen& sc, const SweepArgs& a, int y0, int y1, int z0, int z1, int block_x,
                               hipStream_t s) {
-  if (sc_xface_in_use(a)) return hipErrorInvalidValue;       // planes: the binary model only
   ScParams<L, R> p = make_sc<L, R>(g, ph, sc, a, 0, y0, z0);
   p.G[0] = (R)sc.G[0];
   p.G[1] = (R)0;
@@ -1028,6 +1111,26 @@ static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometr
   dim3 grid((nx + block_x - 1) / block_x, y1 - y0, L::dim == 3 ? z1 - z0 : 1);
   if (grid.y == 0 || grid.z == 0) return hipSuccess;
   p.xcd_shift = xcd_shift_for(grid.y, grid.x);      // the force stencil's rho / phi rows: neighbouring rows on one XCD
+  if (sc_xface_in_use(a)) {
+    // connected x faces through planes (slf_module_set_xface_planes: sets 0 and 2 of the binary model's three)
+    if constexpr (L::dim == 3) {
+      if (general || g.indirect) return hipErrorInvalidValue;
+      if (macro) {
+        if (prop == PROP_AA_ODD) hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AA_ODD, false, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AB, false, false, true>), grid, block, 0, s, p);
+        return hipGetLastError();
+      }
+      if (prop == PROP_AA_EVEN) {
+        hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_EVEN, false, false, false, true>), grid, block, 0, s, p);
+        return hipGetLastError();
+      }
+      if (!row || grid.x != 1) return hipErrorInvalidValue;
+      if (prop == PROP_AB) hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AB, false, true, false, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_ODD, false, true, false, true>), grid, block, 0, s, p);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  }
   if (g.indirect) {      // active-node slots: per-node kernels with translated neighbours (the node map is always read)
     if (macro) {
       if (prop == PROP_AA_ODD) hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AA_ODD, true, true>), grid, block, 0, s, p);

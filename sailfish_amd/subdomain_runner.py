@@ -1389,7 +1389,7 @@ class NNSubdomainRunner(SubdomainRunner):
     _nnx = None
 
     def _nn_x_faces_only(self):
-        if not getattr(self.config, 'hip_xface', True) or self.dim != 3 or len(self._sim.grids) != 2 or \
+        if not getattr(self.config, 'hip_xface', True) or self.dim != 3 or len(self._sim.grids) not in (1, 2) or \
                 not getattr(self.backend, 'supports_xface_planes', False):
             return False
         if not xface.supported_nn(self._sim.grid, self._desc, self.indirect):
@@ -1402,7 +1402,7 @@ class NNSubdomainRunner(SubdomainRunner):
         kernels -- the sweeps fill and read the planes -- so the step program of the general case (pack -> exchange ->
         unpack, per kind) moves them as it stands."""
         spec = self._spec
-        nnx = xface.NNPlanes(self.backend, self.module, self._sim.grid, self._desc)
+        nnx = xface.NNPlanes(self.backend, self.module, self._sim.grid, self._desc, n_lat=len(self._sim.grids))
         by_neighbour = {}
         for face, nid in sorted(spec.connecting_subdomains()):
             by_neighbour.setdefault(nid, []).append(xface.LOW if face == spec.X_LOW else xface.HIGH)
@@ -1433,7 +1433,7 @@ class NNSubdomainRunner(SubdomainRunner):
                     link.packs, link.unpacks = [[], []], [[], []]
         self._nnx = nnx
         nnx.shared = bool(zc)
-        self.config.logger.debug('subdomain %d: binary model over x-face planes (%s)' % (
+        self.config.logger.debug('subdomain %d: Shan-Chen model over x-face planes (%s)' % (
             spec.id, 'the neighbours\' memory mapped here' if zc else type(self._connector).__name__))
         for kind in all_links:
             for nid in all_links[kind]:
@@ -1484,7 +1484,7 @@ class NNSubdomainRunner(SubdomainRunner):
         if not hasattr(self, '_halo_mode'):
             return
         self.backend.sync_stream(*self._all_streams())
-        self._nnx.materialise([self.gpu_dist(g, self._halo_copy) for g in (0, 1)], self._halo_mode == 'push', self._calc_stream,
+        self._nnx.materialise([self.gpu_dist(g, self._halo_copy) for g in range(self._nnx.n_lat)], self._halo_mode == 'push', self._calc_stream,
                               self._nnx_parity)
         self.backend.sync_stream(self._calc_stream)
 

@@ -343,17 +343,20 @@ NN_FIELDS = 2    # rho, phi
 
 
 def supported_nn(grid, desc, indirect=False):
-    """Can a binary Shan-Chen module built from `desc` take x-face planes?  What slf_module_set_xface_planes checks:
+    """Can a Shan-Chen module (binary or single-component) built from `desc` take x-face planes?  What
+    slf_module_set_xface_planes checks:
     fluid-only D3Q19, direct addressing, y and z wrapped inside the kernels (every plane entry an edge node reads is then
     written in the same step), rows of 2 .. 1024 nodes, whole-row kernels; both access patterns."""
     from sailfish_amd import hipabi
-    if int(desc.simtype) != hipabi.SLF_SIM_SHAN_CHEN_BINARY:
+    if int(desc.simtype) not in (hipabi.SLF_SIM_SHAN_CHEN_BINARY, hipabi.SLF_SIM_SHAN_CHEN_SINGLE):
         return False
     variant = os.environ.get('SLF_VARIANT')
     if variant is not None and not (int(variant) & 8):
         return False
-    if os.environ.get('SLF_SC_FUSED', '2') != '2' or os.environ.get('SLF_SC_XFACE', '1') == '0':
-        return False        # the planes are served by ShanChenPrepareDensities / ShanChenCollideAndPropagateFusedV only
+    if os.environ.get('SLF_SC_XFACE', '1') == '0':
+        return False
+    if int(desc.simtype) == hipabi.SLF_SIM_SHAN_CHEN_BINARY and os.environ.get('SLF_SC_FUSED', '2') != '2':
+        return False        # binary: the planes are served by ShanChenPrepareDensities / ShanChenCollideAndPropagateFusedV only
     nx = desc.lat_nx - 2
     return grid.dim == 3 and grid.Q == 19 and not indirect and bool(desc.fluid_only) and 2 <= nx <= 1024 and \
         bool(desc.periodic_fused[1]) and bool(desc.periodic_fused[2]) and not desc.periodic_fused[0]
@@ -366,13 +369,14 @@ class NNPlanes(object):
     face's part.  Set p of the population planes is written by the sweep of the steps of parity p and read by the two
     kernels of the following step; set p of the density planes is written and read within the steps of parity p."""
 
-    def __init__(self, backend, module, grid, desc):
+    def __init__(self, backend, module, grid, desc, n_lat=2):
         self.backend, self.module, self.grid, self.desc = backend, module, grid, desc
         self.dtype = np.float32 if desc.precision == 4 else np.float64
         self.isz = self.dtype().itemsize
+        self.n_lat = int(n_lat)                              # 2: binary model; 1: single component (field 0 of the densities)
         self.n_dist = face_count(desc)                       # one lattice, one face
         self.n_macro = NN_FIELDS * desc.arr_ny * desc.arr_nz
-        self.count = {'dist': 2 * self.n_dist, 'macro': self.n_macro}      # elements per face and kind
+        self.count = {'dist': self.n_lat * self.n_dist, 'macro': self.n_macro}      # elements per face and kind
         self.send = dict((k, [[0, 0], [0, 0]]) for k in self.count)
         self.recv = dict((k, [[0, 0], [0, 0]]) for k in self.count)
         self.shared = False
@@ -385,13 +389,13 @@ class NNPlanes(object):
         par = it & 1
         ds, dr = self.send['dist'][par], self.recv['dist'][1 - par]
         off = self.n_dist * self.isz
-        for lat in (0, 1):
+        for lat in range(self.n_lat):
             q.xface_planes(self.module, lat, *[a + lat * off if a else 0 for a in (ds[LOW], ds[HIGH], dr[LOW], dr[HIGH])])
         ms, mr = self.send['macro'][par], self.recv['macro'][par]
         q.xface_planes(self.module, 2, ms[LOW], ms[HIGH], mr[LOW], mr[HIGH])
 
     def unbind(self):
-        for which in (0, 1, 2):
+        for which in list(range(self.n_lat)) + [2]:
             self.backend.set_xface_planes(self.module, which, 0, 0, 0, 0)
 
     def own_buffers(self):

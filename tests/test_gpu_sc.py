@@ -271,6 +271,37 @@ def test_sc_x_slabs_through_planes(size, nsub, precision, potential, pattern, mo
                 np.testing.assert_allclose(gd, o.real(od), **tol)
 
 
+@pytest.mark.parametrize('mode', ['one stream', 'events', 'copies'])
+@pytest.mark.parametrize('pattern', ['AB', 'AA'])
+@pytest.mark.parametrize('size,nsub,precision', [((40, 9, 8), 2, 'single'), ((200, 34, 5), 3, 'single'), ((130, 16, 6), 2, 'double')])
+def test_single_component_x_slabs_through_planes(size, nsub, precision, pattern, mode, monkeypatch):
+    """The single-component model (PrepareMacroFields + CollideAndPropagate, reference lb_single.py:242-347) over the same
+    planes: one lattice, field 0 of the density planes.  Equal to the oracle group bit for bit, both access patterns, an
+    odd and an even number of steps, the three orderings of a same-process group."""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from tests._oracle_group import OracleNNGroup
+    if mode == 'events':
+        monkeypatch.setenv('SLF_GROUP_ONE_STREAM', '0')
+    elif mode == 'copies':
+        monkeypatch.setenv('SLF_XFACE_SHARE', '0')
+    steps = 12 if nsub == 3 else 11
+    sim_cls, _ = _sc.make_single_sim(3)
+    cfg = _sc.single_config(3, size, pattern=pattern, fused=True)
+    cfg.update(G=-1.2, sc_potential='linear', precision=precision, subdomains=nsub, conn_axis='x')
+    og = OracleNNGroup(sim_cls, 3, 'EqualSubdomainsGeometry3D', dict(cfg), single=True)
+    og.run(steps)
+    gcfg = dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0)
+    ctrl = LBSimulationController(sim_cls, geo_mod.EqualSubdomainsGeometry3D, default_config=gcfg)
+    ctrl.run(ignore_cmdline=True)
+    assert len(ctrl.runners) == nsub
+    for r, o in zip(ctrl.runners, og.subs):
+        assert r._nnx is not None and r._nnx.n_lat == 1 and r._nnx.shared == (mode != 'copies')
+        assert np.array_equal(r._sim.rho, o.real(o.rho))
+        gd = r._debug_get_dist(grid_num=0)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+        assert np.array_equal(gd, o.real(o.current())), 'subdomain %d' % r._spec.id
+
+
 def test_sc_x_slab_planes_refuse_what_they_do_not_serve():
     """The planes are for the two kernels that know them: a module with indirect addressing, or whose y / z axes are not
     wrapped inside the kernels, does not take them (and the runner keeps the ghost columns)."""

@@ -223,7 +223,7 @@ def test_shan_chen_mixture_one_process_per_subdomain(axis, nsub, tmp_path):
         text = res.stdout.decode(errors='replace')
         assert res.returncode == 0, text[-3000:]
         # slabs along x: no ghost columns, the kernels write / read dense planes in the neighbour's memory (xface.NNPlanes)
-        assert ('binary model over x-face planes' in text) == (axis == 'x' and name == 'many'), text[-3000:]
+        assert ('Shan-Chen model over x-face planes' in text) == (axis == 'x' and name == 'many'), text[-3000:]
     got = merge_subdomains(str(tmp_path / 'many'), 1, steps, save=False)
     ref = merge_subdomains(str(tmp_path / 'one'), 1, steps, save=False)
     assert set(got) == set(ref) and 'rho' in ref and 'phi' in ref

@@ -454,6 +454,37 @@ PYEOF
       done
     done
     ;;
+  r6s4)   # single-component Shan-Chen over the planes: parity; 256^3 in 4 x-slabs with / without
+    ( time timeout 1500 python -m pytest tests/test_gpu_sc.py -m gpu -q -x --durations=5 ) > $O/pytest_sc_all.log 2>&1; tail -12 $O/pytest_sc_all.log
+    ( time timeout 900 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q -x -k "shan_chen" --durations=5 ) > $O/pytest_sc_ranks.log 2>&1; tail -5 $O/pytest_sc_ranks.log
+    cat > /tmp/scs4.py <<PYEOF
+import sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
+sys.path.insert(0, '$GRAFT_REPO_ROOT/tools')
+from examples.sc_phase_separation import PhaseSeparationSim, VapourSubdomain
+from sailfish.controller import LBSimulationController
+from sailfish.geo import EqualSubdomainsGeometry3D
+from sailfish.subdomain import Subdomain3D
+import numpy as np
+class Vapour3D(Subdomain3D):
+    def boundary_conditions(self, hx, hy, hz):
+        pass
+    def initial_conditions(self, sim, hx, hy, hz):
+        sim.rho[:] = 0.693 + 0.01 * np.sin(hx * 12.9898 + hy * 78.233 + hz * 37.719)
+class Sim3D(PhaseSeparationSim):
+    subdomain = Vapour3D
+n = int(sys.argv[1])
+c = LBSimulationController(Sim3D, EqualSubdomainsGeometry3D, default_config=dict(lat_nx=256, lat_ny=256, lat_nz=256, grid='D3Q19', periodic_x=True, periodic_y=True, periodic_z=True, subdomains=n, conn_axis='x', access_pattern=sys.argv[2], mode='benchmark', max_iters=300, benchmark_sample_from=100, perf_stats_every=0))
+c.run(ignore_cmdline=True)
+PYEOF
+    for pat in AA AB; do
+      for n in 4 1; do
+        for xf in 1 0; do
+          echo "single-component $pat planes $xf subdomains $n: $(SLF_SC_XFACE=$xf timeout 300 python /tmp/scs4.py $n $pat 2>&1 | grep 'Total MLUPS\|Error\|error' | tail -1)" | tee -a $O/scs_x_slabs.txt
+        done
+      done
+    done
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
