@@ -447,13 +447,18 @@ int slf_module_set_xface_buffers(slf_module* m, void* send_low, void* send_high,
  *         1 = phi).  "ShanChenPrepareDensities" stores rho and phi of the subdomain's first / last column into
  *         send_low / send_high; the edge lanes of "ShanChenCollideAndPropagateFusedV" take the five stencil values per
  *         field that lie across the face from recv_low / recv_high (the neighbour's send_high / send_low of the SAME
- *         step) and never touch the ghost columns.  No markers: every entry that is read has been written in the step.
+ *         step) and never touch the ghost columns.  No markers: an entry is either rewritten every step (a node whose
+ *         density the pass forms) or never (a node the pass skips, a ghost row) -- FILL every entry of the send planes
+ *         once from the fields, before the first step and after every host-side write of the state
+ *         (`CollectContinuousData` on column x = 1 / nx of rho and phi: xface.NNPlanes.prime); a wet edge node in a row
+ *         next to a y / z face that is neither wrapped in-sweep nor a wall reads ghost-row entries, whose content is the
+ *         caller's business as it is with ghost columns.
  * The single-component model (`PrepareMacroFields` / `CollideAndPropagate`, reference lb_single.py:242-347) takes sets 0
  * and 2 (field 0 of the density planes; same size).
- * A connected face needs all of its sets.  For fluid-only D3Q19 modules, direct addressing, y and z wrapped inside the
- * sweep, x not; both access patterns (in place: the even step stores what the neighbour's odd step pulls into the own
- * row of the plane, as the single-fluid kernels do); only the two kernels named above run with planes set (the others
- * refuse). */
+ * A connected face needs all of its sets.  For D3Q19 modules with direct addressing, x not wrapped inside the sweep; with
+ * or without a node map; both access patterns (in place: the even step stores what the neighbour's odd step pulls into
+ * the own row of the plane, as the single-fluid kernels do); only the kernels named above run with planes set (the
+ * others refuse). */
 int slf_module_set_xface_planes(slf_module* m, int32_t which, void* send_low, void* send_high, void* recv_low,
                                 void* recv_high);
 

@@ -178,6 +178,9 @@ class LocalGroup(object):
                     nb._nnx_place(kind, r._spec.id)
                     r._nnx.shared = nb._nnx.shared = True
         for r in self.runners:
+            if getattr(r, '_nnx', None) is not None and r._nnx.shared:
+                r._nnx_prime()          # the send planes are final now: the densities the pass in front never rewrites
+        for r in self.runners:
             if r._xface is None:
                 continue
             sp = r._spec

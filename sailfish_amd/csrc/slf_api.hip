@@ -1368,12 +1368,10 @@ static int check_xface_planes(const slf_module* m, int32_t which, void* send_low
   if (which < 0 || which > 2) return fail(SLF_ERR_INVALID, "x-face planes: 0 / 1 = populations of lattice 0 / 1, 2 = densities");
   if (send_low || send_high || recv_low || recv_high) {
     const slf::Geometry& g = m->geo;
-    if (m->sel.lattice != 1 || g.indirect || !m->sc.enabled || !(g.variant & 8) || m->sel.general)
-      return fail(SLF_ERR_UNSUPPORTED, "x-face planes: fluid-only D3Q19 Shan-Chen modules with direct addressing (whole-row kernels)");
+    if (m->sel.lattice != 1 || g.indirect || !m->sc.enabled || !(g.variant & 8))
+      return fail(SLF_ERR_UNSUPPORTED, "x-face planes: D3Q19 Shan-Chen modules with direct addressing (whole-row kernels)");
     if (m->sc.enabled == 2 && which == 1) return fail(SLF_ERR_INVALID, "x-face planes: the single-component model has one lattice");
     if (g.wrap[0]) return fail(SLF_ERR_INVALID, "x-face planes make no sense with x wrapped inside the sweep");
-    if (!g.wrap[1] || !g.wrap[2])
-      return fail(SLF_ERR_UNSUPPORTED, "x-face planes: y and z must be wrapped inside the sweep (every entry an edge node reads is written each step)");
     if (g.lat_nx - 2 > 1024 || g.lat_nx - 2 < 2) return fail(SLF_ERR_UNSUPPORTED, "x-face planes: rows of 2 .. 1024 nodes");
     if ((send_low == nullptr) != (recv_low == nullptr) || (send_high == nullptr) != (recv_high == nullptr))
       return fail(SLF_ERR_INVALID, "a connected face needs both its send and its receive plane");

@@ -258,9 +258,11 @@ __device__ __forceinline__ void sc_store(const Geometry& g, R (&f)[L::Q], R* dou
 // Populations: per lattice the single-fluid scheme (slf_sweep.h x_face_receive / x_face_send_own_row, row_push's xsend).
 // Densities: the force stencil of an edge node reads the neighbour subdomain's first / last column; the pass in front
 // (sc_macro_kernel) stores rho and phi of ITS edge nodes into a send plane [z][field][y] over the padded (arr_ny x arr_nz)
-// plane, and the sweep's edge lanes take the five values per field that sit across the face from the receive plane.  For
-// fluid-only subdomains whose y and z axes are wrapped inside the kernels: every entry that is read has been written in
-// the same step, so the density planes need no "nothing crossed here" marker.
+// plane, and the sweep's edge lanes take the five values per field that sit across the face from the receive plane.  The
+// density planes carry no "nothing crossed here" marker: an entry is either rewritten every step (a node whose density the
+// pass in front forms) or never (a node that pass skips, a ghost row), and the caller fills every entry once from the
+// fields as they are -- before the first step and after every host-side write of the state (xface.NNPlanes.prime): what a
+// ghost column would have held.
 template <class L, class R, bool PULL>
 __device__ __forceinline__ void sc_face_receive(const R* const (&xrecv)[2], R (&f)[L::Q], int x, int nx, const FaceRows& fr) {
   // PULL (the odd in-place step): the value sits in the row the pull reads from, (y, z) - e_I; else in the node's own row
@@ -382,7 +384,7 @@ __device__ __forceinline__ void sc_accel_edge(const R* field, R G, R rho, int po
 // the launches whose options ask for output (bit 0), which run the VOUT = true instantiation.
 template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool VOUT = true, bool XF = false>
 __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) {
-  static_assert(!XF || (!GENERAL && !INDIRECT), "x-face planes: fluid-only subdomains, direct addressing");
+  static_assert(!XF || !INDIRECT, "x-face planes: direct addressing");
   const Geometry& g = p.g;
   bool live;
   const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live, p.xcd_shift);
@@ -530,8 +532,8 @@ __global__ void __launch_bounds__(1024) sc_sweep_kernel(const ScParams<L, R> p) 
 template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool OWNV = false, bool PULL = false, bool XF = false>
 __global__ void __launch_bounds__(1024, (sizeof(R) == 4 && L::dim == 3 && (ROW || PROP == PROP_AA_EVEN)) ? (OWNV ? SLF_SC_FUSEDV_WAVES : SLF_SC_FUSED_WAVES) : 4)
 sc_fused_kernel(const ScParams<L, R> p) {
-  static_assert(!XF || (!GENERAL && OWNV && !PULL && ROW == (PROP != PROP_AA_EVEN)),
-                "x-face planes: fluid-only subdomains, whole-row kernels for the x-streaming steps");
+  static_assert(!XF || (OWNV && !PULL && ROW == (PROP != PROP_AA_EVEN)),
+                "x-face planes: whole-row kernels for the x-streaming steps, the sweep that forms its own moments");
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
@@ -724,7 +726,7 @@ sc_fused_kernel(const ScParams<L, R> p) {
 // PrepareMacroFields: density of every wet node
 template <class L, class R, int PROP, bool GENERAL, bool INDIRECT = false, bool XF = false>
 __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p) {
-  static_assert(!XF || (!GENERAL && !INDIRECT), "x-face planes: fluid-only subdomains, direct addressing");
+  static_assert(!XF || !INDIRECT, "x-face planes: direct addressing");
   const Geometry& g = p.g;
   bool live;
   const ScNode n = sc_node<L>(g, p.y0, p.z0, g.lat_nx - 2, live, p.xcd_shift);
@@ -755,8 +757,7 @@ __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p)
 template <class L, class R, int PROP, bool GENERAL, bool ROW = false, bool INDIRECT = false, bool XF = false>
 __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p) {
   static_assert(!(ROW && INDIRECT), "indirect addressing: per-node kernels only");
-  static_assert(!XF || (!GENERAL && !INDIRECT && ROW == (PROP != PROP_AA_EVEN)),
-                "x-face planes: fluid-only subdomains, whole-row kernels for the x-streaming steps");
+  static_assert(!XF || (!INDIRECT && ROW == (PROP != PROP_AA_EVEN)), "x-face planes: whole-row kernels for the x-streaming steps");
   const Geometry& g = p.g;
   const int nx = g.lat_nx - 2;
   bool live;
@@ -933,15 +934,19 @@ static hipError_t sc_macro2(Prop prop, bool general, const Geometry& g, const Ph
     // connected x faces through planes: edge lanes take the entering populations from the receive planes and store their
     // densities for the neighbours (the module was checked when the planes were set: slf_module_set_xface_planes)
     if constexpr (L::dim == 3) {
-      if (general || g.indirect) return hipErrorInvalidValue;
+      if (g.indirect) return hipErrorInvalidValue;
       p.xcd_shift = xcd_shift_for(grid.y, grid.x);        // 32 consecutive rows write one line of a plane: one XCD
+#define SLF_SCM_XF(P, G)                                                                                            \
+  do {                                                                                                               \
+    if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, P, G, false, true, true>), grid, block, 0, s, p);            \
+    else hipLaunchKernelGGL((sc_macro_kernel<L, R, P, G, false, false, true>), grid, block, 0, s, p);                \
+  } while (0)
       if (prop == PROP_AA_ODD) {
-        if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AA_ODD, false, false, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AA_ODD, false, false, false, true>), grid, block, 0, s, p);
+        if (general) SLF_SCM_XF(PROP_AA_ODD, true); else SLF_SCM_XF(PROP_AA_ODD, false);
       } else {          // two-copy and the even in-place step: the node's own slots
-        if (vout) hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((sc_macro_kernel<L, R, PROP_AB, false, false, false, true>), grid, block, 0, s, p);
+        if (general) SLF_SCM_XF(PROP_AB, true); else SLF_SCM_XF(PROP_AB, false);
       }
+#undef SLF_SCM_XF
       return hipGetLastError();
     }
     return hipErrorInvalidValue;
@@ -1063,14 +1068,20 @@ static hipError_t sc_fused2(Prop prop, bool general, const Geometry& g, const Ph
   } while (0)
   if (sc_xface_in_use(a)) {
     if constexpr (L::dim == 3) {
-      if (general || !a.sc_local_velocity) return hipErrorInvalidValue;
+      if (!a.sc_local_velocity) return hipErrorInvalidValue;
+#define SLF_SCF_XF(P, ROW)                                                                                                   \
+  do {                                                                                                                        \
+    if (general) hipLaunchKernelGGL((sc_fused_kernel<L, R, P, true, ROW, true, false, true>), grid, block, park, s, p);       \
+    else hipLaunchKernelGGL((sc_fused_kernel<L, R, P, false, ROW, true, false, true>), grid, block, park, s, p);              \
+  } while (0)
       if (prop == PROP_AA_EVEN) {
-        hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AA_EVEN, false, false, true, false, true>), grid, block, park, s, p);
+        SLF_SCF_XF(PROP_AA_EVEN, false);
         return hipGetLastError();
       }
       if (!row || grid.x != 1) return hipErrorInvalidValue;
-      if (prop == PROP_AB) hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AB, false, true, true, false, true>), grid, block, park, s, p);
-      else hipLaunchKernelGGL((sc_fused_kernel<L, R, PROP_AA_ODD, false, true, true, false, true>), grid, block, park, s, p);
+      if (prop == PROP_AB) SLF_SCF_XF(PROP_AB, true);
+      else SLF_SCF_XF(PROP_AA_ODD, true);
+#undef SLF_SCF_XF
       return hipGetLastError();
     }
     return hipErrorInvalidValue;
@@ -1114,19 +1125,25 @@ static hipError_t scs_launch2(bool macro, Prop prop, bool general, const Geometr
   if (sc_xface_in_use(a)) {
     // connected x faces through planes (slf_module_set_xface_planes: sets 0 and 2 of the binary model's three)
     if constexpr (L::dim == 3) {
-      if (general || g.indirect) return hipErrorInvalidValue;
+      if (g.indirect) return hipErrorInvalidValue;
+#define SLF_SCS_XF(KERN, P, ...)                                                                             \
+  do {                                                                                                        \
+    if (general) hipLaunchKernelGGL((KERN<L, R, P, true, __VA_ARGS__>), grid, block, 0, s, p);                \
+    else hipLaunchKernelGGL((KERN<L, R, P, false, __VA_ARGS__>), grid, block, 0, s, p);                       \
+  } while (0)
       if (macro) {
-        if (prop == PROP_AA_ODD) hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AA_ODD, false, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scs_macro_kernel<L, R, PROP_AB, false, false, true>), grid, block, 0, s, p);
+        if (prop == PROP_AA_ODD) SLF_SCS_XF(scs_macro_kernel, PROP_AA_ODD, false, true);
+        else SLF_SCS_XF(scs_macro_kernel, PROP_AB, false, true);
         return hipGetLastError();
       }
       if (prop == PROP_AA_EVEN) {
-        hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_EVEN, false, false, false, true>), grid, block, 0, s, p);
+        SLF_SCS_XF(scs_sweep_kernel, PROP_AA_EVEN, false, false, true);
         return hipGetLastError();
       }
       if (!row || grid.x != 1) return hipErrorInvalidValue;
-      if (prop == PROP_AB) hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AB, false, true, false, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((scs_sweep_kernel<L, R, PROP_AA_ODD, false, true, false, true>), grid, block, 0, s, p);
+      if (prop == PROP_AB) SLF_SCS_XF(scs_sweep_kernel, PROP_AB, true, false, true);
+      else SLF_SCS_XF(scs_sweep_kernel, PROP_AA_ODD, true, false, true);
+#undef SLF_SCS_XF
       return hipGetLastError();
     }
     return hipErrorInvalidValue;

@@ -1394,6 +1394,11 @@ class NNSubdomainRunner(SubdomainRunner):
             return False
         if not xface.supported_nn(self._sim.grid, self._desc, self.indirect):
             return False
+        # (An edge node in a row next to a y / z face that is not wrapped inside the kernels reads ghost-row entries of the
+        # density planes.  They hold what prime() found in the neighbour's ghost row -- the +inf every field is created
+        # with outside the lattice, make_scalar_field -- which is what the ghost COLUMN of such a row holds as well: no
+        # node owns that position, so build_macro_links never delivers anything there.  A node that computes a force must
+        # not sit there in either scheme; a wall does not care.)
         return self._x_slabs_line_up()
 
     def _init_nn_planes(self):
@@ -1475,8 +1480,25 @@ class NNSubdomainRunner(SubdomainRunner):
         self._connector.quiesce(self)       # zero-copy transports: the neighbours write into these planes themselves
         self._nnx.reset(self._calc_stream)
         self.backend.sync_stream(self._calc_stream)
+        self._connector.quiesce(self)       # ... and I into theirs: everybody has cleared before anybody fills
+        self._nnx_prime()
+        group = getattr(self, '_group', None)
+        if group is not None and self._nnx.shared:
+            # subdomains of one process reset one at a time: what the neighbours had filled in my planes went with the
+            # clearing above
+            for r in group.runners:
+                if r is not self and getattr(r, '_nnx', None) is not None:
+                    r._nnx_prime()
         self._connector.quiesce(self)
         self.__dict__.pop('_halo_mode', None)
+
+    def _nnx_prime(self):
+        """The density planes I send, from the fields as they are on the device now (xface.NNPlanes.prime)."""
+        fields = [self.gpu_field(fp.buffer) for fp in self._sim._scalar_fields if fp.abstract.need_nn]
+        self._nnx.prime(fields, self._calc_stream)
+        if self.config.access_pattern == 'AA':
+            self._nnx.prime_own([self.gpu_dist(g, 0) for g in range(self._nnx.n_lat)], self._calc_stream)
+        self.backend.sync_stream(self._calc_stream)
 
     def _materialise_halo(self):
         if self._nnx is None:

@@ -344,9 +344,9 @@ NN_FIELDS = 2    # rho, phi
 
 def supported_nn(grid, desc, indirect=False):
     """Can a Shan-Chen module (binary or single-component) built from `desc` take x-face planes?  What
-    slf_module_set_xface_planes checks:
-    fluid-only D3Q19, direct addressing, y and z wrapped inside the kernels (every plane entry an edge node reads is then
-    written in the same step), rows of 2 .. 1024 nodes, whole-row kernels; both access patterns."""
+    slf_module_set_xface_planes checks: D3Q19, direct addressing, rows of 2 .. 1024 nodes, whole-row kernels, x not wrapped
+    inside the kernels; both access patterns, with or without a node map.  (Which rows of a density plane an edge node may
+    read is the runner's check: NNSubdomainRunner._nn_x_faces_only.)"""
     from sailfish_amd import hipabi
     if int(desc.simtype) not in (hipabi.SLF_SIM_SHAN_CHEN_BINARY, hipabi.SLF_SIM_SHAN_CHEN_SINGLE):
         return False
@@ -358,8 +358,7 @@ def supported_nn(grid, desc, indirect=False):
     if int(desc.simtype) == hipabi.SLF_SIM_SHAN_CHEN_BINARY and os.environ.get('SLF_SC_FUSED', '2') != '2':
         return False        # binary: the planes are served by ShanChenPrepareDensities / ShanChenCollideAndPropagateFusedV only
     nx = desc.lat_nx - 2
-    return grid.dim == 3 and grid.Q == 19 and not indirect and bool(desc.fluid_only) and 2 <= nx <= 1024 and \
-        bool(desc.periodic_fused[1]) and bool(desc.periodic_fused[2]) and not desc.periodic_fused[0]
+    return grid.dim == 3 and grid.Q == 19 and not indirect and 2 <= nx <= 1024 and not desc.periodic_fused[0]
 
 
 class NNPlanes(object):
@@ -419,14 +418,75 @@ class NNPlanes(object):
                         out.append((a, self.count[kind] * self.isz))
         return out
 
+    def _buffers(self, which, kind):
+        out = []
+        for par in (0, 1):
+            for f in (LOW, HIGH):
+                a = which[kind][par][f]
+                if a and (a, self.count[kind] * self.isz) not in out:
+                    out.append((a, self.count[kind] * self.isz))
+        return out
+
     def reset(self, stream=None):
-        """All bits set: nothing has crossed the faces, the arrays count (state written from the host).  Shared planes: only
-        what this subdomain receives (its send planes are a neighbour's input and are cleared by that neighbour)."""
-        bufs = self.own_buffers()
+        """Population planes, all bits set: nothing has crossed the faces, the arrays count (state written from the host).
+        Shared planes: only what this subdomain receives (its send planes are a neighbour's input and are cleared by that
+        neighbour).  The density planes carry no markers: prime() defines them."""
+        bufs = self._buffers(self.recv, 'dist')
         if not self.shared:
-            bufs = bufs + [b for b in self.send_buffers() if b not in bufs]
+            bufs = bufs + [b for b in self._buffers(self.send, 'dist') if b not in bufs]
         for a, nbytes in bufs:
             self.backend.memset_buf(a, 0xFF, nbytes, stream)
+
+    def prime(self, fields, stream=None):
+        """Every entry of MY density send planes (both parities) from the first / last real column of `fields` (device
+        addresses of rho [, phi]) as they are now: the densities of nodes the density pass never rewrites (walls, ghost
+        rows) -- what the neighbour's ghost column would hold -- and a defined start for the others.  After the state was
+        written from the host, and once the send planes are final (shared planes: after the neighbours' planes were
+        adopted)."""
+        b, d = self.backend, self.desc
+        nx = d.lat_nx - 2
+        for par in (0, 1):
+            for face in (LOW, HIGH):
+                plane = self.send['macro'][par][face]
+                if not plane:
+                    continue
+                x = 1 if face == LOW else nx
+                for j, field in enumerate(fields):
+                    key = ('prime', field, plane, j)
+                    if key not in self._kernels:
+                        # node box: columns = y (stride arr_nx), rows = z; plane [z][field][y]
+                        self._kernels[key] = b.get_kernel(self.module, 'CollectContinuousData', (64,),
+                                                          [field, plane + j * d.arr_ny * self.isz, 1, x, d.arr_nx, d.arr_ny,
+                                                           d.arr_nx * d.arr_ny, d.arr_nz, d.arr_ny, NN_FIELDS * d.arr_ny],
+                                                          'PPiiiiiiii')
+                    b.run_kernel(self._kernels[key], None, stream)
+
+    def prime_own(self, dists, stream=None):
+        """In-place pattern: the population planes of the EVEN steps (set 0) from my first / last real column as it is
+        now -- entry (row, direction I) = slot opp(I) of the edge node of that row, which is where the even step leaves
+        what it also stores into the plane.  For the entries no step ever writes: an edge node the node map excludes never
+        sends, and the neighbour's odd step would fall back to its ghost column, which nothing maintains here (a wall node
+        of the single-component model, whose density the pass in front forms too, pulls from such a node: an infinity out
+        of the ghost column would end up in its density and from there in the force on the fluid next to it).  With ghost
+        columns the exchange delivers exactly these values, unchanged, every step."""
+        b, d = self.backend, self.desc
+        nx = d.lat_nx - 2
+        for face in (LOW, HIGH):
+            plane = self.send['dist'][0][face]
+            if not plane:
+                continue
+            x = 1 if face == LOW else nx
+            leaving = self.enter[HIGH] if face == LOW else self.enter[LOW]      # e_x < 0 leave through the low face
+            for lat, dist in enumerate(dists):
+                for k, q in enumerate(leaving):
+                    dst = plane + lat * self.n_dist * self.isz + k * d.arr_ny * self.isz
+                    key = ('own', dist, dst, q)
+                    if key not in self._kernels:
+                        self._kernels[key] = b.get_kernel(self.module, 'CollectContinuousData', (64,),
+                                                          [dist, dst, 1 << self.grid.idx_opposite[q], x, d.arr_nx, d.arr_ny,
+                                                           d.arr_nx * d.arr_ny, d.arr_nz, d.arr_ny, NXD * d.arr_ny],
+                                                          'PPiiiiiiii')
+                    b.run_kernel(self._kernels[key], None, stream)
 
     def materialise(self, dists, pushed, stream, parity):
         """Writes the population planes received in the steps of `parity` into the arrays `dists` = (lattice 0, lattice 1)

@@ -202,8 +202,8 @@ def test_example_starts_its_own_ranks(pattern, axis, nsub, tmp_path):
         assert np.array_equal(got[name], ref[name], equal_nan=True), name
 
 
-@pytest.mark.parametrize('axis,nsub', [('x', 2), ('z', 2), ('y', 4)])
-def test_shan_chen_mixture_one_process_per_subdomain(axis, nsub, tmp_path):
+@pytest.mark.parametrize('axis,nsub,transport', [('x', 2, 'auto'), ('x', 3, 'torch'), ('z', 2, 'auto'), ('y', 4, 'auto')])
+def test_shan_chen_mixture_one_process_per_subdomain(axis, nsub, transport, tmp_path):
     """The binary Shan-Chen model with one PROCESS per subdomain on the one GPU of the box: the density planes that the
     force kernel reads across the seam and the distributions both travel through the device-side peer transport
     (connector.PeerConnector, receive buffers by step parity), and the merged fields equal the single-subdomain run of
@@ -214,6 +214,7 @@ def test_shan_chen_mixture_one_process_per_subdomain(axis, nsub, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'SLF_DIST_BACKEND', 'SLF_FORCE_DEVICE'):
         env.pop(k, None)
+    env['SLF_HALO_TRANSPORT'] = transport        # torch: the planes as torch.distributed messages (staged through the host)
     steps = 10
     common = ['--max_iters=%d' % steps, '--every=%d' % steps, '--conn_axis=' + axis, '--verbose', '--nooutput_compress',
               '--perf_stats_every=0']

@@ -485,6 +485,10 @@ PYEOF
       done
     done
     ;;
+  r6s5)   # the planes with node maps (walls): all Shan-Chen tests + the processes
+    ( time timeout 1500 python -m pytest tests/test_gpu_sc.py -m gpu -q --durations=5 ) > $O/pytest_sc_all.log 2>&1; tail -15 $O/pytest_sc_all.log
+    ( time timeout 900 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q -k "shan_chen" --durations=5 ) > $O/pytest_sc_ranks.log 2>&1; tail -8 $O/pytest_sc_ranks.log
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
