@@ -141,7 +141,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--quick', action='store_true')
-    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,3g8,3x8,3z8,4; not in the default set: 6xa,6xb,6za,6zb, 7a-7d indirect addressing, 8a,8b single-component Shan-Chen, 9a,9b cylinder / sphere)')
+    ap.add_argument('--only', default='', help='comma separated configuration ids (0,1,2,2b,2c,5a,5b,3,3b,3g8,3x8,3z8,4; not in the default set: 6xa,6xb,6za,6zb, 7a-7d indirect addressing, 8a,8b single-component Shan-Chen, 9a,9b cylinder / sphere, 4x4,8x4,5x3 x-slabs of one process)')
     args = ap.parse_args()
     if not args.only:
         # one fresh process per configuration: what a configuration measures must not depend on what ran before it in
@@ -323,6 +323,23 @@ def main():
         res.append(run('9b: examples/sphere_3d.py D3Q19 BGK 512x256x256 (AA)', SphereSim, LBGeometry3D,
                        dict(lat_nx=512, lat_ny=256, lat_nz=256, access_pattern='AA', max_iters=int(1500 * it),
                             benchmark_sample_from=int(500 * it)), 152))
+    # ---- several x-slabs of ONE process on this GPU (controller.LocalGroup; round 6): the Shan-Chen models over the x-face
+    # planes, the force-driven pipe with its cuts on 128-byte lines
+    if '4x4' in only:
+        res.append(run('4x4: binary Shan-Chen D3Q19 256^3 in 4 x-slabs, one process (AB)', SeparationSim, EqualSubdomainsGeometry3D,
+                       dict(lat_nx=256, lat_ny=256, lat_nz=256, subdomains=4, conn_axis='x', access_pattern='AB',
+                            max_iters=int(900 * it), benchmark_sample_from=int(300 * it)), 516))
+    if '8x4' in only:
+        res.append(run('8x4: single-component Shan-Chen D3Q19 256^3 in 4 x-slabs, one process (AA)', PhaseSeparation3D,
+                       EqualSubdomainsGeometry3D,
+                       dict(lat_nx=256, lat_ny=256, lat_nz=256, grid='D3Q19', periodic_x=True, periodic_y=True, periodic_z=True,
+                            subdomains=4, conn_axis='x', access_pattern='AA', seed=11, max_iters=int(1500 * it),
+                            benchmark_sample_from=int(500 * it)), 3 * 76 + 8))
+    if '5x3' in only:
+        res.append(run('5x3: D3Q19 BGK force-driven pipe 512x256x256 in 3 x-slabs (160 / 192 / 160), one process (AA)', Pipe3D,
+                       EqualSubdomainsGeometry3D,
+                       dict(lat_nx=512, lat_ny=256, lat_nz=256, visc=0.05, subdomains=3, conn_axis='x', access_pattern='AA',
+                            max_iters=int(1500 * it), benchmark_sample_from=int(500 * it)), 152))
     if args.out:
         with open(args.out, 'w') as fh:
             for r in filter(None, res):
