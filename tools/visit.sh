@@ -489,6 +489,10 @@ PYEOF
     ( time timeout 1500 python -m pytest tests/test_gpu_sc.py -m gpu -q --durations=5 ) > $O/pytest_sc_all.log 2>&1; tail -15 $O/pytest_sc_all.log
     ( time timeout 900 python -m pytest tests/test_gpu_two_ranks.py -m gpu -q -k "shan_chen" --durations=5 ) > $O/pytest_sc_ranks.log 2>&1; tail -8 $O/pytest_sc_ranks.log
     ;;
+  r6s6)   # the x-slab configurations of bench_configs + the Shan-Chen tests with the last host-side changes
+    timeout 900 python tools/bench_configs.py --only 4x4,8x4,5x3,4,8a,5a 2>/dev/null | grep '^{' > $O/configs_x_slabs.jsonl; cut -c1-220 $O/configs_x_slabs.jsonl
+    ( time timeout 1500 python -m pytest tests/test_gpu_sc.py tests/test_gpu_two_ranks.py -m gpu -q -k "sc or shan" --durations=5 ) > $O/pytest_sc_last.log 2>&1; tail -6 $O/pytest_sc_last.log
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
