@@ -22,8 +22,10 @@
 
 namespace slf {
 
+// TURB (--regularized / --subgrid): workgroups of at most 512 threads, i.e. 256 VGPRs -- the non-equilibrium flux tensor on
+// top of the collision does not fit the 128 of a 1024-thread workgroup (76-152 bytes of scratch per lane in the odd step).
 template <class L, class R, int MODEL, int PROP, bool GENERAL, bool INDIRECT = false, bool ROUNDOFF = false, bool TURB = false>
-__global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) {
+__global__ void __launch_bounds__(TURB ? 512 : 1024) sweep_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
   const int gy = p.y0 + (int)blockIdx.y;
   const int gz = (L::dim == 3) ? p.z0 + (int)blockIdx.z : 0;
@@ -101,8 +103,13 @@ __global__ void __launch_bounds__(1024) sweep_kernel(const SweepParams<L, R> p) 
 // The x-streaming steps translate every neighbour ONCE: node x - e_i (the pull) is node x + e_opp(i) (the push), so the
 // 18 entries of the dense table serve both; consecutive active nodes of a row have consecutive slots, so the gathers
 // through them are as good as dense.  Same node code (node_update<..., INDIRECT>), same results.
-template <class L, class R, int MODEL, int PROP>
-__global__ void __launch_bounds__(256, 4) slot_sweep_kernel(const SweepParams<L, R> p) {
+// BCL: the module's boundary-condition level (Geometry::bc_level, as the whole-row kernels): a porous medium or a pipe of
+// bounce-back walls is level 0 and carries none of the outflow / slip / do-nothing code, whose merged populations the
+// level-2 instantiation of the two-copy step keeps in 32 bytes of scratch per lane at its 128 VGPRs.
+// Double precision D3Q19: two waves per SIMD, i.e. 256 VGPRs -- at the 128 of four waves every instantiation kept 100-330
+// bytes per lane in scratch, more than the 304 bytes of populations a node moves.
+template <class L, class R, int MODEL, int PROP, int BCL = 2>
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 && L::Q > 9) ? 2 : 4) slot_sweep_kernel(const SweepParams<L, R> p) {
   const Geometry& g = p.g;
   const uint32_t si = blockIdx.x * 256u + threadIdx.x;
   if (si >= p.n_slots) return;
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(256, 4) slot_sweep_kernel(const SweepParams<L,
   });
   R rho, v[3];
   bool wet = true;
-  node_update<L, R, MODEL, PROP, true, true, FORCE_RUNTIME, 2, false>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
+  node_update<L, R, MODEL, PROP, true, true, FORCE_RUNTIME, BCL, false>(p, f, code, kind, gi, ox, oy, oz, rho, v, wet, si);
   if (wet) check_invalid<R>(p.status, p.options, rho, gx, gy, gz);
   if ((p.options & 1u) && wet) {
     p.rho[gi] = rho;
@@ -446,6 +453,10 @@ static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& 
       return hipGetLastError();
     }
     if (ph.regularized || ph.subgrid) {       // --regularized / --subgrid=les-smagorinsky (BGK only; checked at module creation)
+      if (block.x > 512) {                    // these instantiations: at most 512 threads per workgroup (launch bounds)
+        block.x = 512;
+        grid.x = (g.lat_nx - 2 + 511) / 512;
+      }
       if (g.indirect) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, true, false, true>), grid, block, 0, s, p);
       else if (general) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, false, false, true>), grid, block, 0, s, p);
       else hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, false, false, false, true>), grid, block, 0, s, p);
@@ -456,7 +467,18 @@ static hipError_t launch_sweep4(bool general, const Geometry& g, const Physics& 
     SweepParams<L, R> q = p;
     q.y1 = y1;
     q.z1 = (L::dim == 3) ? z1 : 1;
-    hipLaunchKernelGGL((slot_sweep_kernel<L, R, MODEL, PROP>), dim3((q.n_slots + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, q);
+    const dim3 sgrid((q.n_slots + 255) / 256, 1, 1), sblock(256, 1, 1);
+    // (single-precision BGK, odd in-place step: the level-0 instantiation comes out of the register allocator with 28 bytes
+    // of scratch at 128 VGPRs where level 1 has none at 124 -- profiles/r06/kernels_resources.txt -- so level 1 serves both)
+    constexpr bool skip0 = sizeof(R) == 4 && MODEL == 0 && PROP == PROP_AA_ODD && L::Q > 9;
+    if constexpr (!skip0) {
+      if (g.bc_level == 0) {
+        hipLaunchKernelGGL((slot_sweep_kernel<L, R, MODEL, PROP, 0>), sgrid, sblock, 0, s, q);
+        return hipGetLastError();
+      }
+    }
+    if (g.bc_level <= 1) hipLaunchKernelGGL((slot_sweep_kernel<L, R, MODEL, PROP, 1>), sgrid, sblock, 0, s, q);
+    else hipLaunchKernelGGL((slot_sweep_kernel<L, R, MODEL, PROP, 2>), sgrid, sblock, 0, s, q);
     return hipGetLastError();
   }
   if (g.indirect) hipLaunchKernelGGL((sweep_kernel<L, R, MODEL, PROP, true, true>), grid, block, 0, s, p);

@@ -493,6 +493,28 @@ PYEOF
     timeout 900 python tools/bench_configs.py --only 4x4,8x4,5x3,4,8a,5a 2>/dev/null | grep '^{' > $O/configs_x_slabs.jsonl; cut -c1-220 $O/configs_x_slabs.jsonl
     ( time timeout 1500 python -m pytest tests/test_gpu_sc.py tests/test_gpu_two_ranks.py -m gpu -q -k "sc or shan" --durations=5 ) > $O/pytest_sc_last.log 2>&1; tail -6 $O/pytest_sc_last.log
     ;;
+  r6s7)   # slot sweep per boundary-condition level, f64 launch bounds, LES kernels with 512-thread workgroups
+    ( time timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_runner.py tests/test_gpu_reg_les.py tests/test_gpu_sc.py -m gpu -q -k "indirect or reg_les or turb or regularized or smagorinsky or roundoff or les" --durations=5 ) > $O/pytest_indirect_les.log 2>&1; tail -8 $O/pytest_indirect_les.log
+    timeout 900 python tools/bench_configs.py --only 7a,7c 2>/dev/null | grep '^{' > $O/configs_indirect.jsonl; cut -c1-200 $O/configs_indirect.jsonl
+    for opt in "" "--subgrid=les-smagorinsky" "--regularized"; do
+      echo "ldc_3d 256^3 AA $opt: $(timeout 300 python examples/ldc_3d.py --lat_nx=256 --lat_ny=256 --lat_nz=256 --visc=0.01 --access_pattern=AA --mode=benchmark --max_iters=600 --benchmark_sample_from=200 --perf_stats_every=0 $opt 2>&1 | grep 'Total MLUPS')" | tee -a $O/les_rates.txt
+    done
+    ;;
+  r6end)   # after the last kernel-source change of the round: PMC passes, bench lines, kernel statistics, every GPU test
+    for pat in AA AB; do
+      PMC_SIZES_ONLY=1 BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh pmc; cp $O/pmc_summary.txt $O/pmc_sizes_${pat}_512_final.txt
+      [ $pat = AA ] && kern="slf::fast_" || kern="slf::fast_row_kernel"
+      python tools/traffic_update.py --from-pmc $O/pmc --kernel "$kern" --key D3Q19_bgk_f32_${pat}_512_fused
+      rm -rf $O/pmc
+    done
+    cp profiles/traffic.json $O/traffic.json
+    timeout 900 python bench.py 2>&1 | tail -1 > $O/bench_final.json; cut -c1-400 $O/bench_final.json
+    timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_driver_cmd_final.json; cut -c1-300 $O/bench_driver_cmd_final.json
+    for pat in AA AB; do
+      BENCH_ARGS="--access_pattern $pat" bash tools/gpu.sh trace; cp $O/kernel_stats.csv $O/kernel_stats_${pat}_final.csv; rm -rf $O/trace
+    done
+    ( time timeout 2700 python -m pytest tests -m gpu -q --durations=12 ) > $O/pytest_gpu_final.log 2>&1; tail -22 $O/pytest_gpu_final.log
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
