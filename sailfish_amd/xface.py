@@ -393,31 +393,6 @@ class NNPlanes(object):
         ms, mr = self.send['macro'][par], self.recv['macro'][par]
         q.xface_planes(self.module, 2, ms[LOW], ms[HIGH], mr[LOW], mr[HIGH])
 
-    def unbind(self):
-        for which in list(range(self.n_lat)) + [2]:
-            self.backend.set_xface_planes(self.module, which, 0, 0, 0, 0)
-
-    def own_buffers(self):
-        """Addresses and byte counts of what this subdomain RECEIVES into (its own memory in every transport)."""
-        out = []
-        for kind in ('dist', 'macro'):
-            for par in (0, 1):
-                for f in (LOW, HIGH):
-                    a = self.recv[kind][par][f]
-                    if a and (a, self.count[kind] * self.isz) not in out:
-                        out.append((a, self.count[kind] * self.isz))
-        return out
-
-    def send_buffers(self):
-        out = []
-        for kind in ('dist', 'macro'):
-            for par in (0, 1):
-                for f in (LOW, HIGH):
-                    a = self.send[kind][par][f]
-                    if a and (a, self.count[kind] * self.isz) not in out:
-                        out.append((a, self.count[kind] * self.isz))
-        return out
-
     def _buffers(self, which, kind):
         out = []
         for par in (0, 1):
