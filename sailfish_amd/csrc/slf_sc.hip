@@ -297,6 +297,22 @@ __device__ __forceinline__ void sc_face_send_own_row(R* const (&xsend)[2], const
     });
   }
 }
+// Odd in-place step next to a connected x face, fluid-only instantiations: what the edge node would pull out of the
+// ghost column arrives through the plane (sc_face_receive overrides it), so its lane pulls from its own x -- a line the
+// wave fetches anyway -- instead of from the ghost column, a line of its own per direction and row: +29 % reads on the
+// 64-node rows of a four-way split of 256^3 (profiles/r06/pmc_summary_scs_4x_planes_before_skip.txt).  As slf_row.hip's
+// SKIP_GHOST_PULL, and under the same condition: rows whose y / z neighbours are real or wrapped rows (every entry they
+// read is then written by the neighbour's even step -- or was filled by NNPlanes.prime_own after a host-side write).
+__device__ __forceinline__ ScNode sc_pull_node(const Geometry& g, const ScNode& n, int nx, bool recv_lo, bool recv_hi) {
+  ScNode m = n;
+  const bool inner = (g.wrap[1] || (n.gy > 1 && n.gy < g.lat_ny - 2)) && (g.dim < 3 || g.wrap[2] || (n.gz > 1 && n.gz < g.lat_nz - 2));
+  if (inner) {
+    if (recv_lo && n.gx == 1) m.ox.m = 0;
+    if (recv_hi && n.gx == nx) m.ox.p = 0;
+  }
+  return m;
+}
+
 // row of (y, z) in a density plane, and the offsets to its y / z neighbours (wrapped like the arrays)
 struct ScMacroRows {
   int row;
@@ -403,7 +419,11 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
   const size_t ds = g.dist_size;
   R f[L::Q];
   // lattice 0
-  sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
+  if constexpr (XF && PROP == PROP_AA_ODD && !GENERAL) {
+    sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, sc_pull_node(g, n, g.lat_nx - 2, p.xrecv[0][0] != nullptr, p.xrecv[0][1] != nullptr));
+  } else {
+    sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
+  }
   if constexpr (XF) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[0], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
   const R rho0 = density<L, R>(f);
   R v[3] = {(R)0, (R)0, (R)0};
@@ -413,7 +433,11 @@ __global__ void __launch_bounds__(1024) sc_macro_kernel(const ScParams<L, R> p) 
     if constexpr (L::dim == 3) v[2] = p.omega[0] * momentum<L, R, 2>(f);
   }
   // lattice 1
-  sc_load<L, R, PROP, INDIRECT>(f, (const R*)p.d_out, ds, n, p.nodes, si);
+  if constexpr (XF && PROP == PROP_AA_ODD && !GENERAL) {
+    sc_load<L, R, PROP, INDIRECT>(f, (const R*)p.d_out, ds, sc_pull_node(g, n, g.lat_nx - 2, p.xrecv[1][0] != nullptr, p.xrecv[1][1] != nullptr));
+  } else {
+    sc_load<L, R, PROP, INDIRECT>(f, (const R*)p.d_out, ds, n, p.nodes, si);
+  }
   if constexpr (XF) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[1], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
   const R rho1 = density<L, R>(f);
   p.rho0[gi] = rho0;
@@ -625,6 +649,9 @@ sc_fused_kernel(const ScParams<L, R> p) {
     if constexpr (PULL) {
       static_assert(OWNV && ROW && PROP == PROP_AA_ODD, "the aligned pull serves the whole-row odd step");
       sc_pull_rows<L, R>(fa, fb, p.d_in, p.d_in2, ds, n, nx);
+    } else if constexpr (XF && PROP == PROP_AA_ODD && !GENERAL) {
+      sc_load<L, R, PROP>(fa, p.d_in, ds, sc_pull_node(g, n, nx, p.xrecv[0][0] != nullptr, p.xrecv[0][1] != nullptr));
+      sc_load<L, R, PROP>(fb, p.d_in2, ds, sc_pull_node(g, n, nx, p.xrecv[1][0] != nullptr, p.xrecv[1][1] != nullptr));
     } else {
       sc_load<L, R, PROP>(fa, p.d_in, ds, n);
       sc_load<L, R, PROP>(fb, p.d_in2, ds, n);
@@ -742,7 +769,11 @@ __global__ void __launch_bounds__(1024) scs_macro_kernel(const ScParams<L, R> p)
     if (kind_is_excluded(kind)) return;
   }
   R f[L::Q];
-  sc_load<L, R, PROP, INDIRECT>(f, p.d_in, g.dist_size, n, p.nodes, si);
+  if constexpr (XF && PROP == PROP_AA_ODD && !GENERAL) {
+    sc_load<L, R, PROP, INDIRECT>(f, p.d_in, g.dist_size, sc_pull_node(g, n, g.lat_nx - 2, p.xrecv[0][0] != nullptr, p.xrecv[0][1] != nullptr));
+  } else {
+    sc_load<L, R, PROP, INDIRECT>(f, p.d_in, g.dist_size, n, p.nodes, si);
+  }
   if constexpr (XF) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[0], f, n.gx, g.lat_nx - 2, face_rows<L>(g, n.gy, n.gz));
   const R rho = density<L, R>(f);
   p.rho0[n.gi] = rho;
@@ -785,7 +816,11 @@ __global__ void __launch_bounds__(1024) scs_sweep_kernel(const ScParams<L, R> p)
   const bool wet = kind_is_wet(kind) && active;
   const size_t ds = g.dist_size;
   R f[L::Q];
-  sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
+  if constexpr (XF && PROP == PROP_AA_ODD && !GENERAL) {
+    sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, sc_pull_node(g, n, nx, p.xrecv[0][0] != nullptr, p.xrecv[0][1] != nullptr));
+  } else {
+    sc_load<L, R, PROP, INDIRECT>(f, p.d_in, ds, n, p.nodes, si);
+  }
   if constexpr (XF) {
     if (live) sc_face_receive<L, R, PROP == PROP_AA_ODD>(p.xrecv[0], f, n.gx, nx, face_rows<L>(g, n.gy, n.gz));
   }

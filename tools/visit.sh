@@ -515,6 +515,27 @@ PYEOF
     done
     ( time timeout 2700 python -m pytest tests -m gpu -q --durations=12 ) > $O/pytest_gpu_final.log 2>&1; tail -22 $O/pytest_gpu_final.log
     ;;
+  r6s8)   # bytes and kernel times of the Shan-Chen x-slab configurations (planes) beside their undivided twins
+    TRACE_CONFIGS="4x4 8x4" bash tools/gpu.sh tracecfg pmccfg; rm -rf $O/trace_cfg*/ $O/pmc_cfg*/
+    ;;
+  r6s9)   # ghost-pull skip of the Shan-Chen planes in the odd in-place step: parity, bytes, rates
+    ( time timeout 1500 python -m pytest tests/test_gpu_sc.py tests/test_gpu_two_ranks.py -m gpu -q -k "sc or shan" --durations=3 ) > $O/pytest_sc_skip.log 2>&1; tail -6 $O/pytest_sc_skip.log
+    TRACE_CONFIGS="8x4" bash tools/gpu.sh pmccfg; rm -rf $O/pmc_cfg*/
+    cat > /tmp/sc4.py <<PYEOF
+import sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
+from examples.binary_fluid.sc_separation_3d import SeparationSim
+from sailfish.controller import LBSimulationController
+from sailfish.geo import EqualSubdomainsGeometry3D
+n = int(sys.argv[1])
+c = LBSimulationController(SeparationSim, EqualSubdomainsGeometry3D, default_config=dict(lat_nx=256, lat_ny=256, lat_nz=256, subdomains=n, conn_axis='x', access_pattern=sys.argv[2], mode='benchmark', max_iters=300, benchmark_sample_from=100, perf_stats_every=0))
+c.run(ignore_cmdline=True)
+PYEOF
+    for rep in 1 2; do
+      echo "binary AA planes 4 x-slabs: $(timeout 300 python /tmp/sc4.py 4 AA 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_skip_rates.txt
+    done
+    timeout 900 python tools/bench_configs.py --only 8x4 2>/dev/null | grep '^{' | cut -c1-160 | tee -a $O/sc_skip_rates.txt
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
