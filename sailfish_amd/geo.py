@@ -61,6 +61,8 @@ def _split_rows(total, parts, align, tolerance=0.15):
         sizes = [b - a for a, b in zip(cuts, cuts[1:])]
         if min(sizes) > 0 and max(abs(n - mean) for n in sizes) <= tolerance * mean:
             return list(zip(cuts, sizes))
+    if align and align > 32:        # whole waves do not fit: whole lines, at the tolerance of balanced slabs
+        return _split_rows(total, parts, 32, min(tolerance, 0.15))
     return _split(total, parts)
 
 
@@ -68,9 +70,33 @@ def _add_split_options(group, axes):
     group.add_argument('--subdomains', help='number of subdomains', type=int, default=1)
     group.add_argument('--conn_axis', type=str, default='x', choices=axes,
                        help='axis along which the subdomains will be connected')
-    group.add_argument('--slab_align', type=int, default=32,
-                       help='cut along x at multiples of this many nodes where every slab stays within 15 %% of the '
-                            'equal share: rows then end on a 128-byte line (0: equal pieces, as the reference)')
+    group.add_argument('--slab_align', type=int, default=None,
+                       help='cut along x at multiples of this many nodes where every slab stays within --slab_tolerance of '
+                            'the equal share: rows then end on a 128-byte line (0: equal pieces, as the reference; default: '
+                            '32, or 64 = whole waves when every subdomain runs on the one device of this process)')
+    group.add_argument('--slab_tolerance', type=float, default=None,
+                       help='how far a slab may deviate from the equal share for the sake of --slab_align (default 0.15; '
+                            '0.3 on one device, where the slabs run one after the other and their balance does not matter)')
+
+
+def _row_split_rule(config):
+    """(align, tolerance) of the cuts along x.  Slabs that run on DIFFERENT devices must be balanced: a GPU per slab waits
+    for the widest one.  Slabs of one process on one device run one after the other (controller.LocalGroup), so only the
+    sum of their times counts -- and that is smallest when every row is made of whole waves: the force-driven pipe
+    512 x 256 x 256 in three x-slabs, 170 / 170 / 172: 30.0 GMLUPS, 160 / 192 / 160: 33.6-34.1, 192 / 128 / 192: 34.7-35.5
+    (profiles/r06/slab_align_ab.txt, slab_align64.txt).  One device = --gpus names one entry (several entries start a process
+    each, even on one device) and this is not one rank of several (torchrun / the controller's own ranks: WORLD_SIZE > 1)."""
+    import os
+    gpus = getattr(config, 'gpus', None)
+    if gpus is not None and not isinstance(gpus, (list, tuple)):
+        gpus = [gpus]
+    one_device = gpus is not None and len(gpus) == 1 and int(os.environ.get('WORLD_SIZE', '1')) <= 1
+    align, tol = getattr(config, 'slab_align', None), getattr(config, 'slab_tolerance', None)
+    if align is None:
+        align = 64 if one_device else 32
+    if tol is None:
+        tol = 0.3 if one_device else 0.15
+    return align, tol
 
 
 class EqualSubdomainsGeometry2D(LBGeometry2D):
@@ -84,7 +110,7 @@ class EqualSubdomainsGeometry2D(LBGeometry2D):
     def subdomains(self):
         s = self.config.subdomains
         if self.config.conn_axis == 'x':
-            return [SubdomainSpec2D((o, 0), (n, self.gy)) for o, n in _split_rows(self.gx, s, getattr(self.config, 'slab_align', 32))]
+            return [SubdomainSpec2D((o, 0), (n, self.gy)) for o, n in _split_rows(self.gx, s, *_row_split_rule(self.config))]
         return [SubdomainSpec2D((0, o), (self.gx, n)) for o, n in _split(self.gy, s)]
 
 
@@ -98,7 +124,7 @@ class EqualSubdomainsGeometry3D(LBGeometry3D):
         s = self.config.subdomains
         if self.config.conn_axis == 'x':
             return [SubdomainSpec3D((o, 0, 0), (n, self.gy, self.gz))
-                    for o, n in _split_rows(self.gx, s, getattr(self.config, 'slab_align', 32))]
+                    for o, n in _split_rows(self.gx, s, *_row_split_rule(self.config))]
         elif self.config.conn_axis == 'y':
             return [SubdomainSpec3D((0, o, 0), (self.gx, n, self.gz)) for o, n in _split(self.gy, s)]
         return [SubdomainSpec3D((0, 0, o), (self.gx, self.gy, n)) for o, n in _split(self.gz, s)]

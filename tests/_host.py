@@ -41,6 +41,7 @@ def make_config(dim, **kw):
     c.max_iters = 10
     c.subdomains = 1
     c.conn_axis = 'x'
+    c.gpus = 0                  # the controller's default: one device (geo._row_split_rule cuts x-slabs accordingly)
     c.grid = 'D2Q9' if dim == 2 else 'D3Q19'
     c.visc = 0.01
     c.model = 'bgk'

@@ -186,7 +186,7 @@ def test_more_reference_examples_load_unchanged(module, sim, dim, extra):
         assert desc.simtype in (hipabi.SLF_SIM_SHAN_CHEN_BINARY, hipabi.SLF_SIM_SHAN_CHEN_SINGLE)
 
 
-def test_x_slabs_are_cut_on_line_boundaries_where_the_balance_allows():
+def test_x_slabs_are_cut_on_line_boundaries_where_the_balance_allows(monkeypatch):
     """geo._split_rows: cuts along x at multiples of 32 nodes (a 128-byte line of single-precision values) when every
     slab stays within 15 % of the equal share; the reference's equal pieces otherwise, always for --slab_align=0, and along
     y / z (reference geo.py:113-135)."""
@@ -208,3 +208,15 @@ def test_x_slabs_are_cut_on_line_boundaries_where_the_balance_allows():
         Cfg.conn_axis, Cfg.slab_align = axis, align
         specs = geo.EqualSubdomainsGeometry3D(Cfg).subdomains()
         assert [s.size['xyz'.index(axis)] for s in specs] == want
+    # the defaults: slabs of one process on ONE device run one after the other -- whole waves matter, balance does not;
+    # a device per slab (or a rank of several): lines, within 15 % of the equal share
+    Cfg.conn_axis, Cfg.slab_align = 'x', None
+    for gpus, world, want in ((0, None, [192, 128, 192]), ([0], None, [192, 128, 192]), ([0, 1, 2], None, [160, 192, 160]),
+                              ([0, 0, 0], None, [160, 192, 160]), ([0], '3', [160, 192, 160]), (None, None, [160, 192, 160])):
+        Cfg.gpus = gpus
+        if world is None:
+            monkeypatch.delenv('WORLD_SIZE', raising=False)
+        else:
+            monkeypatch.setenv('WORLD_SIZE', world)
+        assert [s.size[0] for s in geo.EqualSubdomainsGeometry3D(Cfg).subdomains()] == want
+    assert geo._split_rows(512, 3, 64, 0.3) == [(0, 192), (192, 128), (320, 192)]

@@ -336,7 +336,7 @@ def main():
                             subdomains=4, conn_axis='x', access_pattern='AA', seed=11, max_iters=int(1500 * it),
                             benchmark_sample_from=int(500 * it)), 3 * 76 + 8))
     if '5x3' in only:
-        res.append(run('5x3: D3Q19 BGK force-driven pipe 512x256x256 in 3 x-slabs (160 / 192 / 160), one process (AA)', Pipe3D,
+        res.append(run('5x3: D3Q19 BGK force-driven pipe 512x256x256 in 3 x-slabs, one process (AA)', Pipe3D,
                        EqualSubdomainsGeometry3D,
                        dict(lat_nx=512, lat_ny=256, lat_nz=256, visc=0.05, subdomains=3, conn_axis='x', access_pattern='AA',
                             max_iters=int(1500 * it), benchmark_sample_from=int(500 * it)), 152))

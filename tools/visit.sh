@@ -536,6 +536,17 @@ PYEOF
     done
     timeout 900 python tools/bench_configs.py --only 8x4 2>/dev/null | grep '^{' | cut -c1-160 | tee -a $O/sc_skip_rates.txt
     ;;
+  r6s10)  # the pipe in 3 x-slabs with cuts on whole waves (192 / 128 / 192) against 160 / 192 / 160
+    P="--lat_nx=512 --lat_ny=256 --lat_nz=256 --subdomains=3 --conn_axis=x --visc=0.05 --access_pattern=AA --mode=benchmark --max_iters=600 --benchmark_sample_from=200 --perf_stats_every=0"
+    for rep in 1 2; do
+      echo "pipe AA align 32 tol 0.15: $(timeout 300 python examples/poiseuille_3d.py $P 2>&1 | grep 'Total MLUPS')" | tee -a $O/slab_align64.txt
+      echo "pipe AA align 64 tol 0.3: $(timeout 300 python examples/poiseuille_3d.py $P --slab_align=64 --slab_tolerance=0.3 2>&1 | grep 'Total MLUPS')" | tee -a $O/slab_align64.txt
+    done
+    ;;
+  r6s11)  # x cuts on whole waves for slabs of one process on one device (the new default): every multi-subdomain GPU test
+    ( time timeout 2400 python -m pytest tests -m gpu -q -k "subdomain or slab or group or planes or ranks or xface or config4 or example or launch" --durations=5 ) > $O/pytest_slabs_waves.log 2>&1; tail -8 $O/pytest_slabs_waves.log
+    timeout 900 python tools/bench_configs.py --only 5x3,3g8 2>/dev/null | grep '^{' | cut -c1-200 | tee $O/configs_slab_waves.txt
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
