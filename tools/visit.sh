@@ -547,6 +547,10 @@ PYEOF
     ( time timeout 2400 python -m pytest tests -m gpu -q -k "subdomain or slab or group or planes or ranks or xface or config4 or example or launch" --durations=5 ) > $O/pytest_slabs_waves.log 2>&1; tail -8 $O/pytest_slabs_waves.log
     timeout 900 python tools/bench_configs.py --only 5x3,3g8 2>/dev/null | grep '^{' | cut -c1-200 | tee $O/configs_slab_waves.txt
     ;;
+  r6all)  # every GPU test + smoke, as the driver runs them at round end
+    bash tools/gpu.sh smoke
+    ( time timeout 2700 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
