@@ -551,6 +551,17 @@ PYEOF
     bash tools/gpu.sh smoke
     ( time timeout 2700 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu_final.log 2>&1; tail -16 $O/pytest_gpu_final.log
     ;;
+  r6s12)  # binary Shan-Chen 256^3, one PROCESS per x-slab on the one GPU (planes in the neighbour's memory, peer transport)
+    A="--lat_nx=256 --lat_ny=256 --lat_nz=256 --conn_axis=x --mode=benchmark --max_iters=400 --benchmark_sample_from=150 --perf_stats_every=0"
+    for n in 4 2; do
+      g=$(python -c "print(' '.join(['0'] * $n))")
+      for xf in 1 0; do
+        echo "processes $n planes $xf: $(SLF_SC_XFACE=$xf timeout 600 python tests/_sc_ranks_script.py $A --subdomains=$n --gpus $g 2>&1 | grep 'Total MLUPS\|rror' | tail -2)" | tee -a $O/sc_processes.txt
+      done
+    done
+    echo "one process 4 slabs: $(timeout 600 python tests/_sc_ranks_script.py $A --subdomains=4 --gpus 0 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_processes.txt
+    echo "undivided: $(timeout 600 python tests/_sc_ranks_script.py $A --subdomains=1 --gpus 0 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_processes.txt
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
