@@ -347,6 +347,55 @@ def test_sc_walls_x_slabs_through_planes(single, pattern, mode, monkeypatch):
     assert not ctrl.runners[0]._subdomain.fluid_map()[..., -1].all() and not ctrl.runners[1]._subdomain.fluid_map()[..., 0].all()
 
 
+@pytest.mark.parametrize('single,pattern', [(False, 'AB'), (False, 'AA'), (True, 'AB')])
+def test_sc_closed_box_x_slabs_through_planes(single, pattern):
+    """x NOT periodic: the first and the last of three x-slabs have one connected face each (planes) and one wall (ghost
+    columns, never read by a node that computes a force); walls along y too, z wrapped in-kernel.  Every wet node equal to
+    the oracle group bit for bit.  (Not the single-component model in place: its density pass also visits the wall nodes
+    -- the reference's PrepareMacroFields skips excluded nodes only, lb_single_fluid.mako:143-146 -- and in the odd step a
+    wall node on the rim of the lattice pulls from the ghost layer, whose populations are the equilibrium of the +inf every
+    field holds outside the lattice: an infinite wall density, NaN forces next to it.  With or without planes, on one
+    subdomain or three: a property of that combination)"""
+    from sailfish_amd import geo as geo_mod
+    from sailfish_amd.controller import LBSimulationController
+    from sailfish_amd.node_type import NTFullBBWall
+    from tests._oracle_group import OracleNNGroup
+    base, _ = (_sc.make_single_sim if single else _sc.make_sim)(3)
+
+    class Boxed(base.subdomain):
+        def boundary_conditions(self, hx, hy, hz):
+            wall = (hx == 0) | (hx == self.gx - 1) | (hy == 0) | (hy == self.gy - 1)
+            self.set_node(wall, NTFullBBWall)
+
+    class Sim(base):
+        subdomain = Boxed
+
+    size = (30, 12, 8)
+    cfg = (_sc.single_config if single else _sc.config)(3, size, pattern=pattern)
+    if single:
+        cfg.update(G=-1.2, sc_potential='linear')
+    cfg.update(periodic_x=False, periodic_y=False, subdomains=3, conn_axis='x')
+    steps = 12 if pattern == 'AA' else 11
+    og = OracleNNGroup(Sim, 3, 'EqualSubdomainsGeometry3D', dict(cfg), single=single)
+    og.run(steps)
+    ctrl = LBSimulationController(Sim, geo_mod.EqualSubdomainsGeometry3D,
+                                  default_config=dict(cfg, max_iters=steps, quiet=True, perf_stats_every=0))
+    ctrl.run(ignore_cmdline=True)
+    assert len(ctrl.runners) == 3
+    from sailfish_amd import xface
+    for i, (r, o) in enumerate(zip(ctrl.runners, og.subs)):
+        assert r._nnx is not None
+        connected = [bool(r._nnx.recv['macro'][0][f]) for f in (xface.LOW, xface.HIGH)]
+        assert connected == [i > 0, i < 2]
+        wet = r._subdomain.fluid_map()
+        assert wet.any() and not wet.all()
+        assert np.array_equal(r._sim.rho[wet], o.real(o.rho)[wet])
+        lattices = [o.current()] if single else list(o.current())
+        for grid_num, od in enumerate(lattices):
+            gd = r._debug_get_dist(grid_num=grid_num)[(slice(None),) + tuple(r._spec._nonghost_slice)]
+            assert np.array_equal(gd[:, wet], o.real(o.dense(od))[:, wet]), 'subdomain %d lattice %d' % (r._spec.id, grid_num)
+
+
 def test_sc_x_slab_planes_refuse_what_they_do_not_serve():
     """The planes are for the kernels that know them: a module with indirect addressing does not take them, and a runner
     whose y / z periodicity is made by the ghost-layer kernels (images that live in the arrays, not in the planes) keeps

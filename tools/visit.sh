@@ -562,6 +562,9 @@ PYEOF
     echo "one process 4 slabs: $(timeout 600 python tests/_sc_ranks_script.py $A --subdomains=4 --gpus 0 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_processes.txt
     echo "undivided: $(timeout 600 python tests/_sc_ranks_script.py $A --subdomains=1 --gpus 0 2>&1 | grep 'Total MLUPS')" | tee -a $O/sc_processes.txt
     ;;
+  r6s13)  # closed box in three x-slabs through the planes
+    ( time timeout 900 python -m pytest tests/test_gpu_sc.py -m gpu -q -k "closed_box" --durations=3 ) > $O/pytest_sc_box.log 2>&1; tail -12 $O/pytest_sc_box.log
+    ;;
   r6final)   # round-6 evidence visit: everything DESIGN.md / profiles/traffic.json quote for the shipped kernels
     export SLF_PEER_TIMEOUT_S=60
     bash tools/gpu.sh host smoke
