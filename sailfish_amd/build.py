@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libsailfish_hip.so')
-SOURCES = ['slf_kernels.hip', 'slf_fast.hip', 'slf_row.hip', 'slf_sc.hip', 'slf_resident.hip', 'slf_api.hip']
+SOURCES = ['slf_kernels.hip', 'slf_slots.hip', 'slf_fast.hip', 'slf_row.hip', 'slf_sc.hip', 'slf_resident.hip', 'slf_api.hip']
 HEADERS = ['slf_kernels.h', 'slf_lattice.h', 'slf_node.h', 'slf_sweep.h', 'slf_rowpush.h', os.path.join('..', '..', 'include', 'sailfish_hip.h')]
 
 # -ffp-contract=off: fixed IEEE operation order (DESIGN.md "arithmetic contract");

@@ -274,6 +274,9 @@ __device__ __forceinline__ void x_face_send_own_row(const SweepParams<L, R>& p, 
 // pre-collision boundary conditions, collision, half-way bounce-back stores (reference
 // lb_single_fluid.mako:175-228).  Shared by all sweep kernels so that they differ only in access shape.
 constexpr uint32_t INVALID_NODE = 0xffffffffu;
+// the sweep of an indirectly addressed module over its slots (slf_slots.hip; called from slf_kernels.hip)
+template <class L, class R>
+hipError_t launch_slot_sweep(int model, int prop, int bc_level, const SweepParams<L, R>& q, hipStream_t s);
 constexpr uint32_t OPTION_CHECK_INVALID = 4u;   // kernel `options`: 1 save macro fields, 2 bulk (reference), 4 this
 
 // On-GPU invalid value check (reference checkInvalidValues, geo_helpers.mako:193-213, enabled by
